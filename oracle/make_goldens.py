@@ -1,0 +1,211 @@
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE in the build container.
+
+TEST INFRASTRUCTURE.  Runs only where /root/reference exists (never on the
+GPU box).  Imports FastDiffSR/model/fastdiffsr_modules/{diffusion,unet}.py
+with stub modules for the two unused imports the image lacks (torchvision,
+thop), loads the portable synthetic weights (fastdiffsr_amd/synth.py) into the
+reference's nn.Modules, injects fixed noise by patching torch.randn /
+torch.randn_like (SURVEY.md 8c recipe) and stores inputs-by-seed + expected
+outputs.  Fixtures are DATA (arrays); no reference source text is stored.
+
+Usage:  python oracle/make_goldens.py            (writes tests/golden/)
+"""
+import hashlib
+import os
+import sys
+import types
+from unittest import mock
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REF = '/root/reference/FastDiffSR'
+OUT = os.path.join(ROOT, 'tests', 'golden')
+
+from fastdiffsr_amd.arch import UNetConfig, FASTDIFFSR_UNET, FASTDIFFSR_SCHEDULE_VAL, SCHEDULE_BUFFERS  # noqa: E402
+from fastdiffsr_amd.synth import synth_state_dict, state_dict_sha256, synth_inputs  # noqa: E402
+
+
+def import_reference():
+    tv = types.ModuleType('torchvision')
+    tvm = types.ModuleType('torchvision.models')
+    tvm.vgg19 = None
+    tv.models = tvm
+    thop = types.ModuleType('thop')
+    thop.profile = None
+    thop.clever_format = None
+    sys.modules.setdefault('torchvision', tv)
+    sys.modules.setdefault('torchvision.models', tvm)
+    sys.modules.setdefault('thop', thop)
+    sys.path.insert(0, REF)
+    from model.fastdiffsr_modules import diffusion, unet
+    return diffusion, unet
+
+
+def build_ref(diffusion, unet, cfg: UNetConfig, sched: dict, seed=0):
+    net = unet.UNet(in_channel=cfg.in_channel, out_channel=cfg.out_channel, norm_groups=cfg.norm_groups,
+                    inner_channel=cfg.inner_channel, channel_mults=list(cfg.channel_mults),
+                    attn_res=list(cfg.attn_res), res_blocks=cfg.res_blocks, dropout=cfg.dropout,
+                    image_size=cfg.image_size)
+    G = diffusion.GaussianDiffusion(net, image_size=cfg.image_size, channels=3, loss_type='l1',
+                                    conditional=True, schedule_opt=sched, scale=4)
+    G.set_loss('cpu')
+    G.set_new_noise_schedule(sched, 'cpu')
+    sd = synth_state_dict(cfg, seed)
+    ref_keys = [k for k in net.state_dict().keys()]
+    assert ref_keys == list(sd.keys()), 'schema order mismatch vs reference state_dict'
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    G.eval()
+    return G, net, sd
+
+
+def sha(a: np.ndarray) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def ref_sample_loop(G, cond, noise):
+    """Batched oracle = manual p_sample loop + res2img (bypasses the B>=2 crash)."""
+    T = G.num_timesteps
+    it = iter(range(1, T))
+    traj = []
+    with torch.no_grad(), mock.patch.object(torch, 'randn_like', lambda x: noise[next(it)]):
+        img = noise[0]
+        for t in reversed(range(T)):
+            img = G.p_sample(img, t, condition_x=cond)
+            traj.append(img.clone())
+        out = G.res2img(img, cond)
+    return out, traj
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    diffusion, unet = import_reference()
+
+    # ---- (i) schedule tables: every branch the reference implements ------------
+    sched = {}
+    cases = [('linear_cosine', 20, 1e-6, 1e-2), ('linear_cosine', 10, 1e-6, 1e-2),
+             ('linear', 2000, 1e-6, 1e-2), ('quad', 50, 1e-4, 2e-2), ('warmup10', 40, 1e-4, 2e-2),
+             ('warmup50', 40, 1e-4, 2e-2), ('const', 16, 1e-4, 2e-2), ('jsd', 16, 1e-4, 2e-2),
+             ('cosine', 100, 1e-4, 2e-2)]
+    for name, T, ls, le in cases:
+        b = diffusion.make_beta_schedule(name, T, ls, le)
+        b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else b
+        sched[f'betas/{name}/{T}'] = np.asarray(b, dtype=np.float64)
+    for T in (20, 10):
+        G = diffusion.GaussianDiffusion(None, image_size=256, conditional=True)
+        G.set_new_noise_schedule(dict(schedule='linear_cosine', n_timestep=T, linear_start=1e-6, linear_end=1e-2), 'cpu')
+        for k in SCHEDULE_BUFFERS:
+            sched[f'buf/{T}/{k}'] = getattr(G, k).numpy()
+        sched[f'buf/{T}/sqrt_alphas_cumprod_prev_f64'] = np.asarray(G.sqrt_alphas_cumprod_prev, dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, 'schedule.npz'), **sched)
+
+    # ---- (ii) small real-tensor UNet golden: inner=32 ---------------------------
+    cfg_s = UNetConfig(in_channel=6, out_channel=3, inner_channel=32, norm_groups=32,
+                       channel_mults=(1, 2, 4, 4), attn_res=(16,), res_blocks=2, dropout=0.2, image_size=32)
+    Gs, net_s, sd_s = build_ref(diffusion, unet, cfg_s, FASTDIFFSR_SCHEDULE_VAL, seed=7)
+    g = torch.Generator().manual_seed(11)
+    x_s = torch.randn(2, 6, 32, 32, generator=g)
+    small = {'x': x_s.numpy(), 'weights_sha256': np.array(state_dict_sha256(sd_s))}
+    with torch.no_grad():
+        for i, nl in enumerate((0.5, 6.634494e-07, 0.99)):
+            nlv = torch.full((2, 1), nl, dtype=torch.float32)
+            small[f'eps/{i}'] = net_s(x_s, nlv).numpy()
+            small[f'nl/{i}'] = nlv.numpy()
+        # per-sample different noise levels (training-style call)
+        nlv = torch.tensor([[0.3], [0.8]], dtype=torch.float32)
+        small['eps/3'] = net_s(x_s, nlv).numpy()
+        small['nl/3'] = nlv.numpy()
+        # sub-module goldens (wiring checks for the restatement)
+        t = net_s.noise_level_mlp(nlv)
+        small['t_mlp'] = t.numpy()
+        small['posenc'] = net_s.noise_level_mlp[0](nlv).numpy()
+        h = net_s.downs[0](x_s)
+        small['downs0'] = h.numpy()
+        small['downs1'] = net_s.downs[1](h, t).numpy()
+        xm = torch.randn(2, 128, 4, 4, generator=g)
+        small['mid_in'] = xm.numpy()
+        small['mid0'] = net_s.mid[0](xm, t).numpy()
+        small['clam'] = net_s.mid[0].ca(xm).numpy()
+        small['slam'] = net_s.mid[0].sa(xm).numpy()
+        xu = torch.randn(2, 128, 4, 4, generator=g)
+        up_idx = [i for i, m in enumerate(net_s.ups) if isinstance(m, unet.Upsample)][0]
+        dn_idx = [i for i, m in enumerate(net_s.downs) if isinstance(m, unet.Downsample)][0]
+        small['up_in'] = xu.numpy()
+        small['up_idx'] = np.array(up_idx)
+        small['up_out'] = net_s.ups[up_idx](xu).numpy()
+        xd = torch.randn(2, 32, 16, 16, generator=g)
+        small['down_in'] = xd.numpy()
+        small['down_idx'] = np.array(dn_idx)
+        small['down_out'] = net_s.downs[dn_idx](xd).numpy()
+    np.savez_compressed(os.path.join(OUT, 'unet_small.npz'), **small)
+
+    # ---- (iii) full-width UNet (inner=64) forward with portable weights --------
+    cfg = UNetConfig(**FASTDIFFSR_UNET)
+    G, net, sd = build_ref(diffusion, unet, cfg, FASTDIFFSR_SCHEDULE_VAL, seed=0)
+    full = {'weights_sha256': np.array(state_dict_sha256(sd))}
+    g = torch.Generator().manual_seed(21)
+    x64 = torch.randn(1, 6, 64, 64, generator=g)
+    x32 = torch.randn(2, 6, 32, 32, generator=g)
+    full['x64_sha256'] = np.array(sha(x64.numpy()))
+    full['x32_sha256'] = np.array(sha(x32.numpy()))
+    with torch.no_grad():
+        full['eps64'] = net(x64, torch.full((1, 1), 0.5)).numpy()
+        full['eps32'] = net(x32, torch.tensor([[0.0209801132], [0.9919746]])).numpy()
+    np.savez_compressed(os.path.join(OUT, 'unet_full.npz'), **full)
+
+    # ---- (iv) 20-step trajectories ----------------------------------------------
+    traj = {}
+    cond, noise = synth_inputs(2, 32, 32, 20)
+    traj['cond32_sha256'] = np.array(sha(cond.numpy()))
+    traj['noise32_sha256'] = np.array(sha(noise.numpy()))
+    out, xs = ref_sample_loop(G, cond, noise)
+    traj['traj32'] = torch.stack(xs).numpy()          # [20,2,3,32,32], x_t after step t=19..0
+    traj['out32'] = out.numpy()
+    # B=1 through the reference's own p_sample_loop (continous=True) -- the real entry point
+    it = iter(range(1, 20))
+    c1, n1 = cond[:1], noise[:, :1]
+    with mock.patch.object(torch, 'randn', lambda *a, **k: n1[0]), \
+            mock.patch.object(torch, 'randn_like', lambda x: n1[next(it)]), \
+            mock.patch.object(diffusion, 'tqdm', lambda it_, **k: it_):
+        ret = G.super_resolution(c1, continous=True)
+    traj['continous32_b1'] = ret.numpy()               # [8,3,32,32]
+    it = iter(range(1, 20))
+    with mock.patch.object(torch, 'randn', lambda *a, **k: n1[0]), \
+            mock.patch.object(torch, 'randn_like', lambda x: n1[next(it)]), \
+            mock.patch.object(diffusion, 'tqdm', lambda it_, **k: it_):
+        traj['final32_b1'] = G.super_resolution(c1, continous=False).numpy()
+    cond64, noise64 = synth_inputs(1, 64, 64, 20)
+    out64, _ = ref_sample_loop(G, cond64, noise64)
+    traj['out64'] = out64.numpy()
+    traj['cond64_sha256'] = np.array(sha(cond64.numpy()))
+    np.savez_compressed(os.path.join(OUT, 'sample_loop.npz'), **traj)
+
+    # ---- (v) training loss (a20), dropout off ------------------------------------
+    tr = {}
+    g = torch.Generator().manual_seed(31)
+    hr = torch.rand(2, 3, 32, 32, generator=g) * 2 - 1
+    sr = (hr + 0.2 * torch.randn(2, 3, 32, 32, generator=g)).clamp(-1, 1)
+    nz = torch.randn(2, 3, 32, 32, generator=g)
+    t_fixed = 7
+    lo, hi = G.sqrt_alphas_cumprod_prev[t_fixed - 1], G.sqrt_alphas_cumprod_prev[t_fixed]
+    gam = np.array([lo + 0.25 * (hi - lo), lo + 0.75 * (hi - lo)])
+    with mock.patch.object(np.random, 'randint', lambda a, b: t_fixed), \
+            mock.patch.object(np.random, 'uniform', lambda a, b, size: gam):
+        Gs_eval = G
+        Gs_eval.eval()
+        loss = Gs_eval({'HR': hr, 'SR': sr}, noise=nz)
+    tr.update(hr=hr.numpy(), sr=sr.numpy(), noise=nz.numpy(), gamma=gam.astype(np.float64),
+              loss=np.array(loss.item(), dtype=np.float64),
+              img2res=G.img2res(hr, sr).numpy(), res2img=G.res2img(nz, sr).numpy())
+    np.savez_compressed(os.path.join(OUT, 'train_loss.npz'), **tr)
+
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == '__main__':
+    main()

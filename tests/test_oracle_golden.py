@@ -1,0 +1,164 @@
+"""Pin the oracle (oracle/fdsr_oracle.py) against outputs of the reference itself
+(tests/golden/*.npz, made by oracle/make_goldens.py in the build container)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from fastdiffsr_amd.arch import UNetConfig, FASTDIFFSR_UNET, FASTDIFFSR_SCHEDULE_VAL, SCHEDULE_BUFFERS
+from fastdiffsr_amd.synth import synth_state_dict, state_dict_sha256, synth_inputs
+from oracle import fdsr_oracle as O
+
+TOL = 2e-6   # SURVEY section 7 stage 1: restatement vs reference <= 2e-6
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def test_beta_schedules_all_branches(golden_dir):
+    g = _load(golden_dir, 'schedule.npz')
+    n = 0
+    for key in g.files:
+        if not key.startswith('betas/'):
+            continue
+        _, name, T = key.split('/')
+        ls, le = (1e-6, 1e-2) if name in ('linear_cosine', 'linear') else (1e-4, 2e-2)
+        b = O.make_beta_schedule(name, int(T), ls, le)
+        np.testing.assert_allclose(b, g[key], rtol=0, atol=1e-15)
+        n += 1
+    assert n == 9
+    with pytest.raises(NotImplementedError):
+        O.make_beta_schedule('nope', 10)
+
+
+@pytest.mark.parametrize('T', [20, 10])
+def test_schedule_buffers_bit_exact(golden_dir, T):
+    g = _load(golden_dir, 'schedule.npz')
+    tab = O.schedule_tables(dict(schedule='linear_cosine', n_timestep=T, linear_start=1e-6, linear_end=1e-2))
+    for k in SCHEDULE_BUFFERS:
+        assert tab[k].dtype == np.float32
+        np.testing.assert_array_equal(tab[k], g[f'buf/{T}/{k}'])
+    np.testing.assert_array_equal(tab['sqrt_alphas_cumprod_prev_f64'], g[f'buf/{T}/sqrt_alphas_cumprod_prev_f64'])
+    if T == 20:   # SURVEY App. B eyeball values
+        assert abs(tab['betas'][0] - 0.0160) < 5e-5 and tab['betas'][-1] == np.float32(0.999)
+        assert abs(tab['sqrt_alphas_cumprod_prev_f64'][20] - 6.63449433e-07) < 1e-15
+
+
+@pytest.fixture(scope='module')
+def small(golden_dir):
+    g = _load(golden_dir, 'unet_small.npz')
+    cfg = UNetConfig(in_channel=6, out_channel=3, inner_channel=32, norm_groups=32,
+                     channel_mults=(1, 2, 4, 4), attn_res=(16,), res_blocks=2, dropout=0.2, image_size=32)
+    sd = synth_state_dict(cfg, seed=7)
+    assert state_dict_sha256(sd) == str(g['weights_sha256'])
+    return g, cfg, O.to_torch_sd(sd)
+
+
+def test_unet_small_forward(small):
+    g, cfg, sd = small
+    x = torch.from_numpy(g['x'])
+    with torch.no_grad():
+        for i in range(4):
+            eps = O.unet_forward(sd, cfg, x, torch.from_numpy(g[f'nl/{i}']))
+            assert np.abs(eps.numpy() - g[f'eps/{i}']).max() <= TOL
+
+
+def test_unet_small_submodules(small):
+    g, cfg, sd = small
+    nl = torch.from_numpy(g['nl/3'])
+    x = torch.from_numpy(g['x'])
+    with torch.no_grad():
+        np.testing.assert_allclose(O.positional_encoding(nl, 32).numpy(), g['posenc'], atol=1e-7)
+        t = O.noise_level_mlp(sd, nl, 32)
+        np.testing.assert_allclose(t.numpy(), g['t_mlp'], atol=TOL)
+        h = torch.nn.functional.conv2d(x, sd['downs.0.weight'], sd['downs.0.bias'], padding=1)
+        np.testing.assert_allclose(h.numpy(), g['downs0'], atol=TOL)
+        np.testing.assert_allclose(O.resnet_block(sd, 'downs.1', h, t, 32, False).numpy(), g['downs1'], atol=TOL)
+        xm = torch.from_numpy(g['mid_in'])
+        np.testing.assert_allclose(O.clam(sd, 'mid.0.ca', xm).numpy(), g['clam'], atol=TOL)
+        np.testing.assert_allclose(O.slam(sd, 'mid.0.sa', xm).numpy(), g['slam'], atol=TOL)
+        m0 = O.resnet_block(sd, 'mid.0', xm, t, 32, False)
+        m0 = O.slam(sd, 'mid.0.sa', O.clam(sd, 'mid.0.ca', m0))
+        np.testing.assert_allclose(m0.numpy(), g['mid0'], atol=TOL)
+        F = torch.nn.functional
+        up = f"ups.{int(g['up_idx'])}"
+        xu = F.interpolate(torch.from_numpy(g['up_in']), scale_factor=2, mode='nearest')
+        np.testing.assert_allclose(F.conv2d(xu, sd[f'{up}.conv.weight'], sd[f'{up}.conv.bias'], padding=1).numpy(),
+                                   g['up_out'], atol=TOL)
+        dn = f"downs.{int(g['down_idx'])}"
+        np.testing.assert_allclose(
+            F.conv2d(torch.from_numpy(g['down_in']), sd[f'{dn}.conv.weight'], sd[f'{dn}.conv.bias'], stride=2, padding=1).numpy(),
+            g['down_out'], atol=TOL)
+
+
+@pytest.fixture(scope='module')
+def full(golden_dir):
+    cfg = UNetConfig(**FASTDIFFSR_UNET)
+    sd = synth_state_dict(cfg, seed=0)
+    g = _load(golden_dir, 'unet_full.npz')
+    assert state_dict_sha256(sd) == str(g['weights_sha256'])
+    return cfg, O.to_torch_sd(sd), O.schedule_tables(FASTDIFFSR_SCHEDULE_VAL)
+
+
+def test_unet_full_forward(full, golden_dir):
+    cfg, sd, _ = full
+    g = _load(golden_dir, 'unet_full.npz')
+    gen = torch.Generator().manual_seed(21)
+    x64 = torch.randn(1, 6, 64, 64, generator=gen)
+    x32 = torch.randn(2, 6, 32, 32, generator=gen)
+    with torch.no_grad():
+        e64 = O.unet_forward(sd, cfg, x64, torch.full((1, 1), 0.5))
+        e32 = O.unet_forward(sd, cfg, x32, torch.tensor([[0.0209801132], [0.9919746]]))
+    assert np.abs(e64.numpy() - g['eps64']).max() <= TOL
+    assert np.abs(e32.numpy() - g['eps32']).max() <= TOL
+
+
+def test_sample_loop_trajectory(full, golden_dir):
+    cfg, sd, tab = full
+    g = _load(golden_dir, 'sample_loop.npz')
+    cond, noise = synth_inputs(2, 32, 32, 20)
+    out, traj = O.p_sample_loop(sd, cfg, tab, cond, noise, return_trajectory=True)
+    tr = torch.stack(traj).numpy()
+    # per-step: the first steps are chaotic in x0 but clamped; bound is absolute
+    assert np.abs(tr - g['traj32']).max() <= 2e-5
+    assert np.abs(out.numpy() - g['out32']).max() <= 2e-5
+    # B=1 through the reference's own p_sample_loop entry point
+    out1 = O.p_sample_loop(sd, cfg, tab, cond[:1], noise[:, :1])
+    assert np.abs(out1.numpy() - g['final32_b1']).max() <= 2e-5
+    assert np.abs(out1.numpy() - g['continous32_b1'][-1]).max() <= 2e-5
+    # continous=True keeps x_in + 7 frames at t = 18,15,...,0
+    assert O.continuous_frames(20) == [18, 15, 12, 9, 6, 3, 0]
+    frames = [O.res2img(traj[19 - t][:1], cond[:1]).numpy() for t in O.continuous_frames(20)]
+    assert np.abs(np.concatenate(frames) - g['continous32_b1'][1:]).max() <= 2e-5
+
+
+def test_sample_loop_64(full, golden_dir):
+    cfg, sd, tab = full
+    g = _load(golden_dir, 'sample_loop.npz')
+    cond, noise = synth_inputs(1, 64, 64, 20)
+    out = O.p_sample_loop(sd, cfg, tab, cond, noise)
+    assert np.abs(out.numpy() - g['out64']).max() <= 2e-5
+
+
+def test_training_loss(full, golden_dir):
+    cfg, sd, _ = full
+    g = _load(golden_dir, 'train_loss.npz')
+    hr, sr, nz = (torch.from_numpy(g[k]) for k in ('hr', 'sr', 'noise'))
+    np.testing.assert_array_equal(O.img2res(hr, sr).numpy(), g['img2res'])
+    np.testing.assert_array_equal(O.res2img(nz, sr).numpy(), g['res2img'])
+    gamma = torch.FloatTensor(g['gamma'])      # reference casts the numpy draw to fp32 (diffusion.py:246)
+    with torch.no_grad():
+        loss = O.p_losses(sd, cfg, hr, sr, gamma, nz)
+    assert abs(loss.item() - float(g['loss'])) <= 1e-3 * abs(float(g['loss'])) * 1e-2 + 1e-2
+
+
+def test_tensor2img_psnr():
+    t = torch.tensor([[[-1.5, -1.0], [0.0, 1.0]]] * 3)
+    img = O.tensor2img_u8(t)
+    assert img.shape == (2, 2, 3) and img.dtype == np.uint8
+    assert img[0, 0, 0] == 0 and img[0, 1, 0] == 0 and img[1, 0, 0] == 128 and img[1, 1, 0] == 255
+    assert O.psnr_u8(img, img) == float('inf')
+    b = img.copy(); b[0, 0, 0] = 10
+    assert abs(O.psnr_u8(img, b) - 20 * np.log10(255 / np.sqrt(100 / 12))) < 1e-9
