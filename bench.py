@@ -1,0 +1,178 @@
+"""Headline benchmark: 256x256 SR images/s at T=20 (BASELINE.json), one process per GPU.
+
+A "step" = one full 20-step conditional sampling pass (20 UNet forwards + 20 posterior
+updates) over one batch of synthetic inputs per GPU; inputs (cond, noise) are resident in
+HBM before the timed region.  Default workload = BASELINE configs[1]: x4 64->256,
+batch=16 per GPU, T=20, random-init UNet, fp32.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--no-cpu-baseline]
+  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+FLOPS_PER_IMAGE = 5.3662e12      # 20 x 268.31 GFLOP
+PEAK_F32_MFMA = 157.3            # TFLOP/s, MI355X_MICROARCH.md (f32 matrix = f32 vector peak)
+
+
+def host_cores():
+    """CPU threads this process may really use: affinity mask capped by the cgroup CPU quota."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+        try:
+            txt = open(path).read().split()
+            if path.endswith('cpu.max'):
+                if txt[0] != 'max':
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return n
+
+
+def cpu_baseline(cfg, sd, budget_s=20.0):
+    """The oracle (CPU restatement of the reference loop) timed on the host cores, on a BOUNDED
+    sample: the first k reverse steps (t = 19, 18, ...) of ONE 256x256 image, as many as fit in
+    ~budget_s after one warm-up UNet forward; images/s = 1 / (20 * mean step time).  Every step
+    costs the same (one UNet forward + the posterior update).  Reported baseline only."""
+    from oracle import fdsr_oracle as O
+    from fastdiffsr_amd.arch import FASTDIFFSR_SCHEDULE_VAL
+    from fastdiffsr_amd.synth import synth_inputs
+    cores = host_cores()
+    threads = max(1, min(cores, 64))
+    torch.set_num_threads(threads)
+    tsd = O.to_torch_sd(sd)
+    tab = O.schedule_tables(FASTDIFFSR_SCHEDULE_VAL)
+    cond, noise = synth_inputs(1, 256, 256, 20)
+    with torch.no_grad():
+        O.unet_forward(tsd, cfg, torch.cat([cond, noise[0]], 1), torch.full((1, 1), 0.5))   # warm-up
+        img, k, t0 = noise[0], 0, time.perf_counter()
+        for t in reversed(range(20)):
+            img = O.p_sample(tsd, cfg, tab, img, t, cond, noise[k + 1] if t > 0 else None)
+            k += 1
+            if time.perf_counter() - t0 > budget_s:
+                break
+        dt = time.perf_counter() - t0
+    step = dt / k
+    return {'value': 1.0 / (20 * step), 'unit': 'images/s', 'cores': threads, 'kind': 'port',
+            'sample': f'{k} of 20 reverse steps of 1 image, 256x256, fp32, PyTorch-CPU restatement (oracle/), '
+                      f'{dt:.1f} s after 1 warm-up forward, {threads} threads (host reports {cores} usable)'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--batch', type=int, default=16, help='images per GPU per step')
+    ap.add_argument('--size', type=int, default=256)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-profile', action='store_true', help='skip the per-conv HIP-event timing')
+    ap.add_argument('--graph', action='store_true', help='replay the 20-step loop as a hipGraph')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    distributed = world > 1
+    if args.gpus != world and distributed:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+
+    import torch.distributed as dist
+    from fastdiffsr_amd.arch import UNetConfig, FASTDIFFSR_UNET, FASTDIFFSR_SCHEDULE_VAL
+    from fastdiffsr_amd.engine import Engine
+    from fastdiffsr_amd.schedule import schedule_buffers, sampling_scalars
+    from fastdiffsr_amd.synth import synth_state_dict, synth_inputs
+    from fastdiffsr_amd import parallel
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if distributed:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+
+    cfg = UNetConfig(**FASTDIFFSR_UNET)
+    # weights: rank 0 builds the random-init UNet, ONE RCCL broadcast replicates it
+    sd = synth_state_dict(cfg, 0) if rank == 0 else None
+    if distributed:
+        sd = parallel.broadcast_state_dict(sd, cfg, src=0, device=dev)
+    eng = Engine(cfg)
+    eng.load_state_dict(sd)
+    bufs, sp = schedule_buffers(FASTDIFFSR_SCHEDULE_VAL)
+    eng.set_schedule(sampling_scalars(bufs, sp))
+
+    B, S = args.batch, args.size
+    # independent per-GPU batch (weak scaling): rank r samples its own B images
+    cond, noise = synth_inputs(B, S, S, 20, cond_seed=1234 + rank, noise_seed=4321 + rank)
+    cond, noise = cond.to(dev), noise.to(dev)
+    out = torch.empty(B, 3, S, S, device=dev)
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        eng.sample(cond, noise, out=out, graph=args.graph)
+    sync()
+    profile = (not args.no_profile) and not args.graph
+    if profile:
+        eng.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.sample(cond, noise, out=out, graph=args.graph)
+    sync()
+    dt = time.perf_counter() - t0
+    prof = eng.profile_end() if profile else None
+    if distributed:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert torch.isfinite(out).all()
+
+    if rank == 0:
+        ips = world * B * args.steps / dt
+        res = {
+            'metric': '256x256 SR images/sec at T=20', 'value': ips, 'unit': 'images/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'x4 64->256, batch={B}/GPU, T=20, random-init FastDiffSR UNet (inner 64, mults 1-2-4-4), '
+                                   f'{S}x{S}, fp32 (BASELINE configs[1])',
+                       'batch_per_gpu': B, 'global_batch': B * world, 'timesteps': 20, 'hipgraph': bool(args.graph),
+                       'parallelism': f'dp{world} (independent batches, weights broadcast once)'},
+            'whole_path_tflops': ips / world * FLOPS_PER_IMAGE / 1e12,
+        }
+        if prof and prof['conv_ms'] > 0:
+            ach = prof['conv_flops'] / (prof['conv_ms'] * 1e-3) / 1e12
+            res['roofline'] = {'bound': 'mfma', 'kernel': 'conv_mfma_f32_kernel (3x3 implicit-GEMM family)',
+                               'achieved': ach, 'peak': PEAK_F32_MFMA, 'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MFMA,
+                               'traffic': None, 'launches': prof['launches'],
+                               'avg_launch_ms': prof['conv_ms'] / max(prof['launches'], 1),
+                               'algorithmic_gbytes_per_s': prof['conv_bytes'] / (prof['conv_ms'] * 1e-3) / 1e9,
+                               'conv_time_share': prof['conv_ms'] * 1e-3 / dt}
+        if world == 1 and not args.no_cpu_baseline:
+            res['cpu_baseline'] = cpu_baseline(cfg, sd)
+        print(json.dumps(res), flush=True)
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

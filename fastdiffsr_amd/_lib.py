@@ -1,0 +1,78 @@
+"""ctypes binding of include/fdsr.h.  Fails loudly when libfdsr_hip.so is missing:
+there is no CPU or PyTorch fallback behind this package."""
+import ctypes as C
+import os
+
+from .build import LIB
+
+FDSR_MAX_MULTS = 8
+FDSR_SAMPLE_GRAPH = 1
+
+
+class FdsrConfig(C.Structure):
+    _fields_ = [('in_channel', C.c_int32), ('out_channel', C.c_int32), ('inner_channel', C.c_int32),
+                ('norm_groups', C.c_int32), ('n_mults', C.c_int32), ('channel_mults', C.c_int32 * FDSR_MAX_MULTS),
+                ('res_blocks', C.c_int32), ('dropout', C.c_float), ('image_size', C.c_int32)]
+
+
+class FdsrSchedule(C.Structure):
+    _fields_ = [('n_timestep', C.c_int32), ('noise_level', C.POINTER(C.c_float)), ('sqrt_recip', C.POINTER(C.c_float)),
+                ('sqrt_recipm1', C.POINTER(C.c_float)), ('coef1', C.POINTER(C.c_float)), ('coef2', C.POINTER(C.c_float)),
+                ('sigma', C.POINTER(C.c_float))]
+
+
+class FdsrError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f'libfdsr_hip error {code}: {msg}')
+        self.code = code
+
+
+_lib = None
+
+# name -> (restype, argtypes); every symbol include/fdsr.h declares
+SYMBOLS = {
+    'fdsr_create': (C.c_int, [C.POINTER(FdsrConfig), C.POINTER(C.c_void_p)]),
+    'fdsr_destroy': (None, [C.c_void_p]),
+    'fdsr_last_error': (C.c_char_p, [C.c_void_p]),
+    'fdsr_version': (C.c_char_p, []),
+    'fdsr_num_weights': (C.c_int, [C.c_void_p]),
+    'fdsr_weight_info': (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int),
+                                   C.POINTER(C.c_int)]),
+    'fdsr_load_weight': (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int]),
+    'fdsr_weights_complete': (C.c_int, [C.c_void_p]),
+    'fdsr_set_schedule': (C.c_int, [C.c_void_p, C.POINTER(FdsrSchedule)]),
+    'fdsr_workspace_bytes': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
+    'fdsr_unet_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                    C.c_size_t, C.c_void_p]),
+    'fdsr_sample': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                              C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]),
+    'fdsr_set_debug': (C.c_int, [C.c_void_p, C.c_int]),
+    'fdsr_debug_tensor': (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                    C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    'fdsr_profile_begin': (C.c_int, [C.c_void_p]),
+    'fdsr_profile_end': (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                   C.POINTER(C.c_double)]),
+}
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB):
+        raise ImportError(
+            f'{LIB} is missing: build it with `python -m fastdiffsr_amd.build` (or __graft_entry__.build()). '
+            'fastdiffsr_amd has no CPU/PyTorch fallback for the sampling path.')
+    lib = C.CDLL(LIB)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)      # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(handle, rc):
+    if rc != 0:
+        msg = load().fdsr_last_error(handle)
+        raise FdsrError(rc, msg.decode() if msg else '?')

@@ -1,0 +1,835 @@
+// Host side of libfdsr_hip.so: execution plan of the FastDiffSR UNet, checkpoint
+// repacking, workspace planning, the 20-step sampling loop and the C ABI
+// (include/fdsr.h).  The plan is derived from the same hyper-parameters the
+// reference's factory passes to unet.UNet (model/networks.py:94-104) and follows
+// UNet.__init__/forward (model/fastdiffsr_modules/unet.py:224-323).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/fdsr.h"
+#include "fdsr_kernels.h"
+
+using namespace fdsr;
+
+namespace {
+
+thread_local std::string g_global_error;
+
+struct WeightEntry {
+  std::string key;
+  std::vector<int64_t> shape;
+  bool live = true;
+  bool loaded = false;
+  // sink: how the tensor is stored on the device
+  enum Sink { RAW, CONV_PACK, NOISE_W, NOISE_B } sink = RAW;
+  size_t dev_off = 0;      // float offset into the parameter arena
+  int ks = 1, cin_pad = 0, cout_pad = 0;   // CONV_PACK
+  int row_off = 0;                          // NOISE_W / NOISE_B: first row inside the concatenated table
+};
+
+struct TensorDesc {
+  int C = 0;
+  int level = 0;        // spatial = (H >> level, W >> level)
+  bool persistent = false;
+  int first_def = -1, last_use = -1;
+  size_t off = 0;       // byte offset inside the workspace (per plan)
+  std::string name;     // reference module whose output this is ("" for temporaries)
+};
+
+struct Op {
+  enum Kind { GN_STATS, CONV, CLAM, SLAM } kind;
+  std::string name;
+  int src0 = -1, src1 = -1, dst = -1, res = -1;
+  ConvKind ck = CONV3_S1;
+  int C0 = 0, C1 = 0, Cout = 0;
+  int lvl_in = 0, lvl_out = 0;
+  int gn_slot = -1;
+  int w = -1, b = -1, gamma = -1, beta = -1;   // weight-entry indices
+  int temb_off = -1;
+  int fc1 = -1, fc2 = -1;
+};
+
+struct ShapePlan {
+  int N = 0, H = 0, W = 0;
+  bool debug = false;
+  size_t bytes = 0;
+  size_t off_stats = 0, off_temb = 0, off_gate = 0;
+  std::vector<size_t> tensor_off;
+};
+
+struct GraphEntry {
+  const void *cond, *noise, *out, *traj, *ws;
+  int N, H, W;
+  hipGraphExec_t exec;
+};
+
+}  // namespace
+
+struct fdsr_engine {
+  fdsr_config cfg{};
+  std::string err;
+  std::vector<WeightEntry> weights;
+  std::map<std::string, int> key2w;
+  std::vector<TensorDesc> tensors;
+  std::vector<Op> ops;
+  int t_in = -1, t_eps = -1, CP = 8;
+  int n_gn_slots = 0, TE = 0, Cmid = 0;
+  int w_freq = -1;   // synthetic entry: positional-encoding frequencies
+  size_t param_floats = 0, noise_w_off = 0, noise_b_off = 0;
+  int w_mlp[4] = {-1, -1, -1, -1};
+  float* d_params = nullptr;
+  bool kernels_ready = false;
+  // schedule
+  int T = 0;
+  std::vector<float> s_nl, s_recip, s_recipm1, s_c1, s_c2, s_sigma;
+  // plan cache
+  ShapePlan plan;
+  bool debug = false;
+  // profiling
+  bool profiling = false;
+  std::vector<hipEvent_t> ev_pool;
+  size_t ev_used = 0;
+  double prof_flops = 0, prof_bytes = 0;
+  std::vector<GraphEntry> graphs;
+};
+
+namespace {
+
+int fail(fdsr_handle h, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (h) h->err = buf; else g_global_error = buf;
+  return code;
+}
+
+#define HIPCHK(h, expr)                                                                     \
+  do {                                                                                      \
+    hipError_t e__ = (expr);                                                                \
+    if (e__ != hipSuccess)                                                                  \
+      return fail(h, FDSR_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+  } while (0)
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+int round_up(int v, int a) { return (v + a - 1) / a * a; }
+
+int add_weight(fdsr_handle h, const std::string& key, std::vector<int64_t> shape, bool live) {
+  WeightEntry w;
+  w.key = key;
+  w.shape = std::move(shape);
+  w.live = live;
+  h->weights.push_back(w);
+  h->key2w[key] = (int)h->weights.size() - 1;
+  return (int)h->weights.size() - 1;
+}
+
+size_t numel(const std::vector<int64_t>& s) {
+  size_t n = 1;
+  for (auto d : s) n *= (size_t)d;
+  return n;
+}
+
+int new_tensor(fdsr_handle h, int C, int level, const std::string& name = "") {
+  TensorDesc t;
+  t.C = C;
+  t.level = level;
+  t.name = name;
+  h->tensors.push_back(t);
+  return (int)h->tensors.size() - 1;
+}
+
+// conv weight entry -> packed [tap][Cout_pad][Cin_pad]
+void mark_conv_pack(fdsr_handle h, int widx, ConvKind ck, int cin_store, int C0, int C1, int cout) {
+  int KC, BN;
+  conv_tile_config(ck, C0, C1, cout, &KC, &BN);
+  WeightEntry& w = h->weights[widx];
+  w.sink = WeightEntry::CONV_PACK;
+  w.ks = ck == CONV1 ? 1 : 3;
+  w.cin_pad = round_up(cin_store, KC);
+  w.cout_pad = round_up(cout, BN);
+}
+
+// Build the static plan (ops, tensors, weight schema).  unet.py:224-323.
+int build_plan(fdsr_handle h) {
+  const fdsr_config& c = h->cfg;
+  const int ic = c.inner_channel, G = c.norm_groups;
+  if (c.n_mults < 1 || c.n_mults > FDSR_MAX_MULTS) return fail(h, FDSR_E_INVALID, "n_mults out of range");
+  if (ic % G != 0 || ic % 16 != 0) return fail(h, FDSR_E_INVALID, "inner_channel must be a multiple of norm_groups and of 16");
+  if (c.in_channel < 1 || c.in_channel > 8) return fail(h, FDSR_E_INVALID, "in_channel must be in [1,8]");
+  if (c.out_channel < 1 || c.out_channel > 32) return fail(h, FDSR_E_INVALID, "out_channel must be in [1,32]");
+  h->CP = 8;
+
+  add_weight(h, "noise_level_mlp.1.weight", {ic * 4, ic}, true);
+  add_weight(h, "noise_level_mlp.1.bias", {ic * 4}, true);
+  add_weight(h, "noise_level_mlp.3.weight", {ic, ic * 4}, true);
+  add_weight(h, "noise_level_mlp.3.bias", {ic}, true);
+
+  h->t_in = new_tensor(h, h->CP, 0, "input");
+  h->tensors[h->t_in].persistent = true;
+
+  struct Feat { int t, C; };
+  std::vector<Feat> feats;
+  int cur = -1, curC = 0, lvl = 0;
+  int te = 0;
+
+  auto conv_plain = [&](const std::string& wkey, const std::string& name, ConvKind ck, int src, int Cin_store, int Cin_real,
+                        int Cout, int lvl_in, int lvl_out) -> int {
+    const int ks = ck == CONV1 ? 1 : 3;
+    int wi = add_weight(h, wkey + ".weight", {Cout, Cin_real, ks, ks}, true);
+    int bi = add_weight(h, wkey + ".bias", {Cout}, true);
+    mark_conv_pack(h, wi, ck, Cin_store, Cin_store, 0, Cout);
+    Op op;
+    op.kind = Op::CONV;
+    op.name = name;
+    op.ck = ck;
+    op.src0 = src;
+    op.C0 = Cin_store;
+    op.Cout = Cout;
+    op.lvl_in = lvl_in;
+    op.lvl_out = lvl_out;
+    op.w = wi;
+    op.b = bi;
+    op.dst = new_tensor(h, Cout, lvl_out, name);
+    h->ops.push_back(op);
+    return op.dst;
+  };
+
+  auto res_block = [&](const std::string& p, int x0, int C0, int x1, int C1, int Cout, bool with_attn) -> int {
+    const int Cin = C0 + C1;
+    if (Cin % G || Cout % G) return fail(h, FDSR_E_INVALID, "%s: channels not divisible by norm_groups", p.c_str());
+    if (Cin % 16 || (C1 && C0 % 16)) return fail(h, FDSR_E_INVALID, "%s: channel counts must be multiples of 16", p.c_str());
+    const std::string r = p + ".res_block";
+    int wn = add_weight(h, r + ".noise_func.noise_func.0.weight", {Cout, ic}, true);
+    int bn = add_weight(h, r + ".noise_func.noise_func.0.bias", {Cout}, true);
+    h->weights[wn].sink = WeightEntry::NOISE_W;
+    h->weights[wn].row_off = te;
+    h->weights[bn].sink = WeightEntry::NOISE_B;
+    h->weights[bn].row_off = te;
+    const int my_te = te;
+    te += Cout;
+    int g1 = add_weight(h, r + ".block1.block.0.weight", {Cin}, true);
+    int b1 = add_weight(h, r + ".block1.block.0.bias", {Cin}, true);
+    int w1 = add_weight(h, r + ".block1.block.3.weight", {Cout, Cin, 3, 3}, true);
+    int c1 = add_weight(h, r + ".block1.block.3.bias", {Cout}, true);
+    int g2 = add_weight(h, r + ".block2.block.0.weight", {Cout}, true);
+    int b2 = add_weight(h, r + ".block2.block.0.bias", {Cout}, true);
+    int w2 = add_weight(h, r + ".block2.block.3.weight", {Cout, Cout, 3, 3}, true);
+    int c2 = add_weight(h, r + ".block2.block.3.bias", {Cout}, true);
+    mark_conv_pack(h, w1, CONV3_S1, Cin, C0, C1, Cout);
+    mark_conv_pack(h, w2, CONV3_S1, Cout, Cout, 0, Cout);
+    int wr = -1, br = -1;
+    if (Cin != Cout) {
+      wr = add_weight(h, r + ".res_conv.weight", {Cout, Cin, 1, 1}, true);
+      br = add_weight(h, r + ".res_conv.bias", {Cout}, true);
+      mark_conv_pack(h, wr, CONV1, Cin, C0, C1, Cout);
+    } else if (C1) {
+      return fail(h, FDSR_E_INVALID, "%s: identity residual over a concatenated input is not supported", p.c_str());
+    }
+    add_weight(h, p + ".conv.weight", {Cout, Cout, 1, 1}, false);   // dead layer, unet.py:212
+    add_weight(h, p + ".conv.bias", {Cout}, false);
+
+    // block1: GN -> Swish -> conv3x3, + noise shift
+    Op s1; s1.kind = Op::GN_STATS; s1.name = r + ".block1.gn"; s1.src0 = x0; s1.src1 = x1; s1.C0 = C0; s1.C1 = C1;
+    s1.lvl_in = lvl; s1.gn_slot = h->n_gn_slots++;
+    h->ops.push_back(s1);
+    Op k1; k1.kind = Op::CONV; k1.name = r + ".block1"; k1.ck = CONV3_S1; k1.src0 = x0; k1.src1 = x1; k1.C0 = C0; k1.C1 = C1;
+    k1.Cout = Cout; k1.lvl_in = k1.lvl_out = lvl; k1.gn_slot = s1.gn_slot; k1.gamma = g1; k1.beta = b1; k1.w = w1; k1.b = c1;
+    k1.temb_off = my_te; k1.dst = new_tensor(h, Cout, lvl, r + ".block1");
+    h->ops.push_back(k1);
+    // GN stats of h1
+    Op s2; s2.kind = Op::GN_STATS; s2.name = r + ".block2.gn"; s2.src0 = k1.dst; s2.C0 = Cout; s2.lvl_in = lvl;
+    s2.gn_slot = h->n_gn_slots++;
+    h->ops.push_back(s2);
+    const int out = new_tensor(h, Cout, lvl, with_attn ? r : p);
+    int res_src = x0;
+    if (wr >= 0) {   // res_conv 1x1 on the raw (concatenated) input, written into `out` first
+      Op kr; kr.kind = Op::CONV; kr.name = r + ".res_conv"; kr.ck = CONV1; kr.src0 = x0; kr.src1 = x1; kr.C0 = C0; kr.C1 = C1;
+      kr.Cout = Cout; kr.lvl_in = kr.lvl_out = lvl; kr.w = wr; kr.b = br; kr.dst = out;
+      h->ops.push_back(kr);
+      res_src = out;
+    }
+    Op k2; k2.kind = Op::CONV; k2.name = r + ".block2"; k2.ck = CONV3_S1; k2.src0 = k1.dst; k2.C0 = Cout; k2.Cout = Cout;
+    k2.lvl_in = k2.lvl_out = lvl; k2.gn_slot = s2.gn_slot; k2.gamma = g2; k2.beta = b2; k2.w = w2; k2.b = c2; k2.res = res_src;
+    k2.dst = out;
+    h->ops.push_back(k2);
+    int result = out;
+    if (with_attn) {
+      if (Cout % 16) return fail(h, FDSR_E_INVALID, "CLAM needs channels divisible by 16");
+      int f1 = add_weight(h, p + ".ca.fc1.weight", {Cout / 16, Cout, 1, 1}, true);
+      int f2 = add_weight(h, p + ".ca.fc2.weight", {Cout, Cout / 16, 1, 1}, true);
+      int s7 = add_weight(h, p + ".sa.conv1.weight", {1, 2, 7, 7}, true);
+      Op ca; ca.kind = Op::CLAM; ca.name = p + ".ca"; ca.src0 = out; ca.C0 = Cout; ca.lvl_in = lvl; ca.fc1 = f1; ca.fc2 = f2;
+      h->ops.push_back(ca);
+      Op sa; sa.kind = Op::SLAM; sa.name = p + ".sa"; sa.src0 = out; sa.C0 = Cout; sa.lvl_in = lvl; sa.w = s7;
+      sa.dst = new_tensor(h, Cout, lvl, p);
+      h->ops.push_back(sa);
+      h->Cmid = std::max(h->Cmid, Cout);
+      result = sa.dst;
+    }
+    return result;
+  };
+
+  // downs
+  int idx = 0;
+  cur = conv_plain("downs.0", "downs.0", CONV3_S1, h->t_in, h->CP, c.in_channel, ic, 0, 0);
+  curC = ic;
+  feats.push_back({cur, curC});
+  idx = 1;
+  for (int ind = 0; ind < c.n_mults; ++ind) {
+    const bool is_last = ind == c.n_mults - 1;
+    const int cm = ic * c.channel_mults[ind];
+    for (int rb = 0; rb < c.res_blocks; ++rb) {
+      int o = res_block("downs." + std::to_string(idx), cur, curC, -1, 0, cm, false);
+      if (o < 0) return o;
+      cur = o; curC = cm; ++idx;
+      feats.push_back({cur, curC});
+    }
+    if (!is_last) {
+      const std::string p = "downs." + std::to_string(idx);
+      cur = conv_plain(p + ".conv", p, CONV3_S2, cur, curC, curC, curC, lvl, lvl + 1);
+      ++lvl; ++idx;
+      feats.push_back({cur, curC});
+    }
+  }
+  // mid
+  {
+    int o = res_block("mid.0", cur, curC, -1, 0, curC, true);
+    if (o < 0) return o;
+    cur = o;
+    o = res_block("mid.1", cur, curC, -1, 0, curC, false);
+    if (o < 0) return o;
+    cur = o;
+  }
+  // ups
+  idx = 0;
+  for (int ind = c.n_mults - 1; ind >= 0; --ind) {
+    const bool is_last = ind < 1;
+    const int cm = ic * c.channel_mults[ind];
+    for (int rb = 0; rb < c.res_blocks + 1; ++rb) {
+      Feat f = feats.back();
+      feats.pop_back();
+      int o = res_block("ups." + std::to_string(idx), cur, curC, f.t, f.C, cm, false);   // cat((x, skip)) unet.py:319
+      if (o < 0) return o;
+      cur = o; curC = cm; ++idx;
+    }
+    if (!is_last) {
+      const std::string p = "ups." + std::to_string(idx);
+      cur = conv_plain(p + ".conv", p, CONV3_UP, cur, curC, curC, curC, lvl, lvl - 1);
+      --lvl; ++idx;
+    }
+  }
+  // final_conv = Block(pre, out_channel)
+  {
+    if (curC % G) return fail(h, FDSR_E_INVALID, "final_conv: channels not divisible by norm_groups");
+    int g = add_weight(h, "final_conv.block.0.weight", {curC}, true);
+    int b = add_weight(h, "final_conv.block.0.bias", {curC}, true);
+    int w = add_weight(h, "final_conv.block.3.weight", {c.out_channel, curC, 3, 3}, true);
+    int cb = add_weight(h, "final_conv.block.3.bias", {c.out_channel}, true);
+    mark_conv_pack(h, w, CONV3_S1, curC, curC, 0, c.out_channel);
+    Op s; s.kind = Op::GN_STATS; s.name = "final_conv.gn"; s.src0 = cur; s.C0 = curC; s.lvl_in = lvl; s.gn_slot = h->n_gn_slots++;
+    h->ops.push_back(s);
+    Op k; k.kind = Op::CONV; k.name = "final_conv"; k.ck = CONV3_S1; k.src0 = cur; k.C0 = curC; k.Cout = c.out_channel;
+    k.lvl_in = k.lvl_out = lvl; k.gn_slot = s.gn_slot; k.gamma = g; k.beta = b; k.w = w; k.b = cb;
+    k.dst = new_tensor(h, c.out_channel, lvl, "final_conv");
+    h->ops.push_back(k);
+    h->t_eps = k.dst;
+    h->tensors[h->t_eps].persistent = true;
+  }
+  if (lvl != 0) return fail(h, FDSR_E_INVALID, "internal: level bookkeeping");
+  h->TE = te;
+
+  // The schema order must follow torch's state_dict(): per module, registration order.
+  // The reference registers res_block (noise_func, block1, block2, res_conv), then conv,
+  // then ca, sa -- add_weight() above was called in that order for every block.
+
+  // parameter arena layout
+  size_t off = 0;
+  auto take = [&](size_t n) { size_t o = off; off += align_up(n, 64); return o; };
+  const size_t noise_w_off = h->noise_w_off = take((size_t)h->TE * ic);
+  const size_t noise_b_off = h->noise_b_off = take((size_t)h->TE);
+  h->w_mlp[0] = h->key2w["noise_level_mlp.1.weight"]; h->w_mlp[1] = h->key2w["noise_level_mlp.1.bias"];
+  h->w_mlp[2] = h->key2w["noise_level_mlp.3.weight"]; h->w_mlp[3] = h->key2w["noise_level_mlp.3.bias"];
+  for (auto& w : h->weights) {
+    if (!w.live) continue;
+    switch (w.sink) {
+      case WeightEntry::RAW: w.dev_off = take(numel(w.shape)); break;
+      case WeightEntry::CONV_PACK: w.dev_off = take((size_t)w.ks * w.ks * w.cout_pad * w.cin_pad); break;
+      case WeightEntry::NOISE_W: w.dev_off = noise_w_off + (size_t)w.row_off * ic; break;
+      case WeightEntry::NOISE_B: w.dev_off = noise_b_off + (size_t)w.row_off; break;
+    }
+  }
+  // positional-encoding frequency table (not a checkpoint tensor): filled at device init
+  {
+    WeightEntry f;
+    f.key = "__posenc_freq";
+    f.shape = {ic / 2};
+    f.live = false;
+    f.loaded = true;
+    f.dev_off = take(ic / 2);
+    h->weights.push_back(f);
+    h->w_freq = (int)h->weights.size() - 1;
+  }
+  h->param_floats = off;
+
+  // liveness
+  for (size_t i = 0; i < h->ops.size(); ++i) {
+    const Op& op = h->ops[i];
+    auto use = [&](int t) { if (t >= 0) h->tensors[t].last_use = (int)i; };
+    use(op.src0); use(op.src1); use(op.res);
+    if (op.dst >= 0) {
+      if (h->tensors[op.dst].first_def < 0) h->tensors[op.dst].first_def = (int)i;
+      h->tensors[op.dst].last_use = std::max(h->tensors[op.dst].last_use, (int)i);
+    }
+  }
+  return FDSR_OK;
+}
+
+int ensure_device(fdsr_handle h) {
+  if (h->d_params) return FDSR_OK;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(h, FDSR_E_HIP, "no HIP device visible: the FastDiffSR engine has no CPU fallback");
+  HIPCHK(h, hipMalloc((void**)&h->d_params, h->param_floats * sizeof(float)));
+  HIPCHK(h, hipMemset(h->d_params, 0, h->param_floats * sizeof(float)));
+  // unet.py:27-31: step = arange(count)/count ; exp(-ln(1e4) * step), in fp32
+  const int half = h->cfg.inner_channel / 2;
+  std::vector<float> fr(half);
+  for (int k = 0; k < half; ++k) {
+    const float step = (float)k / (float)half;
+    fr[k] = expf((float)(-std::log(1e4)) * step);
+  }
+  HIPCHK(h, hipMemcpy(h->d_params + h->weights[h->w_freq].dev_off, fr.data(), half * sizeof(float), hipMemcpyHostToDevice));
+  if (!h->kernels_ready) {
+    HIPCHK(h, kernels_init());
+    h->kernels_ready = true;
+  }
+  return FDSR_OK;
+}
+
+struct Block { size_t off, size; bool free; };
+
+// Workspace plan for (N,H,W): stats | temb | gate | activation arena (liveness-reused).
+int make_shape_plan(fdsr_handle h, int N, int H, int W, ShapePlan* sp) {
+  const int down = 1 << (h->cfg.n_mults - 1);
+  if (N < 1 || H < down || W < down || H % down || W % down)
+    return fail(h, FDSR_E_INVALID, "batch>=1 and H,W multiples of %d required (got %d,%d,%d)", down, N, H, W);
+  sp->N = N; sp->H = H; sp->W = W; sp->debug = h->debug;
+  size_t off = 0;
+  sp->off_stats = off; off += align_up((size_t)h->n_gn_slots * N * h->cfg.norm_groups * 2 * sizeof(double), 256);
+  sp->off_temb = off;  off += align_up((size_t)N * h->TE * sizeof(float), 256);
+  sp->off_gate = off;  off += align_up((size_t)N * std::max(h->Cmid, 1) * sizeof(float), 256);
+  const size_t arena0 = off;
+  sp->tensor_off.assign(h->tensors.size(), 0);
+  auto tbytes = [&](const TensorDesc& t) {
+    return align_up((size_t)N * (H >> t.level) * (W >> t.level) * t.C * sizeof(float), 256);
+  };
+  std::vector<Block> blocks;
+  size_t arena_end = 0;
+  auto alloc = [&](size_t need) -> size_t {
+    for (size_t i = 0; i < blocks.size(); ++i)
+      if (blocks[i].free && blocks[i].size >= need) {
+        if (blocks[i].size > need) {
+          Block rest{blocks[i].off + need, blocks[i].size - need, true};
+          blocks[i].size = need;
+          blocks.insert(blocks.begin() + i + 1, rest);
+        }
+        blocks[i].free = false;
+        return blocks[i].off;
+      }
+    if (!blocks.empty() && blocks.back().free) {   // grow the trailing free block
+      blocks.back().size = need;
+      blocks.back().free = false;
+      arena_end = blocks.back().off + need;
+      return blocks.back().off;
+    }
+    blocks.push_back(Block{arena_end, need, false});
+    arena_end += need;
+    return blocks.back().off;
+  };
+  auto release = [&](size_t o) {
+    for (size_t i = 0; i < blocks.size(); ++i)
+      if (blocks[i].off == o && !blocks[i].free) {
+        blocks[i].free = true;
+        if (i + 1 < blocks.size() && blocks[i + 1].free) { blocks[i].size += blocks[i + 1].size; blocks.erase(blocks.begin() + i + 1); }
+        if (i > 0 && blocks[i - 1].free) { blocks[i - 1].size += blocks[i].size; blocks.erase(blocks.begin() + i); }
+        return;
+      }
+  };
+  // persistent tensors first
+  for (size_t t = 0; t < h->tensors.size(); ++t)
+    if (h->tensors[t].persistent) sp->tensor_off[t] = alloc(tbytes(h->tensors[t]));
+  for (size_t i = 0; i < h->ops.size(); ++i) {
+    const Op& op = h->ops[i];
+    if (op.dst >= 0 && !h->tensors[op.dst].persistent && h->tensors[op.dst].first_def == (int)i)
+      sp->tensor_off[op.dst] = alloc(tbytes(h->tensors[op.dst]));
+    if (!h->debug)
+      for (size_t t = 0; t < h->tensors.size(); ++t)
+        if (!h->tensors[t].persistent && h->tensors[t].last_use == (int)i && h->tensors[t].first_def >= 0)
+          release(sp->tensor_off[t]);
+  }
+  for (auto& o : sp->tensor_off) o += arena0;
+  sp->bytes = arena0 + arena_end;
+  return FDSR_OK;
+}
+
+int get_plan(fdsr_handle h, int N, int H, int W) {
+  if (h->plan.N == N && h->plan.H == H && h->plan.W == W && h->plan.debug == h->debug && h->plan.bytes) return FDSR_OK;
+  ShapePlan sp;
+  int rc = make_shape_plan(h, N, H, W, &sp);
+  if (rc) return rc;
+  h->plan = sp;
+  return FDSR_OK;
+}
+
+double conv_flops(const Op& op, int N, int H, int W) {
+  const int ks = op.ck == CONV1 ? 1 : 3;
+  const double px = (double)N * (H >> op.lvl_out) * (W >> op.lvl_out);
+  // algorithmic: real input channels (the packed input counts its 6 real channels)
+  return 2.0 * px * op.Cout * (double)(op.C0 + op.C1) * ks * ks;
+}
+
+// One UNet forward over the plan; input already packed in tensor t_in.
+int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, float nl_scalar, hipStream_t st) {
+  const ShapePlan& sp = h->plan;
+  const int G = h->cfg.norm_groups;
+  double* stats = reinterpret_cast<double*>(ws + sp.off_stats);
+  float* temb = reinterpret_cast<float*>(ws + sp.off_temb);
+  float* gate = reinterpret_cast<float*>(ws + sp.off_gate);
+  auto P = [&](int widx) -> const float* { return widx >= 0 ? h->d_params + h->weights[widx].dev_off : nullptr; };
+  auto TP = [&](int t) -> float* { return t >= 0 ? reinterpret_cast<float*>(ws + sp.tensor_off[t]) : nullptr; };
+
+  HIPCHK(h, hipMemsetAsync(stats, 0, (size_t)h->n_gn_slots * N * G * 2 * sizeof(double), st));
+  {
+    TembParams tp;
+    tp.freq = P(h->w_freq);
+    tp.w1 = P(h->w_mlp[0]);
+    tp.b1 = P(h->w_mlp[1]);
+    tp.w2 = P(h->w_mlp[2]);
+    tp.b2 = P(h->w_mlp[3]);
+    tp.wn = h->d_params + h->noise_w_off;   // all 22 noise_func Linear layers, concatenated by rows
+    tp.bn = h->d_params + h->noise_b_off;
+    tp.nl_dev = nl_dev;
+    tp.nl_scalar = nl_scalar;
+    tp.temb = temb;
+    tp.inner = h->cfg.inner_channel;
+    tp.TE = h->TE;
+    tp.N = N;
+    HIPCHK(h, launch_temb(tp, st));
+  }
+  for (const Op& op : h->ops) {
+    const int Hi = H >> op.lvl_in, Wi = W >> op.lvl_in;
+    switch (op.kind) {
+      case Op::GN_STATS:
+        HIPCHK(h, launch_gn_stats(TP(op.src0), TP(op.src1), op.C0, op.C1, N, Hi * Wi, G,
+                                  stats + (size_t)op.gn_slot * N * G * 2, st));
+        break;
+      case Op::CONV: {
+        ConvParams p{};
+        const WeightEntry& w = h->weights[op.w];
+        p.x0 = TP(op.src0);
+        p.x1 = TP(op.src1);
+        p.w = P(op.w);
+        p.bias = P(op.b);
+        p.temb = op.temb_off >= 0 ? temb : nullptr;
+        p.temb_stride = h->TE;
+        p.temb_off = op.temb_off >= 0 ? op.temb_off : 0;
+        p.res = TP(op.res);
+        p.out = TP(op.dst);
+        if (op.gn_slot >= 0) {
+          p.gn_stats = stats + (size_t)op.gn_slot * N * G * 2;
+          p.gn_gamma = P(op.gamma);
+          p.gn_beta = P(op.beta);
+        }
+        p.N = N; p.Hin = Hi; p.Win = Wi;
+        p.Hout = H >> op.lvl_out; p.Wout = W >> op.lvl_out;
+        p.C0 = op.C0; p.C1 = op.C1; p.Cout = op.Cout;
+        p.Cin_pad = w.cin_pad; p.Cout_pad = w.cout_pad;
+        p.G = G; p.cpg = (op.C0 + op.C1) / G; p.gn_eps = 1e-5f;
+        const bool timed = h->profiling && op.ck != CONV1;
+        if (timed) {
+          if (h->ev_used + 2 > h->ev_pool.size()) {
+            for (int k = 0; k < 256; ++k) { hipEvent_t e; HIPCHK(h, hipEventCreate(&e)); h->ev_pool.push_back(e); }
+          }
+          HIPCHK(h, hipEventRecord(h->ev_pool[h->ev_used++], st));
+        }
+        HIPCHK(h, launch_conv(op.ck, p, st));
+        if (timed) {
+          HIPCHK(h, hipEventRecord(h->ev_pool[h->ev_used++], st));
+          double f = conv_flops(op, N, H, W);
+          if (op.src0 == h->t_in) f *= (double)h->cfg.in_channel / h->CP;
+          h->prof_flops += f;
+          // algorithmic bytes: input read once + output written once
+          h->prof_bytes += 4.0 * N * ((double)Hi * Wi * (op.C0 + op.C1) + (double)p.Hout * p.Wout * op.Cout);
+        }
+        break;
+      }
+      case Op::CLAM:
+        HIPCHK(h, launch_clam_gate(TP(op.src0), N, Hi * Wi, op.C0, P(op.fc1), P(op.fc2), op.C0 / 16, gate, st));
+        break;
+      case Op::SLAM:
+        HIPCHK(h, launch_slam(TP(op.src0), gate, P(op.w), N, Hi, Wi, op.C0, TP(op.dst), nullptr, st));
+        break;
+    }
+  }
+  return FDSR_OK;
+}
+
+int check_ready(fdsr_handle h, bool need_schedule) {
+  for (const auto& w : h->weights)
+    if (w.live && !w.loaded) return fail(h, FDSR_E_STATE, "weight '%s' has not been loaded", w.key.c_str());
+  if (need_schedule && h->T <= 0) return fail(h, FDSR_E_STATE, "fdsr_set_schedule has not been called");
+  return FDSR_OK;
+}
+
+int check_ws(fdsr_handle h, void* ws, size_t bytes) {
+  if (!ws || (reinterpret_cast<uintptr_t>(ws) & 255)) return fail(h, FDSR_E_WORKSPACE, "workspace must be a 256-byte aligned device pointer");
+  if (bytes < h->plan.bytes) return fail(h, FDSR_E_WORKSPACE, "workspace too small: %zu < %zu bytes", bytes, h->plan.bytes);
+  return FDSR_OK;
+}
+
+int sample_body(fdsr_handle h, const float* cond, const float* noise, float* out, float* traj, int N, int H, int W,
+                char* ws, hipStream_t st) {
+  float* xin = reinterpret_cast<float*>(ws + h->plan.tensor_off[h->t_in]);
+  float* eps = reinterpret_cast<float*>(ws + h->plan.tensor_off[h->t_eps]);
+  const size_t img = (size_t)N * 3 * H * W;
+  // x_in = cond, img = randn(shape)                                       diffusion.py:204-208
+  HIPCHK(h, launch_nchw_to_nhwc(cond, xin, N, 3, H, W, h->CP, 0, 1, st));
+  HIPCHK(h, launch_nchw_to_nhwc(noise, xin, N, 3, H, W, h->CP, 3, 0, st));
+  for (int k = 0; k < h->T; ++k) {                                        // for i in reversed(range(T))  :209
+    const int t = h->T - 1 - k;
+    int rc = run_unet(h, N, H, W, ws, nullptr, h->s_nl[t], st);
+    if (rc) return rc;
+    PosteriorParams pp{};
+    pp.eps = eps;
+    pp.xin = xin;
+    pp.noise = t > 0 ? noise + (size_t)(k + 1) * img : nullptr;           // zeros at t == 0  :189
+    pp.traj = traj ? traj + (size_t)k * img : nullptr;
+    pp.out = t == 0 ? out : nullptr;
+    pp.N = N; pp.HW = H * W; pp.CP = h->CP;
+    pp.c_recip = h->s_recip[t]; pp.c_recipm1 = h->s_recipm1[t];
+    pp.coef1 = h->s_c1[t]; pp.coef2 = h->s_c2[t]; pp.sigma = h->s_sigma[t];
+    HIPCHK(h, launch_posterior(pp, st));
+  }
+  return FDSR_OK;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+extern "C" {
+
+const char* fdsr_version(void) { return "fdsr-hip 0.1 (gfx950, f32 MFMA 32x32x2 implicit-GEMM conv, NHWC)"; }
+
+const char* fdsr_last_error(fdsr_handle h) { return h ? h->err.c_str() : g_global_error.c_str(); }
+
+int fdsr_create(const fdsr_config* cfg, fdsr_handle* out) {
+  if (!cfg || !out) return fail(nullptr, FDSR_E_INVALID, "null argument");
+  fdsr_engine* h = new fdsr_engine();
+  h->cfg = *cfg;
+  int rc = build_plan(h);
+  if (rc) {
+    g_global_error = h->err;
+    delete h;
+    return rc;
+  }
+  *out = h;
+  return FDSR_OK;
+}
+
+void fdsr_destroy(fdsr_handle h) {
+  if (!h) return;
+  for (auto& g : h->graphs) (void)hipGraphExecDestroy(g.exec);
+  for (auto e : h->ev_pool) (void)hipEventDestroy(e);
+  if (h->d_params) (void)hipFree(h->d_params);
+  delete h;
+}
+
+int fdsr_num_weights(fdsr_handle h) {
+  if (!h) return FDSR_E_INVALID;
+  return (int)h->weights.size() - 1;   // without the synthetic frequency table
+}
+
+int fdsr_weight_info(fdsr_handle h, int idx, char* key, int key_cap, int64_t shape[4], int* ndim, int* live) {
+  if (!h || idx < 0 || idx >= fdsr_num_weights(h)) return fail(h, FDSR_E_INVALID, "weight index out of range");
+  const WeightEntry& w = h->weights[idx];
+  if (key && key_cap > 0) {
+    strncpy(key, w.key.c_str(), key_cap - 1);
+    key[key_cap - 1] = 0;
+  }
+  if (shape) for (int i = 0; i < 4; ++i) shape[i] = i < (int)w.shape.size() ? w.shape[i] : 1;
+  if (ndim) *ndim = (int)w.shape.size();
+  if (live) *live = w.live ? 1 : 0;
+  return FDSR_OK;
+}
+
+int fdsr_load_weight(fdsr_handle h, const char* key, const float* host, const int64_t* shape, int ndim) {
+  if (!h || !key || !host || !shape) return fail(h, FDSR_E_INVALID, "null argument");
+  auto it = h->key2w.find(key);
+  if (it == h->key2w.end()) return fail(h, FDSR_E_KEY, "unexpected key '%s'", key);
+  WeightEntry& w = h->weights[it->second];
+  if (ndim != (int)w.shape.size()) return fail(h, FDSR_E_KEY, "'%s': rank %d, expected %zu", key, ndim, w.shape.size());
+  for (int i = 0; i < ndim; ++i)
+    if (shape[i] != w.shape[i]) return fail(h, FDSR_E_KEY, "'%s': dim %d is %lld, expected %lld", key, i, (long long)shape[i], (long long)w.shape[i]);
+  if (!w.live) { w.loaded = true; return FDSR_OK; }   // never executed (unet.py:212): schema only
+  int rc = ensure_device(h);
+  if (rc) return rc;
+  float* dst = h->d_params + w.dev_off;
+  if (w.sink == WeightEntry::CONV_PACK) {
+    const int Cout = (int)w.shape[0], Cin = (int)w.shape[1], ks = w.ks;
+    std::vector<float> pk((size_t)ks * ks * w.cout_pad * w.cin_pad, 0.f);
+    for (int co = 0; co < Cout; ++co)
+      for (int ci = 0; ci < Cin; ++ci)
+        for (int t = 0; t < ks * ks; ++t)
+          pk[((size_t)t * w.cout_pad + co) * w.cin_pad + ci] = host[((size_t)co * Cin + ci) * ks * ks + t];
+    HIPCHK(h, hipMemcpy(dst, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
+  } else {
+    HIPCHK(h, hipMemcpy(dst, host, numel(w.shape) * sizeof(float), hipMemcpyHostToDevice));
+  }
+  w.loaded = true;
+  for (auto& g : h->graphs) (void)hipGraphExecDestroy(g.exec);   // weights are baked by address only, but be safe
+  h->graphs.clear();
+  return FDSR_OK;
+}
+
+int fdsr_weights_complete(fdsr_handle h) {
+  if (!h) return 0;
+  for (const auto& w : h->weights)
+    if (w.live && !w.loaded) return 0;
+  return 1;
+}
+
+int fdsr_set_schedule(fdsr_handle h, const fdsr_schedule* s) {
+  if (!h || !s || s->n_timestep < 1 || !s->noise_level || !s->sqrt_recip || !s->sqrt_recipm1 || !s->coef1 || !s->coef2 || !s->sigma)
+    return fail(h, FDSR_E_INVALID, "bad schedule");
+  h->T = s->n_timestep;
+  auto cp = [&](std::vector<float>& v, const float* p) { v.assign(p, p + s->n_timestep); };
+  cp(h->s_nl, s->noise_level); cp(h->s_recip, s->sqrt_recip); cp(h->s_recipm1, s->sqrt_recipm1);
+  cp(h->s_c1, s->coef1); cp(h->s_c2, s->coef2); cp(h->s_sigma, s->sigma);
+  for (auto& g : h->graphs) (void)hipGraphExecDestroy(g.exec);
+  h->graphs.clear();
+  return FDSR_OK;
+}
+
+int fdsr_workspace_bytes(fdsr_handle h, int batch, int height, int width, size_t* bytes) {
+  if (!h || !bytes) return fail(h, FDSR_E_INVALID, "null argument");
+  ShapePlan sp;
+  int rc = make_shape_plan(h, batch, height, width, &sp);
+  if (rc) return rc;
+  *bytes = sp.bytes;
+  return FDSR_OK;
+}
+
+int fdsr_unet_forward(fdsr_handle h, const float* x_nchw, const float* noise_level, float* eps_nchw, int batch, int height,
+                      int width, void* workspace, size_t workspace_bytes, void* hip_stream) {
+  if (!h || !x_nchw || !noise_level || !eps_nchw) return fail(h, FDSR_E_INVALID, "null argument");
+  int rc = check_ready(h, false);
+  if (rc) return rc;
+  if ((rc = get_plan(h, batch, height, width))) return rc;
+  if ((rc = check_ws(h, workspace, workspace_bytes))) return rc;
+  hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+  char* ws = reinterpret_cast<char*>(workspace);
+  float* xin = reinterpret_cast<float*>(ws + h->plan.tensor_off[h->t_in]);
+  HIPCHK(h, launch_nchw_to_nhwc(x_nchw, xin, batch, h->cfg.in_channel, height, width, h->CP, 0, 1, st));
+  if ((rc = run_unet(h, batch, height, width, ws, noise_level, 0.f, st))) return rc;
+  const float* eps = reinterpret_cast<const float*>(ws + h->plan.tensor_off[h->t_eps]);
+  HIPCHK(h, launch_nhwc_to_nchw(eps, eps_nchw, batch, h->cfg.out_channel, height, width, h->cfg.out_channel, st));
+  return FDSR_OK;
+}
+
+int fdsr_sample(fdsr_handle h, const float* cond_nchw, const float* noise, float* out_nchw, float* traj_nchw, int batch,
+                int height, int width, void* workspace, size_t workspace_bytes, void* hip_stream, int flags) {
+  if (!h || !cond_nchw || !noise || !out_nchw) return fail(h, FDSR_E_INVALID, "null argument");
+  if (h->cfg.in_channel != 6 || h->cfg.out_channel != 3)
+    return fail(h, FDSR_E_INVALID, "conditional sampling needs in_channel=6, out_channel=3");
+  int rc = check_ready(h, true);
+  if (rc) return rc;
+  if ((rc = get_plan(h, batch, height, width))) return rc;
+  if ((rc = check_ws(h, workspace, workspace_bytes))) return rc;
+  hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+  char* ws = reinterpret_cast<char*>(workspace);
+  const bool use_graph = (flags & FDSR_SAMPLE_GRAPH) && !h->profiling && st != nullptr;
+  if (!use_graph) return sample_body(h, cond_nchw, noise, out_nchw, traj_nchw, batch, height, width, ws, st);
+
+  for (auto& g : h->graphs)
+    if (g.cond == cond_nchw && g.noise == noise && g.out == out_nchw && g.traj == traj_nchw && g.ws == workspace &&
+        g.N == batch && g.H == height && g.W == width) {
+      HIPCHK(h, hipGraphLaunch(g.exec, st));
+      return FDSR_OK;
+    }
+  // capture the whole T-step loop once (all per-step scalars are kernel arguments)
+  hipGraph_t graph = nullptr;
+  HIPCHK(h, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+  rc = sample_body(h, cond_nchw, noise, out_nchw, traj_nchw, batch, height, width, ws, st);
+  hipError_t e = hipStreamEndCapture(st, &graph);
+  if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+  if (e != hipSuccess) return fail(h, FDSR_E_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+  GraphEntry ge{cond_nchw, noise, out_nchw, traj_nchw, workspace, batch, height, width, nullptr};
+  e = hipGraphInstantiate(&ge.exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (e != hipSuccess) return fail(h, FDSR_E_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+  if (h->graphs.size() >= 8) { (void)hipGraphExecDestroy(h->graphs.front().exec); h->graphs.erase(h->graphs.begin()); }
+  h->graphs.push_back(ge);
+  HIPCHK(h, hipGraphLaunch(ge.exec, st));
+  return FDSR_OK;
+}
+
+int fdsr_set_debug(fdsr_handle h, int on) {
+  if (!h) return FDSR_E_INVALID;
+  h->debug = on != 0;
+  return FDSR_OK;
+}
+
+int fdsr_debug_tensor(fdsr_handle h, const char* name, const float** dev_ptr, int* n, int* hgt, int* wid, int* ch) {
+  if (!h || !name) return fail(h, FDSR_E_INVALID, "null argument");
+  if (!h->plan.bytes) return fail(h, FDSR_E_STATE, "no forward has run yet");
+  for (size_t t = 0; t < h->tensors.size(); ++t)
+    if (h->tensors[t].name == name) {
+      if (dev_ptr) *dev_ptr = reinterpret_cast<const float*>(h->plan.tensor_off[t]);   // offset; caller adds the workspace base
+      if (n) *n = h->plan.N;
+      if (hgt) *hgt = h->plan.H >> h->tensors[t].level;
+      if (wid) *wid = h->plan.W >> h->tensors[t].level;
+      if (ch) *ch = h->tensors[t].C;
+      return FDSR_OK;
+    }
+  return fail(h, FDSR_E_KEY, "no tensor named '%s'", name);
+}
+
+int fdsr_profile_begin(fdsr_handle h) {
+  if (!h) return FDSR_E_INVALID;
+  h->profiling = true;
+  h->ev_used = 0;
+  h->prof_flops = h->prof_bytes = 0;
+  return FDSR_OK;
+}
+
+int fdsr_profile_end(fdsr_handle h, int* launches, double* conv_ms, double* conv_flops_out, double* conv_bytes) {
+  if (!h) return FDSR_E_INVALID;
+  h->profiling = false;
+  double ms = 0;
+  if (h->ev_used) HIPCHK(h, hipEventSynchronize(h->ev_pool[h->ev_used - 1]));
+  for (size_t i = 0; i + 1 < h->ev_used; i += 2) {
+    float m = 0;
+    HIPCHK(h, hipEventElapsedTime(&m, h->ev_pool[i], h->ev_pool[i + 1]));
+    ms += m;
+  }
+  if (launches) *launches = (int)(h->ev_used / 2);
+  if (conv_ms) *conv_ms = ms;
+  if (conv_flops_out) *conv_flops_out = h->prof_flops;
+  if (conv_bytes) *conv_bytes = h->prof_bytes;
+  h->ev_used = 0;
+  return FDSR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,97 @@
+// Launch interfaces of the gfx950 kernels (fdsr_kernels.hip) used by the engine.
+// Internal header: not part of the C ABI (include/fdsr.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fdsr {
+
+// One convolution launch.  Activations are NHWC fp32.  The input is the virtual
+// concat of (x0: C0 channels, x1: C1 channels) -- reference unet.py:319
+// torch.cat((x, feats.pop()), dim=1) -- optionally nearest-upsampled x2
+// (unet.py:66-74) and optionally passed through GroupNorm+Swish (unet.py:89-101)
+// while it is staged into LDS.
+struct ConvParams {
+  const float* x0;
+  const float* x1;       // may be null (C1 == 0)
+  const float* w;        // packed [tap][Cout_pad][Cin_pad]
+  const float* bias;     // [Cout]
+  const float* temb;     // [N][temb_stride] + temb_off, or null (FeatureWiseAffine shift, unet.py:38-54)
+  const float* res;      // residual [N,Hout,Wout,Cout] or null (may alias out)
+  float* out;            // [N,Hout,Wout,Cout]
+  const double* gn_stats;  // [N][G][2] (sum, sumsq) of the GN input, or null
+  const float* gn_gamma;   // [C0+C1]
+  const float* gn_beta;
+  double* out_stats;       // optional: accumulate (sum,sumsq) of OUT per (n, group) for the next GN
+  int out_cpg;             // channels per group of out (Cout / G)
+  int N, Hin, Win;       // source tensor dims (before upsample)
+  int Hout, Wout;
+  int C0, C1, Cout;
+  int Cin_pad, Cout_pad;
+  int G, cpg;            // groups, channels per group of the GN input
+  float gn_eps;
+  int temb_stride, temb_off;
+};
+
+enum ConvKind { CONV3_S1 = 0, CONV3_S2 = 1, CONV3_UP = 2, CONV1 = 3 };
+
+// KC (K-chunk) / BN (Cout tile) the launcher will use for this shape; the packer
+// pads weights accordingly.
+void conv_tile_config(ConvKind kind, int C0, int C1, int Cout, int* KC, int* BN);
+hipError_t launch_conv(ConvKind kind, const ConvParams& p, hipStream_t s);
+// Raise the dynamic-LDS limit of every kernel that needs more than 64 KB.  Must run
+// once per process before any launch (and outside stream capture).
+hipError_t kernels_init();
+
+// (sum, sumsq) per (n, group) of the virtual concat (x0,x1), accumulated in fp64
+// atomics into stats[N][G][2] (must be zeroed beforehand).
+hipError_t launch_gn_stats(const float* x0, const float* x1, int C0, int C1, int N, int HW,
+                           int G, double* stats, hipStream_t s);
+
+// noise-level embedding: PositionalEncoding -> Linear -> Swish -> Linear
+// (unet.py:22-35, :242-248) and the per-ResnetBlock shift Linear(inner -> Cout)
+// (unet.py:38-54) for all blocks at once.  nl_dev: [N] per-sample levels or null
+// (then nl_scalar is used for every sample).  out temb[N][TE].
+struct TembParams {
+  const float* freq;  // [inner/2]   exp(-ln(1e4) * k/(inner/2))
+  const float* w1;    // [4*inner][inner]
+  const float* b1;
+  const float* w2;    // [inner][4*inner]
+  const float* b2;
+  const float* wn;    // [TE][inner]   all noise_func weights concatenated
+  const float* bn;    // [TE]
+  const float* nl_dev;
+  float nl_scalar;
+  float* temb;        // [N][TE]
+  int inner, TE, N;
+};
+hipError_t launch_temb(const TembParams& p, hipStream_t s);
+
+// CLAM (unet.py:123-149): gate[N][C] = sigmoid(fc2(relu(fc1(avg))) + fc2(relu(fc1(max))))
+hipError_t launch_clam_gate(const float* x, int N, int HW, int C, const float* fc1 /*[C/16][C]*/,
+                            const float* fc2 /*[C][C/16]*/, int Cr, float* gate, hipStream_t s);
+// SLAM applied to (x * gate) (unet.py:151-173): out = y * sigmoid(conv7x7([mean_c y, max_c y]))
+hipError_t launch_slam(const float* x, const float* gate, const float* w7 /*[2][7][7]*/,
+                       int N, int H, int W, int C, float* out, float* map_scratch /*[N][2][H][W]*/,
+                       hipStream_t s);
+
+// layout changes at the boundary
+hipError_t launch_nchw_to_nhwc(const float* src, float* dst, int N, int Csrc, int H, int W,
+                               int Cdst, int c_off, int zero_rest, hipStream_t s);
+hipError_t launch_nhwc_to_nchw(const float* src, float* dst, int N, int C, int H, int W,
+                               int Csrc_stride, hipStream_t s);
+
+// one reverse-diffusion update (diffusion.py:157-190) on the packed state tensor
+// xin [N,H,W,CP]: channels [0,3) = cond, [3,6) = x_t.
+struct PosteriorParams {
+  const float* eps;    // [N,H,W,3]
+  float* xin;          // [N,H,W,CP]
+  const float* noise;  // [N,3,H,W] NCHW or null (t == 0)
+  float* traj;         // [N,3,H,W] NCHW or null: x_{t-1}
+  float* out;          // [N,3,H,W] NCHW or null: res2img(x_0, cond) at the last step
+  int N, HW, CP;
+  float c_recip, c_recipm1, coef1, coef2, sigma;
+};
+hipError_t launch_posterior(const PosteriorParams& p, hipStream_t s);
+
+}  // namespace fdsr

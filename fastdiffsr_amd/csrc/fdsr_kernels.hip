@@ -1,0 +1,627 @@
+// gfx950 (MI355X / CDNA4) kernels of the FastDiffSR sampling path.
+//
+// Layout: every activation is NHWC fp32 in HBM.  The convolutions are implicit
+// GEMMs on the exact-fp32 matrix instruction v_mfma_f32_32x32x2_f32
+// (M = 32 output pixels, N = 32 output channels, K = 2 input channels per issue):
+//   * one 256-thread workgroup = 4 wave64 = an 8x16 output-pixel tile x BN channels
+//   * per K-chunk (KC input channels) the input halo tile is staged ONCE into LDS
+//     -- GroupNorm-apply + Swish fused into that staging (unet.py:89-101) -- and
+//     reused by all 9 taps; the weight slab [tap][BN][KC] is staged next to it
+//   * LDS rows are KC+4 floats: 16-byte aligned for ds_write_b128 / ds_read_b128
+//     and (KC+4)/4 odd, so the 16 lanes of a ds_read_b128 group hit 16 distinct
+//     16-byte slots (conflict-free); each lane reads 4 consecutive k of its
+//     pixel row at once and feeds 4 MFMAs from it
+//   * global loads of chunk k+1 are issued before the MFMAs of chunk k (register
+//     prefetch), 2 workgroups per CU cover each other's staging phases
+//   * epilogue: + bias + per-sample noise-embedding shift (unet.py:38-54) +
+//     residual, stored NHWC (each lane owns one output channel: 128-B segments)
+// Everything else on the path (GroupNorm statistics, CLAM/SLAM, the posterior
+// update, layout changes at the boundary) is HBM-bound streaming code.
+#include "fdsr_kernels.h"
+
+namespace fdsr {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float silu_f(float v) {
+  // x * sigmoid(x) (unet.py:57-59); v_exp_f32 + v_rcp_f32, ~3e-7 relative
+  return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+}
+
+// ---------------------------------------------------------------------------
+// convolution
+// ---------------------------------------------------------------------------
+template <int KS, int STRIDE, bool UP, int KC, int BN, int WM>
+struct ConvCfg {
+  static constexpr int TH = 8, TW = 16;
+  static constexpr int PAD = KS / 2;
+  static constexpr int HH = (TH - 1) * STRIDE + KS;
+  static constexpr int HWD = (TW - 1) * STRIDE + KS;
+  static constexpr int NPIX = HH * HWD;
+  static constexpr int S = KC + 4;
+  static constexpr int Q = KC / 4;
+  static constexpr int RPP = 256 / Q;  // LDS rows covered per pass of the 256 threads
+  static constexpr int NIN = (NPIX + RPP - 1) / RPP;
+  static constexpr int WROWS = KS * KS * BN;
+  static constexpr int NW = (WROWS + RPP - 1) / RPP;
+  static constexpr int WN = 4 / WM;
+  static constexpr int MB = 4 / WM;
+  static constexpr int NB = BN / 32 / WN;
+  static constexpr int LDS_FLOATS = NPIX * S + WROWS * S;
+  static_assert(256 % Q == 0, "Q must divide 256");
+  static_assert(BN % (32 * WN) == 0, "BN/WN must be a multiple of 32");
+  static_assert(KC % 8 == 0, "KC multiple of 8");
+};
+
+template <int KS, int STRIDE, bool UP, int KC, int BN, int WM>
+__global__ void __launch_bounds__(256, 2) conv_mfma_f32_kernel(const ConvParams p) {
+  using Cfg = ConvCfg<KS, STRIDE, UP, KC, BN, WM>;
+  constexpr int TH = Cfg::TH, TW = Cfg::TW, PAD = Cfg::PAD, HWD = Cfg::HWD, NPIX = Cfg::NPIX;
+  constexpr int S = Cfg::S, Q = Cfg::Q, RPP = Cfg::RPP, NIN = Cfg::NIN, WROWS = Cfg::WROWS, NW = Cfg::NW;
+  constexpr int WN = Cfg::WN, MB = Cfg::MB, NB = Cfg::NB;
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sIn = smem;
+  float* sW = smem + NPIX * S;
+  float* sScale = smem + Cfg::LDS_FLOATS;
+  const int Cin = p.C0 + p.C1;
+  float* sShift = sScale + Cin;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+
+  // ---- workgroup -> (image, pixel tile, Cout tile); XCD-aware: the Cout tiles of
+  // one pixel tile and neighbouring pixel tiles are dealt to the same XCD (L2) ----
+  const int nco = p.Cout_pad / BN;
+  const int tilesX = (p.Wout + TW - 1) / TW, tilesY = (p.Hout + TH - 1) / TH;
+  int bid;
+  {
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = b & 7, k = b >> 3;
+    bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
+  }
+  const int cot = bid % nco;
+  int pt = bid / nco;
+  const int tx = pt % tilesX;
+  pt /= tilesX;
+  const int ty = pt % tilesY;
+  const int n = pt / tilesY;
+  const int oy0 = ty * TH, ox0 = tx * TW, co0 = cot * BN;
+
+  const bool gn = p.gn_stats != nullptr;
+  if (gn) {
+    // finalize GroupNorm statistics into per-channel scale/shift:
+    // y = (x-mean)*rstd*gamma+beta = x*scale + shift   (unet.py:93, eps inside sqrt)
+    const double inv_cnt = 1.0 / ((double)p.cpg * (double)p.Hin * (double)p.Win);
+    for (int c = tid; c < Cin; c += 256) {
+      const int g = c / p.cpg;
+      const double sum = p.gn_stats[((size_t)n * p.G + g) * 2 + 0];
+      const double sq = p.gn_stats[((size_t)n * p.G + g) * 2 + 1];
+      const double mean = sum * inv_cnt;
+      double var = sq * inv_cnt - mean * mean;
+      var = var < 0.0 ? 0.0 : var;
+      const float rstd = (float)(1.0 / sqrt(var + (double)p.gn_eps));
+      const float sc = rstd * p.gn_gamma[c];
+      sScale[c] = sc;
+      sShift[c] = p.gn_beta[c] - (float)mean * sc;
+    }
+  }
+
+  // ---- chunk-invariant staging indices ----
+  const int q = tid % Q;      // float4 slot inside the KC chunk
+  const int row0 = tid / Q;   // first LDS row this thread fills
+  int in_pix[NIN];            // source pixel index, -1 = zero padding, -2 = no row
+#pragma unroll
+  for (int i = 0; i < NIN; ++i) {
+    const int pix = row0 + i * RPP;
+    int v = -2;
+    if (pix < NPIX) {
+      const int hy = pix / HWD, hx = pix % HWD;
+      const int iy = oy0 * STRIDE - PAD + hy, ix = ox0 * STRIDE - PAD + hx;
+      if (UP) {
+        const bool ok = iy >= 0 && iy < p.Hout && ix >= 0 && ix < p.Wout;
+        v = ok ? (n * p.Hin + (iy >> 1)) * p.Win + (ix >> 1) : -1;   // nearest x2: src = floor(dst/2)
+      } else {
+        const bool ok = iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
+        v = ok ? (n * p.Hin + iy) * p.Win + ix : -1;
+      }
+    }
+    in_pix[i] = v;
+  }
+
+  f32x4 rin[NIN];
+  f32x4 rw[NW];
+  auto prefetch = [&](int kc) {
+    const int cbase = kc * KC;
+    const float* base;
+    int Cs, cc;
+    if (cbase < p.C0) { base = p.x0; Cs = p.C0; cc = cbase + q * 4; }
+    else { base = p.x1; Cs = p.C1; cc = cbase - p.C0 + q * 4; }
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (in_pix[i] >= 0) v = *reinterpret_cast<const f32x4*>(base + (size_t)in_pix[i] * Cs + cc);
+      rin[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      const int row = row0 + i * RPP;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (row < WROWS) {
+        const int tap = row / BN, co = row % BN;
+        v = *reinterpret_cast<const f32x4*>(p.w + ((size_t)tap * p.Cout_pad + co0 + co) * p.Cin_pad + cbase + q * 4);
+      }
+      rw[i] = v;
+    }
+  };
+  auto stage = [&](int kc) {
+    const int c = kc * KC + q * 4;
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (gn) {
+      sc = *reinterpret_cast<const f32x4*>(sScale + c);
+      sh = *reinterpret_cast<const f32x4*>(sShift + c);
+    }
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) {
+      if (in_pix[i] == -2) continue;
+      f32x4 v = rin[i];
+      if (gn && in_pix[i] >= 0) {   // conv zero-pads the ACTIVATED tensor
+        v = v * sc + sh;
+        v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w);
+      }
+      *reinterpret_cast<f32x4*>(sIn + (row0 + i * RPP) * S + q * 4) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      const int row = row0 + i * RPP;
+      if (row < WROWS) *reinterpret_cast<f32x4*>(sW + row * S + q * 4) = rw[i];
+    }
+  };
+
+  // ---- MFMA operand addresses (floats).  A: lane l -> pixel row l&31, k-quad l>>5 ----
+  const int r31 = lane & 31, h = lane >> 5;
+  int abase[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const int pp = (wm * MB + mb) * 32 + r31;
+    const int pr = pp / TW, pc = pp % TW;
+    abase[mb] = ((pr * STRIDE) * HWD + pc * STRIDE) * S + 4 * h;
+  }
+  int bbase[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) bbase[nb] = ((wn * NB + nb) * 32 + r31) * S + 4 * h;
+
+  f32x16 acc[MB][NB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mb][nb][i] = 0.f;
+
+  const int nk = p.Cin_pad / KC;
+  prefetch(0);
+  for (int kc = 0; kc < nk; ++kc) {
+    __syncthreads();   // previous chunk's LDS reads done (and scale/shift visible)
+    stage(kc);
+    __syncthreads();
+    if (kc + 1 < nk) prefetch(kc + 1);   // in flight under the MFMAs below
+#pragma unroll
+    for (int tap = 0; tap < KS * KS; ++tap) {
+      const int ky = tap / KS, kx = tap % KS;
+      const int aoff = (ky * HWD + kx) * S;
+      const int boff = tap * BN * S;
+#pragma unroll
+      for (int ks = 0; ks < KC / 8; ++ks) {
+        f32x4 a[MB], b[NB];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) a[mb] = *reinterpret_cast<const f32x4*>(sIn + abase[mb] + aoff + ks * 8);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) b[nb] = *reinterpret_cast<const f32x4*>(sW + bbase[nb] + boff + ks * 8);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+              acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb][s], b[nb][s], acc[mb][nb], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue: C/D map col = lane&31 (Cout), row = (i&3) + 8*(i>>2) + 4*(lane>>5) (pixel) ----
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int co = co0 + (wn * NB + nb) * 32 + r31;
+    const bool cok = co < p.Cout;
+    float add = 0.f;
+    if (cok) {
+      add = p.bias[co];
+      if (p.temb) add += p.temb[(size_t)n * p.temb_stride + p.temb_off + co];
+    }
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int pp = (wm * MB + mb) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        const int oy = oy0 + pp / TW, ox = ox0 + pp % TW;
+        if (cok && oy < p.Hout && ox < p.Wout) {
+          const size_t off = ((size_t)(n * p.Hout + oy) * p.Wout + ox) * p.Cout + co;
+          float v = acc[mb][nb][i] + add;
+          if (p.res) v += p.res[off];
+          p.out[off] = v;
+        }
+      }
+    }
+  }
+}
+
+template <int KS, int STRIDE, bool UP, int KC, int BN, int WM>
+static hipError_t launch_conv_t(const ConvParams& p, hipStream_t s) {
+  using Cfg = ConvCfg<KS, STRIDE, UP, KC, BN, WM>;
+  auto kfn = conv_mfma_f32_kernel<KS, STRIDE, UP, KC, BN, WM>;
+  const size_t lds = (size_t)(Cfg::LDS_FLOATS + 2 * (p.C0 + p.C1)) * sizeof(float);
+  const int tilesX = (p.Wout + Cfg::TW - 1) / Cfg::TW, tilesY = (p.Hout + Cfg::TH - 1) / Cfg::TH;
+  const int nwg = p.N * tilesX * tilesY * (p.Cout_pad / BN);
+  hipLaunchKernelGGL(kfn, dim3(nwg), dim3(256), lds, s, p);
+  return hipGetLastError();
+}
+
+template <int KS, int STRIDE, bool UP, int KC, int BN, int WM>
+static hipError_t init_conv_t() {
+  auto kfn = conv_mfma_f32_kernel<KS, STRIDE, UP, KC, BN, WM>;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+// every instantiation the dispatcher below can pick: X(KS, STRIDE, UP, KC, BN, WM)
+#define FDSR_CONV_INSTANCES(X)                                                          \
+  X(3, 1, false, 8, 32, 4) X(3, 1, false, 8, 64, 2) X(3, 1, false, 16, 32, 4) X(3, 1, false, 16, 64, 2) \
+  X(3, 2, false, 16, 32, 4) X(3, 2, false, 16, 64, 2) X(3, 1, true, 16, 32, 4) X(3, 1, true, 16, 64, 2)   \
+  X(1, 1, false, 64, 32, 4) X(1, 1, false, 64, 64, 2) X(1, 1, false, 32, 32, 4) X(1, 1, false, 32, 64, 2) \
+  X(1, 1, false, 16, 32, 4) X(1, 1, false, 16, 64, 2)
+
+void conv_tile_config(ConvKind kind, int C0, int C1, int Cout, int* KC, int* BN) {
+  *BN = Cout <= 32 ? 32 : 64;
+  if (kind == CONV1) {
+    if (C0 % 64 == 0 && C1 % 64 == 0) *KC = 64;
+    else if (C0 % 32 == 0 && C1 % 32 == 0) *KC = 32;
+    else *KC = 16;
+  } else {
+    *KC = (C0 + C1 <= 8) ? 8 : 16;
+  }
+}
+
+hipError_t launch_conv(ConvKind kind, const ConvParams& p, hipStream_t s) {
+  int KC, BN;
+  conv_tile_config(kind, p.C0, p.C1, p.Cout, &KC, &BN);
+  int ks = kind == CONV1 ? 1 : 3, stride = kind == CONV3_S2 ? 2 : 1;
+  bool up = kind == CONV3_UP;
+#define X(KS_, ST_, UP_, KC_, BN_, WM_) \
+  if (ks == KS_ && stride == ST_ && up == UP_ && KC == KC_ && BN == BN_) return launch_conv_t<KS_, ST_, UP_, KC_, BN_, WM_>(p, s);
+  FDSR_CONV_INSTANCES(X)
+#undef X
+  return hipErrorInvalidValue;
+}
+
+// ---------------------------------------------------------------------------
+// GroupNorm statistics: (sum, sumsq) per (n, group) over the virtual concat
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) gn_stats_kernel(const float* __restrict__ x0, const float* __restrict__ x1,
+                                                       int C0, int C1, int HW, int G, int slab, double* stats) {
+  extern __shared__ __attribute__((aligned(16))) float sred[];   // [2][C]
+  const int C = C0 + C1, cols = C >> 2, tid = threadIdx.x;
+  const int n = blockIdx.y;
+  const int p0 = blockIdx.x * slab;
+  const int p1 = min(p0 + slab, HW);
+  for (int i = tid; i < 2 * C; i += 256) sred[i] = 0.f;
+  __syncthreads();
+  const int rows = 256 / cols;   // launcher guarantees cols <= 256
+  const int col = tid % cols, r = tid / cols;
+  if (r < rows) {
+    const int c = col * 4;
+    const float* base;
+    int Cs, cc;
+    if (c < C0) { base = x0; Cs = C0; cc = c; } else { base = x1; Cs = C1; cc = c - C0; }
+    base += (size_t)n * HW * Cs + cc;
+    f32x4 s0 = {0, 0, 0, 0}, q0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0}, q1 = {0, 0, 0, 0};
+    int pix = p0 + r;
+    for (; pix + rows < p1; pix += 2 * rows) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(base + (size_t)pix * Cs);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(base + (size_t)(pix + rows) * Cs);
+      s0 += a; q0 += a * a; s1 += b; q1 += b * b;
+    }
+    if (pix < p1) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(base + (size_t)pix * Cs);
+      s0 += a; q0 += a * a;
+    }
+    s0 += s1; q0 += q1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      atomicAdd(&sred[c + k], s0[k]);
+      atomicAdd(&sred[C + c + k], q0[k]);
+    }
+  }
+  __syncthreads();
+  if (tid < G) {
+    const int cpg = C / G;
+    double a = 0.0, b = 0.0;
+    for (int k = 0; k < cpg; ++k) { a += (double)sred[tid * cpg + k]; b += (double)sred[C + tid * cpg + k]; }
+    atomicAdd(&stats[((size_t)n * G + tid) * 2 + 0], a);
+    atomicAdd(&stats[((size_t)n * G + tid) * 2 + 1], b);
+  }
+}
+
+hipError_t launch_gn_stats(const float* x0, const float* x1, int C0, int C1, int N, int HW, int G,
+                           double* stats, hipStream_t s) {
+  const int C = C0 + C1;
+  if (C % 4 || C0 % 4 || C / 4 > 256 || C % G) return hipErrorInvalidValue;
+  const int slab = HW >= 16384 ? 512 : 128;
+  dim3 grid((HW + slab - 1) / slab, N);
+  hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(256), 2 * C * sizeof(float), s, x0, x1, C0, C1, HW, G, slab, stats);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// noise-level embedding + all per-block shifts
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) temb_kernel(const TembParams p) {
+  extern __shared__ __attribute__((aligned(16))) float st[];   // enc[inner] | hid[4*inner] | t[inner]
+  const int inner = p.inner, hid = 4 * inner, tid = threadIdx.x, n = blockIdx.x;
+  float* enc = st;
+  float* hbuf = st + inner;
+  float* tv = hbuf + hid;
+  const float nl = p.nl_dev ? p.nl_dev[n] : p.nl_scalar;
+  const int half = inner / 2;
+  for (int k = tid; k < half; k += 256) {   // unet.py:27-35: cat([sin, cos], -1)
+    const float e = nl * p.freq[k];
+    enc[k] = sinf(e);
+    enc[half + k] = cosf(e);
+  }
+  __syncthreads();
+  for (int j = tid; j < hid; j += 256) {
+    float a = p.b1[j];
+    const float* w = p.w1 + (size_t)j * inner;
+    for (int k = 0; k < inner; ++k) a = fmaf(w[k], enc[k], a);
+    hbuf[j] = a / (1.0f + expf(-a));
+  }
+  __syncthreads();
+  for (int j = tid; j < inner; j += 256) {
+    float a = p.b2[j];
+    const float* w = p.w2 + (size_t)j * hid;
+    for (int k = 0; k < hid; ++k) a = fmaf(w[k], hbuf[k], a);
+    tv[j] = a;
+  }
+  __syncthreads();
+  for (int o = tid; o < p.TE; o += 256) {
+    float a = p.bn[o];
+    const float* w = p.wn + (size_t)o * inner;
+    for (int k = 0; k < inner; ++k) a = fmaf(w[k], tv[k], a);
+    p.temb[(size_t)n * p.TE + o] = a;
+  }
+}
+
+hipError_t launch_temb(const TembParams& p, hipStream_t s) {
+  hipLaunchKernelGGL(temb_kernel, dim3(p.N), dim3(256), (size_t)6 * p.inner * sizeof(float), s, p);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// CLAM gate: global avg / max pool -> shared MLP -> sigmoid       (unet.py:123-149)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__global__ void __launch_bounds__(1024) clam_gate_kernel(const float* __restrict__ x, int HW, int C, const float* __restrict__ fc1,
+                                                         const float* __restrict__ fc2, int Cr, float* gate) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // psum[rows][C] | pmax[rows][C] | avg[C] | mx[C] | ha[Cr] | hm[Cr]
+  const int tid = threadIdx.x, n = blockIdx.x;
+  const int rows = max(1, 1024 / C);
+  float* psum = sm;
+  float* pmax = psum + rows * C;
+  float* avg = pmax + rows * C;
+  float* mx = avg + C;
+  float* ha = mx + C;
+  float* hm = ha + Cr;
+  const int c = tid % C, r = tid / C;
+  if (r < rows && tid < rows * C) {
+    const float* base = x + (size_t)n * HW * C + c;
+    float s = 0.f, m = -INFINITY;
+    for (int pix = r; pix < HW; pix += rows) {
+      const float v = base[(size_t)pix * C];
+      s += v;
+      m = fmaxf(m, v);
+    }
+    psum[r * C + c] = s;
+    pmax[r * C + c] = m;
+  }
+  __syncthreads();
+  for (int cc = tid; cc < C; cc += 1024) {
+    float s = 0.f, m = -INFINITY;
+    for (int rr = 0; rr < rows; ++rr) { s += psum[rr * C + cc]; m = fmaxf(m, pmax[rr * C + cc]); }
+    avg[cc] = s / (float)HW;
+    mx[cc] = m;
+  }
+  __syncthreads();
+  const int wave = tid >> 6, lane = tid & 63, nwave = 16;
+  for (int j = wave; j < 2 * Cr; j += nwave) {   // fc1 + ReLU on both pooled vectors
+    const int jj = j % Cr;
+    const float* v = j < Cr ? avg : mx;
+    float a = 0.f;
+    for (int k = lane; k < C; k += 64) a = fmaf(fc1[(size_t)jj * C + k], v[k], a);
+    a = wave_sum(a);
+    if (lane == 0) (j < Cr ? ha : hm)[jj] = fmaxf(a, 0.f);
+  }
+  __syncthreads();
+  for (int cc = tid; cc < C; cc += 1024) {
+    float a = 0.f, b = 0.f;
+    for (int j = 0; j < Cr; ++j) { a = fmaf(fc2[(size_t)cc * Cr + j], ha[j], a); b = fmaf(fc2[(size_t)cc * Cr + j], hm[j], b); }
+    const float o = a + b;
+    gate[(size_t)n * C + cc] = 1.0f / (1.0f + expf(-o));
+  }
+}
+
+hipError_t launch_clam_gate(const float* x, int N, int HW, int C, const float* fc1, const float* fc2, int Cr,
+                            float* gate, hipStream_t s) {
+  if (C > 1024) return hipErrorInvalidValue;
+  const int rows = 1024 / C > 0 ? 1024 / C : 1;
+  const size_t lds = (size_t)(2 * rows * C + 2 * C + 2 * Cr) * sizeof(float);
+  hipLaunchKernelGGL(clam_gate_kernel, dim3(N), dim3(1024), lds, s, x, HW, C, fc1, fc2, Cr, gate);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// SLAM on y = x*gate: channel mean/max -> 7x7 conv -> sigmoid -> scale   (unet.py:151-173)
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) slam_kernel(const float* __restrict__ x, const float* __restrict__ gate,
+                                                    const float* __restrict__ w7, int H, int W, int C, float* out) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // map[2][HW] | sig[HW] | w[98]
+  const int HW = H * W, tid = threadIdx.x, n = blockIdx.x;
+  float* mp = sm;
+  float* sig = sm + 2 * HW;
+  float* wk = sig + HW;
+  const int wave = tid >> 6, lane = tid & 63;
+  if (tid < 98) wk[tid] = w7[tid];
+  const float* xb = x + (size_t)n * HW * C;
+  const float* gb = gate + (size_t)n * C;
+  for (int pix = wave; pix < HW; pix += 16) {
+    float s = 0.f, m = -INFINITY;
+    for (int c = lane * 4; c < C; c += 256) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(xb + (size_t)pix * C + c);
+      const f32x4 g = *reinterpret_cast<const f32x4*>(gb + c);
+      const f32x4 y = g * v;
+      s += (y.x + y.y) + (y.z + y.w);
+      m = fmaxf(m, fmaxf(fmaxf(y.x, y.y), fmaxf(y.z, y.w)));
+    }
+    s = wave_sum(s);
+    m = wave_max(m);
+    if (lane == 0) { mp[pix] = s / (float)C; mp[HW + pix] = m; }
+  }
+  __syncthreads();
+  for (int pix = tid; pix < HW; pix += 1024) {
+    const int y = pix / W, xx = pix % W;
+    float a = 0.f;
+    for (int ch = 0; ch < 2; ++ch)
+      for (int ky = 0; ky < 7; ++ky) {
+        const int iy = y + ky - 3;
+        if (iy < 0 || iy >= H) continue;
+        for (int kx = 0; kx < 7; ++kx) {
+          const int ix = xx + kx - 3;
+          if (ix < 0 || ix >= W) continue;
+          a = fmaf(wk[(ch * 7 + ky) * 7 + kx], mp[ch * HW + iy * W + ix], a);
+        }
+      }
+    sig[pix] = 1.0f / (1.0f + expf(-a));
+  }
+  __syncthreads();
+  float* ob = out + (size_t)n * HW * C;
+  for (int pix = wave; pix < HW; pix += 16) {
+    const float sg = sig[pix];
+    for (int c = lane * 4; c < C; c += 256) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(xb + (size_t)pix * C + c);
+      const f32x4 g = *reinterpret_cast<const f32x4*>(gb + c);
+      *reinterpret_cast<f32x4*>(ob + (size_t)pix * C + c) = sg * (g * v);
+    }
+  }
+}
+
+hipError_t launch_slam(const float* x, const float* gate, const float* w7, int N, int H, int W, int C, float* out,
+                       float* /*map_scratch*/, hipStream_t s) {
+  const size_t lds = (size_t)(3 * H * W + 128) * sizeof(float);
+  if (lds > 150 * 1024 || C % 4) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(slam_kernel, dim3(N), dim3(1024), lds, s, x, gate, w7, H, W, C, out);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// boundary layout changes
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int Csrc,
+                                                           int HW, int Cdst, int c_off, int zero_rest, size_t total) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const size_t n = i / HW, pix = i % HW;
+  float* d = dst + i * Cdst;
+  if (zero_rest)
+    for (int c = 0; c < Cdst; ++c)
+      if (c < c_off || c >= c_off + Csrc) d[c] = 0.f;
+  for (int c = 0; c < Csrc; ++c) d[c_off + c] = src[(n * Csrc + c) * HW + pix];
+}
+
+hipError_t launch_nchw_to_nhwc(const float* src, float* dst, int N, int Csrc, int H, int W, int Cdst, int c_off,
+                               int zero_rest, hipStream_t s) {
+  const size_t total = (size_t)N * H * W;
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, dst, Csrc, H * W,
+                     Cdst, c_off, zero_rest, total);
+  return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256) nhwc_to_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int HW,
+                                                           int stride, size_t total) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const size_t n = i / HW, pix = i % HW;
+  for (int c = 0; c < C; ++c) dst[(n * C + c) * HW + pix] = src[i * stride + c];
+}
+
+hipError_t launch_nhwc_to_nchw(const float* src, float* dst, int N, int C, int H, int W, int stride, hipStream_t s) {
+  const size_t total = (size_t)N * H * W;
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, dst, C, H * W, stride,
+                     total);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// reverse-diffusion update                                   (diffusion.py:157-190)
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) posterior_kernel(const PosteriorParams p) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t total = (size_t)p.N * p.HW;
+  if (i >= total) return;
+  const size_t n = i / p.HW, pix = i % p.HW;
+  float* xs = p.xin + i * p.CP;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float x = xs[3 + c];
+    const float e = p.eps[i * 3 + c];
+    // two separately rounded products, then subtract: no fma contraction
+    const float a = __fmul_rn(p.c_recip, x);
+    const float b = __fmul_rn(p.c_recipm1, e);
+    float x0 = __fsub_rn(a, b);
+    x0 = fminf(fmaxf(x0, -1.f), 1.f);                                        // clamp_(-1, 1)  :178-179
+    const float mean = __fadd_rn(__fmul_rn(p.coef1, x0), __fmul_rn(p.coef2, x));   // :161-165
+    float xn = mean;
+    const size_t o = (n * 3 + c) * p.HW + pix;
+    if (p.noise) xn = __fadd_rn(mean, __fmul_rn(p.noise[o], p.sigma));       // :189-190
+    xs[3 + c] = xn;
+    if (p.traj) p.traj[o] = xn;
+    if (p.out) p.out[o] = fminf(fmaxf(xn, -1.f), 1.f) / 2.0f + xs[c];        // res2img :275-281
+  }
+}
+
+hipError_t launch_posterior(const PosteriorParams& p, hipStream_t s) {
+  const size_t total = (size_t)p.N * p.HW;
+  hipLaunchKernelGGL(posterior_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p);
+  return hipGetLastError();
+}
+
+hipError_t kernels_init() {
+  hipError_t e;
+#define X(KS_, ST_, UP_, KC_, BN_, WM_) \
+  if ((e = init_conv_t<KS_, ST_, UP_, KC_, BN_, WM_>()) != hipSuccess) return e;
+  FDSR_CONV_INSTANCES(X)
+#undef X
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(slam_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+}  // namespace fdsr

@@ -1,0 +1,163 @@
+"""Python handle around libfdsr_hip.so (include/fdsr.h).  PyTorch is used only for
+device memory, streams and tensors at the boundary."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .arch import UNetConfig
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class Engine:
+    def __init__(self, cfg: UNetConfig):
+        self.lib = _lib.load()
+        self.cfg = cfg
+        c = _lib.FdsrConfig()
+        c.in_channel, c.out_channel, c.inner_channel = cfg.in_channel, cfg.out_channel, cfg.inner_channel
+        c.norm_groups = cfg.norm_groups
+        c.n_mults = len(cfg.channel_mults)
+        if c.n_mults > _lib.FDSR_MAX_MULTS:
+            raise ValueError('too many channel multipliers')
+        for i, m in enumerate(cfg.channel_mults):
+            c.channel_mults[i] = int(m)
+        c.res_blocks, c.dropout, c.image_size = cfg.res_blocks, float(cfg.dropout), int(cfg.image_size)
+        h = C.c_void_p()
+        rc = self.lib.fdsr_create(C.byref(c), C.byref(h))
+        if rc != 0:
+            raise _lib.FdsrError(rc, self.lib.fdsr_last_error(None).decode())
+        self.h = h
+        self._ws = None
+        self._keep = None
+        self.T = 0
+
+    def __del__(self):
+        try:
+            if getattr(self, 'h', None):
+                self.lib.fdsr_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # -- schema / weights ---------------------------------------------------
+    def schema(self):
+        out = []
+        n = self.lib.fdsr_num_weights(self.h)
+        buf = C.create_string_buffer(256)
+        shape = (C.c_int64 * 4)()
+        nd, live = C.c_int(), C.c_int()
+        for i in range(n):
+            _lib.check(self.h, self.lib.fdsr_weight_info(self.h, i, buf, 256, shape, C.byref(nd), C.byref(live)))
+            out.append((buf.value.decode(), tuple(int(shape[k]) for k in range(nd.value)), bool(live.value)))
+        return out
+
+    def load_weight(self, key, value):
+        a = np.ascontiguousarray(value.detach().cpu().numpy() if isinstance(value, torch.Tensor) else value,
+                                 dtype=np.float32)
+        shape = (C.c_int64 * max(a.ndim, 1))(*a.shape)
+        _lib.check(self.h, self.lib.fdsr_load_weight(self.h, key.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim))
+
+    def load_state_dict(self, sd, prefix=''):
+        """sd: key -> tensor/ndarray for every key of the UNet schema (strict)."""
+        keys = [k for k, _, _ in self.schema()]
+        missing = [k for k in keys if prefix + k not in sd]
+        if missing:
+            raise KeyError(f'missing keys in state_dict: {missing[:4]}... ({len(missing)})')
+        for k in keys:
+            self.load_weight(k, sd[prefix + k])
+
+    @property
+    def weights_complete(self):
+        return bool(self.lib.fdsr_weights_complete(self.h))
+
+    # -- schedule -------------------------------------------------------------
+    def set_schedule(self, scalars):
+        T = int(len(scalars['noise_level']))
+        arrs = {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in scalars.items()}
+        s = _lib.FdsrSchedule()
+        s.n_timestep = T
+        fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+        s.noise_level, s.sqrt_recip, s.sqrt_recipm1 = fp(arrs['noise_level']), fp(arrs['sqrt_recip']), fp(arrs['sqrt_recipm1'])
+        s.coef1, s.coef2, s.sigma = fp(arrs['coef1']), fp(arrs['coef2']), fp(arrs['sigma'])
+        _lib.check(self.h, self.lib.fdsr_set_schedule(self.h, C.byref(s)))
+        self.T = T
+
+    # -- execution --------------------------------------------------------------
+    def workspace_bytes(self, B, H, W):
+        n = C.c_size_t()
+        _lib.check(self.h, self.lib.fdsr_workspace_bytes(self.h, B, H, W, C.byref(n)))
+        return int(n.value)
+
+    def _workspace(self, B, H, W, device):
+        need = self.workspace_bytes(B, H, W)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != device:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=device)
+        return self._ws
+
+    @staticmethod
+    def _check_input(t, name):
+        if not t.is_cuda:
+            raise RuntimeError(f'{name} must live on the GPU: the HIP engine has no CPU path')
+        if t.dtype != torch.float32:
+            raise TypeError(f'{name} must be float32')
+        return t.contiguous()
+
+    def unet_forward(self, x, noise_level):
+        x = self._check_input(x, 'x')
+        B, Cin, H, W = x.shape
+        nl = self._check_input(noise_level.to(x.device), 'noise_level').reshape(-1)
+        if nl.numel() != B:
+            raise ValueError('noise_level must have one entry per sample')
+        ws = self._workspace(B, H, W, x.device)
+        out = torch.empty(B, self.cfg.out_channel, H, W, device=x.device, dtype=torch.float32)
+        st = torch.cuda.current_stream(x.device).cuda_stream
+        _lib.check(self.h, self.lib.fdsr_unet_forward(self.h, _ptr(x), _ptr(nl), _ptr(out), B, H, W, _ptr(ws), ws.numel(),
+                                                      C.c_void_p(st)))
+        self._keep = (x, nl)
+        return out
+
+    def sample(self, cond, noise, want_traj=False, graph=False, out=None, traj=None):
+        cond = self._check_input(cond, 'cond')
+        noise = self._check_input(noise, 'noise')
+        B, _, H, W = cond.shape
+        if tuple(noise.shape) != (self.T, B, 3, H, W):
+            raise ValueError(f'noise must be [{self.T},{B},3,{H},{W}], got {tuple(noise.shape)}')
+        ws = self._workspace(B, H, W, cond.device)
+        if out is None:
+            out = torch.empty(B, 3, H, W, device=cond.device, dtype=torch.float32)
+        if want_traj and traj is None:
+            traj = torch.empty(self.T, B, 3, H, W, device=cond.device, dtype=torch.float32)
+        st = torch.cuda.current_stream(cond.device).cuda_stream
+        flags = _lib.FDSR_SAMPLE_GRAPH if graph else 0
+        _lib.check(self.h, self.lib.fdsr_sample(self.h, _ptr(cond), _ptr(noise), _ptr(out), _ptr(traj if want_traj else None),
+                                                B, H, W, _ptr(ws), ws.numel(), C.c_void_p(st), flags))
+        self._keep = (cond, noise, out, traj)
+        return (out, traj) if want_traj else out
+
+    # -- introspection ----------------------------------------------------------
+    def set_debug(self, on=True):
+        _lib.check(self.h, self.lib.fdsr_set_debug(self.h, int(on)))
+
+    def debug_tensor(self, name):
+        """Output of reference module `name` from the last forward, as an NCHW torch tensor."""
+        off = C.c_void_p()
+        n, hh, ww, ch = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        _lib.check(self.h, self.lib.fdsr_debug_tensor(self.h, name.encode(), C.byref(off), C.byref(n), C.byref(hh),
+                                                      C.byref(ww), C.byref(ch)))
+        o = int(off.value or 0)
+        cnt = n.value * hh.value * ww.value * ch.value
+        flat = self._ws[o:o + 4 * cnt].view(torch.float32)
+        return flat.view(n.value, hh.value, ww.value, ch.value).permute(0, 3, 1, 2).contiguous()
+
+    def profile_begin(self):
+        _lib.check(self.h, self.lib.fdsr_profile_begin(self.h))
+
+    def profile_end(self):
+        n, ms, fl, by = C.c_int(), C.c_double(), C.c_double(), C.c_double()
+        _lib.check(self.h, self.lib.fdsr_profile_end(self.h, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by)))
+        return dict(launches=n.value, conv_ms=ms.value, conv_flops=fl.value, conv_bytes=by.value)

@@ -1,0 +1,60 @@
+"""Multi-GPU layout of the sampling path: one process per GPU, images sharded
+across ranks, weights replicated by ONE broadcast from rank 0 (RCCL over xGMI when
+the backend is "nccl"; the same code runs on gloo for the CPU tests).  Sampling
+itself needs no collective: no operator of the path mixes batch elements
+(GroupNorm, noise level, CLAM/SLAM pools are all per sample)."""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .arch import UNetConfig, param_schema
+
+
+def shard_range(total, rank, world):
+    """Contiguous, balanced [lo, hi) slice of `total` images for `rank`."""
+    base, rem = divmod(int(total), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def flatten_state_dict(sd, cfg: UNetConfig):
+    keys = list(param_schema(cfg).keys())
+    return np.concatenate([np.asarray(sd[k], dtype=np.float32).reshape(-1) for k in keys])
+
+
+def unflatten_state_dict(flat, cfg: UNetConfig):
+    out, off = OrderedDict(), 0
+    for k, shp in param_schema(cfg).items():
+        n = int(np.prod(shp))
+        out[k] = np.asarray(flat[off:off + n]).reshape(shp)
+        off += n
+    assert off == len(flat)
+    return out
+
+
+def broadcast_state_dict(sd, cfg: UNetConfig, src=0, device='cpu'):
+    """Rank `src` passes its state dict (others pass None); everyone returns the same dict.
+    One packed fp32 message (95.2 MB for the FastDiffSR UNet)."""
+    n = sum(int(np.prod(s)) for s in param_schema(cfg).values())
+    if dist.get_rank() == src:
+        buf = torch.from_numpy(flatten_state_dict(sd, cfg)).to(device)
+    else:
+        buf = torch.empty(n, dtype=torch.float32, device=device)
+    dist.broadcast(buf, src=src)
+    return unflatten_state_dict(buf.cpu().numpy(), cfg)
+
+
+def gather_images(local, total, world, rank, dst=0):
+    """Collect per-rank [b_r,3,H,W] results on `dst` in global image order (optional; the
+    reference's val loop consumes images one at a time)."""
+    sizes = [shard_range(total, r, world)[1] - shard_range(total, r, world)[0] for r in range(world)]
+    bmax = max(sizes)
+    pad = torch.zeros((bmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[:local.shape[0]] = local
+    bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
+    dist.gather(pad, bufs, dst=dst)
+    if rank != dst:
+        return None
+    return torch.cat([b[:s] for b, s in zip(bufs, sizes)], dim=0)

@@ -1,0 +1,91 @@
+"""`UNet` facade: the constructor and call surface of the reference denoiser
+(FastDiffSR/model/fastdiffsr_modules/unet.py:224-323) over the HIP engine.
+
+The module owns nn.Parameters in exactly the reference's module hierarchy, so
+`state_dict()` / `load_state_dict(strict=True)` exchange reference checkpoints
+key for key (317 tensors, including the 22 never-executed `<blk>.conv` layers of
+unet.py:212).  `forward(x, time)` runs libfdsr_hip.so; there is no PyTorch
+implementation of the network in this package.
+"""
+import math
+
+import torch
+from torch import nn
+
+from .arch import UNetConfig, param_schema
+from .engine import Engine
+
+
+class _Holder(nn.Module):
+    """Parameter container standing in for one reference sub-module."""
+
+    def extra_repr(self):
+        return ', '.join(f'{k}{tuple(v.shape)}' for k, v in self._parameters.items())
+
+
+def _holder_path(root, parts):
+    m = root
+    for p in parts:
+        if p not in m._modules:
+            m.add_module(p, _Holder())
+        m = m._modules[p]
+    return m
+
+
+class UNet(nn.Module):
+    def __init__(self, in_channel=6, out_channel=3, inner_channel=32, norm_groups=32, channel_mults=(1, 2, 4, 4),
+                 attn_res=(8), res_blocks=3, dropout=0, with_noise_level_emb=True, image_size=256):
+        super().__init__()
+        if not with_noise_level_emb:
+            raise NotImplementedError('the HIP engine implements the noise-level-conditioned UNet only')
+        self.cfg = UNetConfig(in_channel=in_channel, out_channel=out_channel, inner_channel=inner_channel,
+                              norm_groups=norm_groups, channel_mults=tuple(channel_mults), attn_res=attn_res,
+                              res_blocks=res_blocks, dropout=dropout, image_size=image_size)
+        self._schema = param_schema(self.cfg)
+        for key, shape in self._schema.items():
+            parts = key.split('.')
+            holder = _holder_path(self, parts[:-1])
+            holder.register_parameter(parts[-1], nn.Parameter(self._default_init(parts[-1], shape, key)))
+        self._engine = None
+        self._uploaded_version = None
+
+    def _default_init(self, leaf, shape, key):
+        """PyTorch's default initialisers (Conv2d/Linear: kaiming_uniform(a=sqrt 5) and
+        bias ~ U(+-1/sqrt(fan_in)); GroupNorm: weight 1, bias 0)."""
+        t = torch.empty(shape)
+        if '.block.0.' in key:          # GroupNorm
+            return t.fill_(1.0 if leaf == 'weight' else 0.0)
+        if leaf == 'weight':
+            nn.init.kaiming_uniform_(t, a=math.sqrt(5))
+            return t
+        wshape = self._schema[key[:-len('bias')] + 'weight']
+        fan_in = 1
+        for d in wshape[1:]:
+            fan_in *= d
+        bound = 1.0 / math.sqrt(fan_in)
+        return t.uniform_(-bound, bound)
+
+    # -- engine plumbing ---------------------------------------------------------
+    @property
+    def engine(self) -> Engine:
+        if self._engine is None:
+            self._engine = Engine(self.cfg)
+        return self._engine
+
+    def _param_version(self):
+        return tuple(p._version for p in self.parameters()) + tuple(id(p.data) for p in self.parameters())
+
+    def sync_weights(self, force=False):
+        """Upload parameters to the engine if they changed since the last upload."""
+        ver = self._param_version()
+        if force or ver != self._uploaded_version:
+            sd = {k: v for k, v in self.state_dict().items()}
+            self.engine.load_state_dict(sd)
+            self._uploaded_version = ver
+
+    def forward(self, x, time):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
+            raise NotImplementedError(
+                'training (autograd through the HIP UNet) is not implemented yet; call under torch.no_grad() / eval()')
+        self.sync_weights()
+        return self.engine.unet_forward(x, time)

@@ -1,0 +1,141 @@
+/*
+ * fdsr.h -- C ABI of libfdsr_hip.so, the MI355X (gfx950) engine behind the
+ * FastDiffSR 20-step sampling path.
+ *
+ * The reference (Meng-333/FastDiffSR) is pure Python and has no FFI of its
+ * own; the drop-in boundary is the duck-typed netG surface that
+ * FastDiffSR/model/model.py (class DDPM) calls.  Each entry point below names
+ * the reference interface it stands behind (file:line under
+ * /root/reference/FastDiffSR/).  The Python facade in fastdiffsr_amd/
+ * (diffusion.py, unet.py) binds these with ctypes and re-exposes the
+ * reference's class/method names; INTEGRATION.md shows the stub a reference
+ * maintainer would add.
+ *
+ * Conventions
+ *  - every function returns 0 on success or a negative FDSR_E_* code; nothing
+ *    throws across the ABI; fdsr_last_error() gives the message.
+ *  - tensors at the boundary are fp32, NCHW, contiguous, DEVICE pointers
+ *    (the layout the reference's tensors have, LRHR_dataset.py:113-119);
+ *    weights are handed over as HOST pointers in the reference checkpoint
+ *    layout (Conv2d [Cout,Cin,kh,kw], Linear [out,in]) and repacked inside.
+ *  - the caller owns every tensor and the workspace; the library owns its
+ *    packed weights and captured graphs.  One handle per device; a handle is
+ *    not thread-safe.  All work is stream-ordered on `stream` and asynchronous:
+ *    no entry point synchronises the device.
+ *  - H and W must be multiples of 2^(n_mults-1) (three stride-2 stages => 8).
+ */
+#ifndef FDSR_H_
+#define FDSR_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FDSR_OK 0
+#define FDSR_E_INVALID (-1)   /* bad argument / unsupported configuration  */
+#define FDSR_E_KEY (-2)       /* unknown checkpoint key or shape mismatch  */
+#define FDSR_E_STATE (-3)     /* weights / schedule missing                */
+#define FDSR_E_WORKSPACE (-4) /* workspace too small or misaligned         */
+#define FDSR_E_HIP (-5)       /* HIP runtime error (see fdsr_last_error)   */
+
+#define FDSR_MAX_MULTS 8
+
+typedef struct fdsr_engine* fdsr_handle;
+
+/* Hyper-parameters of unet.UNet(...) exactly as networks.define_G passes them
+ * (model/networks.py:94-104; ctor model/fastdiffsr_modules/unet.py:224-297). */
+typedef struct fdsr_config {
+  int32_t in_channel;    /* 6 = cat(cond SR image, x_t)                    */
+  int32_t out_channel;   /* 3                                              */
+  int32_t inner_channel; /* 64                                             */
+  int32_t norm_groups;   /* 32                                             */
+  int32_t n_mults;
+  int32_t channel_mults[FDSR_MAX_MULTS]; /* {1,2,4,4}                      */
+  int32_t res_blocks;    /* 2                                              */
+  float dropout;         /* 0.2; identity in eval (sampling) mode          */
+  int32_t image_size;    /* informational; the UNet is fully convolutional */
+} fdsr_config;
+
+/* Per-timestep scalars the reverse process reads (diffusion.py:109-155; only
+ * these five buffers + the fp64 sqrt_alphas_cumprod_prev list are used by
+ * p_sample, :157-190).  All arrays have n_timestep entries, index = t. */
+typedef struct fdsr_schedule {
+  int32_t n_timestep;
+  const float* noise_level;      /* fp32(sqrt_alphas_cumprod_prev[t+1])  :169-170 */
+  const float* sqrt_recip;       /* sqrt_recip_alphas_cumprod[t]         :157-159 */
+  const float* sqrt_recipm1;     /* sqrt_recipm1_alphas_cumprod[t]                 */
+  const float* coef1;            /* posterior_mean_coef1[t]              :161-165 */
+  const float* coef2;            /* posterior_mean_coef2[t]                        */
+  const float* sigma;            /* exp(0.5*posterior_log_variance_clipped[t]) :190 */
+} fdsr_schedule;
+
+/* -- lifetime ------------------------------------------------------------ */
+/* unet.UNet.__init__ + GaussianDiffusion.__init__ (unet.py:224, diffusion.py:78). */
+int fdsr_create(const fdsr_config* cfg, fdsr_handle* out);
+void fdsr_destroy(fdsr_handle h);
+/* Message of the last failing call on this handle (or the global one if h==NULL). */
+const char* fdsr_last_error(fdsr_handle h);
+/* "gfx950 f32-mfma ..." build string. */
+const char* fdsr_version(void);
+
+/* -- checkpoint schema: nn.Module.state_dict()/load_state_dict (model.py:135,159) */
+int fdsr_num_weights(fdsr_handle h);
+/* idx-th tensor of the UNet schema (keys without the 'denoise_fn.' prefix), in
+ * state_dict order.  live=0 for the 22 never-executed `<blk>.conv` layers
+ * (unet.py:212) that exist only in checkpoints. */
+int fdsr_weight_info(fdsr_handle h, int idx, char* key, int key_cap,
+                     int64_t shape[4], int* ndim, int* live);
+/* Hand over one checkpoint tensor (host pointer, reference layout). */
+int fdsr_load_weight(fdsr_handle h, const char* key, const float* host,
+                     const int64_t* shape, int ndim);
+/* 1 when every live tensor has been loaded. */
+int fdsr_weights_complete(fdsr_handle h);
+
+/* GaussianDiffusion.set_new_noise_schedule (diffusion.py:109-155). */
+int fdsr_set_schedule(fdsr_handle h, const fdsr_schedule* s);
+
+/* -- execution ------------------------------------------------------------ */
+/* Bytes of device scratch fdsr_unet_forward / fdsr_sample need for this shape. */
+int fdsr_workspace_bytes(fdsr_handle h, int batch, int height, int width, size_t* bytes);
+
+/* UNet.forward(x, noise_level) (unet.py:299-323), eval mode.
+ *   x_nchw      [B,in_channel,H,W]   noise_level [B]   eps_nchw [B,out_channel,H,W] */
+int fdsr_unet_forward(fdsr_handle h, const float* x_nchw, const float* noise_level,
+                      float* eps_nchw, int batch, int height, int width,
+                      void* workspace, size_t workspace_bytes, void* hip_stream);
+
+/* GaussianDiffusion.p_sample_loop, conditional branch (diffusion.py:192-221),
+ * batched as B independent B=1 runs (the reference crashes for B>=2, :215-216).
+ *   cond_nchw [B,3,H,W]        the bicubic-upsampled LR image (x_in)
+ *   noise     [T,B,3,H,W]      noise[0] = x_T (`randn(shape)` :207), noise[k] =
+ *                              the `randn_like` of step t = T-k (:189), k=1..T-1
+ *   out_nchw  [B,3,H,W]        res2img(x_0, cond) (:214, :275-281) == ret_img[-1]
+ *   traj_nchw [T,B,3,H,W] or NULL: x_t after every step (t = T-1..0), for
+ *                              continous=True frames and parity tests.
+ * flags: FDSR_SAMPLE_GRAPH replays the 20-step loop as one captured hipGraph. */
+#define FDSR_SAMPLE_GRAPH 1
+int fdsr_sample(fdsr_handle h, const float* cond_nchw, const float* noise,
+                float* out_nchw, float* traj_nchw, int batch, int height, int width,
+                void* workspace, size_t workspace_bytes, void* hip_stream, int flags);
+
+/* -- introspection for parity tests and bench.py -------------------------- */
+/* When on, the next plan keeps every layer output in its own buffer. */
+int fdsr_set_debug(fdsr_handle h, int on);
+/* Device pointer (NHWC fp32, inside the workspace of the last forward) and shape
+ * of the output of reference module `name` ("downs.4", "mid.0", "ups.7", ...). */
+int fdsr_debug_tensor(fdsr_handle h, const char* name, const float** dev_ptr,
+                      int* n, int* hgt, int* wid, int* ch);
+/* Timing hooks: record hipEvents on `stream` around every launch of the
+ * dominant kernel family (the 3x3 MFMA convolutions) during the next calls,
+ * then read back count / total milliseconds / algorithmic FLOPs. */
+int fdsr_profile_begin(fdsr_handle h);
+int fdsr_profile_end(fdsr_handle h, int* launches, double* conv_ms, double* conv_flops,
+                     double* conv_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FDSR_H_ */

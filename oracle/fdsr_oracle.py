@@ -154,7 +154,8 @@ def resnet_block(sd, p: str, x: Tensor, t: Tensor, groups: int, has_res_conv: bo
 
 
 def unet_forward(sd: Dict[str, Tensor], cfg: UNetConfig, x: Tensor, noise_level: Tensor,
-                 dropout_masks: Optional[Dict[str, Tensor]] = None) -> Tensor:
+                 dropout_masks: Optional[Dict[str, Tensor]] = None,
+                 capture: Optional[Dict[str, Tensor]] = None) -> Tensor:
     """UNet.forward                                           unet.py:299-323
 
     sd keys carry no 'denoise_fn.' prefix.  x: [B,in_channel,H,W]; noise_level: [B,1]."""
@@ -180,6 +181,8 @@ def unet_forward(sd: Dict[str, Tensor], cfg: UNetConfig, x: Tensor, noise_level:
                 x = slam(sd, f'{L.name}.sa', clam(sd, f'{L.name}.ca', x))
         elif L.kind == 'final':
             x = block(sd, L.name, x, G)
+        if capture is not None:
+            capture[L.name] = x      # output of reference module L.name (test introspection)
         if i < n_down:
             feats.append(x)
     return x
