@@ -1,0 +1,135 @@
+"""Host-side logic that needs no GPU: schedule algebra, schema via the C ABI, plan and
+workspace errors, config reader, sharding."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from fastdiffsr_amd import _lib
+from fastdiffsr_amd.arch import (UNetConfig, FASTDIFFSR_UNET, FASTDIFFSR_SCHEDULE_VAL, SCHEDULE_BUFFERS, build_layers,
+                                 param_schema, dead_keys)
+from fastdiffsr_amd.config import parse_json_with_comments, dict_to_nonedict
+from fastdiffsr_amd.engine import Engine
+from fastdiffsr_amd.parallel import shard_range, flatten_state_dict, unflatten_state_dict
+from fastdiffsr_amd.schedule import make_beta_schedule, schedule_buffers, sampling_scalars
+from fastdiffsr_amd.synth import synth_state_dict, state_dict_sha256
+from oracle import fdsr_oracle as O
+
+
+def test_product_schedule_equals_oracle_and_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'schedule.npz'))
+    for key in [k for k in g.files if k.startswith('betas/')]:
+        _, name, T = key.split('/')
+        ls, le = (1e-6, 1e-2) if name in ('linear_cosine', 'linear') else (1e-4, 2e-2)
+        np.testing.assert_array_equal(make_beta_schedule(name, int(T), ls, le), g[key])
+        np.testing.assert_array_equal(make_beta_schedule(name, int(T), ls, le), O.make_beta_schedule(name, int(T), ls, le))
+    for T in (20, 10):
+        opt = dict(schedule='linear_cosine', n_timestep=T, linear_start=1e-6, linear_end=1e-2)
+        bufs, sp = schedule_buffers(opt)
+        assert list(bufs.keys()) == list(SCHEDULE_BUFFERS)          # registration order = state_dict order
+        for k in SCHEDULE_BUFFERS:
+            np.testing.assert_array_equal(bufs[k], g[f'buf/{T}/{k}'])
+        np.testing.assert_array_equal(sp, g[f'buf/{T}/sqrt_alphas_cumprod_prev_f64'])
+    with pytest.raises(NotImplementedError):
+        make_beta_schedule('bogus', 5)
+
+
+def test_sampling_scalars_match_reference_formation():
+    bufs, sp = schedule_buffers(FASTDIFFSR_SCHEDULE_VAL)
+    sc = sampling_scalars(bufs, sp)
+    assert all(v.dtype == np.float32 and v.shape == (20,) for v in sc.values())
+    assert sc['noise_level'][19] == np.float32(sp[20]) and abs(sc['noise_level'][19] - 6.634494e-07) < 1e-12
+    # sigma = exp(0.5*logvar) in fp32 (diffusion.py:190), NOT sqrt(posterior_variance)
+    np.testing.assert_array_equal(sc['sigma'], (0.5 * torch.from_numpy(bufs['posterior_log_variance_clipped'])).exp().numpy())
+    assert abs(sc['sigma'][0] - 1e-10) < 1e-16 and sc['coef1'][0] == 1.0 and sc['coef2'][0] == 0.0
+
+
+@pytest.mark.parametrize('kw', [FASTDIFFSR_UNET,
+                                dict(in_channel=6, out_channel=3, inner_channel=32, channel_mults=(1, 2, 4, 4), res_blocks=2),
+                                dict(in_channel=6, out_channel=3, inner_channel=64, channel_mults=(1, 2, 4, 8, 8), res_blocks=1),
+                                dict(in_channel=3, out_channel=3, inner_channel=32, channel_mults=(1, 2), res_blocks=3)])
+def test_native_plan_schema_matches_python_schema(kw):
+    """csrc/fdsr_engine.cpp derives the same checkpoint schema as arch.param_schema (C ABI, no GPU)."""
+    cfg = UNetConfig(**kw)
+    eng = Engine(cfg)
+    py = param_schema(cfg)
+    native = eng.schema()
+    assert [k for k, _, _ in native] == list(py.keys())
+    assert all(tuple(py[k]) == s for k, s, _ in native)
+    assert sorted(k for k, _, live in native if not live) == sorted(dead_keys(cfg))
+    assert not eng.weights_complete
+
+
+def test_fastdiffsr_counts():
+    cfg = UNetConfig(**FASTDIFFSR_UNET)
+    sch = param_schema(cfg)
+    assert len(sch) == 317
+    assert sum(int(np.prod(s)) for s in sch.values()) == 23802277
+    dead = sum(int(np.prod(sch[k])) for k in dead_keys(cfg))
+    assert dead == 892864
+    kinds = [L.kind for L in build_layers(cfg)]
+    assert kinds.count('res') == 22 and kinds.count('down') == 3 and kinds.count('up') == 3
+
+
+def test_plan_rejects_bad_configs_and_shapes():
+    with pytest.raises(_lib.FdsrError):
+        Engine(UNetConfig(in_channel=6, out_channel=3, inner_channel=48, channel_mults=(1, 2)))     # 48 % 32 != 0
+    with pytest.raises(_lib.FdsrError):
+        Engine(UNetConfig(in_channel=9, out_channel=3, inner_channel=32, channel_mults=(1, 2)))
+    eng = Engine(UNetConfig(**FASTDIFFSR_UNET))
+    for bad in [(0, 64, 64), (1, 60, 64), (1, 64, 4)]:
+        with pytest.raises(_lib.FdsrError):
+            eng.workspace_bytes(*bad)
+    a, b = eng.workspace_bytes(1, 64, 64), eng.workspace_bytes(4, 64, 64)
+    assert 0 < a < b <= 4 * a + 4096
+    # liveness reuse keeps the B=16 256x256 workspace near 2 GiB (every-layer-distinct would be ~8 GiB)
+    assert eng.workspace_bytes(16, 256, 256) < 3 * 2 ** 30
+    eng.set_debug(True)
+    assert eng.workspace_bytes(1, 64, 64) > a
+
+
+def test_synth_weights_are_pinned():
+    cfg = UNetConfig(**FASTDIFFSR_UNET)
+    sd = synth_state_dict(cfg, 0)
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'unet_full.npz'))
+    assert state_dict_sha256(sd) == str(g['weights_sha256'])
+    flat = flatten_state_dict(sd, cfg)
+    back = unflatten_state_dict(flat, cfg)
+    assert all(np.array_equal(back[k], sd[k]) for k in sd)
+
+
+def test_config_reader():
+    txt = '{\n "name": "x", // comment\n "model": {"which_model_G": "fastdiffsr", // c2\n "unet": {"inner_channel": 64}}\n}'
+    opt = dict_to_nonedict(parse_json_with_comments(txt))
+    assert opt['model']['which_model_G'] == 'fastdiffsr' and opt['model']['unet']['inner_channel'] == 64
+    assert opt['missing'] is None and opt['model']['nope'] is None
+
+
+def test_shard_range():
+    for total, world in [(512, 8), (16, 3), (5, 8), (256, 8)]:
+        spans = [shard_range(total, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == total
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+        sizes = [hi - lo for lo, hi in spans]
+        assert max(sizes) - min(sizes) <= 1
+
+
+def test_facade_state_dict_roundtrip_cpu():
+    from fastdiffsr_amd import diffusion, unet
+    net = unet.UNet(**{**FASTDIFFSR_UNET, 'channel_mults': [1, 2, 4, 4]})
+    G = diffusion.GaussianDiffusion(net, image_size=256, channels=3, loss_type='l1', conditional=True, schedule_opt=None)
+    G.set_loss('cpu')
+    G.set_new_noise_schedule(FASTDIFFSR_SCHEDULE_VAL, 'cpu')
+    sd = G.state_dict()
+    assert len(sd) == 329 and list(sd.keys())[:12] == list(SCHEDULE_BUFFERS)   # own buffers first, as in the reference
+    ck = {('denoise_fn.' + k): torch.from_numpy(v) for k, v in synth_state_dict(net.cfg, 0).items()}
+    ck.update({k: sd[k] for k in SCHEDULE_BUFFERS})
+    G.load_state_dict(ck, strict=True)
+    assert torch.equal(G.state_dict()['denoise_fn.downs.0.weight'], ck['denoise_fn.downs.0.weight'])
+    with pytest.raises(RuntimeError):
+        G.load_state_dict({k: v for k, v in ck.items() if 'mid.0.conv' not in k}, strict=True)   # dead keys are required
+    with pytest.raises((RuntimeError, _lib.FdsrError)):
+        G.super_resolution(torch.zeros(1, 3, 32, 32))            # CPU tensor / no GPU: fails loudly, no fallback
+    with pytest.raises(NotImplementedError):
+        G.sample(1)
