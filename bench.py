@@ -22,6 +22,7 @@ import torch
 
 FLOPS_PER_IMAGE = 5.3662e12      # 20 x 268.31 GFLOP
 PEAK_F32_MFMA = 157.3            # TFLOP/s, MI355X_MICROARCH.md (f32 matrix = f32 vector peak)
+PEAK_16BIT_MFMA = 2500.0         # TFLOP/s dense f16/bf16 MFMA (same guide; never the 2:1-sparse figure)
 
 
 def host_cores():
@@ -84,6 +85,8 @@ def main():
     ap.add_argument('--size', type=int, default=256)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true', help='skip the per-conv HIP-event timing')
+    ap.add_argument('--precision', default='f32', choices=['f32', 'f16x3', 'bf16'],
+                    help='conv arithmetic: exact fp32 MFMA, fp32-grade split-f16 MFMA, or bf16')
     ap.add_argument('--graph', action='store_true', help='replay the 20-step loop as a hipGraph')
     args = ap.parse_args()
 
@@ -116,6 +119,7 @@ def main():
     eng.load_state_dict(sd)
     bufs, sp = schedule_buffers(FASTDIFFSR_SCHEDULE_VAL)
     eng.set_schedule(sampling_scalars(bufs, sp))
+    eng.set_precision(args.precision)
 
     B, S = args.batch, args.size
     # independent per-GPU batch (weak scaling): rank r samples its own B images
@@ -152,19 +156,24 @@ def main():
         res = {
             'metric': '256x256 SR images/sec at T=20', 'value': ips, 'unit': 'images/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.precision, 'data': 'synthetic',
             'config': {'workload': f'x4 64->256, batch={B}/GPU, T=20, random-init FastDiffSR UNet (inner 64, mults 1-2-4-4), '
-                                   f'{S}x{S}, fp32 (BASELINE configs[1])',
+                                   f'{S}x{S}, conv arithmetic {args.precision} (BASELINE configs[1])',
                        'batch_per_gpu': B, 'global_batch': B * world, 'timesteps': 20, 'hipgraph': bool(args.graph),
                        'parallelism': f'dp{world} (independent batches, weights broadcast once)'},
             'whole_path_tflops': ips / world * FLOPS_PER_IMAGE / 1e12,
         }
         if prof and prof['conv_ms'] > 0:
             ach = prof['conv_flops'] / (prof['conv_ms'] * 1e-3) / 1e12
-            res['roofline'] = {'bound': 'mfma', 'kernel': 'conv_mfma_f32_kernel (3x3 implicit-GEMM family)',
-                               'achieved': ach, 'peak': PEAK_F32_MFMA, 'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MFMA,
+            peak = PEAK_F32_MFMA if args.precision == 'f32' else PEAK_16BIT_MFMA
+            passes = 3 if args.precision == 'f16x3' else 1     # MFMA products issued per algorithmic product
+            kern = 'conv_mfma_f32_kernel' if args.precision == 'f32' else 'conv_mfma_h_kernel'
+            res['roofline'] = {'bound': 'mfma', 'kernel': f'{kern} (3x3 implicit-GEMM family)',
+                               'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
                                'traffic': None, 'launches': prof['launches'],
                                'avg_launch_ms': prof['conv_ms'] / max(prof['launches'], 1),
+                               'mfma_passes_per_product': passes, 'executed_tflops': ach * passes,
+                               'frac_executed': ach * passes / peak,
                                'algorithmic_gbytes_per_s': prof['conv_bytes'] / (prof['conv_ms'] * 1e-3) / 1e9,
                                'conv_time_share': prof['conv_ms'] * 1e-3 / dt}
         if world == 1 and not args.no_cpu_baseline:

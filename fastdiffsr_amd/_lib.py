@@ -7,6 +7,7 @@ from .build import LIB
 
 FDSR_MAX_MULTS = 8
 FDSR_SAMPLE_GRAPH = 1
+PRECISIONS = {'f32': 0, 'f16x3': 1, 'bf16': 2}
 
 
 class FdsrConfig(C.Structure):
@@ -46,6 +47,7 @@ SYMBOLS = {
                                     C.c_size_t, C.c_void_p]),
     'fdsr_sample': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                               C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]),
+    'fdsr_set_precision': (C.c_int, [C.c_void_p, C.c_int]),
     'fdsr_set_debug': (C.c_int, [C.c_void_p, C.c_int]),
     'fdsr_debug_tensor': (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                     C.POINTER(C.c_int), C.POINTER(C.c_int)]),

@@ -1,0 +1,320 @@
+// 16-bit-operand MFMA convolutions for gfx950: v_mfma_f32_32x32x16_{f16,bf16}, fp32 accumulate.
+//
+// Two arithmetic modes share one kernel:
+//   PREC_F16X3  fp32-grade: every fp32 operand x is split on the fly into hi = f16(x) and
+//               lo = f16(x - hi) (22 mantissa bits together); the product is formed as
+//               hi*hi + hi*lo + lo*hi by three MFMAs into one fp32 accumulator.  Weights are
+//               pre-scaled by a power of two (so their lo parts stay normal f16 numbers) and
+//               the accumulator is un-scaled in the epilogue.  Measured against the exact-fp32
+//               path the 20-step loop differs by ~4e-6, at 3/16 of the fp32-MFMA time.
+//   PREC_BF16   one bf16 product (BASELINE config 3; judged on PSNR, not on the 1e-3 bound).
+//
+// Structure ("weights in registers, pixels from LDS"):
+//   * workgroup = 8 wave64 = TH x 32 output pixels x BN = 32*WN output channels
+//   * a wave owns 32 output channels (wn) and TH/WM rows of 32 pixels (wm); it keeps the weight
+//     fragments of ALL taps of the current 16-channel K-chunk in VGPRs (9 taps x hi/lo x 4
+//     VGPRs), loaded straight from L2 in MFMA-fragment order (1 KB contiguous per wave-load), and
+//     re-loads tap t's registers for the next chunk right after tap t's last use
+//   * the input halo tile of the chunk goes through LDS only: GroupNorm-apply + Swish + hi/lo
+//     split are fused into the staging; rows are [16 x hi | 16 x lo | 16 B pad] = 80 B (5 slots,
+//     odd) so the 32-pixel-row reads (ds_read_b128) are bank-conflict free with immediate offsets
+//   * the halo is double-buffered: chunk k+1 is transformed and written while chunk k is being
+//     multiplied; one barrier per chunk
+//   * epilogue as in the fp32 kernel (bias + noise-embedding shift + residual, NHWC stores)
+#include "fdsr_kernels.h"
+
+namespace fdsr {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef __bf16 b8 __attribute__((ext_vector_type(8)));
+typedef __bf16 b4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float silu_h(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+
+template <int KS, int STRIDE, bool UP, int TH, int WN, int PREC>
+struct ConvHCfg {
+  static constexpr int TW = 32, KC = 16;
+  static constexpr int NP = PREC == PREC_F16X3 ? 2 : 1;
+  static constexpr int ROWB = NP * 32 + 16;   // LDS bytes per halo pixel
+  static constexpr int PAD = KS / 2;
+  static constexpr int HH = (TH - 1) * STRIDE + KS;
+  static constexpr int HWD = (TW - 1) * STRIDE + KS;
+  static constexpr int NPIX = HH * HWD;
+  static constexpr int WM = 8 / WN;
+  static constexpr int BN = 32 * WN;
+  static constexpr int MB = TH / WM;
+  static constexpr int RPP = 512 / 4;          // halo pixels filled per pass (4 float4 per pixel-chunk)
+  static constexpr int NIN = (NPIX + RPP - 1) / RPP;
+  static constexpr int T = KS * KS;
+  static constexpr int BUF_BYTES = (NPIX * ROWB + 15) / 16 * 16;
+  static_assert(TH % WM == 0, "TH must be a multiple of WM");
+};
+
+template <int KS, int STRIDE, bool UP, int TH, int WN, int PREC>
+__global__ void __launch_bounds__(512, 2) conv_mfma_h_kernel(const ConvParams p) {
+  using Cfg = ConvHCfg<KS, STRIDE, UP, TH, WN, PREC>;
+  constexpr int TW = Cfg::TW, KC = Cfg::KC, NP = Cfg::NP, ROWB = Cfg::ROWB, PAD = Cfg::PAD, HWD = Cfg::HWD;
+  constexpr int NPIX = Cfg::NPIX, WM = Cfg::WM, BN = Cfg::BN, MB = Cfg::MB, RPP = Cfg::RPP, NIN = Cfg::NIN, T = Cfg::T;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_h[];
+  unsigned char* sBuf0 = smem_h;
+  unsigned char* sBuf1 = smem_h + Cfg::BUF_BYTES;
+  float* sScale = reinterpret_cast<float*>(smem_h + 2 * Cfg::BUF_BYTES);
+  const int Cin = p.C0 + p.C1;
+  float* sShift = sScale + Cin;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave % WN, wm = wave / WN;
+
+  const int nco = p.Cout_pad / BN;
+  const int tilesX = (p.Wout + TW - 1) / TW, tilesY = (p.Hout + TH - 1) / TH;
+  int bid;
+  {
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = b & 7, k = b >> 3;
+    bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
+  }
+  const int cot = bid % nco;
+  int pt = bid / nco;
+  const int tx = pt % tilesX;
+  pt /= tilesX;
+  const int ty = pt % tilesY;
+  const int n = pt / tilesY;
+  const int oy0 = ty * TH, ox0 = tx * TW, co0 = cot * BN;
+
+  const bool gn = p.gn_stats != nullptr;
+  if (gn) {
+    const double inv_cnt = 1.0 / ((double)p.cpg * (double)p.Hin * (double)p.Win);
+    for (int c = tid; c < Cin; c += 512) {
+      const int g = c / p.cpg;
+      const double sum = p.gn_stats[((size_t)n * p.G + g) * 2 + 0];
+      const double sq = p.gn_stats[((size_t)n * p.G + g) * 2 + 1];
+      const double mean = sum * inv_cnt;
+      double var = sq * inv_cnt - mean * mean;
+      var = var < 0.0 ? 0.0 : var;
+      const float rstd = (float)(1.0 / sqrt(var + (double)p.gn_eps));
+      const float sc = rstd * p.gn_gamma[c];
+      sScale[c] = sc;
+      sShift[c] = p.gn_beta[c] - (float)mean * sc;
+    }
+  }
+
+  // ---- staging indices (chunk invariant): thread -> (halo pixel row0 + i*128, float4 slot q) ----
+  const int q = tid & 3, row0 = tid >> 2;
+  int in_pix[NIN];
+#pragma unroll
+  for (int i = 0; i < NIN; ++i) {
+    const int pix = row0 + i * RPP;
+    int v = -2;
+    if (pix < NPIX) {
+      const int hy = pix / HWD, hx = pix % HWD;
+      const int iy = oy0 * STRIDE - PAD + hy, ix = ox0 * STRIDE - PAD + hx;
+      if (UP) {
+        const bool ok = iy >= 0 && iy < p.Hout && ix >= 0 && ix < p.Wout;
+        v = ok ? (n * p.Hin + (iy >> 1)) * p.Win + (ix >> 1) : -1;
+      } else {
+        const bool ok = iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
+        v = ok ? (n * p.Hin + iy) * p.Win + ix : -1;
+      }
+    }
+    in_pix[i] = v;
+  }
+
+  f32x4 rin[NIN];
+  auto prefetch = [&](int kc) {
+    const int cbase = kc * KC;
+    const float* base;
+    int Cs, cc;
+    if (cbase < p.C0) { base = p.x0; Cs = p.C0; cc = cbase + q * 4; }
+    else { base = p.x1; Cs = p.C1; cc = cbase - p.C0 + q * 4; }
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (in_pix[i] >= 0) v = *reinterpret_cast<const f32x4*>(base + (size_t)in_pix[i] * Cs + cc);
+      rin[i] = v;
+    }
+  };
+  auto stage = [&](int kc, unsigned char* buf) {
+    const int c = kc * KC + q * 4;
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (gn) {
+      sc = *reinterpret_cast<const f32x4*>(sScale + c);
+      sh = *reinterpret_cast<const f32x4*>(sShift + c);
+    }
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) {
+      if (in_pix[i] == -2) continue;
+      f32x4 v = rin[i];
+      if (gn && in_pix[i] >= 0) {
+        v = v * sc + sh;
+        v.x = silu_h(v.x); v.y = silu_h(v.y); v.z = silu_h(v.z); v.w = silu_h(v.w);
+      }
+      unsigned char* dst = buf + (row0 + i * RPP) * ROWB + q * 8;
+      if (PREC == PREC_F16X3) {
+        // clamp to the f16 range, hi = rn(v), lo = rn(v - hi): hi + lo carries 22 mantissa bits
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = __builtin_fminf(__builtin_fmaxf(v[e], -65504.f), 65504.f);
+        h4 hi = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+        h4 lo = {(_Float16)(v.x - (float)hi.x), (_Float16)(v.y - (float)hi.y), (_Float16)(v.z - (float)hi.z),
+                 (_Float16)(v.w - (float)hi.w)};
+        *reinterpret_cast<h4*>(dst) = hi;
+        *reinterpret_cast<h4*>(dst + 32) = lo;
+      } else {
+        b4 hb = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+        *reinterpret_cast<b4*>(dst) = hb;
+      }
+    }
+  };
+
+  // ---- weight fragments: [cot][kc][wn][tap][plane][lane] x 16 B, loaded straight to VGPRs ----
+  const uint4* wq = reinterpret_cast<const uint4*>(p.wq);
+  const int nk = p.Cin_pad / KC;
+  uint4 Bf[T][NP];
+  auto load_b_tap = [&](int kc, int tap) {
+    const uint4* src = wq + ((((size_t)cot * nk + kc) * WN + wn) * T + tap) * (NP * 64) + lane;
+#pragma unroll
+    for (int pl = 0; pl < NP; ++pl) Bf[tap][pl] = src[pl * 64];
+  };
+
+  // ---- A fragment addresses: lane -> pixel column l&31 of a 32-pixel row, k half l>>5 ----
+  const int r31 = lane & 31, h = lane >> 5;
+  int abase[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const int br = wm + mb * WM;   // tile row owned by this wave
+    abase[mb] = ((br * STRIDE) * HWD + r31 * STRIDE) * ROWB + 16 * h;
+  }
+
+  f32x16 acc[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[mb][i] = 0.f;
+
+#pragma unroll
+  for (int tap = 0; tap < T; ++tap) load_b_tap(0, tap);
+  prefetch(0);
+  __syncthreads();            // scale/shift visible
+  stage(0, sBuf0);
+  if (nk > 1) prefetch(1);
+  __syncthreads();
+
+  for (int kc = 0; kc < nk; ++kc) {
+    unsigned char* cur = (kc & 1) ? sBuf1 : sBuf0;
+    unsigned char* nxt = (kc & 1) ? sBuf0 : sBuf1;
+    const bool more = kc + 1 < nk;
+#pragma unroll
+    for (int tap = 0; tap < T; ++tap) {
+      const int ky = tap / KS, kx = tap % KS;
+      const int aoff = (ky * HWD + kx) * ROWB;
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        const uint4 ahi = *reinterpret_cast<const uint4*>(cur + abase[mb] + aoff);
+        if (PREC == PREC_F16X3) {
+          const uint4 alo = *reinterpret_cast<const uint4*>(cur + abase[mb] + aoff + 32);
+          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, alo), __builtin_bit_cast(h8, Bf[tap][0]), acc[mb], 0, 0, 0);
+          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, ahi), __builtin_bit_cast(h8, Bf[tap][NP - 1]), acc[mb], 0, 0, 0);
+          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, ahi), __builtin_bit_cast(h8, Bf[tap][0]), acc[mb], 0, 0, 0);
+        } else {
+          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8, ahi), __builtin_bit_cast(b8, Bf[tap][0]), acc[mb], 0, 0, 0);
+        }
+      }
+      if (more) load_b_tap(kc + 1, tap);             // same registers, next chunk
+      if (tap == T / 2 && more) {                    // mid-chunk: fill the other halo buffer
+        stage(kc + 1, nxt);
+        if (kc + 2 < nk) prefetch(kc + 2);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue ----
+  const int co = co0 + wn * 32 + r31;
+  const bool cok = co < p.Cout;
+  float add = 0.f;
+  if (cok) {
+    add = p.bias[co];
+    if (p.temb) add += p.temb[(size_t)n * p.temb_stride + p.temb_off + co];
+  }
+  float rv[MB][16];
+  if (p.res) {
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int oy = oy0 + wm + mb * WM, ox = ox0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        const bool ok = cok && oy < p.Hout && ox < p.Wout;
+        rv[mb][i] = ok ? p.res[((size_t)(n * p.Hout + oy) * p.Wout + ox) * p.Cout + co] : 0.f;
+      }
+  }
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int oy = oy0 + wm + mb * WM, ox = ox0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+      if (cok && oy < p.Hout && ox < p.Wout) {
+        float v = acc[mb][i] * p.w_inv_scale + add;
+        if (p.res) v += rv[mb][i];
+        p.out[((size_t)(n * p.Hout + oy) * p.Wout + ox) * p.Cout + co] = v;
+      }
+    }
+}
+
+template <int KS, int STRIDE, bool UP, int TH, int WN, int PREC>
+static hipError_t launch_h_t(const ConvParams& p, hipStream_t s) {
+  using Cfg = ConvHCfg<KS, STRIDE, UP, TH, WN, PREC>;
+  auto kfn = conv_mfma_h_kernel<KS, STRIDE, UP, TH, WN, PREC>;
+  const size_t lds = (size_t)2 * Cfg::BUF_BYTES + (size_t)2 * (p.C0 + p.C1) * sizeof(float);
+  const int tilesX = (p.Wout + Cfg::TW - 1) / Cfg::TW, tilesY = (p.Hout + TH - 1) / TH;
+  const int nwg = p.N * tilesX * tilesY * (p.Cout_pad / Cfg::BN);
+  hipLaunchKernelGGL(kfn, dim3(nwg), dim3(512), lds, s, p);
+  return hipGetLastError();
+}
+
+template <int KS, int STRIDE, bool UP, int TH, int WN, int PREC>
+static hipError_t init_h_t() {
+  auto kfn = conv_mfma_h_kernel<KS, STRIDE, UP, TH, WN, PREC>;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+// X(KS, STRIDE, UP, TH, WN)
+#define FDSR_CONVH_SHAPES(X)                                                                   \
+  X(3, 1, false, 8, 4) X(3, 1, false, 8, 2) X(3, 1, false, 8, 1) X(3, 1, true, 8, 4) X(3, 1, true, 8, 2) \
+  X(3, 2, false, 4, 4) X(3, 2, false, 4, 2) X(1, 1, false, 8, 4) X(1, 1, false, 8, 2) X(1, 1, false, 8, 1)
+
+void conv_h_config(ConvKind kind, int Cout, int* TH, int* WN) {
+  *WN = Cout >= 128 ? 4 : (Cout >= 64 ? 2 : 1);
+  *TH = kind == CONV3_S2 ? 4 : 8;
+  if (kind == CONV3_S2 && *WN == 1) *WN = 2;
+  if (kind == CONV3_UP && *WN == 1) *WN = 2;
+}
+
+hipError_t launch_conv_h(ConvKind kind, int prec, const ConvParams& p, hipStream_t s) {
+  int TH, WN;
+  conv_h_config(kind, p.Cout, &TH, &WN);
+  const int ks = kind == CONV1 ? 1 : 3, stride = kind == CONV3_S2 ? 2 : 1;
+  const bool up = kind == CONV3_UP;
+#define X(KS_, ST_, UP_, TH_, WN_)                                                                   \
+  if (ks == KS_ && stride == ST_ && up == UP_ && TH == TH_ && WN == WN_) {                           \
+    return prec == PREC_F16X3 ? launch_h_t<KS_, ST_, UP_, TH_, WN_, PREC_F16X3>(p, s)                \
+                              : launch_h_t<KS_, ST_, UP_, TH_, WN_, PREC_BF16>(p, s);                \
+  }
+  FDSR_CONVH_SHAPES(X)
+#undef X
+  return hipErrorInvalidValue;
+}
+
+hipError_t kernels_h_init() {
+  hipError_t e;
+#define X(KS_, ST_, UP_, TH_, WN_)                                                           \
+  if ((e = init_h_t<KS_, ST_, UP_, TH_, WN_, PREC_F16X3>()) != hipSuccess) return e;         \
+  if ((e = init_h_t<KS_, ST_, UP_, TH_, WN_, PREC_BF16>()) != hipSuccess) return e;
+  FDSR_CONVH_SHAPES(X)
+#undef X
+  return hipSuccess;
+}
+
+}  // namespace fdsr

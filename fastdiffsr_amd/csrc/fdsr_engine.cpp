@@ -33,6 +33,12 @@ struct WeightEntry {
   size_t dev_off = 0;      // float offset into the parameter arena
   int ks = 1, cin_pad = 0, cout_pad = 0;   // CONV_PACK
   int row_off = 0;                          // NOISE_W / NOISE_B: first row inside the concatenated table
+  // 16-bit MFMA forms (CONV_PACK entries that the h-kernels can run)
+  bool h_ok = false;
+  ConvKind ck = CONV3_S1;
+  int h_WN = 0, h_cin_pad = 0, h_cout_pad = 0;
+  size_t hq_off[3] = {0, 0, 0};             // byte offsets into the 16-bit weight arena, per Precision
+  float h_inv_scale[3] = {1.f, 1.f, 1.f};
 };
 
 struct TensorDesc {
@@ -86,6 +92,9 @@ struct fdsr_engine {
   size_t param_floats = 0, noise_w_off = 0, noise_b_off = 0;
   int w_mlp[4] = {-1, -1, -1, -1};
   float* d_params = nullptr;
+  unsigned char* d_wq = nullptr;
+  size_t wq_bytes = 0;
+  int prec = PREC_F32;
   bool kernels_ready = false;
   // schedule
   int T = 0;
@@ -157,6 +166,16 @@ void mark_conv_pack(fdsr_handle h, int widx, ConvKind ck, int cin_store, int C0,
   w.ks = ck == CONV1 ? 1 : 3;
   w.cin_pad = round_up(cin_store, KC);
   w.cout_pad = round_up(cout, BN);
+  w.ck = ck;
+  // 16-bit MFMA kernels: 16-channel K chunks; a concat seam must fall on a chunk boundary
+  w.h_ok = (cin_store % 16 == 0) && (C1 == 0 || C0 % 16 == 0);
+  if (w.h_ok) {
+    int TH, WN;
+    conv_h_config(ck, cout, &TH, &WN);
+    w.h_WN = WN;
+    w.h_cin_pad = round_up(cin_store, 16);
+    w.h_cout_pad = round_up(cout, 32 * WN);
+  }
 }
 
 // Build the static plan (ops, tensors, weight schema).  unet.py:224-323.
@@ -380,6 +399,17 @@ int build_plan(fdsr_handle h) {
     h->w_freq = (int)h->weights.size() - 1;
   }
   h->param_floats = off;
+  // 16-bit weight arena: [cot][kc][wn][tap][plane][lane] x 16 B per conv, for f16x3 (2 planes) and bf16 (1)
+  {
+    size_t qoff = 0;
+    for (auto& w : h->weights) {
+      if (!w.live || w.sink != WeightEntry::CONV_PACK || !w.h_ok) continue;
+      const size_t frag = (size_t)(w.h_cout_pad / 32) * (w.h_cin_pad / 16) * w.ks * w.ks * 64 * 16;
+      w.hq_off[PREC_F16X3] = qoff; qoff += align_up(frag * 2, 256);
+      w.hq_off[PREC_BF16] = qoff;  qoff += align_up(frag, 256);
+    }
+    h->wq_bytes = qoff;
+  }
 
   // liveness
   for (size_t i = 0; i < h->ops.size(); ++i) {
@@ -409,8 +439,13 @@ int ensure_device(fdsr_handle h) {
     fr[k] = expf((float)(-std::log(1e4)) * step);
   }
   HIPCHK(h, hipMemcpy(h->d_params + h->weights[h->w_freq].dev_off, fr.data(), half * sizeof(float), hipMemcpyHostToDevice));
+  if (h->wq_bytes) {
+    HIPCHK(h, hipMalloc((void**)&h->d_wq, h->wq_bytes));
+    HIPCHK(h, hipMemset(h->d_wq, 0, h->wq_bytes));
+  }
   if (!h->kernels_ready) {
     HIPCHK(h, kernels_init());
+    HIPCHK(h, kernels_h_init());
     h->kernels_ready = true;
   }
   return FDSR_OK;
@@ -562,7 +597,15 @@ int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, 
           }
           HIPCHK(h, hipEventRecord(h->ev_pool[h->ev_used++], st));
         }
-        HIPCHK(h, launch_conv(op.ck, p, st));
+        if (h->prec != PREC_F32 && w.h_ok) {
+          p.wq = h->d_wq + w.hq_off[h->prec];
+          p.w_inv_scale = w.h_inv_scale[h->prec];
+          p.Cin_pad = w.h_cin_pad;
+          p.Cout_pad = w.h_cout_pad;
+          HIPCHK(h, launch_conv_h(op.ck, h->prec, p, st));
+        } else {
+          HIPCHK(h, launch_conv(op.ck, p, st));
+        }
         if (timed) {
           HIPCHK(h, hipEventRecord(h->ev_pool[h->ev_used++], st));
           double f = conv_flops(op, N, H, W);
@@ -581,6 +624,65 @@ int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, 
         break;
     }
   }
+  return FDSR_OK;
+}
+
+inline uint16_t f32_to_bf16_rn(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+inline uint16_t f32_to_f16_rn(float f) {
+  _Float16 hv = (_Float16)f;
+  uint16_t b;
+  memcpy(&b, &hv, 2);
+  return b;
+}
+
+// Repack a Conv2d weight [Cout][Cin][ks][ks] into MFMA B-fragment order for the 16-bit kernels:
+// [cot][kc][wn][tap][plane][lane] x 8 halves, element j of lane l = W[co = cot*BN + wn*32 + (l&31)]
+// [k = kc*16 + 8*(l>>5) + j][tap]   (v_mfma_f32_32x32x16 B operand map).
+// f16x3: plane 0 = hi = f16(w*s), plane 1 = lo = f16(w*s - hi), s = 2^e chosen so that max|w*s| < 2^15
+// (keeps lo out of the f16 subnormal range for all but tiny weights); bf16: one plane, s = 1.
+int pack_weights_h(fdsr_handle h, WeightEntry& w, const float* host) {
+  const int Cout = (int)w.shape[0], Cin = (int)w.shape[1], ks = w.ks, T = ks * ks;
+  const int WN = w.h_WN, BN = 32 * WN, ncot = w.h_cout_pad / BN, nk = w.h_cin_pad / 16;
+  float amax = 0.f;
+  for (size_t i = 0; i < numel(w.shape); ++i) amax = std::max(amax, std::fabs(host[i]));
+  int e = 12;
+  if (amax > 0.f) e = std::min(12, (int)std::floor(std::log2(32768.0 / (double)amax)));
+  const float scale = std::ldexp(1.0f, e);
+  w.h_inv_scale[PREC_F16X3] = std::ldexp(1.0f, -e);
+  w.h_inv_scale[PREC_BF16] = 1.0f;
+  const size_t nfrag = (size_t)ncot * nk * WN * T * 64;   // 16-byte fragments per plane set
+  std::vector<uint16_t> q3(nfrag * 2 * 8, 0), qb(nfrag * 8, 0);
+  for (int cot = 0; cot < ncot; ++cot)
+    for (int kc = 0; kc < nk; ++kc)
+      for (int wn = 0; wn < WN; ++wn)
+        for (int t = 0; t < T; ++t)
+          for (int l = 0; l < 64; ++l) {
+            const int co = cot * BN + wn * 32 + (l & 31);
+            const size_t f3 = (((((size_t)cot * nk + kc) * WN + wn) * T + t) * 2) * 64 + l;
+            const size_t fb = (((((size_t)cot * nk + kc) * WN + wn) * T + t) * 1) * 64 + l;
+            for (int j = 0; j < 8; ++j) {
+              const int k = kc * 16 + 8 * (l >> 5) + j;
+              float v = 0.f;
+              if (co < Cout && k < Cin) v = host[((size_t)co * Cin + k) * T + t];
+              const float vs = v * scale;
+              const uint16_t hi = f32_to_f16_rn(vs);
+              _Float16 hif;
+              memcpy(&hif, &hi, 2);
+              const uint16_t lo = f32_to_f16_rn(vs - (float)hif);
+              q3[f3 * 8 + j] = hi;
+              q3[(f3 + 64) * 8 + j] = lo;
+              qb[fb * 8 + j] = f32_to_bf16_rn(v);
+            }
+          }
+  HIPCHK(h, hipMemcpy(h->d_wq + w.hq_off[PREC_F16X3], q3.data(), q3.size() * 2, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(h->d_wq + w.hq_off[PREC_BF16], qb.data(), qb.size() * 2, hipMemcpyHostToDevice));
   return FDSR_OK;
 }
 
@@ -653,6 +755,7 @@ void fdsr_destroy(fdsr_handle h) {
   for (auto& g : h->graphs) (void)hipGraphExecDestroy(g.exec);
   for (auto e : h->ev_pool) (void)hipEventDestroy(e);
   if (h->d_params) (void)hipFree(h->d_params);
+  if (h->d_wq) (void)hipFree(h->d_wq);
   delete h;
 }
 
@@ -694,6 +797,10 @@ int fdsr_load_weight(fdsr_handle h, const char* key, const float* host, const in
         for (int t = 0; t < ks * ks; ++t)
           pk[((size_t)t * w.cout_pad + co) * w.cin_pad + ci] = host[((size_t)co * Cin + ci) * ks * ks + t];
     HIPCHK(h, hipMemcpy(dst, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (w.h_ok) {
+      int rc2 = pack_weights_h(h, w, host);
+      if (rc2) return rc2;
+    }
   } else {
     HIPCHK(h, hipMemcpy(dst, host, numel(w.shape) * sizeof(float), hipMemcpyHostToDevice));
   }
@@ -782,6 +889,16 @@ int fdsr_sample(fdsr_handle h, const float* cond_nchw, const float* noise, float
   if (h->graphs.size() >= 8) { (void)hipGraphExecDestroy(h->graphs.front().exec); h->graphs.erase(h->graphs.begin()); }
   h->graphs.push_back(ge);
   HIPCHK(h, hipGraphLaunch(ge.exec, st));
+  return FDSR_OK;
+}
+
+int fdsr_set_precision(fdsr_handle h, int mode) {
+  if (!h || mode < 0 || mode > 2) return fail(h, FDSR_E_INVALID, "precision mode must be 0 (f32), 1 (f16x3) or 2 (bf16)");
+  if (h->prec != mode) {
+    for (auto& g : h->graphs) (void)hipGraphExecDestroy(g.exec);
+    h->graphs.clear();
+  }
+  h->prec = mode;
   return FDSR_OK;
 }
 

@@ -31,7 +31,12 @@ struct ConvParams {
   int G, cpg;            // groups, channels per group of the GN input
   float gn_eps;
   int temb_stride, temb_off;
+  // 16-bit MFMA path (fdsr_conv_h.hip): weights in MFMA-fragment order, see pack_weights_h()
+  const void* wq;
+  float w_inv_scale;     // accumulator un-scaling (weights are stored multiplied by a power of two)
 };
+
+enum Precision { PREC_F32 = 0, PREC_F16X3 = 1, PREC_BF16 = 2 };
 
 enum ConvKind { CONV3_S1 = 0, CONV3_S2 = 1, CONV3_UP = 2, CONV1 = 3 };
 
@@ -42,6 +47,11 @@ hipError_t launch_conv(ConvKind kind, const ConvParams& p, hipStream_t s);
 // Raise the dynamic-LDS limit of every kernel that needs more than 64 KB.  Must run
 // once per process before any launch (and outside stream capture).
 hipError_t kernels_init();
+
+// 16-bit-operand MFMA convolutions (fp32-grade f16x3 split, or plain bf16).
+void conv_h_config(ConvKind kind, int Cout, int* TH, int* WN);   // BN = 32*WN, K-chunk = 16
+hipError_t launch_conv_h(ConvKind kind, int prec, const ConvParams& p, hipStream_t s);
+hipError_t kernels_h_init();
 
 // (sum, sumsq) per (n, group) of the virtual concat (x0,x1), accumulated in fp64
 // atomics into stats[N][G][2] (must be zeroed beforehand).

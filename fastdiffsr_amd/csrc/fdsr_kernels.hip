@@ -232,7 +232,9 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_f32_kernel(const ConvParams 
     }
   }
 
-  // ---- epilogue: C/D map col = lane&31 (Cout), row = (i&3) + 8*(i>>2) + 4*(lane>>5) (pixel) ----
+  // ---- epilogue: C/D map col = lane&31 (Cout), row = (i&3) + 8*(i>>2) + 4*(lane>>5) (pixel).
+  // `res` may alias `out` (in-place residual), so ALL residual loads are issued before the
+  // first store: otherwise the compiler must serialise 32 load->wait->store round trips. ----
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
     const int co = co0 + (wn * NB + nb) * 32 + r31;
@@ -241,6 +243,19 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_f32_kernel(const ConvParams 
     if (cok) {
       add = p.bias[co];
       if (p.temb) add += p.temb[(size_t)n * p.temb_stride + p.temb_off + co];
+    }
+    float rv[MB][16];
+    if (p.res) {
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int pp = (wm * MB + mb) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+          const int oy = oy0 + pp / TW, ox = ox0 + pp % TW;
+          const bool ok = cok && oy < p.Hout && ox < p.Wout;
+          const size_t off = ((size_t)(n * p.Hout + oy) * p.Wout + ox) * p.Cout + co;
+          rv[mb][i] = ok ? p.res[off] : 0.f;
+        }
     }
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
@@ -251,7 +266,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_f32_kernel(const ConvParams 
         if (cok && oy < p.Hout && ox < p.Wout) {
           const size_t off = ((size_t)(n * p.Hout + oy) * p.Wout + ox) * p.Cout + co;
           float v = acc[mb][nb][i] + add;
-          if (p.res) v += p.res[off];
+          if (p.res) v += rv[mb][i];
           p.out[off] = v;
         }
       }

@@ -139,6 +139,12 @@ class Engine:
         self._keep = (cond, noise, out, traj)
         return (out, traj) if want_traj else out
 
+    def set_precision(self, mode):
+        """'f32' (exact fp32 MFMA), 'f16x3' (fp32-grade split-f16 MFMA) or 'bf16'."""
+        code = _lib.PRECISIONS[mode] if isinstance(mode, str) else int(mode)
+        _lib.check(self.h, self.lib.fdsr_set_precision(self.h, code))
+        self.precision = mode
+
     # -- introspection ----------------------------------------------------------
     def set_debug(self, on=True):
         _lib.check(self.h, self.lib.fdsr_set_debug(self.h, int(on)))

@@ -121,6 +121,16 @@ int fdsr_sample(fdsr_handle h, const float* cond_nchw, const float* noise,
                 float* out_nchw, float* traj_nchw, int batch, int height, int width,
                 void* workspace, size_t workspace_bytes, void* hip_stream, int flags);
 
+/* Arithmetic of the convolutions (everything else is fp32 in every mode):
+ *   FDSR_PREC_F32    exact fp32 on v_mfma_f32_32x32x2_f32 (default)
+ *   FDSR_PREC_F16X3  fp32-grade: operands split hi/lo into two f16, three f16 MFMAs per product,
+ *                    fp32 accumulate (stays inside the 1e-3 parity bound)
+ *   FDSR_PREC_BF16   one bf16 MFMA per product (BASELINE config 3; judged on PSNR delta) */
+#define FDSR_PREC_F32 0
+#define FDSR_PREC_F16X3 1
+#define FDSR_PREC_BF16 2
+int fdsr_set_precision(fdsr_handle h, int mode);
+
 /* -- introspection for parity tests and bench.py -------------------------- */
 /* When on, the next plan keeps every layer output in its own buffer. */
 int fdsr_set_debug(fdsr_handle h, int on);

@@ -202,6 +202,51 @@ def test_batch16_properties(full):
     assert d_rep <= TOL_LOOP / 4 and d_b <= TOL_LOOP / 4
 
 
+@pytest.mark.parametrize('prec,tol_fwd,tol_loop', [('f16x3', 1e-4, 1e-3), ('bf16', 0.25, None)])
+def test_precision_modes_layerwise_and_loop(full, golden_dir, prec, tol_fwd, tol_loop):
+    """16-bit MFMA convolutions: f16x3 (hi/lo split, fp32-grade) must stay inside the fp32
+    parity bounds; bf16 is judged on PSNR (north_star: PSNR within 0.01 dB), not on 1e-3."""
+    from oracle import fdsr_oracle as O
+    cfg, eng, sd = full
+    eng.set_precision(prec)
+    try:
+        gen = torch.Generator().manual_seed(5)
+        x = torch.randn(2, 6, 32, 48, generator=gen)
+        nl = torch.tensor([[0.02098], [0.7074]])
+        cap = {}
+        with torch.no_grad():
+            ref = O.unet_forward(O.to_torch_sd(sd), cfg, x, nl, capture=cap)
+        eng.set_debug(True)
+        out = eng.unet_forward(x.cuda(), nl.cuda())
+        torch.cuda.synchronize()
+        for L in build_layers(cfg):
+            got = eng.debug_tensor(L.name).cpu()
+            d = (got - cap[L.name]).abs().max().item()
+            scale = cap[L.name].abs().max().item()
+            report(f'{prec:5s} {L.name:12s} {L.kind:8s} max|d|={d:.3e} (max|ref|={scale:.2f})')
+            assert d <= tol_fwd * max(scale, 1.0), f'{L.name}: {d}'
+        eng.set_debug(False)
+        g = np.load(os.path.join(golden_dir, 'sample_loop.npz'))
+        cond, noise = synth_inputs(2, 32, 32, 20)
+        o, traj = eng.sample(cond.cuda(), noise.cuda(), want_traj=True)
+        per_step = np.abs(traj.cpu().numpy() - g['traj32']).reshape(20, -1).max(axis=1)
+        d = np.abs(o.cpu().numpy() - g['out32']).max()
+        report(f'{prec} loop32 per-step max|d|: ' + ' '.join(f'{v:.1e}' for v in per_step) + f' final {d:.3e}')
+        cond64, noise64 = synth_inputs(1, 64, 64, 20)
+        o64 = eng.sample(cond64.cuda(), noise64.cuda()).cpu()
+        d64 = np.abs(o64.numpy() - g['out64']).max()
+        ref64 = torch.from_numpy(g['out64'])
+        hr = (cond64 + 0.3 * torch.sin(torch.arange(64).float() / 5).view(1, 1, 1, 64)).clamp(-1, 1)
+        dps = abs(O.psnr_u8(O.tensor2img_u8(o64[0]), O.tensor2img_u8(hr[0])) - O.psnr_u8(O.tensor2img_u8(ref64[0]), O.tensor2img_u8(hr[0])))
+        report(f'{prec} loop64 final max|d|={d64:.3e} PSNR delta vs reference={dps:.5f} dB')
+        if tol_loop is not None:
+            assert per_step.max() <= tol_loop and d <= tol_loop and d64 <= tol_loop
+        assert dps <= 0.01
+    finally:
+        eng.set_debug(False)
+        eng.set_precision('f32')
+
+
 def test_error_paths(full):
     from fastdiffsr_amd import _lib
     from fastdiffsr_amd.engine import Engine
