@@ -202,19 +202,32 @@ __global__ void __launch_bounds__(512, 2) conv_mfma_h_kernel(const ConvParams p)
   if (nk > 1) prefetch(1);
   __syncthreads();
 
+  // A fragments are double-buffered over taps: the reads of tap t+1 are issued before the MFMAs
+  // of tap t, so LDS latency hides under 3*MB MFMAs instead of being exposed per read.
+  uint4 Af[2][MB][NP];
+  auto load_a = [&](int slot, const unsigned char* cur, int tap) {
+    const int ky = tap / KS, kx = tap % KS;
+    const int aoff = (ky * HWD + kx) * ROWB;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl)
+        Af[slot][mb][pl] = *reinterpret_cast<const uint4*>(cur + abase[mb] + aoff + 32 * pl);
+  };
+
   for (int kc = 0; kc < nk; ++kc) {
     unsigned char* cur = (kc & 1) ? sBuf1 : sBuf0;
     unsigned char* nxt = (kc & 1) ? sBuf0 : sBuf1;
     const bool more = kc + 1 < nk;
+    load_a(0, cur, 0);
 #pragma unroll
     for (int tap = 0; tap < T; ++tap) {
-      const int ky = tap / KS, kx = tap % KS;
-      const int aoff = (ky * HWD + kx) * ROWB;
+      if (tap + 1 < T) load_a((tap + 1) & 1, cur, tap + 1);
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) {
-        const uint4 ahi = *reinterpret_cast<const uint4*>(cur + abase[mb] + aoff);
+        const uint4 ahi = Af[tap & 1][mb][0];
         if (PREC == PREC_F16X3) {
-          const uint4 alo = *reinterpret_cast<const uint4*>(cur + abase[mb] + aoff + 32);
+          const uint4 alo = Af[tap & 1][mb][NP - 1];
           acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, alo), __builtin_bit_cast(h8, Bf[tap][0]), acc[mb], 0, 0, 0);
           acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, ahi), __builtin_bit_cast(h8, Bf[tap][NP - 1]), acc[mb], 0, 0, 0);
           acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, ahi), __builtin_bit_cast(h8, Bf[tap][0]), acc[mb], 0, 0, 0);
@@ -231,13 +244,38 @@ __global__ void __launch_bounds__(512, 2) conv_mfma_h_kernel(const ConvParams p)
     __syncthreads();
   }
 
-  // ---- epilogue ----
+  // ---- epilogue.  Interior tiles take a branch-free path: per-element bounds branches make the
+  // compiler wait vmcnt(0) before every store (64 serialised stores per thread). ----
   const int co = co0 + wn * 32 + r31;
   const bool cok = co < p.Cout;
   float add = 0.f;
   if (cok) {
     add = p.bias[co];
     if (p.temb) add += p.temb[(size_t)n * p.temb_stride + p.temb_off + co];
+  }
+  const bool interior = (oy0 + TH <= p.Hout) && (ox0 + TW <= p.Wout) && (co0 + BN <= p.Cout);
+  if (interior) {
+    float* obase = p.out + ((size_t)(n * p.Hout + oy0 + wm) * p.Wout + ox0 + 4 * h) * p.Cout + co;
+    const size_t rstride = (size_t)WM * p.Wout * p.Cout;
+    float rv[MB][16];
+    if (p.res) {
+      const float* rbase = p.res + (obase - p.out);
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) rv[mb][i] = rbase[mb * rstride + (size_t)((i & 3) + 8 * (i >> 2)) * p.Cout];
+    } else {
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) rv[mb][i] = 0.f;
+    }
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        obase[mb * rstride + (size_t)((i & 3) + 8 * (i >> 2)) * p.Cout] = acc[mb][i] * p.w_inv_scale + add + rv[mb][i];
+    return;
   }
   float rv[MB][16];
   if (p.res) {

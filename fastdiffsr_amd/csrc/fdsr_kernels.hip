@@ -234,7 +234,31 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_f32_kernel(const ConvParams 
 
   // ---- epilogue: C/D map col = lane&31 (Cout), row = (i&3) + 8*(i>>2) + 4*(lane>>5) (pixel).
   // `res` may alias `out` (in-place residual), so ALL residual loads are issued before the
-  // first store: otherwise the compiler must serialise 32 load->wait->store round trips. ----
+  // first store: otherwise the compiler must serialise 32 load->wait->store round trips.
+  // Interior tiles take a branch-free path (per-element bounds branches force vmcnt(0) per store). ----
+  if ((oy0 + TH <= p.Hout) && (ox0 + TW <= p.Wout) && (co0 + BN <= p.Cout)) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const int co = co0 + (wn * NB + nb) * 32 + r31;
+      float add = p.bias[co];
+      if (p.temb) add += p.temb[(size_t)n * p.temb_stride + p.temb_off + co];
+      size_t offs[MB][16];
+      float rv[MB][16];
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int pp = (wm * MB + mb) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+          offs[mb][i] = ((size_t)(n * p.Hout + oy0 + pp / TW) * p.Wout + ox0 + pp % TW) * p.Cout + co;
+          rv[mb][i] = p.res ? p.res[offs[mb][i]] : 0.f;
+        }
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) p.out[offs[mb][i]] = acc[mb][nb][i] + add + rv[mb][i];
+    }
+    return;
+  }
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
     const int co = co0 + (wn * NB + nb) * 32 + r31;
