@@ -62,9 +62,7 @@ __global__ void __launch_bounds__(512, 2) conv_mfma_h_kernel(const ConvParams p)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_h[];
   unsigned char* sBuf0 = smem_h;
   unsigned char* sBuf1 = smem_h + Cfg::BUF_BYTES;
-  float* sScale = reinterpret_cast<float*>(smem_h + 2 * Cfg::BUF_BYTES);
   const int Cin = p.C0 + p.C1;
-  float* sShift = sScale + Cin;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave % WN, wm = wave / WN;
@@ -85,22 +83,7 @@ __global__ void __launch_bounds__(512, 2) conv_mfma_h_kernel(const ConvParams p)
   const int n = pt / tilesY;
   const int oy0 = ty * TH, ox0 = tx * TW, co0 = cot * BN;
 
-  const bool gn = p.gn_stats != nullptr;
-  if (gn) {
-    const double inv_cnt = 1.0 / ((double)p.cpg * (double)p.Hin * (double)p.Win);
-    for (int c = tid; c < Cin; c += 512) {
-      const int g = c / p.cpg;
-      const double sum = p.gn_stats[((size_t)n * p.G + g) * 2 + 0];
-      const double sq = p.gn_stats[((size_t)n * p.G + g) * 2 + 1];
-      const double mean = sum * inv_cnt;
-      double var = sq * inv_cnt - mean * mean;
-      var = var < 0.0 ? 0.0 : var;
-      const float rstd = (float)(1.0 / sqrt(var + (double)p.gn_eps));
-      const float sc = rstd * p.gn_gamma[c];
-      sScale[c] = sc;
-      sShift[c] = p.gn_beta[c] - (float)mean * sc;
-    }
-  }
+  const bool gn = p.gn_scale != nullptr;
 
   // ---- staging indices (chunk invariant): thread -> (halo pixel row0 + i*128, float4 slot q) ----
   const int q = tid & 3, row0 = tid >> 2;
@@ -124,12 +107,17 @@ __global__ void __launch_bounds__(512, 2) conv_mfma_h_kernel(const ConvParams p)
   }
 
   f32x4 rin[NIN];
+  f32x4 rsc = {1.f, 1.f, 1.f, 1.f}, rsh = {0.f, 0.f, 0.f, 0.f};
   auto prefetch = [&](int kc) {
     const int cbase = kc * KC;
     const float* base;
     int Cs, cc;
     if (cbase < p.C0) { base = p.x0; Cs = p.C0; cc = cbase + q * 4; }
     else { base = p.x1; Cs = p.C1; cc = cbase - p.C0 + q * 4; }
+    if (gn) {   // per-(image, channel) GroupNorm scale/shift travel with the input prefetch
+      rsc = *reinterpret_cast<const f32x4*>(p.gn_scale + (size_t)n * Cin + cbase + q * 4);
+      rsh = *reinterpret_cast<const f32x4*>(p.gn_shift + (size_t)n * Cin + cbase + q * 4);
+    }
 #pragma unroll
     for (int i = 0; i < NIN; ++i) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -138,12 +126,7 @@ __global__ void __launch_bounds__(512, 2) conv_mfma_h_kernel(const ConvParams p)
     }
   };
   auto stage = [&](int kc, unsigned char* buf) {
-    const int c = kc * KC + q * 4;
-    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-    if (gn) {
-      sc = *reinterpret_cast<const f32x4*>(sScale + c);
-      sh = *reinterpret_cast<const f32x4*>(sShift + c);
-    }
+    const f32x4 sc = rsc, sh = rsh;
 #pragma unroll
     for (int i = 0; i < NIN; ++i) {
       if (in_pix[i] == -2) continue;
@@ -197,11 +180,12 @@ __global__ void __launch_bounds__(512, 2) conv_mfma_h_kernel(const ConvParams p)
 #pragma unroll
   for (int tap = 0; tap < T; ++tap) load_b_tap(0, tap);
   prefetch(0);
-  __syncthreads();            // scale/shift visible
   stage(0, sBuf0);
   if (nk > 1) prefetch(1);
   __syncthreads();
 
+  constexpr int STG_A = T >= 9 ? 2 : 0, STG_B = T >= 9 ? 6 : 0;
+  const int stage_tap = __builtin_amdgcn_readfirstlane(wave) < 4 ? STG_A : STG_B;
   // A fragments are double-buffered over taps: the reads of tap t+1 are issued before the MFMAs
   // of tap t, so LDS latency hides under 3*MB MFMAs instead of being exposed per read.
   uint4 Af[2][MB][NP];
@@ -236,7 +220,9 @@ __global__ void __launch_bounds__(512, 2) conv_mfma_h_kernel(const ConvParams p)
         }
       }
       if (more) load_b_tap(kc + 1, tap);             // same registers, next chunk
-      if (tap == T / 2 && more) {                    // mid-chunk: fill the other halo buffer
+      // fill the other halo buffer mid-chunk; the two waves that share a SIMD (w, w+4) do their
+      // VALU-heavy staging at different taps so one of them keeps the matrix pipe fed
+      if ((tap == STG_A || tap == STG_B) && more && tap == stage_tap) {
         stage(kc + 1, nxt);
         if (kc + 2 < nk) prefetch(kc + 2);
       }
@@ -245,7 +231,8 @@ __global__ void __launch_bounds__(512, 2) conv_mfma_h_kernel(const ConvParams p)
   }
 
   // ---- epilogue.  Interior tiles take a branch-free path: per-element bounds branches make the
-  // compiler wait vmcnt(0) before every store (64 serialised stores per thread). ----
+  // compiler wait vmcnt(0) before every store.  Each lane also sums its outputs per channel
+  // (sum, sumsq): the consumer's GroupNorm statistics, reduced in a fixed order. ----
   const int co = co0 + wn * 32 + r31;
   const bool cok = co < p.Cout;
   float add = 0.f;
@@ -253,6 +240,7 @@ __global__ void __launch_bounds__(512, 2) conv_mfma_h_kernel(const ConvParams p)
     add = p.bias[co];
     if (p.temb) add += p.temb[(size_t)n * p.temb_stride + p.temb_off + co];
   }
+  float s1 = 0.f, s2 = 0.f;
   const bool interior = (oy0 + TH <= p.Hout) && (ox0 + TW <= p.Wout) && (co0 + BN <= p.Cout);
   if (interior) {
     float* obase = p.out + ((size_t)(n * p.Hout + oy0 + wm) * p.Wout + ox0 + 4 * h) * p.Cout + co;
@@ -273,40 +261,66 @@ __global__ void __launch_bounds__(512, 2) conv_mfma_h_kernel(const ConvParams p)
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-      for (int i = 0; i < 16; ++i)
-        obase[mb * rstride + (size_t)((i & 3) + 8 * (i >> 2)) * p.Cout] = acc[mb][i] * p.w_inv_scale + add + rv[mb][i];
-    return;
-  }
-  float rv[MB][16];
-  if (p.res) {
+      for (int i = 0; i < 16; ++i) {
+        const float v = acc[mb][i] * p.w_inv_scale + add + rv[mb][i];
+        obase[mb * rstride + (size_t)((i & 3) + 8 * (i >> 2)) * p.Cout] = v;
+        s1 += v;
+        s2 += v * v;
+      }
+  } else {
+    float rv[MB][16];
+    if (p.res) {
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int oy = oy0 + wm + mb * WM, ox = ox0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+          const bool ok = cok && oy < p.Hout && ox < p.Wout;
+          rv[mb][i] = ok ? p.res[((size_t)(n * p.Hout + oy) * p.Wout + ox) * p.Cout + co] : 0.f;
+        }
+    }
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int oy = oy0 + wm + mb * WM, ox = ox0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-        const bool ok = cok && oy < p.Hout && ox < p.Wout;
-        rv[mb][i] = ok ? p.res[((size_t)(n * p.Hout + oy) * p.Wout + ox) * p.Cout + co] : 0.f;
+        if (cok && oy < p.Hout && ox < p.Wout) {
+          float v = acc[mb][i] * p.w_inv_scale + add;
+          if (p.res) v += rv[mb][i];
+          p.out[((size_t)(n * p.Hout + oy) * p.Wout + ox) * p.Cout + co] = v;
+          s1 += v;
+          s2 += v * v;
+        }
       }
   }
-#pragma unroll
-  for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int oy = oy0 + wm + mb * WM, ox = ox0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-      if (cok && oy < p.Hout && ox < p.Wout) {
-        float v = acc[mb][i] * p.w_inv_scale + add;
-        if (p.res) v += rv[mb][i];
-        p.out[((size_t)(n * p.Hout + oy) * p.Wout + ox) * p.Cout + co] = v;
-      }
+  if (p.part_out) {
+    // the main loop ended with a barrier: the halo buffers are free
+    float* sp = reinterpret_cast<float*>(smem_h);   // [WM][BN][2]
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    if (h == 0) {
+      sp[(wm * BN + wn * 32 + r31) * 2 + 0] = s1;
+      sp[(wm * BN + wn * 32 + r31) * 2 + 1] = s2;
     }
+    __syncthreads();
+    if (tid < BN && co0 + tid < p.Cout) {
+      float a = 0.f, b = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) { a += sp[(w * BN + tid) * 2 + 0]; b += sp[(w * BN + tid) * 2 + 1]; }
+      float* dst = p.part_out + (((size_t)n * (tilesX * tilesY) + ty * tilesX + tx) * p.Cout + co0 + tid) * 2;
+      dst[0] = a;
+      dst[1] = b;
+    }
+  }
 }
 
 template <int KS, int STRIDE, bool UP, int TH, int WN, int PREC>
-static hipError_t launch_h_t(const ConvParams& p, hipStream_t s) {
+static hipError_t launch_h_t(const ConvParams& p, hipStream_t s, int* tiles) {
   using Cfg = ConvHCfg<KS, STRIDE, UP, TH, WN, PREC>;
   auto kfn = conv_mfma_h_kernel<KS, STRIDE, UP, TH, WN, PREC>;
-  const size_t lds = (size_t)2 * Cfg::BUF_BYTES + (size_t)2 * (p.C0 + p.C1) * sizeof(float);
+  const size_t lds = (size_t)2 * Cfg::BUF_BYTES;
   const int tilesX = (p.Wout + Cfg::TW - 1) / Cfg::TW, tilesY = (p.Hout + TH - 1) / TH;
+  if (tiles) *tiles = tilesX * tilesY;
   const int nwg = p.N * tilesX * tilesY * (p.Cout_pad / Cfg::BN);
   hipLaunchKernelGGL(kfn, dim3(nwg), dim3(512), lds, s, p);
   return hipGetLastError();
@@ -318,27 +332,49 @@ static hipError_t init_h_t() {
   return hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
-// X(KS, STRIDE, UP, TH, WN)
-#define FDSR_CONVH_SHAPES(X)                                                                   \
-  X(3, 1, false, 8, 4) X(3, 1, false, 8, 2) X(3, 1, false, 8, 1) X(3, 1, true, 8, 4) X(3, 1, true, 8, 2) \
-  X(3, 2, false, 4, 4) X(3, 2, false, 4, 2) X(1, 1, false, 8, 4) X(1, 1, false, 8, 2) X(1, 1, false, 8, 1)
+// X(KS, STRIDE, UP, TH, WN): TH in {4, 8, 16} rows of 32 pixels; TH % (8/WN) == 0; accumulators <= 64 VGPRs
+#define FDSR_CONVH_SHAPES(X)                                                                          \
+  X(3, 1, false, 8, 4) X(3, 1, false, 4, 4) X(3, 1, false, 16, 2) X(3, 1, false, 8, 2) X(3, 1, false, 4, 2)    \
+  X(3, 1, false, 16, 1) X(3, 1, false, 8, 1)                                                                  \
+  X(3, 1, true, 8, 4) X(3, 1, true, 4, 4) X(3, 1, true, 16, 2) X(3, 1, true, 8, 2) X(3, 1, true, 4, 2)         \
+  X(3, 2, false, 4, 4) X(3, 2, false, 4, 2)                                                                   \
+  X(1, 1, false, 8, 4) X(1, 1, false, 4, 4) X(1, 1, false, 16, 2) X(1, 1, false, 8, 2) X(1, 1, false, 4, 2)    \
+  X(1, 1, false, 16, 1) X(1, 1, false, 8, 1)
 
+// Output-channel split of the workgroup (weights are packed per WN, so this depends on the layer only).
 void conv_h_config(ConvKind kind, int Cout, int* TH, int* WN) {
   *WN = Cout >= 128 ? 4 : (Cout >= 64 ? 2 : 1);
-  *TH = kind == CONV3_S2 ? 4 : 8;
-  if (kind == CONV3_S2 && *WN == 1) *WN = 2;
-  if (kind == CONV3_UP && *WN == 1) *WN = 2;
+  if ((kind == CONV3_S2 || kind == CONV3_UP) && *WN == 1) *WN = 2;
+  *TH = kind == CONV3_S2 ? 4 : 8;   // default; launch_conv_h picks the final TH from the grid size
 }
 
-hipError_t launch_conv_h(ConvKind kind, int prec, const ConvParams& p, hipStream_t s) {
+// Rows per workgroup tile, chosen per launch: the largest tile that still gives every CU >= 2
+// workgroups; small feature maps fall back to smaller tiles so the 256 CUs are all used.
+static int pick_th(ConvKind kind, int WN, const ConvParams& p) {
+  if (kind == CONV3_S2) return 4;
+  const int cands[3] = {16, 8, 4};
+  const int tilesX = (p.Wout + 31) / 32, nco = p.Cout_pad / (32 * WN);
+  int best = -1;
+  for (int th : cands) {
+    const int WM = 8 / WN;
+    if (th % WM || th / WM > 4) continue;
+    const long wgs = (long)p.N * tilesX * ((p.Hout + th - 1) / th) * nco;
+    best = th;
+    if (wgs >= 512) break;
+  }
+  return best;
+}
+
+hipError_t launch_conv_h(ConvKind kind, int prec, const ConvParams& p, hipStream_t s, int* tiles) {
   int TH, WN;
   conv_h_config(kind, p.Cout, &TH, &WN);
+  TH = pick_th(kind, WN, p);
   const int ks = kind == CONV1 ? 1 : 3, stride = kind == CONV3_S2 ? 2 : 1;
   const bool up = kind == CONV3_UP;
 #define X(KS_, ST_, UP_, TH_, WN_)                                                                   \
   if (ks == KS_ && stride == ST_ && up == UP_ && TH == TH_ && WN == WN_) {                           \
-    return prec == PREC_F16X3 ? launch_h_t<KS_, ST_, UP_, TH_, WN_, PREC_F16X3>(p, s)                \
-                              : launch_h_t<KS_, ST_, UP_, TH_, WN_, PREC_BF16>(p, s);                \
+    return prec == PREC_F16X3 ? launch_h_t<KS_, ST_, UP_, TH_, WN_, PREC_F16X3>(p, s, tiles)         \
+                              : launch_h_t<KS_, ST_, UP_, TH_, WN_, PREC_BF16>(p, s, tiles);         \
   }
   FDSR_CONVH_SHAPES(X)
 #undef X

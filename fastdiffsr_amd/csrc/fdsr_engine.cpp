@@ -45,13 +45,14 @@ struct TensorDesc {
   int C = 0;
   int level = 0;        // spatial = (H >> level, W >> level)
   bool persistent = false;
+  bool need_part = false;  // feeds a GroupNorm: its producer also writes per-tile channel sums
   int first_def = -1, last_use = -1;
   size_t off = 0;       // byte offset inside the workspace (per plan)
   std::string name;     // reference module whose output this is ("" for temporaries)
 };
 
 struct Op {
-  enum Kind { GN_STATS, CONV, CLAM, SLAM } kind;
+  enum Kind { GN_FINALIZE, CONV, CLAM, SLAM } kind;
   std::string name;
   int src0 = -1, src1 = -1, dst = -1, res = -1;
   ConvKind ck = CONV3_S1;
@@ -67,8 +68,11 @@ struct ShapePlan {
   int N = 0, H = 0, W = 0;
   bool debug = false;
   size_t bytes = 0;
-  size_t off_stats = 0, off_temb = 0, off_gate = 0;
+  size_t off_temb = 0, off_gate = 0;
   std::vector<size_t> tensor_off;
+  std::vector<size_t> part_off;    // per tensor: per-tile channel sums [N][max_tiles][C][2] (0 = none)
+  std::vector<size_t> gn_off;      // per GroupNorm slot: scale [N][C] then shift [N][C]
+  std::vector<int> tensor_nt;      // tiles per image its producer actually used (set at launch)
 };
 
 struct GraphEntry {
@@ -88,6 +92,7 @@ struct fdsr_engine {
   std::vector<Op> ops;
   int t_in = -1, t_eps = -1, CP = 8;
   int n_gn_slots = 0, TE = 0, Cmid = 0;
+  std::vector<int> gn_channels;   // per GroupNorm slot
   int w_freq = -1;   // synthetic entry: positional-encoding frequencies
   size_t param_floats = 0, noise_w_off = 0, noise_b_off = 0;
   int w_mlp[4] = {-1, -1, -1, -1};
@@ -258,16 +263,19 @@ int build_plan(fdsr_handle h) {
     add_weight(h, p + ".conv.bias", {Cout}, false);
 
     // block1: GN -> Swish -> conv3x3, + noise shift
-    Op s1; s1.kind = Op::GN_STATS; s1.name = r + ".block1.gn"; s1.src0 = x0; s1.src1 = x1; s1.C0 = C0; s1.C1 = C1;
-    s1.lvl_in = lvl; s1.gn_slot = h->n_gn_slots++;
+    Op s1; s1.kind = Op::GN_FINALIZE; s1.name = r + ".block1.gn"; s1.src0 = x0; s1.src1 = x1; s1.C0 = C0; s1.C1 = C1;
+    s1.lvl_in = lvl; s1.gn_slot = h->n_gn_slots++; s1.gamma = g1; s1.beta = b1;
+    h->tensors[x0].need_part = true;
+    if (x1 >= 0) h->tensors[x1].need_part = true;
     h->ops.push_back(s1);
     Op k1; k1.kind = Op::CONV; k1.name = r + ".block1"; k1.ck = CONV3_S1; k1.src0 = x0; k1.src1 = x1; k1.C0 = C0; k1.C1 = C1;
     k1.Cout = Cout; k1.lvl_in = k1.lvl_out = lvl; k1.gn_slot = s1.gn_slot; k1.gamma = g1; k1.beta = b1; k1.w = w1; k1.b = c1;
     k1.temb_off = my_te; k1.dst = new_tensor(h, Cout, lvl, r + ".block1");
     h->ops.push_back(k1);
     // GN stats of h1
-    Op s2; s2.kind = Op::GN_STATS; s2.name = r + ".block2.gn"; s2.src0 = k1.dst; s2.C0 = Cout; s2.lvl_in = lvl;
-    s2.gn_slot = h->n_gn_slots++;
+    Op s2; s2.kind = Op::GN_FINALIZE; s2.name = r + ".block2.gn"; s2.src0 = k1.dst; s2.C0 = Cout; s2.lvl_in = lvl;
+    s2.gn_slot = h->n_gn_slots++; s2.gamma = g2; s2.beta = b2;
+    h->tensors[k1.dst].need_part = true;
     h->ops.push_back(s2);
     const int out = new_tensor(h, Cout, lvl, with_attn ? r : p);
     int res_src = x0;
@@ -355,7 +363,9 @@ int build_plan(fdsr_handle h) {
     int w = add_weight(h, "final_conv.block.3.weight", {c.out_channel, curC, 3, 3}, true);
     int cb = add_weight(h, "final_conv.block.3.bias", {c.out_channel}, true);
     mark_conv_pack(h, w, CONV3_S1, curC, curC, 0, c.out_channel);
-    Op s; s.kind = Op::GN_STATS; s.name = "final_conv.gn"; s.src0 = cur; s.C0 = curC; s.lvl_in = lvl; s.gn_slot = h->n_gn_slots++;
+    Op s; s.kind = Op::GN_FINALIZE; s.name = "final_conv.gn"; s.src0 = cur; s.C0 = curC; s.lvl_in = lvl; s.gn_slot = h->n_gn_slots++;
+    s.gamma = g; s.beta = b;
+    h->tensors[cur].need_part = true;
     h->ops.push_back(s);
     Op k; k.kind = Op::CONV; k.name = "final_conv"; k.ck = CONV3_S1; k.src0 = cur; k.C0 = curC; k.Cout = c.out_channel;
     k.lvl_in = k.lvl_out = lvl; k.gn_slot = s.gn_slot; k.gamma = g; k.beta = b; k.w = w; k.b = cb;
@@ -460,14 +470,27 @@ int make_shape_plan(fdsr_handle h, int N, int H, int W, ShapePlan* sp) {
     return fail(h, FDSR_E_INVALID, "batch>=1 and H,W multiples of %d required (got %d,%d,%d)", down, N, H, W);
   sp->N = N; sp->H = H; sp->W = W; sp->debug = h->debug;
   size_t off = 0;
-  sp->off_stats = off; off += align_up((size_t)h->n_gn_slots * N * h->cfg.norm_groups * 2 * sizeof(double), 256);
+  sp->gn_off.assign(h->n_gn_slots, 0);
+  for (const Op& op : h->ops)
+    if (op.kind == Op::GN_FINALIZE) {
+      sp->gn_off[op.gn_slot] = off;
+      off += align_up((size_t)2 * N * (op.C0 + op.C1) * sizeof(float), 256);
+    }
   sp->off_temb = off;  off += align_up((size_t)N * h->TE * sizeof(float), 256);
   sp->off_gate = off;  off += align_up((size_t)N * std::max(h->Cmid, 1) * sizeof(float), 256);
   const size_t arena0 = off;
   sp->tensor_off.assign(h->tensors.size(), 0);
-  auto tbytes = [&](const TensorDesc& t) {
+  sp->part_off.assign(h->tensors.size(), 0);
+  sp->tensor_nt.assign(h->tensors.size(), 0);
+  auto act_bytes = [&](const TensorDesc& t) {
     return align_up((size_t)N * (H >> t.level) * (W >> t.level) * t.C * sizeof(float), 256);
   };
+  auto part_bytes = [&](const TensorDesc& t) -> size_t {
+    if (!t.need_part) return 0;
+    const int mt = std::max(conv_max_tiles(H >> t.level, W >> t.level), FDSR_SLAM_PARTS);
+    return align_up((size_t)N * mt * t.C * 2 * sizeof(float), 256);
+  };
+  auto tbytes = [&](const TensorDesc& t) { return act_bytes(t) + part_bytes(t); };
   std::vector<Block> blocks;
   size_t arena_end = 0;
   auto alloc = [&](size_t need) -> size_t {
@@ -513,6 +536,8 @@ int make_shape_plan(fdsr_handle h, int N, int H, int W, ShapePlan* sp) {
           release(sp->tensor_off[t]);
   }
   for (auto& o : sp->tensor_off) o += arena0;
+  for (size_t t = 0; t < h->tensors.size(); ++t)
+    if (h->tensors[t].need_part) sp->part_off[t] = sp->tensor_off[t] + act_bytes(h->tensors[t]);
   sp->bytes = arena0 + arena_end;
   return FDSR_OK;
 }
@@ -535,15 +560,14 @@ double conv_flops(const Op& op, int N, int H, int W) {
 
 // One UNet forward over the plan; input already packed in tensor t_in.
 int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, float nl_scalar, hipStream_t st) {
-  const ShapePlan& sp = h->plan;
+  ShapePlan& sp = h->plan;
   const int G = h->cfg.norm_groups;
-  double* stats = reinterpret_cast<double*>(ws + sp.off_stats);
   float* temb = reinterpret_cast<float*>(ws + sp.off_temb);
   float* gate = reinterpret_cast<float*>(ws + sp.off_gate);
   auto P = [&](int widx) -> const float* { return widx >= 0 ? h->d_params + h->weights[widx].dev_off : nullptr; };
   auto TP = [&](int t) -> float* { return t >= 0 ? reinterpret_cast<float*>(ws + sp.tensor_off[t]) : nullptr; };
 
-  HIPCHK(h, hipMemsetAsync(stats, 0, (size_t)h->n_gn_slots * N * G * 2 * sizeof(double), st));
+  auto PART = [&](int t) -> float* { return (t >= 0 && sp.part_off[t]) ? reinterpret_cast<float*>(ws + sp.part_off[t]) : nullptr; };
   {
     TembParams tp;
     tp.freq = P(h->w_freq);
@@ -564,10 +588,19 @@ int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, 
   for (const Op& op : h->ops) {
     const int Hi = H >> op.lvl_in, Wi = W >> op.lvl_in;
     switch (op.kind) {
-      case Op::GN_STATS:
-        HIPCHK(h, launch_gn_stats(TP(op.src0), TP(op.src1), op.C0, op.C1, N, Hi * Wi, G,
-                                  stats + (size_t)op.gn_slot * N * G * 2, st));
+      case Op::GN_FINALIZE: {
+        GnFinalizeParams g{};
+        g.part0 = PART(op.src0); g.nt0 = sp.tensor_nt[op.src0]; g.C0 = op.C0;
+        g.part1 = PART(op.src1); g.nt1 = op.src1 >= 0 ? sp.tensor_nt[op.src1] : 0; g.C1 = op.C1;
+        if (!g.part0 || g.nt0 <= 0 || (op.src1 >= 0 && (!g.part1 || g.nt1 <= 0)))
+          return fail(h, FDSR_E_STATE, "internal: GroupNorm input of %s has no partial sums", op.name.c_str());
+        g.gamma = P(op.gamma); g.beta = P(op.beta);
+        g.scale = reinterpret_cast<float*>(ws + sp.gn_off[op.gn_slot]);
+        g.shift = g.scale + (size_t)N * (op.C0 + op.C1);
+        g.N = N; g.G = G; g.HW = Hi * Wi; g.eps = 1e-5f;
+        HIPCHK(h, launch_gn_finalize(g, st));
         break;
+      }
       case Op::CONV: {
         ConvParams p{};
         const WeightEntry& w = h->weights[op.w];
@@ -581,15 +614,15 @@ int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, 
         p.res = TP(op.res);
         p.out = TP(op.dst);
         if (op.gn_slot >= 0) {
-          p.gn_stats = stats + (size_t)op.gn_slot * N * G * 2;
-          p.gn_gamma = P(op.gamma);
-          p.gn_beta = P(op.beta);
+          p.gn_scale = reinterpret_cast<const float*>(ws + sp.gn_off[op.gn_slot]);
+          p.gn_shift = p.gn_scale + (size_t)N * (op.C0 + op.C1);
         }
+        p.part_out = op.ck == CONV1 ? nullptr : PART(op.dst);   // res_conv output is overwritten in place by block2
+        int nt = 0;
         p.N = N; p.Hin = Hi; p.Win = Wi;
         p.Hout = H >> op.lvl_out; p.Wout = W >> op.lvl_out;
         p.C0 = op.C0; p.C1 = op.C1; p.Cout = op.Cout;
         p.Cin_pad = w.cin_pad; p.Cout_pad = w.cout_pad;
-        p.G = G; p.cpg = (op.C0 + op.C1) / G; p.gn_eps = 1e-5f;
         const bool timed = h->profiling && op.ck != CONV1;
         if (timed) {
           if (h->ev_used + 2 > h->ev_pool.size()) {
@@ -602,10 +635,11 @@ int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, 
           p.w_inv_scale = w.h_inv_scale[h->prec];
           p.Cin_pad = w.h_cin_pad;
           p.Cout_pad = w.h_cout_pad;
-          HIPCHK(h, launch_conv_h(op.ck, h->prec, p, st));
+          HIPCHK(h, launch_conv_h(op.ck, h->prec, p, st, &nt));
         } else {
-          HIPCHK(h, launch_conv(op.ck, p, st));
+          HIPCHK(h, launch_conv(op.ck, p, st, &nt));
         }
+        sp.tensor_nt[op.dst] = nt;
         if (timed) {
           HIPCHK(h, hipEventRecord(h->ev_pool[h->ev_used++], st));
           double f = conv_flops(op, N, H, W);
@@ -620,7 +654,8 @@ int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, 
         HIPCHK(h, launch_clam_gate(TP(op.src0), N, Hi * Wi, op.C0, P(op.fc1), P(op.fc2), op.C0 / 16, gate, st));
         break;
       case Op::SLAM:
-        HIPCHK(h, launch_slam(TP(op.src0), gate, P(op.w), N, Hi, Wi, op.C0, TP(op.dst), nullptr, st));
+        HIPCHK(h, launch_slam(TP(op.src0), gate, P(op.w), N, Hi, Wi, op.C0, TP(op.dst), PART(op.dst), st));
+        sp.tensor_nt[op.dst] = FDSR_SLAM_PARTS;
         break;
     }
   }

@@ -19,17 +19,14 @@ struct ConvParams {
   const float* temb;     // [N][temb_stride] + temb_off, or null (FeatureWiseAffine shift, unet.py:38-54)
   const float* res;      // residual [N,Hout,Wout,Cout] or null (may alias out)
   float* out;            // [N,Hout,Wout,Cout]
-  const double* gn_stats;  // [N][G][2] (sum, sumsq) of the GN input, or null
-  const float* gn_gamma;   // [C0+C1]
-  const float* gn_beta;
-  double* out_stats;       // optional: accumulate (sum,sumsq) of OUT per (n, group) for the next GN
-  int out_cpg;             // channels per group of out (Cout / G)
+  const float* gn_scale;   // [N][C0+C1] per-channel GroupNorm scale = rstd*gamma (null: no GN+Swish)
+  const float* gn_shift;   // [N][C0+C1] beta - mean*scale        (gn_finalize_kernel writes both)
+  float* part_out;         // optional [N][tiles][Cout][2]: per-tile (sum, sumsq) of OUT per channel,
+                           // the GroupNorm statistics of the next Block, fused into this epilogue
   int N, Hin, Win;       // source tensor dims (before upsample)
   int Hout, Wout;
   int C0, C1, Cout;
   int Cin_pad, Cout_pad;
-  int G, cpg;            // groups, channels per group of the GN input
-  float gn_eps;
   int temb_stride, temb_off;
   // 16-bit MFMA path (fdsr_conv_h.hip): weights in MFMA-fragment order, see pack_weights_h()
   const void* wq;
@@ -43,20 +40,32 @@ enum ConvKind { CONV3_S1 = 0, CONV3_S2 = 1, CONV3_UP = 2, CONV1 = 3 };
 // KC (K-chunk) / BN (Cout tile) the launcher will use for this shape; the packer
 // pads weights accordingly.
 void conv_tile_config(ConvKind kind, int C0, int C1, int Cout, int* KC, int* BN);
-hipError_t launch_conv(ConvKind kind, const ConvParams& p, hipStream_t s);
+hipError_t launch_conv(ConvKind kind, const ConvParams& p, hipStream_t s, int* tiles_per_image);
 // Raise the dynamic-LDS limit of every kernel that needs more than 64 KB.  Must run
 // once per process before any launch (and outside stream capture).
 hipError_t kernels_init();
 
 // 16-bit-operand MFMA convolutions (fp32-grade f16x3 split, or plain bf16).
 void conv_h_config(ConvKind kind, int Cout, int* TH, int* WN);   // BN = 32*WN, K-chunk = 16
-hipError_t launch_conv_h(ConvKind kind, int prec, const ConvParams& p, hipStream_t s);
+hipError_t launch_conv_h(ConvKind kind, int prec, const ConvParams& p, hipStream_t s, int* tiles_per_image);
 hipError_t kernels_h_init();
 
-// (sum, sumsq) per (n, group) of the virtual concat (x0,x1), accumulated in fp64
-// atomics into stats[N][G][2] (must be zeroed beforehand).
-hipError_t launch_gn_stats(const float* x0, const float* x1, int C0, int C1, int N, int HW,
-                           int G, double* stats, hipStream_t s);
+// GroupNorm finalisation: per-tile per-channel partial sums (written by the producers' epilogues,
+// fixed summation order => bitwise reproducible) of the virtual concat (x0: C0, x1: C1 channels)
+// -> per-(n, channel) scale = rstd*gamma and shift = beta - mean*scale (biased variance, eps inside
+// the sqrt: torch.nn.GroupNorm, reference unet.py:93).  Groups may straddle the concat seam.
+struct GnFinalizeParams {
+  const float* part0; int nt0, C0;
+  const float* part1; int nt1, C1;
+  const float* gamma; const float* beta;   // [C0+C1]
+  float* scale; float* shift;              // [N][C0+C1]
+  int N, G, HW;
+  float eps;
+};
+hipError_t launch_gn_finalize(const GnFinalizeParams& p, hipStream_t s);
+// upper bound of tiles_per_image over every conv kernel variant (sizes the partial buffers)
+int conv_max_tiles(int H, int W);
+#define FDSR_SLAM_PARTS 16
 
 // noise-level embedding: PositionalEncoding -> Linear -> Swish -> Linear
 // (unet.py:22-35, :242-248) and the per-ResnetBlock shift Linear(inner -> Cout)
@@ -81,9 +90,9 @@ hipError_t launch_temb(const TembParams& p, hipStream_t s);
 hipError_t launch_clam_gate(const float* x, int N, int HW, int C, const float* fc1 /*[C/16][C]*/,
                             const float* fc2 /*[C][C/16]*/, int Cr, float* gate, hipStream_t s);
 // SLAM applied to (x * gate) (unet.py:151-173): out = y * sigmoid(conv7x7([mean_c y, max_c y]))
+// part_out (optional): [N][FDSR_SLAM_PARTS][C][2] per-wave partial (sum, sumsq) of out per channel.
 hipError_t launch_slam(const float* x, const float* gate, const float* w7 /*[2][7][7]*/,
-                       int N, int H, int W, int C, float* out, float* map_scratch /*[N][2][H][W]*/,
-                       hipStream_t s);
+                       int N, int H, int W, int C, float* out, float* part_out, hipStream_t s);
 
 // layout changes at the boundary
 hipError_t launch_nchw_to_nhwc(const float* src, float* dst, int N, int Csrc, int H, int W,

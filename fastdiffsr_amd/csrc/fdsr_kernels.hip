@@ -64,9 +64,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_f32_kernel(const ConvParams 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sIn = smem;
   float* sW = smem + NPIX * S;
-  float* sScale = smem + Cfg::LDS_FLOATS;
   const int Cin = p.C0 + p.C1;
-  float* sShift = sScale + Cin;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -91,24 +89,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_f32_kernel(const ConvParams 
   const int n = pt / tilesY;
   const int oy0 = ty * TH, ox0 = tx * TW, co0 = cot * BN;
 
-  const bool gn = p.gn_stats != nullptr;
-  if (gn) {
-    // finalize GroupNorm statistics into per-channel scale/shift:
-    // y = (x-mean)*rstd*gamma+beta = x*scale + shift   (unet.py:93, eps inside sqrt)
-    const double inv_cnt = 1.0 / ((double)p.cpg * (double)p.Hin * (double)p.Win);
-    for (int c = tid; c < Cin; c += 256) {
-      const int g = c / p.cpg;
-      const double sum = p.gn_stats[((size_t)n * p.G + g) * 2 + 0];
-      const double sq = p.gn_stats[((size_t)n * p.G + g) * 2 + 1];
-      const double mean = sum * inv_cnt;
-      double var = sq * inv_cnt - mean * mean;
-      var = var < 0.0 ? 0.0 : var;
-      const float rstd = (float)(1.0 / sqrt(var + (double)p.gn_eps));
-      const float sc = rstd * p.gn_gamma[c];
-      sScale[c] = sc;
-      sShift[c] = p.gn_beta[c] - (float)mean * sc;
-    }
-  }
+  const bool gn = p.gn_scale != nullptr;
 
   // ---- chunk-invariant staging indices ----
   const int q = tid % Q;      // float4 slot inside the KC chunk
@@ -134,12 +115,17 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_f32_kernel(const ConvParams 
 
   f32x4 rin[NIN];
   f32x4 rw[NW];
+  f32x4 rsc = {1.f, 1.f, 1.f, 1.f}, rsh = {0.f, 0.f, 0.f, 0.f};
   auto prefetch = [&](int kc) {
     const int cbase = kc * KC;
     const float* base;
     int Cs, cc;
     if (cbase < p.C0) { base = p.x0; Cs = p.C0; cc = cbase + q * 4; }
     else { base = p.x1; Cs = p.C1; cc = cbase - p.C0 + q * 4; }
+    if (gn) {   // y = x*scale + shift, per (image, channel): travels with the input prefetch
+      rsc = *reinterpret_cast<const f32x4*>(p.gn_scale + (size_t)n * Cin + cbase + q * 4);
+      rsh = *reinterpret_cast<const f32x4*>(p.gn_shift + (size_t)n * Cin + cbase + q * 4);
+    }
 #pragma unroll
     for (int i = 0; i < NIN; ++i) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -158,12 +144,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_f32_kernel(const ConvParams 
     }
   };
   auto stage = [&](int kc) {
-    const int c = kc * KC + q * 4;
-    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-    if (gn) {
-      sc = *reinterpret_cast<const f32x4*>(sScale + c);
-      sh = *reinterpret_cast<const f32x4*>(sShift + c);
-    }
+    const f32x4 sc = rsc, sh = rsh;
 #pragma unroll
     for (int i = 0; i < NIN; ++i) {
       if (in_pix[i] == -2) continue;
@@ -234,8 +215,12 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_f32_kernel(const ConvParams 
 
   // ---- epilogue: C/D map col = lane&31 (Cout), row = (i&3) + 8*(i>>2) + 4*(lane>>5) (pixel).
   // `res` may alias `out` (in-place residual), so ALL residual loads are issued before the
-  // first store: otherwise the compiler must serialise 32 load->wait->store round trips.
-  // Interior tiles take a branch-free path (per-element bounds branches force vmcnt(0) per store). ----
+  // first store.  Interior tiles take a branch-free path (per-element bounds branches force a
+  // vmcnt(0) before every store).  Each lane also sums its outputs (sum, sumsq) per channel:
+  // the GroupNorm statistics of the consumer, reduced over the workgroup in a fixed order. ----
+  float s1[NB], s2[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) s1[nb] = s2[nb] = 0.f;
   if ((oy0 + TH <= p.Hout) && (ox0 + TW <= p.Wout) && (co0 + BN <= p.Cout)) {
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
@@ -255,56 +240,86 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_f32_kernel(const ConvParams 
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) p.out[offs[mb][i]] = acc[mb][nb][i] + add + rv[mb][i];
+        for (int i = 0; i < 16; ++i) {
+          const float v = acc[mb][nb][i] + add + rv[mb][i];
+          p.out[offs[mb][i]] = v;
+          s1[nb] += v;
+          s2[nb] += v * v;
+        }
     }
-    return;
-  }
+  } else {
 #pragma unroll
-  for (int nb = 0; nb < NB; ++nb) {
-    const int co = co0 + (wn * NB + nb) * 32 + r31;
-    const bool cok = co < p.Cout;
-    float add = 0.f;
-    if (cok) {
-      add = p.bias[co];
-      if (p.temb) add += p.temb[(size_t)n * p.temb_stride + p.temb_off + co];
-    }
-    float rv[MB][16];
-    if (p.res) {
+    for (int nb = 0; nb < NB; ++nb) {
+      const int co = co0 + (wn * NB + nb) * 32 + r31;
+      const bool cok = co < p.Cout;
+      float add = 0.f;
+      if (cok) {
+        add = p.bias[co];
+        if (p.temb) add += p.temb[(size_t)n * p.temb_stride + p.temb_off + co];
+      }
+      float rv[MB][16];
+      if (p.res) {
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb)
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int pp = (wm * MB + mb) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            const int oy = oy0 + pp / TW, ox = ox0 + pp % TW;
+            const bool ok = cok && oy < p.Hout && ox < p.Wout;
+            const size_t off = ((size_t)(n * p.Hout + oy) * p.Wout + ox) * p.Cout + co;
+            rv[mb][i] = ok ? p.res[off] : 0.f;
+          }
+      }
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int pp = (wm * MB + mb) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
           const int oy = oy0 + pp / TW, ox = ox0 + pp % TW;
-          const bool ok = cok && oy < p.Hout && ox < p.Wout;
-          const size_t off = ((size_t)(n * p.Hout + oy) * p.Wout + ox) * p.Cout + co;
-          rv[mb][i] = ok ? p.res[off] : 0.f;
-        }
-    }
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int pp = (wm * MB + mb) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-        const int oy = oy0 + pp / TW, ox = ox0 + pp % TW;
-        if (cok && oy < p.Hout && ox < p.Wout) {
-          const size_t off = ((size_t)(n * p.Hout + oy) * p.Wout + ox) * p.Cout + co;
-          float v = acc[mb][nb][i] + add;
-          if (p.res) v += rv[mb][i];
-          p.out[off] = v;
+          if (cok && oy < p.Hout && ox < p.Wout) {
+            const size_t off = ((size_t)(n * p.Hout + oy) * p.Wout + ox) * p.Cout + co;
+            float v = acc[mb][nb][i] + add;
+            if (p.res) v += rv[mb][i];
+            p.out[off] = v;
+            s1[nb] += v;
+            s2[nb] += v * v;
+          }
         }
       }
+    }
+  }
+  if (p.part_out) {
+    __syncthreads();                     // every wave is done with the LDS tiles
+    float* sp = smem;                    // [WM][BN][2]
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const float a = s1[nb] + __shfl_xor(s1[nb], 32, 64), b = s2[nb] + __shfl_xor(s2[nb], 32, 64);
+      if (h == 0) {
+        const int cl = (wn * NB + nb) * 32 + r31;
+        sp[(wm * BN + cl) * 2 + 0] = a;
+        sp[(wm * BN + cl) * 2 + 1] = b;
+      }
+    }
+    __syncthreads();
+    if (tid < BN && co0 + tid < p.Cout) {
+      float a = 0.f, b = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) { a += sp[(w * BN + tid) * 2 + 0]; b += sp[(w * BN + tid) * 2 + 1]; }
+      float* dst = p.part_out + (((size_t)n * (tilesX * tilesY) + ty * tilesX + tx) * p.Cout + co0 + tid) * 2;
+      dst[0] = a;
+      dst[1] = b;
     }
   }
 }
 
 template <int KS, int STRIDE, bool UP, int KC, int BN, int WM>
-static hipError_t launch_conv_t(const ConvParams& p, hipStream_t s) {
+static hipError_t launch_conv_t(const ConvParams& p, hipStream_t s, int* tiles) {
   using Cfg = ConvCfg<KS, STRIDE, UP, KC, BN, WM>;
   auto kfn = conv_mfma_f32_kernel<KS, STRIDE, UP, KC, BN, WM>;
-  const size_t lds = (size_t)(Cfg::LDS_FLOATS + 2 * (p.C0 + p.C1)) * sizeof(float);
+  const size_t lds = (size_t)Cfg::LDS_FLOATS * sizeof(float);
   const int tilesX = (p.Wout + Cfg::TW - 1) / Cfg::TW, tilesY = (p.Hout + Cfg::TH - 1) / Cfg::TH;
   const int nwg = p.N * tilesX * tilesY * (p.Cout_pad / BN);
+  if (tiles) *tiles = tilesX * tilesY;
   hipLaunchKernelGGL(kfn, dim3(nwg), dim3(256), lds, s, p);
   return hipGetLastError();
 }
@@ -333,74 +348,71 @@ void conv_tile_config(ConvKind kind, int C0, int C1, int Cout, int* KC, int* BN)
   }
 }
 
-hipError_t launch_conv(ConvKind kind, const ConvParams& p, hipStream_t s) {
+hipError_t launch_conv(ConvKind kind, const ConvParams& p, hipStream_t s, int* tiles) {
   int KC, BN;
   conv_tile_config(kind, p.C0, p.C1, p.Cout, &KC, &BN);
   int ks = kind == CONV1 ? 1 : 3, stride = kind == CONV3_S2 ? 2 : 1;
   bool up = kind == CONV3_UP;
 #define X(KS_, ST_, UP_, KC_, BN_, WM_) \
-  if (ks == KS_ && stride == ST_ && up == UP_ && KC == KC_ && BN == BN_) return launch_conv_t<KS_, ST_, UP_, KC_, BN_, WM_>(p, s);
+  if (ks == KS_ && stride == ST_ && up == UP_ && KC == KC_ && BN == BN_) return launch_conv_t<KS_, ST_, UP_, KC_, BN_, WM_>(p, s, tiles);
   FDSR_CONV_INSTANCES(X)
 #undef X
   return hipErrorInvalidValue;
 }
 
 // ---------------------------------------------------------------------------
-// GroupNorm statistics: (sum, sumsq) per (n, group) over the virtual concat
+// GroupNorm finalisation from the producers' per-tile partial sums
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) gn_stats_kernel(const float* __restrict__ x0, const float* __restrict__ x1,
-                                                       int C0, int C1, int HW, int G, int slab, double* stats) {
-  extern __shared__ __attribute__((aligned(16))) float sred[];   // [2][C]
-  const int C = C0 + C1, cols = C >> 2, tid = threadIdx.x;
-  const int n = blockIdx.y;
-  const int p0 = blockIdx.x * slab;
-  const int p1 = min(p0 + slab, HW);
-  for (int i = tid; i < 2 * C; i += 256) sred[i] = 0.f;
-  __syncthreads();
-  const int rows = 256 / cols;   // launcher guarantees cols <= 256
-  const int col = tid % cols, r = tid / cols;
-  if (r < rows) {
-    const int c = col * 4;
-    const float* base;
-    int Cs, cc;
-    if (c < C0) { base = x0; Cs = C0; cc = c; } else { base = x1; Cs = C1; cc = c - C0; }
-    base += (size_t)n * HW * Cs + cc;
-    f32x4 s0 = {0, 0, 0, 0}, q0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0}, q1 = {0, 0, 0, 0};
-    int pix = p0 + r;
-    for (; pix + rows < p1; pix += 2 * rows) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(base + (size_t)pix * Cs);
-      const f32x4 b = *reinterpret_cast<const f32x4*>(base + (size_t)(pix + rows) * Cs);
-      s0 += a; q0 += a * a; s1 += b; q1 += b * b;
+__global__ void __launch_bounds__(256) gn_finalize_kernel(const GnFinalizeParams p) {
+  extern __shared__ __attribute__((aligned(16))) double sd[];   // [C][2] channel sums | [G][2] mean, rstd
+  const int C = p.C0 + p.C1, tid = threadIdx.x, n = blockIdx.x;
+  double* gs = sd + 2 * C;
+  for (int c = tid; c < C; c += 256) {
+    const float* part;
+    int nt, Cs, cc;
+    if (c < p.C0) { part = p.part0; nt = p.nt0; Cs = p.C0; cc = c; } else { part = p.part1; nt = p.nt1; Cs = p.C1; cc = c - p.C0; }
+    const float* src = part + ((size_t)n * nt * Cs + cc) * 2;
+    double a = 0.0, b = 0.0;
+    for (int t = 0; t < nt; ++t) {          // fixed order: bitwise reproducible
+      const float2 v = *reinterpret_cast<const float2*>(src + (size_t)t * Cs * 2);
+      a += (double)v.x;
+      b += (double)v.y;
     }
-    if (pix < p1) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(base + (size_t)pix * Cs);
-      s0 += a; q0 += a * a;
-    }
-    s0 += s1; q0 += q1;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      atomicAdd(&sred[c + k], s0[k]);
-      atomicAdd(&sred[C + c + k], q0[k]);
-    }
+    sd[2 * c] = a;
+    sd[2 * c + 1] = b;
   }
   __syncthreads();
-  if (tid < G) {
-    const int cpg = C / G;
+  const int cpg = C / p.G;
+  if (tid < p.G) {
     double a = 0.0, b = 0.0;
-    for (int k = 0; k < cpg; ++k) { a += (double)sred[tid * cpg + k]; b += (double)sred[C + tid * cpg + k]; }
-    atomicAdd(&stats[((size_t)n * G + tid) * 2 + 0], a);
-    atomicAdd(&stats[((size_t)n * G + tid) * 2 + 1], b);
+    for (int k = 0; k < cpg; ++k) { a += sd[2 * (tid * cpg + k)]; b += sd[2 * (tid * cpg + k) + 1]; }
+    const double inv = 1.0 / ((double)cpg * (double)p.HW);
+    const double mean = a * inv;
+    double var = b * inv - mean * mean;
+    var = var < 0.0 ? 0.0 : var;
+    gs[2 * tid] = mean;
+    gs[2 * tid + 1] = 1.0 / sqrt(var + (double)p.eps);
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    const int g = c / cpg;
+    const float sc = (float)gs[2 * g + 1] * p.gamma[c];
+    p.scale[(size_t)n * C + c] = sc;
+    p.shift[(size_t)n * C + c] = p.beta[c] - (float)gs[2 * g] * sc;
   }
 }
 
-hipError_t launch_gn_stats(const float* x0, const float* x1, int C0, int C1, int N, int HW, int G,
-                           double* stats, hipStream_t s) {
-  const int C = C0 + C1;
-  if (C % 4 || C0 % 4 || C / 4 > 256 || C % G) return hipErrorInvalidValue;
-  const int slab = HW >= 16384 ? 512 : 128;
-  dim3 grid((HW + slab - 1) / slab, N);
-  hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(256), 2 * C * sizeof(float), s, x0, x1, C0, C1, HW, G, slab, stats);
+hipError_t launch_gn_finalize(const GnFinalizeParams& p, hipStream_t s) {
+  const int C = p.C0 + p.C1;
+  if (C % p.G || C > 2048) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(p.N), dim3(256), (size_t)(2 * C + 2 * p.G) * sizeof(double), s, p);
   return hipGetLastError();
+}
+
+int conv_max_tiles(int H, int W) {
+  // f32 kernel: 8x16 tiles; 16-bit kernels: TH x 32 with TH >= 4
+  const int a = ((H + 7) / 8) * ((W + 15) / 16), b = ((H + 3) / 4) * ((W + 31) / 32);
+  return a > b ? a : b;
 }
 
 // ---------------------------------------------------------------------------
@@ -523,7 +535,8 @@ hipError_t launch_clam_gate(const float* x, int N, int HW, int C, const float* f
 // SLAM on y = x*gate: channel mean/max -> 7x7 conv -> sigmoid -> scale   (unet.py:151-173)
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024) slam_kernel(const float* __restrict__ x, const float* __restrict__ gate,
-                                                    const float* __restrict__ w7, int H, int W, int C, float* out) {
+                                                    const float* __restrict__ w7, int H, int W, int C, float* out,
+                                                    float* part_out) {
   extern __shared__ __attribute__((aligned(16))) float sm[];   // map[2][HW] | sig[HW] | w[98]
   const int HW = H * W, tid = threadIdx.x, n = blockIdx.x;
   float* mp = sm;
@@ -564,21 +577,31 @@ __global__ void __launch_bounds__(1024) slam_kernel(const float* __restrict__ x,
   }
   __syncthreads();
   float* ob = out + (size_t)n * HW * C;
-  for (int pix = wave; pix < HW; pix += 16) {
-    const float sg = sig[pix];
-    for (int c = lane * 4; c < C; c += 256) {
+  // channel chunk outermost so each lane keeps one (sum, sumsq) pair per channel quad: the
+  // per-wave partials are the GroupNorm statistics input of the next block (mid.1.block1)
+  for (int c = lane * 4; c < C; c += 256) {
+    const f32x4 g = *reinterpret_cast<const f32x4*>(gb + c);
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+    for (int pix = wave; pix < HW; pix += 16) {
       const f32x4 v = *reinterpret_cast<const f32x4*>(xb + (size_t)pix * C + c);
-      const f32x4 g = *reinterpret_cast<const f32x4*>(gb + c);
-      *reinterpret_cast<f32x4*>(ob + (size_t)pix * C + c) = sg * (g * v);
+      const f32x4 o = sig[pix] * (g * v);
+      *reinterpret_cast<f32x4*>(ob + (size_t)pix * C + c) = o;
+      a += o;
+      b += o * o;
+    }
+    if (part_out) {
+      float* dst = part_out + (((size_t)n * FDSR_SLAM_PARTS + wave) * C + c) * 2;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { dst[2 * e] = a[e]; dst[2 * e + 1] = b[e]; }
     }
   }
 }
 
 hipError_t launch_slam(const float* x, const float* gate, const float* w7, int N, int H, int W, int C, float* out,
-                       float* /*map_scratch*/, hipStream_t s) {
+                       float* part_out, hipStream_t s) {
   const size_t lds = (size_t)(3 * H * W + 128) * sizeof(float);
   if (lds > 150 * 1024 || C % 4) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(slam_kernel, dim3(N), dim3(1024), lds, s, x, gate, w7, H, W, C, out);
+  hipLaunchKernelGGL(slam_kernel, dim3(N), dim3(1024), lds, s, x, gate, w7, H, W, C, out, part_out);
   return hipGetLastError();
 }
 

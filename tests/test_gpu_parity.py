@@ -197,9 +197,9 @@ def test_batch16_properties(full):
     one = eng.sample(c[i:i + 1].contiguous(), n[:, i:i + 1].contiguous())
     d_b = (one - out[i:i + 1]).abs().max().item()
     report(f'B=16 256x256: rerun max|d|={d_rep:.3e}  batch-independence max|d|={d_b:.3e}')
-    # GroupNorm statistics use fp64 atomics (arrival order differs run to run); the loop's
-    # early steps amplify last-bit differences, so reruns agree to ~1e-4, not bitwise
-    assert d_rep <= TOL_LOOP / 4 and d_b <= TOL_LOOP / 4
+    # no atomics anywhere on the path (GroupNorm statistics are per-tile partials summed in a fixed
+    # order): a rerun is bitwise identical, like the reference's CPU loop (SURVEY 8c noise floor)
+    assert d_rep == 0.0 and d_b <= TOL_LOOP / 4
 
 
 @pytest.mark.parametrize('prec,tol_fwd,tol_loop', [('f16x3', 1e-4, 1e-3), ('bf16', 0.25, None)])
