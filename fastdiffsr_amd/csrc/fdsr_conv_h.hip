@@ -23,6 +23,8 @@
 //   * epilogue as in the fp32 kernel (bias + noise-embedding shift + residual, NHWC stores)
 #include "fdsr_kernels.h"
 
+#include <cstdlib>
+
 namespace fdsr {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -34,7 +36,7 @@ typedef __bf16 b4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float silu_h(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
-template <int KS, int STRIDE, bool UP, int TH, int WN, int PREC>
+template <int KS, int STRIDE, bool UP, int TH, int WN, int PREC, int NW>
 struct ConvHCfg {
   static constexpr int TW = 32, KC = 16;
   static constexpr int NP = PREC == PREC_F16X3 ? 2 : 1;
@@ -43,19 +45,20 @@ struct ConvHCfg {
   static constexpr int HH = (TH - 1) * STRIDE + KS;
   static constexpr int HWD = (TW - 1) * STRIDE + KS;
   static constexpr int NPIX = HH * HWD;
-  static constexpr int WM = 8 / WN;
+  static constexpr int WM = NW / WN;
   static constexpr int BN = 32 * WN;
   static constexpr int MB = TH / WM;
-  static constexpr int RPP = 512 / 4;          // halo pixels filled per pass (4 float4 per pixel-chunk)
+  static constexpr int NT = 64 * NW;           // threads per workgroup
+  static constexpr int RPP = NT / 4;           // halo pixels filled per pass (4 float4 per pixel-chunk)
   static constexpr int NIN = (NPIX + RPP - 1) / RPP;
   static constexpr int T = KS * KS;
   static constexpr int BUF_BYTES = (NPIX * ROWB + 15) / 16 * 16;
   static_assert(TH % WM == 0, "TH must be a multiple of WM");
 };
 
-template <int KS, int STRIDE, bool UP, int TH, int WN, int PREC>
-__global__ void __launch_bounds__(512, 2) conv_mfma_h_kernel(const ConvParams p) {
-  using Cfg = ConvHCfg<KS, STRIDE, UP, TH, WN, PREC>;
+template <int KS, int STRIDE, bool UP, int TH, int WN, int PREC, int NW>
+__global__ void __launch_bounds__(64 * NW, 2) conv_mfma_h_kernel(const ConvParams p) {
+  using Cfg = ConvHCfg<KS, STRIDE, UP, TH, WN, PREC, NW>;
   constexpr int TW = Cfg::TW, KC = Cfg::KC, NP = Cfg::NP, ROWB = Cfg::ROWB, PAD = Cfg::PAD, HWD = Cfg::HWD;
   constexpr int NPIX = Cfg::NPIX, WM = Cfg::WM, BN = Cfg::BN, MB = Cfg::MB, RPP = Cfg::RPP, NIN = Cfg::NIN, T = Cfg::T;
 
@@ -119,33 +122,32 @@ __global__ void __launch_bounds__(512, 2) conv_mfma_h_kernel(const ConvParams p)
       rsh = *reinterpret_cast<const f32x4*>(p.gn_shift + (size_t)n * Cin + cbase + q * 4);
     }
 #pragma unroll
-    for (int i = 0; i < NIN; ++i) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (in_pix[i] >= 0) v = *reinterpret_cast<const f32x4*>(base + (size_t)in_pix[i] * Cs + cc);
-      rin[i] = v;
-    }
+    for (int i = 0; i < NIN; ++i)   // branch-free: padding / unused rows read pixel 0 and are zeroed in stage()
+      rin[i] = *reinterpret_cast<const f32x4*>(base + (size_t)(in_pix[i] < 0 ? 0 : in_pix[i]) * Cs + cc);
   };
   auto stage = [&](int kc, unsigned char* buf) {
     const f32x4 sc = rsc, sh = rsh;
 #pragma unroll
     for (int i = 0; i < NIN; ++i) {
-      if (in_pix[i] == -2) continue;
+      if (NIN * RPP > NPIX && i == NIN - 1 && row0 + i * RPP >= NPIX) continue;   // only the last pass can overrun
       f32x4 v = rin[i];
-      if (gn && in_pix[i] >= 0) {
+      if (gn) {
         v = v * sc + sh;
         v.x = silu_h(v.x); v.y = silu_h(v.y); v.z = silu_h(v.z); v.w = silu_h(v.w);
       }
+      const float keep = in_pix[i] >= 0 ? 1.f : 0.f;   // conv zero-pads the ACTIVATED tensor
       unsigned char* dst = buf + (row0 + i * RPP) * ROWB + q * 8;
       if (PREC == PREC_F16X3) {
-        // clamp to the f16 range, hi = rn(v), lo = rn(v - hi): hi + lo carries 22 mantissa bits
+        // clamp to the f16 range (also maps NaN-free), hi = rn(v), lo = rn(v - hi): 22 mantissa bits
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = __builtin_fminf(__builtin_fmaxf(v[e], -65504.f), 65504.f);
+        for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e] * keep, -65504.f, 65504.f);
         h4 hi = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
         h4 lo = {(_Float16)(v.x - (float)hi.x), (_Float16)(v.y - (float)hi.y), (_Float16)(v.z - (float)hi.z),
                  (_Float16)(v.w - (float)hi.w)};
         *reinterpret_cast<h4*>(dst) = hi;
         *reinterpret_cast<h4*>(dst + 32) = lo;
       } else {
+        v = v * keep;
         b4 hb = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
         *reinterpret_cast<b4*>(dst) = hb;
       }
@@ -184,29 +186,30 @@ __global__ void __launch_bounds__(512, 2) conv_mfma_h_kernel(const ConvParams p)
   if (nk > 1) prefetch(1);
   __syncthreads();
 
-  constexpr int STG_A = T >= 9 ? 2 : 0, STG_B = T >= 9 ? 6 : 0;
-  const int stage_tap = __builtin_amdgcn_readfirstlane(wave) < 4 ? STG_A : STG_B;
   // A fragments are double-buffered over taps: the reads of tap t+1 are issued before the MFMAs
   // of tap t, so LDS latency hides under 3*MB MFMAs instead of being exposed per read.
   uint4 Af[2][MB][NP];
-  auto load_a = [&](int slot, const unsigned char* cur, int tap) {
+  const unsigned char* arow[MB];   // per chunk: halo buffer + this lane's row base; taps are immediates
+  auto load_a = [&](int slot, int tap) {
     const int ky = tap / KS, kx = tap % KS;
     const int aoff = (ky * HWD + kx) * ROWB;
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
       for (int pl = 0; pl < NP; ++pl)
-        Af[slot][mb][pl] = *reinterpret_cast<const uint4*>(cur + abase[mb] + aoff + 32 * pl);
+        Af[slot][mb][pl] = *reinterpret_cast<const uint4*>(arow[mb] + aoff + 32 * pl);
   };
 
   for (int kc = 0; kc < nk; ++kc) {
     unsigned char* cur = (kc & 1) ? sBuf1 : sBuf0;
     unsigned char* nxt = (kc & 1) ? sBuf0 : sBuf1;
     const bool more = kc + 1 < nk;
-    load_a(0, cur, 0);
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) arow[mb] = cur + abase[mb];
+    load_a(0, 0);
 #pragma unroll
     for (int tap = 0; tap < T; ++tap) {
-      if (tap + 1 < T) load_a((tap + 1) & 1, cur, tap + 1);
+      if (tap + 1 < T) load_a((tap + 1) & 1, tap + 1);
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) {
         const uint4 ahi = Af[tap & 1][mb][0];
@@ -220,9 +223,7 @@ __global__ void __launch_bounds__(512, 2) conv_mfma_h_kernel(const ConvParams p)
         }
       }
       if (more) load_b_tap(kc + 1, tap);             // same registers, next chunk
-      // fill the other halo buffer mid-chunk; the two waves that share a SIMD (w, w+4) do their
-      // VALU-heavy staging at different taps so one of them keeps the matrix pipe fed
-      if ((tap == STG_A || tap == STG_B) && more && tap == stage_tap) {
+      if (tap == T / 2 && more) {                    // mid-chunk: fill the other halo buffer
         stage(kc + 1, nxt);
         if (kc + 2 < nk) prefetch(kc + 2);
       }
@@ -314,53 +315,74 @@ __global__ void __launch_bounds__(512, 2) conv_mfma_h_kernel(const ConvParams p)
   }
 }
 
-template <int KS, int STRIDE, bool UP, int TH, int WN, int PREC>
+template <int KS, int STRIDE, bool UP, int TH, int WN, int PREC, int NW>
 static hipError_t launch_h_t(const ConvParams& p, hipStream_t s, int* tiles) {
-  using Cfg = ConvHCfg<KS, STRIDE, UP, TH, WN, PREC>;
-  auto kfn = conv_mfma_h_kernel<KS, STRIDE, UP, TH, WN, PREC>;
+  using Cfg = ConvHCfg<KS, STRIDE, UP, TH, WN, PREC, NW>;
+  auto kfn = conv_mfma_h_kernel<KS, STRIDE, UP, TH, WN, PREC, NW>;
   const size_t lds = (size_t)2 * Cfg::BUF_BYTES;
   const int tilesX = (p.Wout + Cfg::TW - 1) / Cfg::TW, tilesY = (p.Hout + TH - 1) / TH;
   if (tiles) *tiles = tilesX * tilesY;
   const int nwg = p.N * tilesX * tilesY * (p.Cout_pad / Cfg::BN);
-  hipLaunchKernelGGL(kfn, dim3(nwg), dim3(512), lds, s, p);
+  hipLaunchKernelGGL(kfn, dim3(nwg), dim3(Cfg::NT), lds, s, p);
   return hipGetLastError();
 }
 
-template <int KS, int STRIDE, bool UP, int TH, int WN, int PREC>
+template <int KS, int STRIDE, bool UP, int TH, int WN, int PREC, int NW>
 static hipError_t init_h_t() {
-  auto kfn = conv_mfma_h_kernel<KS, STRIDE, UP, TH, WN, PREC>;
+  auto kfn = conv_mfma_h_kernel<KS, STRIDE, UP, TH, WN, PREC, NW>;
   return hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
-// X(KS, STRIDE, UP, TH, WN): TH in {4, 8, 16} rows of 32 pixels; TH % (8/WN) == 0; accumulators <= 64 VGPRs
-#define FDSR_CONVH_SHAPES(X)                                                                          \
-  X(3, 1, false, 8, 4) X(3, 1, false, 4, 4) X(3, 1, false, 16, 2) X(3, 1, false, 8, 2) X(3, 1, false, 4, 2)    \
-  X(3, 1, false, 16, 1) X(3, 1, false, 8, 1)                                                                  \
-  X(3, 1, true, 8, 4) X(3, 1, true, 4, 4) X(3, 1, true, 16, 2) X(3, 1, true, 8, 2) X(3, 1, true, 4, 2)         \
-  X(3, 2, false, 4, 4) X(3, 2, false, 4, 2)                                                                   \
-  X(1, 1, false, 8, 4) X(1, 1, false, 4, 4) X(1, 1, false, 16, 2) X(1, 1, false, 8, 2) X(1, 1, false, 4, 2)    \
-  X(1, 1, false, 16, 1) X(1, 1, false, 8, 1)
+// X(KS, STRIDE, UP, TH, WN, NW): TH rows of 32 pixels, WN waves along Cout, NW waves per workgroup;
+// TH % (NW/WN) == 0 and at most 4 accumulator tiles (64 VGPRs) per wave.
+#define FDSR_CONVH_SHAPES(X)                                                                                   \
+  X(3, 1, false, 8, 4, 8) X(3, 1, false, 4, 4, 8) X(3, 1, false, 16, 2, 8) X(3, 1, false, 8, 2, 8) X(3, 1, false, 4, 2, 8) \
+  X(3, 1, false, 16, 1, 8) X(3, 1, false, 8, 1, 8) X(3, 1, false, 4, 8, 8) X(3, 1, false, 2, 8, 8)                       \
+  X(3, 1, true, 4, 8, 8) X(3, 1, true, 2, 8, 8) X(3, 2, false, 4, 8, 8) X(1, 1, false, 4, 8, 8) X(1, 1, false, 2, 8, 8)    \
+  X(3, 1, true, 8, 4, 8) X(3, 1, true, 4, 4, 8) X(3, 1, true, 16, 2, 8) X(3, 1, true, 8, 2, 8) X(3, 1, true, 4, 2, 8)      \
+  X(3, 2, false, 4, 4, 8) X(3, 2, false, 4, 2, 8)                                                                        \
+  X(1, 1, false, 8, 4, 8) X(1, 1, false, 4, 4, 8) X(1, 1, false, 16, 2, 8) X(1, 1, false, 8, 2, 8) X(1, 1, false, 4, 2, 8) \
+  X(1, 1, false, 16, 1, 8) X(1, 1, false, 8, 1, 8)                                                                       \
+  X(3, 1, false, 4, 4, 4) X(3, 1, false, 2, 4, 4) X(3, 1, false, 8, 2, 4) X(3, 1, false, 4, 2, 4) X(3, 1, false, 16, 1, 4) \
+  X(3, 1, false, 8, 1, 4)                                                                                                \
+  X(3, 1, true, 4, 4, 4) X(3, 1, true, 2, 4, 4) X(3, 1, true, 8, 2, 4) X(3, 1, true, 4, 2, 4)                              \
+  X(3, 2, false, 4, 4, 4) X(3, 2, false, 4, 2, 4)                                                                        \
+  X(1, 1, false, 4, 4, 4) X(1, 1, false, 2, 4, 4) X(1, 1, false, 8, 2, 4) X(1, 1, false, 4, 2, 4) X(1, 1, false, 16, 1, 4) \
+  X(1, 1, false, 8, 1, 4)
 
 // Output-channel split of the workgroup (weights are packed per WN, so this depends on the layer only).
 void conv_h_config(ConvKind kind, int Cout, int* TH, int* WN) {
-  *WN = Cout >= 128 ? 4 : (Cout >= 64 ? 2 : 1);
+  *WN = Cout >= 256 ? 8 : (Cout >= 128 ? 4 : (Cout >= 64 ? 2 : 1));   // 256-wide tiles: the input is staged once
   if ((kind == CONV3_S2 || kind == CONV3_UP) && *WN == 1) *WN = 2;
   *TH = kind == CONV3_S2 ? 4 : 8;   // default; launch_conv_h picks the final TH from the grid size
 }
 
-// Rows per workgroup tile, chosen per launch: the largest tile that still gives every CU >= 2
-// workgroups; small feature maps fall back to smaller tiles so the 256 CUs are all used.
-static int pick_th(ConvKind kind, int WN, const ConvParams& p) {
+static int h_waves() {
+  static int nw = 0;
+  if (!nw) {
+    const char* e = getenv("FDSR_H_WAVES");
+    nw = (e && atoi(e) == 4) ? 4 : 8;
+  }
+  return nw;
+}
+
+// Rows per workgroup tile, chosen per launch: the largest tile (<= 4 accumulator tiles per wave) that
+// still gives every CU its full complement of workgroups; small feature maps fall back to smaller
+// tiles so that all 256 CUs are used.
+static int pick_th(ConvKind kind, int WN, int NW, const ConvParams& p) {
   if (kind == CONV3_S2) return 4;
-  const int cands[3] = {16, 8, 4};
+  const int WM = NW / WN;
   const int tilesX = (p.Wout + 31) / 32, nco = p.Cout_pad / (32 * WN);
+  const long want = NW == 8 ? 512 : 1024;
   int best = -1;
-  for (int th : cands) {
-    const int WM = 8 / WN;
+  for (int th = 16; th >= 1; th >>= 1) {
     if (th % WM || th / WM > 4) continue;
+    if (NW == 8 && th < 4 && WN < 8) continue;
+    if (th < 2) continue;
+    if (NW == 4 && th < 2) continue;
     const long wgs = (long)p.N * tilesX * ((p.Hout + th - 1) / th) * nco;
     best = th;
-    if (wgs >= 512) break;
+    if (wgs >= want) break;
   }
   return best;
 }
@@ -368,13 +390,14 @@ static int pick_th(ConvKind kind, int WN, const ConvParams& p) {
 hipError_t launch_conv_h(ConvKind kind, int prec, const ConvParams& p, hipStream_t s, int* tiles) {
   int TH, WN;
   conv_h_config(kind, p.Cout, &TH, &WN);
-  TH = pick_th(kind, WN, p);
+  const int NW = h_waves();
+  TH = pick_th(kind, WN, NW, p);
   const int ks = kind == CONV1 ? 1 : 3, stride = kind == CONV3_S2 ? 2 : 1;
   const bool up = kind == CONV3_UP;
-#define X(KS_, ST_, UP_, TH_, WN_)                                                                   \
-  if (ks == KS_ && stride == ST_ && up == UP_ && TH == TH_ && WN == WN_) {                           \
-    return prec == PREC_F16X3 ? launch_h_t<KS_, ST_, UP_, TH_, WN_, PREC_F16X3>(p, s, tiles)         \
-                              : launch_h_t<KS_, ST_, UP_, TH_, WN_, PREC_BF16>(p, s, tiles);         \
+#define X(KS_, ST_, UP_, TH_, WN_, NW_)                                                                  \
+  if (ks == KS_ && stride == ST_ && up == UP_ && TH == TH_ && WN == WN_ && NW == NW_) {                   \
+    return prec == PREC_F16X3 ? launch_h_t<KS_, ST_, UP_, TH_, WN_, PREC_F16X3, NW_>(p, s, tiles)         \
+                              : launch_h_t<KS_, ST_, UP_, TH_, WN_, PREC_BF16, NW_>(p, s, tiles);         \
   }
   FDSR_CONVH_SHAPES(X)
 #undef X
@@ -383,9 +406,9 @@ hipError_t launch_conv_h(ConvKind kind, int prec, const ConvParams& p, hipStream
 
 hipError_t kernels_h_init() {
   hipError_t e;
-#define X(KS_, ST_, UP_, TH_, WN_)                                                           \
-  if ((e = init_h_t<KS_, ST_, UP_, TH_, WN_, PREC_F16X3>()) != hipSuccess) return e;         \
-  if ((e = init_h_t<KS_, ST_, UP_, TH_, WN_, PREC_BF16>()) != hipSuccess) return e;
+#define X(KS_, ST_, UP_, TH_, WN_, NW_)                                                           \
+  if ((e = init_h_t<KS_, ST_, UP_, TH_, WN_, PREC_F16X3, NW_>()) != hipSuccess) return e;         \
+  if ((e = init_h_t<KS_, ST_, UP_, TH_, WN_, PREC_BF16, NW_>()) != hipSuccess) return e;
   FDSR_CONVH_SHAPES(X)
 #undef X
   return hipSuccess;

@@ -363,55 +363,67 @@ hipError_t launch_conv(ConvKind kind, const ConvParams& p, hipStream_t s, int* t
 // ---------------------------------------------------------------------------
 // GroupNorm finalisation from the producers' per-tile partial sums
 // ---------------------------------------------------------------------------
+// grid = (N, G / GPW): one workgroup finalises GPW = 4 groups of one image.  Thread (ch, slice):
+// channel ch of the workgroup's 4*cpg channels, tiles t = slice, slice + S, ... in order; the S slice
+// sums are then combined in a fixed order (bitwise reproducible, no atomics).
+#define FDSR_GN_GPW 4
 __global__ void __launch_bounds__(256) gn_finalize_kernel(const GnFinalizeParams p) {
-  extern __shared__ __attribute__((aligned(16))) double sd[];   // [C][2] channel sums | [G][2] mean, rstd
+  __shared__ double sd[256][2];
+  __shared__ double gs[FDSR_GN_GPW][2];
   const int C = p.C0 + p.C1, tid = threadIdx.x, n = blockIdx.x;
-  double* gs = sd + 2 * C;
-  for (int c = tid; c < C; c += 256) {
+  const int cpg = C / p.G;
+  const int g0 = blockIdx.y * FDSR_GN_GPW;
+  const int ng = min(FDSR_GN_GPW, p.G - g0);
+  const int nch = ng * cpg;                 // <= 256 (launcher checks cpg <= 64)
+  const int S = 256 / nch;                  // tile slices per channel
+  const int ch = tid % nch, slice = tid / nch;
+  const int c = g0 * cpg + ch;
+  double a = 0.0, b = 0.0;
+  if (slice < S) {
     const float* part;
     int nt, Cs, cc;
     if (c < p.C0) { part = p.part0; nt = p.nt0; Cs = p.C0; cc = c; } else { part = p.part1; nt = p.nt1; Cs = p.C1; cc = c - p.C0; }
     const float* src = part + ((size_t)n * nt * Cs + cc) * 2;
-    double a = 0.0, b = 0.0;
-    for (int t = 0; t < nt; ++t) {          // fixed order: bitwise reproducible
+    for (int t = slice; t < nt; t += S) {
       const float2 v = *reinterpret_cast<const float2*>(src + (size_t)t * Cs * 2);
       a += (double)v.x;
       b += (double)v.y;
     }
-    sd[2 * c] = a;
-    sd[2 * c + 1] = b;
   }
+  sd[tid][0] = a;
+  sd[tid][1] = b;
   __syncthreads();
-  const int cpg = C / p.G;
-  if (tid < p.G) {
-    double a = 0.0, b = 0.0;
-    for (int k = 0; k < cpg; ++k) { a += sd[2 * (tid * cpg + k)]; b += sd[2 * (tid * cpg + k) + 1]; }
+  if (tid < ng) {
+    double ga = 0.0, gb = 0.0;
+    for (int k = 0; k < cpg; ++k)
+      for (int sl = 0; sl < S; ++sl) { ga += sd[sl * nch + tid * cpg + k][0]; gb += sd[sl * nch + tid * cpg + k][1]; }
     const double inv = 1.0 / ((double)cpg * (double)p.HW);
-    const double mean = a * inv;
-    double var = b * inv - mean * mean;
+    const double mean = ga * inv;
+    double var = gb * inv - mean * mean;
     var = var < 0.0 ? 0.0 : var;
-    gs[2 * tid] = mean;
-    gs[2 * tid + 1] = 1.0 / sqrt(var + (double)p.eps);
+    gs[tid][0] = mean;
+    gs[tid][1] = 1.0 / sqrt(var + (double)p.eps);
   }
   __syncthreads();
-  for (int c = tid; c < C; c += 256) {
-    const int g = c / cpg;
-    const float sc = (float)gs[2 * g + 1] * p.gamma[c];
-    p.scale[(size_t)n * C + c] = sc;
-    p.shift[(size_t)n * C + c] = p.beta[c] - (float)gs[2 * g] * sc;
+  if (tid < nch) {
+    const int g = tid / cpg;
+    const int cc = g0 * cpg + tid;
+    const float sc = (float)gs[g][1] * p.gamma[cc];
+    p.scale[(size_t)n * C + cc] = sc;
+    p.shift[(size_t)n * C + cc] = p.beta[cc] - (float)gs[g][0] * sc;
   }
 }
 
 hipError_t launch_gn_finalize(const GnFinalizeParams& p, hipStream_t s) {
   const int C = p.C0 + p.C1;
-  if (C % p.G || C > 2048) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(p.N), dim3(256), (size_t)(2 * C + 2 * p.G) * sizeof(double), s, p);
+  if (C % p.G || C / p.G > 64) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(p.N, (p.G + FDSR_GN_GPW - 1) / FDSR_GN_GPW), dim3(256), 0, s, p);
   return hipGetLastError();
 }
 
 int conv_max_tiles(int H, int W) {
-  // f32 kernel: 8x16 tiles; 16-bit kernels: TH x 32 with TH >= 4
-  const int a = ((H + 7) / 8) * ((W + 15) / 16), b = ((H + 3) / 4) * ((W + 31) / 32);
+  // f32 kernel: 8x16 tiles; 16-bit kernels: TH x 32 with TH >= 2
+  const int a = ((H + 7) / 8) * ((W + 15) / 16), b = ((H + 1) / 2) * ((W + 31) / 32);
   return a > b ? a : b;
 }
 
