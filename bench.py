@@ -3,7 +3,10 @@
 A "step" = one full 20-step conditional sampling pass (20 UNet forwards + 20 posterior
 updates) over one batch of synthetic inputs per GPU; inputs (cond, noise) are resident in
 HBM before the timed region.  Default workload = BASELINE configs[1]: x4 64->256,
-batch=16 per GPU, T=20, random-init UNet, fp32.
+batch=16 per GPU, T=20, random-init UNet, fp32-grade arithmetic.  The default conv arithmetic is
+"f16x3" (every fp32 operand split hi/lo into two f16, three f16 MFMAs per product, fp32
+accumulate): it meets the fp32 parity bound (|delta| < 1e-3; measured ~3e-6, tests/test_gpu_parity.py)
+at ~3x the throughput of the exact-fp32 MFMA path, which stays available as --precision f32.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--no-cpu-baseline]
   (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
@@ -85,7 +88,7 @@ def main():
     ap.add_argument('--size', type=int, default=256)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true', help='skip the per-conv HIP-event timing')
-    ap.add_argument('--precision', default='f32', choices=['f32', 'f16x3', 'bf16'],
+    ap.add_argument('--precision', default='f16x3', choices=['f32', 'f16x3', 'bf16'],
                     help='conv arithmetic: exact fp32 MFMA, fp32-grade split-f16 MFMA, or bf16')
     ap.add_argument('--graph', action='store_true', help='replay the 20-step loop as a hipGraph')
     args = ap.parse_args()
@@ -168,9 +171,21 @@ def main():
             peak = PEAK_F32_MFMA if args.precision == 'f32' else PEAK_16BIT_MFMA
             passes = 3 if args.precision == 'f16x3' else 1     # MFMA products issued per algorithmic product
             kern = 'conv_mfma_f32_kernel' if args.precision == 'f32' else 'conv_mfma_h_kernel'
+            # HBM bytes per launch from the committed rocprofv3 --pmc passes of THIS command (separate
+            # FETCH_SIZE / WRITE_SIZE runs, gfx950 x2 read correction: tools/pmc_traffic.py); includes the
+            # 1x1 launches of the same kernel family.  null for configurations that were not profiled.
+            traffic = None
+            tf = os.path.join(ROOT, 'profiles', f'r01_pmc_hbm_traffic_{args.precision}_b{B}.json')
+            if S == 256 and os.path.exists(tf):
+                try:
+                    traffic = json.load(open(tf))[kern]['hbm_bytes_per_launch']
+                except Exception:
+                    traffic = None
             res['roofline'] = {'bound': 'mfma', 'kernel': f'{kern} (3x3 implicit-GEMM family)',
                                'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
-                               'traffic': None, 'launches': prof['launches'],
+                               'traffic': traffic, 'traffic_unit': 'bytes/launch (PMC, profiles/)',
+                               'algorithmic_bytes_per_launch': prof['conv_bytes'] / max(prof['launches'], 1),
+                               'launches': prof['launches'],
                                'avg_launch_ms': prof['conv_ms'] / max(prof['launches'], 1),
                                'mfma_passes_per_product': passes, 'executed_tflops': ach * passes,
                                'frac_executed': ach * passes / peak,

@@ -36,11 +36,12 @@ typedef __bf16 b4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float silu_h(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
-template <int KS, int STRIDE, bool UP, int TH, int WN, int PREC, int NW>
+template <int KS, int STRIDE, bool UP, int TH, int WN, int PREC, int KSUB>
 struct ConvHCfg {
-  static constexpr int TW = 32, KC = 16;
+  static constexpr int TW = 32, NW = 8;
+  static constexpr int KC = 16 * KSUB;        // input channels per staged chunk (KSUB > 1 only for 1x1)
   static constexpr int NP = PREC == PREC_F16X3 ? 2 : 1;
-  static constexpr int ROWB = NP * 32 + 16;   // LDS bytes per halo pixel
+  static constexpr int ROWB = NP * 32 * KSUB + 16;   // LDS bytes per halo pixel: KSUB x [16 hi | 16 lo] + pad (odd # of 16-B slots)
   static constexpr int PAD = KS / 2;
   static constexpr int HH = (TH - 1) * STRIDE + KS;
   static constexpr int HWD = (TW - 1) * STRIDE + KS;
@@ -49,18 +50,20 @@ struct ConvHCfg {
   static constexpr int BN = 32 * WN;
   static constexpr int MB = TH / WM;
   static constexpr int NT = 64 * NW;           // threads per workgroup
-  static constexpr int RPP = NT / 4;           // halo pixels filled per pass (4 float4 per pixel-chunk)
+  static constexpr int Q4 = 4 * KSUB;          // float4 slots per pixel-chunk
+  static constexpr int RPP = NT / Q4;          // halo pixels filled per pass
   static constexpr int NIN = (NPIX + RPP - 1) / RPP;
-  static constexpr int T = KS * KS;
+  static constexpr int T = KS * KS * KSUB;     // MFMA k-steps per chunk: spatial taps x 16-channel sub-chunks
+  static_assert(KSUB == 1 || KS == 1, "sub-chunking is for 1x1 only");
   static constexpr int BUF_BYTES = (NPIX * ROWB + 15) / 16 * 16;
   static_assert(TH % WM == 0, "TH must be a multiple of WM");
 };
 
-template <int KS, int STRIDE, bool UP, int TH, int WN, int PREC, int NW>
-__global__ void __launch_bounds__(64 * NW, 2) conv_mfma_h_kernel(const ConvParams p) {
-  using Cfg = ConvHCfg<KS, STRIDE, UP, TH, WN, PREC, NW>;
+template <int KS, int STRIDE, bool UP, int TH, int WN, int PREC, int KSUB>
+__global__ void __launch_bounds__(512, 2) conv_mfma_h_kernel(const ConvParams p) {
+  using Cfg = ConvHCfg<KS, STRIDE, UP, TH, WN, PREC, KSUB>;
   constexpr int TW = Cfg::TW, KC = Cfg::KC, NP = Cfg::NP, ROWB = Cfg::ROWB, PAD = Cfg::PAD, HWD = Cfg::HWD;
-  constexpr int NPIX = Cfg::NPIX, WM = Cfg::WM, BN = Cfg::BN, MB = Cfg::MB, RPP = Cfg::RPP, NIN = Cfg::NIN, T = Cfg::T;
+  constexpr int NPIX = Cfg::NPIX, WM = Cfg::WM, BN = Cfg::BN, MB = Cfg::MB, RPP = Cfg::RPP, NIN = Cfg::NIN, T = Cfg::T, Q4 = Cfg::Q4, NW = Cfg::NW;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_h[];
   unsigned char* sBuf0 = smem_h;
@@ -89,7 +92,7 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_mfma_h_kernel(const ConvParam
   const bool gn = p.gn_scale != nullptr;
 
   // ---- staging indices (chunk invariant): thread -> (halo pixel row0 + i*128, float4 slot q) ----
-  const int q = tid & 3, row0 = tid >> 2;
+  const int q = tid % Q4, row0 = tid / Q4;
   int in_pix[NIN];
 #pragma unroll
   for (int i = 0; i < NIN; ++i) {
@@ -136,7 +139,7 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_mfma_h_kernel(const ConvParam
         v.x = silu_h(v.x); v.y = silu_h(v.y); v.z = silu_h(v.z); v.w = silu_h(v.w);
       }
       const float keep = in_pix[i] >= 0 ? 1.f : 0.f;   // conv zero-pads the ACTIVATED tensor
-      unsigned char* dst = buf + (row0 + i * RPP) * ROWB + q * 8;
+      unsigned char* dst = buf + (row0 + i * RPP) * ROWB + (q >> 2) * (NP * 32) + (q & 3) * 8;
       if (PREC == PREC_F16X3) {
         // clamp to the f16 range (also maps NaN-free), hi = rn(v), lo = rn(v - hi): 22 mantissa bits
 #pragma unroll
@@ -159,7 +162,8 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_mfma_h_kernel(const ConvParam
   const int nk = p.Cin_pad / KC;
   uint4 Bf[T][NP];
   auto load_b_tap = [&](int kc, int tap) {
-    const uint4* src = wq + ((((size_t)cot * nk + kc) * WN + wn) * T + tap) * (NP * 64) + lane;
+    const int ts = tap / KSUB, sub = tap % KSUB;   // packed per 16-channel block: [cot][kc16][wn][spatial tap]
+    const uint4* src = wq + ((((size_t)cot * (nk * KSUB) + kc * KSUB + sub) * WN + wn) * (KS * KS) + ts) * (NP * 64) + lane;
 #pragma unroll
     for (int pl = 0; pl < NP; ++pl) Bf[tap][pl] = src[pl * 64];
   };
@@ -191,8 +195,9 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_mfma_h_kernel(const ConvParam
   uint4 Af[2][MB][NP];
   const unsigned char* arow[MB];   // per chunk: halo buffer + this lane's row base; taps are immediates
   auto load_a = [&](int slot, int tap) {
-    const int ky = tap / KS, kx = tap % KS;
-    const int aoff = (ky * HWD + kx) * ROWB;
+    const int ts = tap / KSUB, sub = tap % KSUB;
+    const int ky = ts / KS, kx = ts % KS;
+    const int aoff = (ky * HWD + kx) * ROWB + sub * (NP * 32);
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -315,10 +320,10 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_mfma_h_kernel(const ConvParam
   }
 }
 
-template <int KS, int STRIDE, bool UP, int TH, int WN, int PREC, int NW>
+template <int KS, int STRIDE, bool UP, int TH, int WN, int PREC, int KSUB>
 static hipError_t launch_h_t(const ConvParams& p, hipStream_t s, int* tiles) {
-  using Cfg = ConvHCfg<KS, STRIDE, UP, TH, WN, PREC, NW>;
-  auto kfn = conv_mfma_h_kernel<KS, STRIDE, UP, TH, WN, PREC, NW>;
+  using Cfg = ConvHCfg<KS, STRIDE, UP, TH, WN, PREC, KSUB>;
+  auto kfn = conv_mfma_h_kernel<KS, STRIDE, UP, TH, WN, PREC, KSUB>;
   const size_t lds = (size_t)2 * Cfg::BUF_BYTES;
   const int tilesX = (p.Wout + Cfg::TW - 1) / Cfg::TW, tilesY = (p.Hout + TH - 1) / TH;
   if (tiles) *tiles = tilesX * tilesY;
@@ -327,28 +332,24 @@ static hipError_t launch_h_t(const ConvParams& p, hipStream_t s, int* tiles) {
   return hipGetLastError();
 }
 
-template <int KS, int STRIDE, bool UP, int TH, int WN, int PREC, int NW>
+template <int KS, int STRIDE, bool UP, int TH, int WN, int PREC, int KSUB>
 static hipError_t init_h_t() {
-  auto kfn = conv_mfma_h_kernel<KS, STRIDE, UP, TH, WN, PREC, NW>;
+  auto kfn = conv_mfma_h_kernel<KS, STRIDE, UP, TH, WN, PREC, KSUB>;
   return hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
-// X(KS, STRIDE, UP, TH, WN, NW): TH rows of 32 pixels, WN waves along Cout, NW waves per workgroup;
-// TH % (NW/WN) == 0 and at most 4 accumulator tiles (64 VGPRs) per wave.
+// X(KS, STRIDE, UP, TH, WN, KSUB): TH rows of 32 pixels, WN of the 8 waves along Cout;
+// TH % (8/WN) == 0 and at most 4 accumulator tiles (64 VGPRs) per wave.
 #define FDSR_CONVH_SHAPES(X)                                                                                   \
-  X(3, 1, false, 8, 4, 8) X(3, 1, false, 4, 4, 8) X(3, 1, false, 16, 2, 8) X(3, 1, false, 8, 2, 8) X(3, 1, false, 4, 2, 8) \
-  X(3, 1, false, 16, 1, 8) X(3, 1, false, 8, 1, 8) X(3, 1, false, 4, 8, 8) X(3, 1, false, 2, 8, 8)                       \
-  X(3, 1, true, 4, 8, 8) X(3, 1, true, 2, 8, 8) X(3, 2, false, 4, 8, 8) X(1, 1, false, 4, 8, 8) X(1, 1, false, 2, 8, 8)    \
-  X(3, 1, true, 8, 4, 8) X(3, 1, true, 4, 4, 8) X(3, 1, true, 16, 2, 8) X(3, 1, true, 8, 2, 8) X(3, 1, true, 4, 2, 8)      \
-  X(3, 2, false, 4, 4, 8) X(3, 2, false, 4, 2, 8)                                                                        \
-  X(1, 1, false, 8, 4, 8) X(1, 1, false, 4, 4, 8) X(1, 1, false, 16, 2, 8) X(1, 1, false, 8, 2, 8) X(1, 1, false, 4, 2, 8) \
-  X(1, 1, false, 16, 1, 8) X(1, 1, false, 8, 1, 8)                                                                       \
-  X(3, 1, false, 4, 4, 4) X(3, 1, false, 2, 4, 4) X(3, 1, false, 8, 2, 4) X(3, 1, false, 4, 2, 4) X(3, 1, false, 16, 1, 4) \
-  X(3, 1, false, 8, 1, 4)                                                                                                \
-  X(3, 1, true, 4, 4, 4) X(3, 1, true, 2, 4, 4) X(3, 1, true, 8, 2, 4) X(3, 1, true, 4, 2, 4)                              \
-  X(3, 2, false, 4, 4, 4) X(3, 2, false, 4, 2, 4)                                                                        \
-  X(1, 1, false, 4, 4, 4) X(1, 1, false, 2, 4, 4) X(1, 1, false, 8, 2, 4) X(1, 1, false, 4, 2, 4) X(1, 1, false, 16, 1, 4) \
-  X(1, 1, false, 8, 1, 4)
+  X(3, 1, false, 8, 4, 1) X(3, 1, false, 4, 4, 1) X(3, 1, false, 16, 2, 1) X(3, 1, false, 8, 2, 1) X(3, 1, false, 4, 2, 1) \
+  X(3, 1, false, 16, 1, 1) X(3, 1, false, 8, 1, 1) X(3, 1, false, 4, 8, 1) X(3, 1, false, 2, 8, 1)                       \
+  X(3, 1, true, 4, 8, 1) X(3, 1, true, 2, 8, 1) X(3, 2, false, 4, 8, 1)                                                  \
+  X(3, 1, true, 8, 4, 1) X(3, 1, true, 4, 4, 1) X(3, 1, true, 16, 2, 1) X(3, 1, true, 8, 2, 1) X(3, 1, true, 4, 2, 1)      \
+  X(3, 2, false, 4, 4, 1) X(3, 2, false, 4, 2, 1)                                                                        \
+  X(1, 1, false, 8, 4, 1) X(1, 1, false, 4, 4, 1) X(1, 1, false, 16, 2, 1) X(1, 1, false, 8, 2, 1) X(1, 1, false, 4, 2, 1) \
+  X(1, 1, false, 16, 1, 1) X(1, 1, false, 8, 1, 1) X(1, 1, false, 4, 8, 1) X(1, 1, false, 2, 8, 1)                       \
+  X(1, 1, false, 8, 4, 4) X(1, 1, false, 4, 4, 4) X(1, 1, false, 8, 2, 4) X(1, 1, false, 4, 2, 4)                         \
+  X(1, 1, false, 8, 1, 4) X(1, 1, false, 4, 8, 4) X(1, 1, false, 2, 8, 4)
 
 // Output-channel split of the workgroup (weights are packed per WN, so this depends on the layer only).
 void conv_h_config(ConvKind kind, int Cout, int* TH, int* WN) {
@@ -357,32 +358,21 @@ void conv_h_config(ConvKind kind, int Cout, int* TH, int* WN) {
   *TH = kind == CONV3_S2 ? 4 : 8;   // default; launch_conv_h picks the final TH from the grid size
 }
 
-static int h_waves() {
-  static int nw = 0;
-  if (!nw) {
-    const char* e = getenv("FDSR_H_WAVES");
-    nw = (e && atoi(e) == 4) ? 4 : 8;
-  }
-  return nw;
-}
-
 // Rows per workgroup tile, chosen per launch: the largest tile (<= 4 accumulator tiles per wave) that
-// still gives every CU its full complement of workgroups; small feature maps fall back to smaller
-// tiles so that all 256 CUs are used.
-static int pick_th(ConvKind kind, int WN, int NW, const ConvParams& p) {
+// still gives every CU two workgroups' worth of work; small feature maps fall back to smaller tiles so
+// that all 256 CUs are used.
+static int pick_th(ConvKind kind, int WN, int ksub, const ConvParams& p) {
   if (kind == CONV3_S2) return 4;
-  const int WM = NW / WN;
+  const int WM = 8 / WN;
   const int tilesX = (p.Wout + 31) / 32, nco = p.Cout_pad / (32 * WN);
-  const long want = NW == 8 ? 512 : 1024;
   int best = -1;
-  for (int th = 16; th >= 1; th >>= 1) {
+  for (int th = 16; th >= 2; th >>= 1) {
     if (th % WM || th / WM > 4) continue;
-    if (NW == 8 && th < 4 && WN < 8) continue;
-    if (th < 2) continue;
-    if (NW == 4 && th < 2) continue;
+    if (th < 4 && WN < 8) continue;
+    if (ksub > 1 && th > 8) continue;          // LDS: 64-channel rows
     const long wgs = (long)p.N * tilesX * ((p.Hout + th - 1) / th) * nco;
     best = th;
-    if (wgs >= want) break;
+    if (wgs >= 512) break;
   }
   return best;
 }
@@ -390,14 +380,15 @@ static int pick_th(ConvKind kind, int WN, int NW, const ConvParams& p) {
 hipError_t launch_conv_h(ConvKind kind, int prec, const ConvParams& p, hipStream_t s, int* tiles) {
   int TH, WN;
   conv_h_config(kind, p.Cout, &TH, &WN);
-  const int NW = h_waves();
-  TH = pick_th(kind, WN, NW, p);
+  // 1x1: stage 64 input channels per barrier when the (concatenated) input allows it
+  const int ksub = (kind == CONV1 && p.Cin_pad % 64 == 0 && (p.C1 == 0 || p.C0 % 64 == 0)) ? 4 : 1;
+  TH = pick_th(kind, WN, ksub, p);
   const int ks = kind == CONV1 ? 1 : 3, stride = kind == CONV3_S2 ? 2 : 1;
   const bool up = kind == CONV3_UP;
-#define X(KS_, ST_, UP_, TH_, WN_, NW_)                                                                  \
-  if (ks == KS_ && stride == ST_ && up == UP_ && TH == TH_ && WN == WN_ && NW == NW_) {                   \
-    return prec == PREC_F16X3 ? launch_h_t<KS_, ST_, UP_, TH_, WN_, PREC_F16X3, NW_>(p, s, tiles)         \
-                              : launch_h_t<KS_, ST_, UP_, TH_, WN_, PREC_BF16, NW_>(p, s, tiles);         \
+#define X(KS_, ST_, UP_, TH_, WN_, KSUB_)                                                                \
+  if (ks == KS_ && stride == ST_ && up == UP_ && TH == TH_ && WN == WN_ && ksub == KSUB_) {               \
+    return prec == PREC_F16X3 ? launch_h_t<KS_, ST_, UP_, TH_, WN_, PREC_F16X3, KSUB_>(p, s, tiles)       \
+                              : launch_h_t<KS_, ST_, UP_, TH_, WN_, PREC_BF16, KSUB_>(p, s, tiles);       \
   }
   FDSR_CONVH_SHAPES(X)
 #undef X
@@ -406,9 +397,9 @@ hipError_t launch_conv_h(ConvKind kind, int prec, const ConvParams& p, hipStream
 
 hipError_t kernels_h_init() {
   hipError_t e;
-#define X(KS_, ST_, UP_, TH_, WN_, NW_)                                                           \
-  if ((e = init_h_t<KS_, ST_, UP_, TH_, WN_, PREC_F16X3, NW_>()) != hipSuccess) return e;         \
-  if ((e = init_h_t<KS_, ST_, UP_, TH_, WN_, PREC_BF16, NW_>()) != hipSuccess) return e;
+#define X(KS_, ST_, UP_, TH_, WN_, KSUB_)                                                          \
+  if ((e = init_h_t<KS_, ST_, UP_, TH_, WN_, PREC_F16X3, KSUB_>()) != hipSuccess) return e;         \
+  if ((e = init_h_t<KS_, ST_, UP_, TH_, WN_, PREC_BF16, KSUB_>()) != hipSuccess) return e;
   FDSR_CONVH_SHAPES(X)
 #undef X
   return hipSuccess;

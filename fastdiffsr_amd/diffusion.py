@@ -22,7 +22,9 @@ class GaussianDiffusion(nn.Module):
         self.denoise_fn = denoise_fn
         self.loss_type = loss_type
         self.conditional = conditional
-        self.use_graph = True     # replay the T-step loop as one hipGraph when inputs are stable
+        # conv arithmetic of the HIP engine: 'f16x3' (fp32-grade split-f16 MFMA, default), 'f32' (exact
+        # fp32 MFMA) or 'bf16' (PSNR-grade); see include/fdsr.h
+        self.precision = 'f16x3'
         # like the reference (:96-98) the schedule is NOT set here; DDPM calls set_new_noise_schedule
 
     def set_loss(self, device):                                   # :101-107
@@ -57,6 +59,7 @@ class GaussianDiffusion(nn.Module):
                 noise[k] = torch.randn_like(x)
         self.denoise_fn.sync_weights()
         eng = self.denoise_fn.engine
+        eng.set_precision(self.precision)
         if not continous:
             return eng.sample(x, noise, graph=False)
         img, traj = eng.sample(x, noise, want_traj=True, graph=False)
