@@ -61,11 +61,11 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB):
+    if not os.path.exists(os.environ.get('FDSR_LIB', LIB)):
         raise ImportError(
             f'{LIB} is missing: build it with `python -m fastdiffsr_amd.build` (or __graft_entry__.build()). '
             'fastdiffsr_amd has no CPU/PyTorch fallback for the sampling path.')
-    lib = C.CDLL(LIB)
+    lib = C.CDLL(os.environ.get('FDSR_LIB', LIB))   # FDSR_LIB: A/B a differently built engine on one box
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)      # AttributeError if the .so does not export it
         fn.restype = res
