@@ -7,6 +7,7 @@ import sys
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 LIB = os.path.join(CSRC, 'libfdsr_hip.so')
 SOURCES = [('fdsr_kernels.hip', ['-O3', '-munsafe-fp-atomics']), ('fdsr_conv_h.hip', ['-O3']),
+           ('fdsr_conv_up2.hip', ['-O3']),
            ('fdsr_engine.cpp', ['-O2'])]
 COMMON = ['--offload-arch=gfx950', '-std=c++17', '-fPIC', '-Wno-unused-result']
 

@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -39,6 +40,8 @@ struct WeightEntry {
   int h_WN = 0, h_cin_pad = 0, h_cout_pad = 0;
   size_t hq_off[3] = {0, 0, 0};             // byte offsets into the 16-bit weight arena, per Precision
   float h_inv_scale[3] = {1.f, 1.f, 1.f};
+  size_t up2_off[3] = {0, 0, 0};            // CONV3_UP only: sub-pixel (4 x 2x2) form
+  float up2_inv_scale[3] = {1.f, 1.f, 1.f};
 };
 
 struct TensorDesc {
@@ -417,6 +420,11 @@ int build_plan(fdsr_handle h) {
       const size_t frag = (size_t)(w.h_cout_pad / 32) * (w.h_cin_pad / 16) * w.ks * w.ks * 64 * 16;
       w.hq_off[PREC_F16X3] = qoff; qoff += align_up(frag * 2, 256);
       w.hq_off[PREC_BF16] = qoff;  qoff += align_up(frag, 256);
+      if (w.ck == CONV3_UP) {   // 16 (parity, tap) slots instead of 9 taps
+        const size_t f2 = (size_t)(w.h_cout_pad / 32) * (w.h_cin_pad / 16) * 16 * 64 * 16;
+        w.up2_off[PREC_F16X3] = qoff; qoff += align_up(f2 * 2, 256);
+        w.up2_off[PREC_BF16] = qoff;  qoff += align_up(f2, 256);
+      }
     }
     h->wq_bytes = qoff;
   }
@@ -635,7 +643,14 @@ int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, 
           p.w_inv_scale = w.h_inv_scale[h->prec];
           p.Cin_pad = w.h_cin_pad;
           p.Cout_pad = w.h_cout_pad;
-          HIPCHK(h, launch_conv_h(op.ck, h->prec, p, st, &nt));
+          static const bool no_up2 = getenv("FDSR_NO_UP2") != nullptr;
+          if (op.ck == CONV3_UP && !no_up2) {
+            p.wq = h->d_wq + w.up2_off[h->prec];
+            p.w_inv_scale = w.up2_inv_scale[h->prec];
+            HIPCHK(h, launch_conv_up2_h(h->prec, p, st, &nt));
+          } else {
+            HIPCHK(h, launch_conv_h(op.ck, h->prec, p, st, &nt));
+          }
         } else {
           HIPCHK(h, launch_conv(op.ck, p, st, &nt));
         }
@@ -718,6 +733,62 @@ int pack_weights_h(fdsr_handle h, WeightEntry& w, const float* host) {
           }
   HIPCHK(h, hipMemcpy(h->d_wq + w.hq_off[PREC_F16X3], q3.data(), q3.size() * 2, hipMemcpyHostToDevice));
   HIPCHK(h, hipMemcpy(h->d_wq + w.hq_off[PREC_BF16], qb.data(), qb.size() * 2, hipMemcpyHostToDevice));
+  if (w.ck != CONV3_UP) return FDSR_OK;
+
+  // Sub-pixel form of Upsample(nearest x2)+Conv3x3 (unet.py:66-74): W2[py][px][a][b] = sum of the 3x3 taps
+  // that land on source offset (a, b) for output parity (py, px); R(0,0)={0} R(0,1)={1,2} R(1,0)={0,1} R(1,1)={2}.
+  auto tapset = [](int par, int a, int* lo, int* hi) {
+    if (par == 0) { if (a == 0) { *lo = 0; *hi = 0; } else { *lo = 1; *hi = 2; } }
+    else          { if (a == 0) { *lo = 0; *hi = 1; } else { *lo = 2; *hi = 2; } }
+  };
+  std::vector<float> w2((size_t)Cout * Cin * 16, 0.f);   // [co][ci][py][px][a][b]
+  float amax2 = 0.f;
+  for (int co = 0; co < Cout; ++co)
+    for (int ci = 0; ci < Cin; ++ci)
+      for (int py = 0; py < 2; ++py)
+        for (int px = 0; px < 2; ++px)
+          for (int a = 0; a < 2; ++a)
+            for (int b = 0; b < 2; ++b) {
+              int y0, y1, x0, x1;
+              tapset(py, a, &y0, &y1);
+              tapset(px, b, &x0, &x1);
+              float acc = 0.f;
+              for (int ky = y0; ky <= y1; ++ky)
+                for (int kx = x0; kx <= x1; ++kx) acc += host[((size_t)co * Cin + ci) * 9 + ky * 3 + kx];
+              w2[((size_t)co * Cin + ci) * 16 + ((py * 2 + px) * 2 + a) * 2 + b] = acc;
+              amax2 = std::max(amax2, std::fabs(acc));
+            }
+  int e2 = 12;
+  if (amax2 > 0.f) e2 = std::min(12, (int)std::floor(std::log2(32768.0 / (double)amax2)));
+  const float scale2 = std::ldexp(1.0f, e2);
+  w.up2_inv_scale[PREC_F16X3] = std::ldexp(1.0f, -e2);
+  w.up2_inv_scale[PREC_BF16] = 1.0f;
+  const size_t nfrag2 = (size_t)ncot * nk * WN * 16 * 64;
+  std::vector<uint16_t> u3(nfrag2 * 2 * 8, 0), ub(nfrag2 * 8, 0);
+  for (int cot = 0; cot < ncot; ++cot)
+    for (int kc = 0; kc < nk; ++kc)
+      for (int wn = 0; wn < WN; ++wn)
+        for (int py = 0; py < 2; ++py)
+          for (int slot = 0; slot < 8; ++slot)
+            for (int l = 0; l < 64; ++l) {
+              const int px = slot >> 2, a = (slot >> 1) & 1, b = slot & 1;
+              const int co = cot * BN + wn * 32 + (l & 31);
+              const size_t fidx = ((((size_t)cot * nk + kc) * WN + wn) * 2 + py) * 8 + slot;
+              for (int j = 0; j < 8; ++j) {
+                const int k = kc * 16 + 8 * (l >> 5) + j;
+                float v = 0.f;
+                if (co < Cout && k < Cin) v = w2[((size_t)co * Cin + k) * 16 + ((py * 2 + px) * 2 + a) * 2 + b];
+                const float vs = v * scale2;
+                const uint16_t hi = f32_to_f16_rn(vs);
+                _Float16 hif;
+                memcpy(&hif, &hi, 2);
+                u3[((fidx * 2 + 0) * 64 + l) * 8 + j] = hi;
+                u3[((fidx * 2 + 1) * 64 + l) * 8 + j] = f32_to_f16_rn(vs - (float)hif);
+                ub[(fidx * 64 + l) * 8 + j] = f32_to_bf16_rn(v);
+              }
+            }
+  HIPCHK(h, hipMemcpy(h->d_wq + w.up2_off[PREC_F16X3], u3.data(), u3.size() * 2, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(h->d_wq + w.up2_off[PREC_BF16], ub.data(), ub.size() * 2, hipMemcpyHostToDevice));
   return FDSR_OK;
 }
 

@@ -49,6 +49,9 @@ hipError_t kernels_init();
 void conv_h_config(ConvKind kind, int Cout, int* TH, int* WN);   // BN = 32*WN, K-chunk = 16
 hipError_t launch_conv_h(ConvKind kind, int prec, const ConvParams& p, hipStream_t s, int* tiles_per_image);
 hipError_t kernels_h_init();
+// Upsample(nearest x2)+Conv3x3 in sub-pixel form (fdsr_conv_up2.hip): four 2x2 convs on the source grid
+// with pre-summed weights packed [cot][kc][wn][py][px*4+a*2+b][plane][lane] x 16 B.
+hipError_t launch_conv_up2_h(int prec, const ConvParams& p, hipStream_t s, int* tiles_per_image);
 
 // GroupNorm finalisation: per-tile per-channel partial sums (written by the producers' epilogues,
 // fixed summation order => bitwise reproducible) of the virtual concat (x0: C0, x1: C1 channels)
