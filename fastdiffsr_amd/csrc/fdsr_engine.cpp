@@ -998,6 +998,14 @@ int fdsr_sample(fdsr_handle h, const float* cond_nchw, const float* noise, float
   return FDSR_OK;
 }
 
+int fdsr_tensor2img_u8(fdsr_handle h, const float* src_nchw, uint8_t* dst_nhwc, int batch, int channels, int height, int width,
+                       float lo, float hi, void* hip_stream) {
+  if (!src_nchw || !dst_nhwc || batch < 1 || channels < 1 || height < 1 || width < 1 || !(hi > lo))
+    return fail(h, FDSR_E_INVALID, "bad tensor2img arguments");
+  HIPCHK(h, launch_tensor2img_u8(src_nchw, dst_nhwc, batch, channels, height, width, lo, hi, reinterpret_cast<hipStream_t>(hip_stream)));
+  return FDSR_OK;
+}
+
 int fdsr_set_precision(fdsr_handle h, int mode) {
   if (!h || mode < 0 || mode > 2) return fail(h, FDSR_E_INVALID, "precision mode must be 0 (f32), 1 (f16x3) or 2 (bf16)");
   if (h->prec != mode) {

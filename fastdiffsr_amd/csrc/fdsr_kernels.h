@@ -103,6 +103,10 @@ hipError_t launch_nchw_to_nhwc(const float* src, float* dst, int N, int Csrc, in
 hipError_t launch_nhwc_to_nchw(const float* src, float* dst, int N, int C, int H, int W,
                                int Csrc_stride, hipStream_t s);
 
+// tensor2img of the val loop (core/metrics.py:16-42): NCHW fp32 -> HWC uint8
+hipError_t launch_tensor2img_u8(const float* src, unsigned char* dst, int N, int C, int H, int W, float lo, float hi,
+                                hipStream_t s);
+
 // one reverse-diffusion update (diffusion.py:157-190) on the packed state tensor
 // xin [N,H,W,CP]: channels [0,3) = cond, [3,6) = x_t.
 struct PosteriorParams {

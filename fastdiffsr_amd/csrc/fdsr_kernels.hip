@@ -689,6 +689,31 @@ hipError_t launch_posterior(const PosteriorParams& p, hipStream_t s) {
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------
+// tensor2img (reference core/metrics.py:16-42): clamp to [lo,hi], rescale to [0,1] in fp32,
+// *255, round half to even (numpy .round()), uint8; NCHW fp32 -> HWC uint8 per image
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) tensor2img_u8_kernel(const float* __restrict__ src, unsigned char* __restrict__ dst,
+                                                            int C, int HW, float lo, float hi, size_t total) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const size_t n = i / HW, pix = i % HW;
+  for (int c = 0; c < C; ++c) {
+    float v = src[(n * C + c) * HW + pix];
+    v = fminf(fmaxf(v, lo), hi);
+    v = __fdiv_rn(__fsub_rn(v, lo), __fsub_rn(hi, lo));
+    dst[i * C + c] = (unsigned char)rintf(__fmul_rn(v, 255.0f));
+  }
+}
+
+hipError_t launch_tensor2img_u8(const float* src, unsigned char* dst, int N, int C, int H, int W, float lo, float hi,
+                                hipStream_t s) {
+  const size_t total = (size_t)N * H * W;
+  hipLaunchKernelGGL(tensor2img_u8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, dst, C, H * W, lo, hi,
+                     total);
+  return hipGetLastError();
+}
+
 hipError_t kernels_init() {
   hipError_t e;
 #define X(KS_, ST_, UP_, KC_, BN_, WM_) \

@@ -131,6 +131,13 @@ int fdsr_sample(fdsr_handle h, const float* cond_nchw, const float* noise,
 #define FDSR_PREC_BF16 2
 int fdsr_set_precision(fdsr_handle h, int mode);
 
+/* -- val-loop helper ------------------------------------------ */
+/* Metrics.tensor2img (core/metrics.py:16-42): clamp to [lo,hi], map to [0,1], *255, round half to
+ * even, uint8.  src [B,C,H,W] fp32 device, dst [B,H,W,C] uint8 device; saves the fp32 D2H copy of
+ * DDPM.get_current_visuals (model/model.py:97-111).  h may be NULL. */
+int fdsr_tensor2img_u8(fdsr_handle h, const float* src_nchw, uint8_t* dst_nhwc, int batch, int channels,
+                       int height, int width, float lo, float hi, void* hip_stream);
+
 /* -- introspection for parity tests and bench.py -------------------------- */
 /* When on, the next plan keeps every layer output in its own buffer. */
 int fdsr_set_debug(fdsr_handle h, int on);

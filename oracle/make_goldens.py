@@ -203,6 +203,29 @@ def main():
               img2res=G.img2res(hr, sr).numpy(), res2img=G.res2img(nz, sr).numpy())
     np.savez_compressed(os.path.join(OUT, 'train_loss.npz'), **tr)
 
+    # ---- (vi) val-loop helpers: the reference's own tensor2img / calculate_psnr --------------------
+    for name in ('cv2', 'skimage', 'skimage.measure', 'lpips', 'matplotlib', 'matplotlib.pyplot', 'torchvision.utils',
+                 'torchvision.transforms', 'core.PerceptualSimilarity'):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules['skimage.measure'].compare_mse = None
+    sys.modules['skimage'].io = None
+    sys.modules['skimage'].data = None
+    sys.modules['torchvision.utils'].make_grid = None
+    sys.modules['torchvision'].transforms = sys.modules['torchvision.transforms']
+    sys.modules['torchvision'].utils = sys.modules['torchvision.utils']
+    import core
+    core.PerceptualSimilarity = sys.modules['core.PerceptualSimilarity']
+    from core import metrics as ref_metrics
+    g = torch.Generator().manual_seed(41)
+    t = torch.randn(3, 24, 40, generator=g) * 0.8
+    t[0, 0, :8] = torch.tensor([-1.5, -1.0, 1.0, 1.5, 0.0, 1 / 255.0 - 1.0, 0.003921569, -0.9960785])
+    img = ref_metrics.tensor2img(t.clone())
+    img2 = ref_metrics.tensor2img((t + 0.05 * torch.randn(3, 24, 40, generator=g)).clone())
+    gray = ref_metrics.tensor2img(t[:1].clone())
+    np.savez_compressed(os.path.join(OUT, 'metrics.npz'), t=t.numpy(), img=img, img2=img2, gray=gray,
+                        psnr=np.array(ref_metrics.calculate_psnr(img, img2), dtype=np.float64),
+                        psnr_same=np.array(ref_metrics.calculate_psnr(img, img), dtype=np.float64))
+
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

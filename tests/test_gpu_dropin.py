@@ -56,3 +56,58 @@ def test_ddpm_call_sequence_matches_oracle():
     b = netG.super_resolution(cond.to(device), False)
     assert torch.equal(a, b) or (a - b).abs().max().item() <= 1e-5
     assert str(netG).startswith('GaussianDiffusion')
+
+
+def test_gpu_tensor2img_bit_exact(golden_dir):
+    """GPU tensor2img (clamp -> uint8 on the device) == the reference's core/metrics.tensor2img, bit for bit."""
+    import os
+    from fastdiffsr_amd import metrics as M
+    from oracle import fdsr_oracle as O
+    g = np.load(os.path.join(golden_dir, 'metrics.npz'))
+    t = torch.from_numpy(g['t'])
+    np.testing.assert_array_equal(M.tensor2img(t.cuda()), g['img'])
+    np.testing.assert_array_equal(M.tensor2img(t[:1].cuda()), g['gray'])
+    big = torch.randn(3, 256, 256, generator=torch.Generator().manual_seed(9)) * 0.7
+    np.testing.assert_array_equal(M.tensor2img(big.cuda()), O.tensor2img_u8(big.clone()))
+
+
+def test_ddpm_wrapper_val_iteration(tmp_path):
+    """One iteration of the reference's val loop (sr_mfe.py:274-324) through fastdiffsr_amd.model.DDPM:
+    create_model -> load_network (reference-format checkpoint) -> feed_data -> test -> visuals -> PSNR."""
+    from fastdiffsr_amd import model as Model, metrics as M
+    from fastdiffsr_amd.arch import UNetConfig, FASTDIFFSR_UNET, SCHEDULE_BUFFERS
+    from fastdiffsr_amd.schedule import schedule_buffers
+    from oracle import fdsr_oracle as O
+    cfg = UNetConfig(**FASTDIFFSR_UNET)
+    sd_np = synth_state_dict(cfg, 0, prefix='denoise_fn.')
+    ckpt = {k: torch.from_numpy(v) for k, v in sd_np.items()}
+    bufs, _ = schedule_buffers(FASTDIFFSR_SCHEDULE_VAL)
+    ckpt.update({k: torch.from_numpy(v) for k, v in bufs.items()})
+    torch.save(ckpt, str(tmp_path / 'I100_E1_gen.pth'))
+    opt = _opt()
+    opt['path'] = {'resume_state': str(tmp_path / 'I100_E1'), 'checkpoint': str(tmp_path)}
+    diffusion = Model.create_model(opt)
+    diffusion.set_new_noise_schedule(opt['model']['beta_schedule']['val'], schedule_phase='val')
+    cond, noise = synth_inputs(1, 64, 64, 20)
+    hr = (cond + 0.3 * torch.sin(torch.arange(64).float() / 5).view(1, 1, 1, 64)).clamp(-1, 1)
+    diffusion.feed_data({'HR': hr, 'SR': cond.clone(), 'LR': cond.clone(), 'Index': torch.tensor([0])})
+    # fixed noise for parity: the facade draws torch.randn / randn_like in the reference's order otherwise
+    with torch.no_grad():
+        diffusion.netG.eval()
+        diffusion.SR = diffusion.netG.p_sample_loop(diffusion.data['SR'], True, noise=noise.cuda())
+        diffusion.netG.train()
+    vis = diffusion.get_current_visuals()
+    assert tuple(vis['SR'].shape) == (8, 3, 64, 64) and vis['SR'].device.type == 'cpu'
+    sr_img = M.tensor2img(vis['SR'][-1])
+    hr_img = M.tensor2img(vis['HR'])
+    sd = O.to_torch_sd({k[len('denoise_fn.'):]: v for k, v in sd_np.items()})
+    ref = O.p_sample_loop(sd, cfg, O.schedule_tables(FASTDIFFSR_SCHEDULE_VAL), cond, noise)
+    ref_img = O.tensor2img_u8(ref[0])
+    d_psnr = abs(M.calculate_psnr(sr_img, hr_img) - O.psnr_u8(ref_img, O.tensor2img_u8(hr[0])))
+    assert d_psnr <= 0.01, d_psnr                                   # north_star: PSNR within 0.01 dB of reference
+    assert (sr_img.astype(int) - ref_img.astype(int)).__abs__().max() <= 1
+    # test() itself (own RNG draws) runs and leaves netG in train mode like the reference (model.py:68)
+    diffusion.test(continous=False)
+    assert diffusion.netG.training and tuple(diffusion.SR.shape) == (1, 3, 64, 64)
+    p = diffusion.save_network(1, 100)
+    assert len(torch.load(p)) == 329

@@ -162,3 +162,21 @@ def test_tensor2img_psnr():
     assert O.psnr_u8(img, img) == float('inf')
     b = img.copy(); b[0, 0, 0] = 10
     assert abs(O.psnr_u8(img, b) - 20 * np.log10(255 / np.sqrt(100 / 12))) < 1e-9
+
+
+def test_metrics_vs_reference_goldens(golden_dir):
+    """tensor2img / PSNR of the val loop against the reference's own core/metrics.py outputs:
+    both the oracle's and the product's host implementations."""
+    from fastdiffsr_amd import metrics as M
+    g = _load(golden_dir, 'metrics.npz')
+    t = torch.from_numpy(g['t'])
+    for impl in (O.tensor2img_u8, M.tensor2img):
+        np.testing.assert_array_equal(impl(t.clone()), g['img'])
+    np.testing.assert_array_equal(M.tensor2img(t[:1].clone()), g['gray'])
+    assert abs(O.psnr_u8(g['img'], g['img2']) - float(g['psnr'])) < 1e-12
+    assert abs(M.calculate_psnr(g['img'], g['img2']) - float(g['psnr'])) < 1e-12
+    assert M.calculate_psnr(g['img'], g['img']) == float('inf') == float(g['psnr_same'])
+    # unpinned (reference needs cv2/skimage): sanity only
+    assert M.calculate_ssim(g['img'], g['img']) > 0.999999
+    assert 0 < M.calculate_ssim(g['img'], g['img2']) < 1
+    assert M.calculate_ergas(g['img'], g['img']) == 0.0
