@@ -1006,6 +1006,68 @@ int fdsr_tensor2img_u8(fdsr_handle h, const float* src_nchw, uint8_t* dst_nhwc, 
   return FDSR_OK;
 }
 
+namespace {
+// Pillow libImaging/Resample.c: bicubic_filter (a = -0.5), precompute_coeffs, normalize_coeffs_8bpc
+double pil_bicubic(double x) {
+  const double a = -0.5;
+  if (x < 0.0) x = -x;
+  if (x < 1.0) return ((a + 2.0) * x - (a + 3.0)) * x * x + 1;
+  if (x < 2.0) return (((x - 5) * x + 8) * x - 4) * a;
+  return 0.0;
+}
+struct ResizeTable { int in_size, out_size, ksize; int* d_bounds; int* d_kk; };
+std::vector<ResizeTable> g_resize_tables;
+
+int get_resize_table(fdsr_handle h, int in_size, int out_size, ResizeTable* out) {
+  for (const auto& t : g_resize_tables)
+    if (t.in_size == in_size && t.out_size == out_size) { *out = t; return FDSR_OK; }
+  const double scale = (double)in_size / (double)out_size;
+  const double filterscale = scale < 1.0 ? 1.0 : scale;
+  const double support = 2.0 * filterscale;
+  const int ksize = (int)std::ceil(support) * 2 + 1;
+  const double ss = 1.0 / filterscale;
+  std::vector<int> bounds((size_t)out_size * 2), kk((size_t)out_size * ksize, 0);
+  std::vector<double> w(ksize);
+  for (int xx = 0; xx < out_size; ++xx) {
+    const double center = (xx + 0.5) * scale;
+    int xmin = (int)(center - support + 0.5);
+    if (xmin < 0) xmin = 0;
+    int xmax = (int)(center + support + 0.5);
+    if (xmax > in_size) xmax = in_size;
+    xmax -= xmin;
+    double ww = 0.0;
+    for (int x = 0; x < xmax; ++x) { w[x] = pil_bicubic((x + xmin - center + 0.5) * ss); ww += w[x]; }
+    for (int x = 0; x < xmax; ++x) {
+      const double v = ww != 0.0 ? w[x] / ww : w[x];
+      kk[(size_t)xx * ksize + x] = v < 0 ? (int)(-0.5 + v * (double)(1 << 22)) : (int)(0.5 + v * (double)(1 << 22));
+    }
+    bounds[2 * xx] = xmin;
+    bounds[2 * xx + 1] = xmax;
+  }
+  ResizeTable t{in_size, out_size, ksize, nullptr, nullptr};
+  HIPCHK(h, hipMalloc((void**)&t.d_bounds, bounds.size() * sizeof(int)));
+  HIPCHK(h, hipMalloc((void**)&t.d_kk, kk.size() * sizeof(int)));
+  HIPCHK(h, hipMemcpy(t.d_bounds, bounds.data(), bounds.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(t.d_kk, kk.data(), kk.size() * sizeof(int), hipMemcpyHostToDevice));
+  g_resize_tables.push_back(t);
+  *out = t;
+  return FDSR_OK;
+}
+}  // namespace
+
+int fdsr_resize_bicubic_u8(fdsr_handle h, const uint8_t* src_nhwc, int batch, int in_h, int in_w, int out_h, int out_w,
+                           uint8_t* tmp, uint8_t* dst_u8_nhwc, float* dst_f32_nchw, void* hip_stream) {
+  if (!src_nhwc || !tmp || (!dst_u8_nhwc && !dst_f32_nchw) || batch < 1 || in_h < 1 || in_w < 1 || out_h < 1 || out_w < 1)
+    return fail(h, FDSR_E_INVALID, "bad resize arguments");
+  ResizeTable tx{}, ty{};
+  int rc = get_resize_table(h, in_w, out_w, &tx);
+  if (rc) return rc;
+  if ((rc = get_resize_table(h, in_h, out_h, &ty))) return rc;
+  HIPCHK(h, launch_resize_bicubic_u8(src_nhwc, tmp, dst_u8_nhwc, dst_f32_nchw, batch, in_h, in_w, out_h, out_w, tx.d_bounds, tx.d_kk,
+                                     tx.ksize, ty.d_bounds, ty.d_kk, ty.ksize, reinterpret_cast<hipStream_t>(hip_stream)));
+  return FDSR_OK;
+}
+
 int fdsr_set_precision(fdsr_handle h, int mode) {
   if (!h || mode < 0 || mode > 2) return fail(h, FDSR_E_INVALID, "precision mode must be 0 (f32), 1 (f16x3) or 2 (bf16)");
   if (h->prec != mode) {

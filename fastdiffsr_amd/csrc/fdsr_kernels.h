@@ -107,6 +107,11 @@ hipError_t launch_nhwc_to_nchw(const float* src, float* dst, int N, int C, int H
 hipError_t launch_tensor2img_u8(const float* src, unsigned char* dst, int N, int C, int H, int W, float lo, float hi,
                                 hipStream_t s);
 
+// PIL-exact 8-bit bicubic resize (two passes) + uint8 -> model tensor; tables built on the host
+hipError_t launch_resize_bicubic_u8(const unsigned char* src, unsigned char* tmp, unsigned char* dst_u8, float* dst_f32, int N,
+                                    int h, int w, int H, int W, const int* bounds_x, const int* kk_x, int ksize_x,
+                                    const int* bounds_y, const int* kk_y, int ksize_y, hipStream_t s);
+
 // one reverse-diffusion update (diffusion.py:157-190) on the packed state tensor
 // xin [N,H,W,CP]: channels [0,3) = cond, [3,6) = x_t.
 struct PosteriorParams {

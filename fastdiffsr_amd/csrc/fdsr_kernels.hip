@@ -714,6 +714,79 @@ hipError_t launch_tensor2img_u8(const float* src, unsigned char* dst, int N, int
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------
+// PIL-exact 8-bit bicubic resize (Pillow libImaging/Resample.c: fixed point, PRECISION_BITS = 22,
+// horizontal pass, clip8, vertical pass, clip8) + the val-time tensor transform (uint8/255*2-1, CHW).
+// bounds[X] = (first tap, tap count), kk[X][ksize] = fixed-point coefficients (host-built tables).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int clip8_fix(int v) {
+  v >>= 22;
+  return v < 0 ? 0 : (v > 255 ? 255 : v);
+}
+
+__global__ void __launch_bounds__(256) resize_h_u8_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst,
+                                                          const int* __restrict__ bounds, const int* __restrict__ kk, int ksize,
+                                                          int h, int w, int W, size_t total) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;   // over N*h*W output pixels
+  if (i >= total) return;
+  const int X = (int)(i % W);
+  const size_t row = i / W;                                  // n*h + y
+  const int xmin = bounds[2 * X], cnt = bounds[2 * X + 1];
+  const int* k = kk + (size_t)X * ksize;
+  int a0 = 1 << 21, a1 = 1 << 21, a2 = 1 << 21;
+  const unsigned char* s = src + (row * w + xmin) * 3;
+  for (int x = 0; x < cnt; ++x) {
+    const int c = k[x];
+    a0 += s[3 * x + 0] * c;
+    a1 += s[3 * x + 1] * c;
+    a2 += s[3 * x + 2] * c;
+  }
+  unsigned char* d = dst + i * 3;
+  d[0] = (unsigned char)clip8_fix(a0);
+  d[1] = (unsigned char)clip8_fix(a1);
+  d[2] = (unsigned char)clip8_fix(a2);
+}
+
+__global__ void __launch_bounds__(256) resize_v_u8_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst_u8,
+                                                          float* __restrict__ dst_f32, const int* __restrict__ bounds,
+                                                          const int* __restrict__ kk, int ksize, int h, int H, int W,
+                                                          size_t total) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;   // over N*H*W output pixels
+  if (i >= total) return;
+  const int X = (int)(i % W);
+  const int Y = (int)((i / W) % H);
+  const size_t n = i / ((size_t)W * H);
+  const int ymin = bounds[2 * Y], cnt = bounds[2 * Y + 1];
+  const int* k = kk + (size_t)Y * ksize;
+  int a0 = 1 << 21, a1 = 1 << 21, a2 = 1 << 21;
+  const unsigned char* s = src + ((n * h + ymin) * W + X) * 3;
+  for (int y = 0; y < cnt; ++y) {
+    const int c = k[y];
+    a0 += s[(size_t)y * W * 3 + 0] * c;
+    a1 += s[(size_t)y * W * 3 + 1] * c;
+    a2 += s[(size_t)y * W * 3 + 2] * c;
+  }
+  const int v[3] = {clip8_fix(a0), clip8_fix(a1), clip8_fix(a2)};
+  if (dst_u8) { dst_u8[i * 3 + 0] = (unsigned char)v[0]; dst_u8[i * 3 + 1] = (unsigned char)v[1]; dst_u8[i * 3 + 2] = (unsigned char)v[2]; }
+  if (dst_f32) {   // ToTensor(): uint8 -> fp32 / 255; then x*2 + (-1)   (data/util.py:66-75)
+    const size_t plane = (size_t)H * W, pix = (size_t)Y * W + X;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      dst_f32[(n * 3 + c) * plane + pix] = __fadd_rn(__fmul_rn(__fdiv_rn((float)v[c], 255.0f), 2.0f), -1.0f);
+  }
+}
+
+hipError_t launch_resize_bicubic_u8(const unsigned char* src, unsigned char* tmp, unsigned char* dst_u8, float* dst_f32, int N,
+                                    int h, int w, int H, int W, const int* bounds_x, const int* kk_x, int ksize_x,
+                                    const int* bounds_y, const int* kk_y, int ksize_y, hipStream_t s) {
+  const size_t t1 = (size_t)N * h * W, t2 = (size_t)N * H * W;
+  hipLaunchKernelGGL(resize_h_u8_kernel, dim3((unsigned)((t1 + 255) / 256)), dim3(256), 0, s, src, tmp, bounds_x, kk_x, ksize_x, h, w,
+                     W, t1);
+  hipLaunchKernelGGL(resize_v_u8_kernel, dim3((unsigned)((t2 + 255) / 256)), dim3(256), 0, s, tmp, dst_u8, dst_f32, bounds_y, kk_y,
+                     ksize_y, h, H, W, t2);
+  return hipGetLastError();
+}
+
 hipError_t kernels_init() {
   hipError_t e;
 #define X(KS_, ST_, UP_, KC_, BN_, WM_) \

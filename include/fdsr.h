@@ -138,6 +138,16 @@ int fdsr_set_precision(fdsr_handle h, int mode);
 int fdsr_tensor2img_u8(fdsr_handle h, const float* src_nchw, uint8_t* dst_nhwc, int batch, int channels,
                        int height, int width, float lo, float hi, void* hip_stream);
 
+/* -- input-pipeline helper ------------------------------------ */
+/* The conditioning image: LR uint8 RGB -> PIL-exact bicubic resize (Image.BICUBIC as used by
+ * data/prepare_data_mfe_dm.py:17-40; Pillow's 8-bit fixed-point two-pass resample, bit for bit) ->
+ * optionally the val-time tensor transform ToTensor()*2-1 (data/util.py:66-75).
+ *   src [B,h,w,3] uint8 device; tmp: B*h*W*3 bytes of device scratch;
+ *   dst_u8 [B,H,W,3] uint8 and/or dst_f32 [B,3,H,W] fp32 in [-1,1] (either may be NULL).  h may be NULL.
+ * The first call for a new (in,out) size builds its coefficient tables (synchronous upload). */
+int fdsr_resize_bicubic_u8(fdsr_handle h, const uint8_t* src_nhwc, int batch, int in_h, int in_w, int out_h,
+                           int out_w, uint8_t* tmp, uint8_t* dst_u8_nhwc, float* dst_f32_nchw, void* hip_stream);
+
 /* -- introspection for parity tests and bench.py -------------------------- */
 /* When on, the next plan keeps every layer output in its own buffer. */
 int fdsr_set_debug(fdsr_handle h, int on);

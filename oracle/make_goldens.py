@@ -226,6 +226,21 @@ def main():
                         psnr=np.array(ref_metrics.calculate_psnr(img, img2), dtype=np.float64),
                         psnr_same=np.array(ref_metrics.calculate_psnr(img, img), dtype=np.float64))
 
+    # ---- (vii) PIL bicubic (the LR -> SR conditioning image, prepare_data_mfe_dm.py:17-40) ---------
+    from PIL import Image
+    import PIL
+    rng = np.random.default_rng(77)
+    bic = {}
+    for name, (h, w, H, W) in {'x4': (64, 64, 256, 256), 'x8': (32, 32, 256, 256), 'ragged': (24, 40, 96, 160)}.items():
+        a = rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+        if name == 'x4':
+            a[:8] = np.array([0, 255, 0], np.uint8)
+            a[8:16, ::2] = 255   # saturating edges / ringing
+        bic[name + '/lr'] = a
+        bic[name + '/sr'] = np.asarray(Image.fromarray(a).resize((W, H), Image.BICUBIC))
+    bic['pil_version'] = np.array(PIL.__version__)
+    np.savez_compressed(os.path.join(OUT, 'bicubic.npz'), **bic)
+
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

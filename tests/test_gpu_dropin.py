@@ -111,3 +111,18 @@ def test_ddpm_wrapper_val_iteration(tmp_path):
     assert diffusion.netG.training and tuple(diffusion.SR.shape) == (1, 3, 64, 64)
     p = diffusion.save_network(1, 100)
     assert len(torch.load(p)) == 329
+
+
+def test_gpu_bicubic_lr_to_sr_bit_exact(golden_dir):
+    """GPU LR->SR conditioning image == PIL Image.BICUBIC (uint8, bit for bit) and == ToTensor()*2-1."""
+    import os
+    from fastdiffsr_amd.data import lr_to_sr
+    from oracle import pil_bicubic as PB
+    g = np.load(os.path.join(golden_dir, 'bicubic.npz'))
+    for name in ('x4', 'x8', 'ragged'):
+        lr, sr = g[name + '/lr'], g[name + '/sr']
+        batch = torch.from_numpy(np.stack([lr, lr[::-1].copy()])).cuda()
+        cond, u8 = lr_to_sr(batch, sr.shape[0], sr.shape[1], want_u8=True)
+        np.testing.assert_array_equal(u8[0].cpu().numpy(), sr)
+        np.testing.assert_array_equal(u8[1].cpu().numpy(), PB.resize_bicubic_u8(lr[::-1].copy(), sr.shape[0], sr.shape[1]))
+        assert torch.equal(cond[0].cpu(), PB.u8_to_model_tensor(sr))

@@ -180,3 +180,15 @@ def test_metrics_vs_reference_goldens(golden_dir):
     assert M.calculate_ssim(g['img'], g['img']) > 0.999999
     assert 0 < M.calculate_ssim(g['img'], g['img2']) < 1
     assert M.calculate_ergas(g['img'], g['img']) == 0.0
+
+
+def test_pil_bicubic_restatement(golden_dir):
+    """oracle/pil_bicubic.py == Pillow's Image.resize(BICUBIC), bit for bit (goldens made by PIL itself)."""
+    from oracle import pil_bicubic as PB
+    g = _load(golden_dir, 'bicubic.npz')
+    for name in ('x4', 'x8', 'ragged'):
+        sr = g[name + '/sr']
+        np.testing.assert_array_equal(PB.resize_bicubic_u8(g[name + '/lr'], sr.shape[0], sr.shape[1]), sr)
+    t = PB.u8_to_model_tensor(g['x4/sr'])
+    assert t.shape == (3, 256, 256) and t.dtype == torch.float32 and float(t.min()) >= -1.0 and float(t.max()) <= 1.0
+    assert t[1, 0, 0] == 1.0 and t[0, 0, 0] == -1.0      # the green band
