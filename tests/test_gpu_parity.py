@@ -262,3 +262,48 @@ def test_error_paths(full):
         e2.unet_forward(torch.zeros(1, 6, 32, 32).cuda(), torch.zeros(1).cuda())
     with pytest.raises(RuntimeError):
         eng.unet_forward(torch.zeros(1, 6, 32, 32), torch.zeros(1))                # CPU tensor: no fallback
+
+
+@pytest.mark.parametrize('kw,shape', [
+    (dict(in_channel=6, out_channel=3, inner_channel=32, channel_mults=(1, 2), res_blocks=3), (2, 40, 72)),
+    (dict(in_channel=6, out_channel=3, inner_channel=64, channel_mults=(1, 2, 4, 8, 8), res_blocks=1), (1, 64, 96)),
+    (dict(in_channel=6, out_channel=3, inner_channel=96, channel_mults=(1, 2, 2), res_blocks=2), (1, 32, 32)),
+])
+def test_other_architectures(kw, shape):
+    """The UNet constructor's other hyper-parameters (channel multipliers incl. 512-channel levels, block
+    counts, inner widths that are not powers of two, ragged sizes) in both fp32-grade modes."""
+    from fastdiffsr_amd.engine import Engine
+    from oracle import fdsr_oracle as O
+    cfg = UNetConfig(**kw)
+    sd = synth_state_dict(cfg, 3)
+    eng = Engine(cfg)
+    eng.load_state_dict(sd)
+    B, H, W = shape
+    gen = torch.Generator().manual_seed(17)
+    x = torch.randn(B, 6, H, W, generator=gen)
+    nl = torch.rand(B, 1, generator=gen)
+    with torch.no_grad():
+        ref = O.unet_forward(O.to_torch_sd(sd), cfg, x, nl)
+    for prec in ('f32', 'f16x3'):
+        eng.set_precision(prec)
+        out = eng.unet_forward(x.cuda(), nl.cuda()).cpu()
+        d = (out - ref).abs().max().item()
+        report(f'arch {kw["inner_channel"]}/{kw["channel_mults"]}/{kw["res_blocks"]} {shape} {prec}: max|d|={d:.3e} (max|ref|={ref.abs().max():.2f})')
+        assert d <= TOL_FWD * max(1.0, ref.abs().max().item())
+
+
+def test_infer_size_512(full):
+    """infer.py runs the same network on 512x512 inputs: one forward against the oracle."""
+    from oracle import fdsr_oracle as O
+    cfg, eng, sd = full
+    gen = torch.Generator().manual_seed(23)
+    x = torch.randn(1, 6, 512, 512, generator=gen)
+    nl = torch.tensor([[0.4681449]])
+    with torch.no_grad():
+        ref = O.unet_forward(O.to_torch_sd(sd), cfg, x, nl)
+    for prec in ('f16x3', 'f32'):
+        eng.set_precision(prec)
+        d = (eng.unet_forward(x.cuda(), nl.cuda()).cpu() - ref).abs().max().item()
+        report(f'512x512 forward {prec}: max|d|={d:.3e}')
+        assert d <= TOL_FWD
+    eng.set_precision('f32')
