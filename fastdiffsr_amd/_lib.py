@@ -69,6 +69,9 @@ def load():
         raise ImportError(
             f'{LIB} is missing: build it with `python -m fastdiffsr_amd.build` (or __graft_entry__.build()). '
             'fastdiffsr_amd has no CPU/PyTorch fallback for the sampling path.')
+    # torch first: it ships its own libamdhip64; loading ours before it would bind this library to the
+    # system copy and leave two HIP runtimes in the process (ours would then see no device)
+    import torch  # noqa: F401
     lib = C.CDLL(os.environ.get('FDSR_LIB', LIB))   # FDSR_LIB: A/B a differently built engine on one box
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)      # AttributeError if the .so does not export it
