@@ -26,6 +26,9 @@ class UNetConfig:
     res_blocks: int = 3
     dropout: float = 0.0
     image_size: int = 256
+    # 'fastdiffsr' (model/fastdiffsr_modules) or 'ddpm' (the SR3 sibling, model/ddpm_modules: integer-time
+    # embedding, Swish before the per-block Linear, SelfAttention where the resolution is in attn_res)
+    variant: str = 'fastdiffsr'
 
     def __post_init__(self):
         self.channel_mults = tuple(int(m) for m in self.channel_mults)
@@ -48,6 +51,8 @@ class Layer:
 def build_layers(cfg: UNetConfig) -> List[Layer]:
     """Layer sequence of UNet.__init__/forward (reference unet.py:252-323)."""
     ic = cfg.inner_channel
+    sr3 = cfg.variant == 'ddpm'
+    now_res = cfg.image_size
     layers: List[Layer] = []
     feat_channels = [ic]
     pre = ic
@@ -58,7 +63,7 @@ def build_layers(cfg: UNetConfig) -> List[Layer]:
         is_last = ind == nm - 1
         cm = ic * cfg.channel_mults[ind]
         for _ in range(cfg.res_blocks):
-            layers.append(Layer('res', f'downs.{idx}', pre, cm))
+            layers.append(Layer('res', f'downs.{idx}', pre, cm, with_attn=sr3 and now_res in cfg.attn_res))
             idx += 1
             feat_channels.append(cm)
             pre = cm
@@ -66,6 +71,7 @@ def build_layers(cfg: UNetConfig) -> List[Layer]:
             layers.append(Layer('down', f'downs.{idx}', pre, pre))
             idx += 1
             feat_channels.append(pre)
+            now_res //= 2
     layers.append(Layer('res', 'mid.0', pre, pre, with_attn=True))
     layers.append(Layer('res', 'mid.1', pre, pre))
     idx = 0
@@ -74,12 +80,13 @@ def build_layers(cfg: UNetConfig) -> List[Layer]:
         cm = ic * cfg.channel_mults[ind]
         for _ in range(cfg.res_blocks + 1):
             cs = feat_channels.pop()
-            layers.append(Layer('res', f'ups.{idx}', pre + cs, cm, cskip=cs))
+            layers.append(Layer('res', f'ups.{idx}', pre + cs, cm, cskip=cs, with_attn=sr3 and now_res in cfg.attn_res))
             idx += 1
             pre = cm
         if not is_last:
             layers.append(Layer('up', f'ups.{idx}', pre, pre))
             idx += 1
+            now_res *= 2
     layers.append(Layer('final', 'final_conv', pre, cfg.out_channel))
     return layers
 
@@ -91,6 +98,8 @@ def param_schema(cfg: UNetConfig) -> "OrderedDict[str, Tuple[int, ...]]":
     (reference unet.py:212) because strict load_state_dict needs them."""
     ic = cfg.inner_channel
     sd: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+    if cfg.variant == 'ddpm':
+        return _param_schema_sr3(cfg)
     sd['noise_level_mlp.1.weight'] = (ic * 4, ic)
     sd['noise_level_mlp.1.bias'] = (ic * 4,)
     sd['noise_level_mlp.3.weight'] = (ic, ic * 4)
@@ -133,8 +142,57 @@ def param_schema(cfg: UNetConfig) -> "OrderedDict[str, Tuple[int, ...]]":
     return sd
 
 
+def _param_schema_sr3(cfg: UNetConfig):
+    """Checkpoint schema of model/ddpm_modules/unet.py (SR3): time_mlp with its inv_freq buffer,
+    per-block `mlp.1` Linear, SelfAttention (norm, qkv, out) where with_attn; no dead `.conv`."""
+    ic = cfg.inner_channel
+    sd = OrderedDict()
+    sd['time_mlp.0.inv_freq'] = (ic // 2,)
+    sd['time_mlp.1.weight'] = (ic * 4, ic)
+    sd['time_mlp.1.bias'] = (ic * 4,)
+    sd['time_mlp.3.weight'] = (ic, ic * 4)
+    sd['time_mlp.3.bias'] = (ic,)
+    for L in build_layers(cfg):
+        p = L.name
+        if L.kind == 'conv_in':
+            sd[f'{p}.weight'] = (L.cout, L.cin, 3, 3)
+            sd[f'{p}.bias'] = (L.cout,)
+        elif L.kind in ('down', 'up'):
+            sd[f'{p}.conv.weight'] = (L.cout, L.cin, 3, 3)
+            sd[f'{p}.conv.bias'] = (L.cout,)
+        elif L.kind == 'res':
+            r = f'{p}.res_block'
+            sd[f'{r}.mlp.1.weight'] = (L.cout, ic)
+            sd[f'{r}.mlp.1.bias'] = (L.cout,)
+            sd[f'{r}.block1.block.0.weight'] = (L.cin,)
+            sd[f'{r}.block1.block.0.bias'] = (L.cin,)
+            sd[f'{r}.block1.block.3.weight'] = (L.cout, L.cin, 3, 3)
+            sd[f'{r}.block1.block.3.bias'] = (L.cout,)
+            sd[f'{r}.block2.block.0.weight'] = (L.cout,)
+            sd[f'{r}.block2.block.0.bias'] = (L.cout,)
+            sd[f'{r}.block2.block.3.weight'] = (L.cout, L.cout, 3, 3)
+            sd[f'{r}.block2.block.3.bias'] = (L.cout,)
+            if L.cin != L.cout:
+                sd[f'{r}.res_conv.weight'] = (L.cout, L.cin, 1, 1)
+                sd[f'{r}.res_conv.bias'] = (L.cout,)
+            if L.with_attn:
+                sd[f'{p}.attn.norm.weight'] = (L.cout,)
+                sd[f'{p}.attn.norm.bias'] = (L.cout,)
+                sd[f'{p}.attn.qkv.weight'] = (L.cout * 3, L.cout, 1, 1)
+                sd[f'{p}.attn.out.weight'] = (L.cout, L.cout, 1, 1)
+                sd[f'{p}.attn.out.bias'] = (L.cout,)
+        elif L.kind == 'final':
+            sd[f'{p}.block.0.weight'] = (L.cin,)
+            sd[f'{p}.block.0.bias'] = (L.cin,)
+            sd[f'{p}.block.3.weight'] = (L.cout, L.cin, 3, 3)
+            sd[f'{p}.block.3.bias'] = (L.cout,)
+    return sd
+
+
 def dead_keys(cfg: UNetConfig):
     out = []
+    if cfg.variant == 'ddpm':
+        return out
     for L in build_layers(cfg):
         if L.kind == 'res':
             out += [f'{L.name}.conv.weight', f'{L.name}.conv.bias']
@@ -153,5 +211,9 @@ SCHEDULE_BUFFERS = (
 FASTDIFFSR_UNET = dict(in_channel=6, out_channel=3, inner_channel=64, norm_groups=32,
                        channel_mults=(1, 2, 4, 4), attn_res=(16,), res_blocks=2,
                        dropout=0.2, image_size=256)
+# SR3 x4 val config (reference config/sr_ddpm_test_64_256.json)
+SR3_UNET = dict(in_channel=6, out_channel=3, inner_channel=64, norm_groups=32, channel_mults=(1, 1, 2, 2, 4, 4),
+                attn_res=(16,), res_blocks=2, dropout=0.2, image_size=256, variant='ddpm')
+SR3_SCHEDULE_VAL = dict(schedule='linear', n_timestep=1000, linear_start=1e-4, linear_end=2e-2)
 FASTDIFFSR_SCHEDULE_VAL = dict(schedule='linear_cosine', n_timestep=20,
                                linear_start=1e-6, linear_end=1e-2)

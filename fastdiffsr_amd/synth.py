@@ -26,11 +26,15 @@ def _rng(key: str, seed: int) -> np.random.Generator:
 
 
 def synth_tensor(key: str, shape, seed: int = 0) -> np.ndarray:
+    if key.endswith('inv_freq'):     # TimeEmbedding buffer (ddpm_modules/unet.py:22-27), formed in fp32 like torch does
+        import torch
+        dim = 2 * shape[0]
+        return torch.exp(torch.arange(0, dim, 2, dtype=torch.float32) * (-np.log(10000) / dim)).numpy()
     g = _rng(key, seed)
     x = g.standard_normal(size=shape, dtype=np.float64)
     if key.endswith('.bias'):
         x *= 0.05
-    elif len(shape) == 1:          # GroupNorm gamma
+    elif len(shape) == 1:          # GroupNorm gamma (incl. attn.norm)
         x = 1.0 + 0.1 * x
     else:
         fan_in = int(np.prod(shape[1:]))

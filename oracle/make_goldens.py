@@ -241,6 +241,44 @@ def main():
     bic['pil_version'] = np.array(PIL.__version__)
     np.savez_compressed(os.path.join(OUT, 'bicubic.npz'), **bic)
 
+    # ---- (viii) SR3 sibling (model/ddpm_modules), SURVEY 8f-4 ------------------------------------
+    from model.ddpm_modules import diffusion as sr3_diffusion, unet as sr3_unet
+    cfg3 = UNetConfig(in_channel=6, out_channel=3, inner_channel=32, norm_groups=32, channel_mults=(1, 2, 2, 4),
+                      attn_res=(8,), res_blocks=1, dropout=0.2, image_size=32, variant='ddpm')
+    net3 = sr3_unet.UNet(in_channel=6, out_channel=3, norm_groups=32, inner_channel=32, channel_mults=[1, 2, 2, 4],
+                         attn_res=[8], res_blocks=1, dropout=0.2, image_size=32)
+    sd3 = synth_state_dict(cfg3, 5)
+    assert list(net3.state_dict().keys()) == list(sd3.keys()), 'SR3 schema order mismatch'
+    net3.load_state_dict({k: torch.from_numpy(v) for k, v in sd3.items()}, strict=True)
+    sched3 = dict(schedule='linear', n_timestep=12, linear_start=1e-4, linear_end=2e-2)
+    G3 = sr3_diffusion.GaussianDiffusion(net3, image_size=32, channels=3, loss_type='l1', conditional=True, schedule_opt=sched3)
+    G3.set_loss('cpu')
+    G3.set_new_noise_schedule(sched3, 'cpu')
+    G3.eval()
+    g = torch.Generator().manual_seed(51)
+    x3 = torch.randn(2, 6, 32, 32, generator=g)
+    s3 = {'weights_sha256': np.array(state_dict_sha256(sd3)), 'x': x3.numpy()}
+    with torch.no_grad():
+        s3['eps_t'] = net3(x3, torch.tensor([3, 999])).numpy()
+        s3['eps_t0'] = net3(x3, torch.tensor([0, 0])).numpy()
+        xa = torch.randn(2, 64, 8, 8, generator=g)
+        attn_name = [n for n, m in net3.named_modules() if isinstance(m, sr3_unet.SelfAttention)][0]
+        s3['attn_in'] = xa.numpy()
+        s3['attn_name'] = np.array(attn_name)
+        s3['attn_out'] = dict(net3.named_modules())[attn_name](xa).numpy()
+    cond3 = torch.rand(2, 3, 32, 32, generator=g) * 2 - 1
+    noise3 = torch.randn(13, 2, 3, 32, 32, generator=g)
+    it3 = iter(range(0, 13))      # randn(shape) for x_T, then one noise_like draw per step (t = 11..0)
+    with torch.no_grad(), mock.patch.object(torch, 'randn', lambda *a, **k: noise3[next(it3)]), \
+            mock.patch.object(sr3_diffusion, 'tqdm', lambda it_, **k: it_):
+        ret3 = G3.p_sample_loop(cond3, continous=True)
+    s3['cond'] = cond3.numpy()
+    s3['noise'] = noise3.numpy()
+    s3['continous'] = ret3.numpy()
+    for k in SCHEDULE_BUFFERS:
+        s3[f'buf/{k}'] = getattr(G3, k).numpy()
+    np.savez_compressed(os.path.join(OUT, 'sr3.npz'), **s3)
+
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

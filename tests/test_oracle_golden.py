@@ -192,3 +192,31 @@ def test_pil_bicubic_restatement(golden_dir):
     t = PB.u8_to_model_tensor(g['x4/sr'])
     assert t.shape == (3, 256, 256) and t.dtype == torch.float32 and float(t.min()) >= -1.0 and float(t.max()) <= 1.0
     assert t[1, 0, 0] == 1.0 and t[0, 0, 0] == -1.0      # the green band
+
+
+def test_sr3_sibling_vs_reference_goldens(golden_dir):
+    """the SR3 sibling (model/ddpm_modules) restated in oracle/sr3_oracle.py against outputs of
+    the reference modules: UNet forward (integer time, self-attention), the attention block, the buffers
+    and the reference's own p_sample_loop(continous=True) at T=12."""
+    from oracle import sr3_oracle as S
+    g = _load(golden_dir, 'sr3.npz')
+    cfg = UNetConfig(in_channel=6, out_channel=3, inner_channel=32, norm_groups=32, channel_mults=(1, 2, 2, 4),
+                     attn_res=(8,), res_blocks=1, dropout=0.2, image_size=32, variant='ddpm')
+    sdn = synth_state_dict(cfg, 5)
+    assert state_dict_sha256(sdn) == str(g['weights_sha256'])
+    sd = O.to_torch_sd(sdn)
+    x = torch.from_numpy(g['x'])
+    with torch.no_grad():
+        assert np.abs(S.unet_forward(sd, cfg, x, torch.tensor([3, 999])).numpy() - g['eps_t']).max() <= TOL
+        assert np.abs(S.unet_forward(sd, cfg, x, torch.tensor([0, 0])).numpy() - g['eps_t0']).max() <= TOL
+        an = str(g['attn_name'])
+        assert np.abs(S.self_attention(sd, an, torch.from_numpy(g['attn_in']), 32).numpy() - g['attn_out']).max() <= TOL
+    tab = O.schedule_tables(dict(schedule='linear', n_timestep=12, linear_start=1e-4, linear_end=2e-2))
+    for k in SCHEDULE_BUFFERS:
+        np.testing.assert_array_equal(tab[k], g[f'buf/{k}'])
+    cond, noise = torch.from_numpy(g['cond']), torch.from_numpy(g['noise'])
+    out, traj = S.p_sample_loop(sd, cfg, tab, cond, noise, return_trajectory=True)
+    ref = g['continous']                      # [x_in(2) | img after t=11 (2) | ... | t=0 (2)]
+    assert ref.shape[0] == 2 + 12 * 2
+    assert np.abs(torch.cat([cond] + traj).numpy() - ref).max() <= 2e-5
+    assert np.abs(out.numpy() - ref[-2:]).max() <= 2e-5
