@@ -13,7 +13,8 @@ PRECISIONS = {'f32': 0, 'f16x3': 1, 'bf16': 2}
 class FdsrConfig(C.Structure):
     _fields_ = [('in_channel', C.c_int32), ('out_channel', C.c_int32), ('inner_channel', C.c_int32),
                 ('norm_groups', C.c_int32), ('n_mults', C.c_int32), ('channel_mults', C.c_int32 * FDSR_MAX_MULTS),
-                ('res_blocks', C.c_int32), ('dropout', C.c_float), ('image_size', C.c_int32)]
+                ('res_blocks', C.c_int32), ('dropout', C.c_float), ('image_size', C.c_int32), ('variant', C.c_int32),
+                ('n_attn_res', C.c_int32), ('attn_res', C.c_int32 * FDSR_MAX_MULTS)]
 
 
 class FdsrSchedule(C.Structure):

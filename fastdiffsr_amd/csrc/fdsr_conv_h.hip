@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(512, 2) conv_mfma_h_kernel(const ConvParams p)
       f32x4 v = rin[i];
       if (gn) {
         v = v * sc + sh;
-        v.x = silu_h(v.x); v.y = silu_h(v.y); v.z = silu_h(v.z); v.w = silu_h(v.w);
+        if (!p.gn_plain) { v.x = silu_h(v.x); v.y = silu_h(v.y); v.z = silu_h(v.z); v.w = silu_h(v.w); }
       }
       const float keep = in_pix[i] >= 0 ? 1.f : 0.f;   // conv zero-pads the ACTIVATED tensor
       unsigned char* dst = buf + (row0 + i * RPP) * ROWB + (q >> 2) * (NP * 32) + (q & 3) * 8;

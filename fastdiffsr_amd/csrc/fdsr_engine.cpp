@@ -55,7 +55,7 @@ struct TensorDesc {
 };
 
 struct Op {
-  enum Kind { GN_FINALIZE, CONV, CLAM, SLAM } kind;
+  enum Kind { GN_FINALIZE, CONV, CLAM, SLAM, ATTN } kind;
   std::string name;
   int src0 = -1, src1 = -1, dst = -1, res = -1;
   ConvKind ck = CONV3_S1;
@@ -65,6 +65,8 @@ struct Op {
   int w = -1, b = -1, gamma = -1, beta = -1;   // weight-entry indices
   int temb_off = -1;
   int fc1 = -1, fc2 = -1;
+  bool no_part = false;   // dst is overwritten later by another producer (res_conv pre-fill)
+  int aux = -1;           // ATTN: scratch tensor for the scores
 };
 
 struct ShapePlan {
@@ -94,9 +96,12 @@ struct fdsr_engine {
   std::vector<TensorDesc> tensors;
   std::vector<Op> ops;
   int t_in = -1, t_eps = -1, CP = 8;
-  int n_gn_slots = 0, TE = 0, Cmid = 0;
+  int n_gn_slots = 0, TE = 0, Cmid = 0, max_qkv = 0;
+  int n_schema = 0;   // checkpoint tensors (the entries after them are synthetic)
   std::vector<int> gn_channels;   // per GroupNorm slot
-  int w_freq = -1;   // synthetic entry: positional-encoding frequencies
+  int w_freq = -1;   // synthetic entry: positional-encoding frequencies (SR3: the checkpoint's inv_freq buffer)
+  int w_zero_bias = -1;   // synthetic zeros for bias-free 1x1 convs (attn.qkv)
+  bool sr3 = false;
   size_t param_floats = 0, noise_w_off = 0, noise_b_off = 0;
   int w_mlp[4] = {-1, -1, -1, -1};
   float* d_params = nullptr;
@@ -196,10 +201,20 @@ int build_plan(fdsr_handle h) {
   if (c.out_channel < 1 || c.out_channel > 32) return fail(h, FDSR_E_INVALID, "out_channel must be in [1,32]");
   h->CP = 8;
 
-  add_weight(h, "noise_level_mlp.1.weight", {ic * 4, ic}, true);
-  add_weight(h, "noise_level_mlp.1.bias", {ic * 4}, true);
-  add_weight(h, "noise_level_mlp.3.weight", {ic, ic * 4}, true);
-  add_weight(h, "noise_level_mlp.3.bias", {ic}, true);
+  h->sr3 = c.variant == FDSR_VARIANT_SR3;
+  const std::string mlp = h->sr3 ? "time_mlp" : "noise_level_mlp";
+  if (h->sr3) h->w_freq = add_weight(h, "time_mlp.0.inv_freq", {ic / 2}, true);   // registered buffer, ddpm_modules/unet.py:27
+  add_weight(h, mlp + ".1.weight", {ic * 4, ic}, true);
+  add_weight(h, mlp + ".1.bias", {ic * 4}, true);
+  add_weight(h, mlp + ".3.weight", {ic, ic * 4}, true);
+  add_weight(h, mlp + ".3.bias", {ic}, true);
+  int now_res = c.image_size;
+  auto attn_here = [&]() {
+    if (!h->sr3) return false;
+    for (int i = 0; i < c.n_attn_res && i < FDSR_MAX_MULTS; ++i)
+      if (c.attn_res[i] == now_res) return true;
+    return false;
+  };
 
   h->t_in = new_tensor(h, h->CP, 0, "input");
   h->tensors[h->t_in].persistent = true;
@@ -236,8 +251,9 @@ int build_plan(fdsr_handle h) {
     if (Cin % G || Cout % G) return fail(h, FDSR_E_INVALID, "%s: channels not divisible by norm_groups", p.c_str());
     if (Cin % 16 || (C1 && C0 % 16)) return fail(h, FDSR_E_INVALID, "%s: channel counts must be multiples of 16", p.c_str());
     const std::string r = p + ".res_block";
-    int wn = add_weight(h, r + ".noise_func.noise_func.0.weight", {Cout, ic}, true);
-    int bn = add_weight(h, r + ".noise_func.noise_func.0.bias", {Cout}, true);
+    const std::string nf = h->sr3 ? r + ".mlp.1" : r + ".noise_func.noise_func.0";   // SR3: Sequential(Swish, Linear)
+    int wn = add_weight(h, nf + ".weight", {Cout, ic}, true);
+    int bn = add_weight(h, nf + ".bias", {Cout}, true);
     h->weights[wn].sink = WeightEntry::NOISE_W;
     h->weights[wn].row_off = te;
     h->weights[bn].sink = WeightEntry::NOISE_B;
@@ -262,8 +278,10 @@ int build_plan(fdsr_handle h) {
     } else if (C1) {
       return fail(h, FDSR_E_INVALID, "%s: identity residual over a concatenated input is not supported", p.c_str());
     }
-    add_weight(h, p + ".conv.weight", {Cout, Cout, 1, 1}, false);   // dead layer, unet.py:212
-    add_weight(h, p + ".conv.bias", {Cout}, false);
+    if (!h->sr3) {
+      add_weight(h, p + ".conv.weight", {Cout, Cout, 1, 1}, false);   // dead layer, unet.py:212
+      add_weight(h, p + ".conv.bias", {Cout}, false);
+    }
 
     // block1: GN -> Swish -> conv3x3, + noise shift
     Op s1; s1.kind = Op::GN_FINALIZE; s1.name = r + ".block1.gn"; s1.src0 = x0; s1.src1 = x1; s1.C0 = C0; s1.C1 = C1;
@@ -284,7 +302,7 @@ int build_plan(fdsr_handle h) {
     int res_src = x0;
     if (wr >= 0) {   // res_conv 1x1 on the raw (concatenated) input, written into `out` first
       Op kr; kr.kind = Op::CONV; kr.name = r + ".res_conv"; kr.ck = CONV1; kr.src0 = x0; kr.src1 = x1; kr.C0 = C0; kr.C1 = C1;
-      kr.Cout = Cout; kr.lvl_in = kr.lvl_out = lvl; kr.w = wr; kr.b = br; kr.dst = out;
+      kr.Cout = Cout; kr.lvl_in = kr.lvl_out = lvl; kr.w = wr; kr.b = br; kr.dst = out; kr.no_part = true;
       h->ops.push_back(kr);
       res_src = out;
     }
@@ -293,7 +311,36 @@ int build_plan(fdsr_handle h) {
     k2.dst = out;
     h->ops.push_back(k2);
     int result = out;
-    if (with_attn) {
+    if (with_attn && h->sr3) {
+      // SelfAttention (ddpm_modules/unet.py:99-127): GN -> qkv 1x1 (no bias) -> softmax(QK^T/sqrt(C)) V -> out 1x1 + x
+      if (Cout % 32) return fail(h, FDSR_E_INVALID, "SelfAttention needs channels divisible by 32");
+      int gw = add_weight(h, p + ".attn.norm.weight", {Cout}, true);
+      int gb = add_weight(h, p + ".attn.norm.bias", {Cout}, true);
+      int wq = add_weight(h, p + ".attn.qkv.weight", {3 * Cout, Cout, 1, 1}, true);
+      int wo = add_weight(h, p + ".attn.out.weight", {Cout, Cout, 1, 1}, true);
+      int bo = add_weight(h, p + ".attn.out.bias", {Cout}, true);
+      mark_conv_pack(h, wq, CONV1, Cout, Cout, 0, 3 * Cout);
+      mark_conv_pack(h, wo, CONV1, Cout, Cout, 0, Cout);
+      h->max_qkv = std::max(h->max_qkv, 3 * Cout);
+      Op sg; sg.kind = Op::GN_FINALIZE; sg.name = p + ".attn.norm"; sg.src0 = out; sg.C0 = Cout; sg.lvl_in = lvl;
+      sg.gn_slot = h->n_gn_slots++; sg.gamma = gw; sg.beta = gb;
+      h->tensors[out].need_part = true;
+      h->ops.push_back(sg);
+      Op kq; kq.kind = Op::CONV; kq.name = p + ".attn.qkv"; kq.ck = CONV1; kq.src0 = out; kq.C0 = Cout; kq.Cout = 3 * Cout;
+      kq.lvl_in = kq.lvl_out = lvl; kq.gn_slot = sg.gn_slot; kq.w = wq; kq.b = -2;   // -2: the shared zero bias
+      kq.dst = new_tensor(h, 3 * Cout, lvl, p + ".attn.qkv");
+      h->ops.push_back(kq);
+      Op at; at.kind = Op::ATTN; at.name = p + ".attn.core"; at.src0 = kq.dst; at.C0 = Cout; at.lvl_in = lvl;
+      at.aux = new_tensor(h, -1, lvl, p + ".attn.scores");    // C = -1: [N][HW][HW] scratch, sized in the shape plan
+      at.dst = new_tensor(h, Cout, lvl, p + ".attn.o");
+      h->ops.push_back(at);
+      Op ko; ko.kind = Op::CONV; ko.name = p + ".attn.out"; ko.ck = CONV1; ko.src0 = at.dst; ko.C0 = Cout; ko.Cout = Cout;
+      ko.lvl_in = ko.lvl_out = lvl; ko.w = wo; ko.b = bo; ko.res = out;
+      ko.dst = new_tensor(h, Cout, lvl, p);
+      h->tensors[out].name = r;   // the block output proper is the attention output
+      h->ops.push_back(ko);
+      result = ko.dst;
+    } else if (with_attn) {
       if (Cout % 16) return fail(h, FDSR_E_INVALID, "CLAM needs channels divisible by 16");
       int f1 = add_weight(h, p + ".ca.fc1.weight", {Cout / 16, Cout, 1, 1}, true);
       int f2 = add_weight(h, p + ".ca.fc2.weight", {Cout, Cout / 16, 1, 1}, true);
@@ -319,7 +366,7 @@ int build_plan(fdsr_handle h) {
     const bool is_last = ind == c.n_mults - 1;
     const int cm = ic * c.channel_mults[ind];
     for (int rb = 0; rb < c.res_blocks; ++rb) {
-      int o = res_block("downs." + std::to_string(idx), cur, curC, -1, 0, cm, false);
+      int o = res_block("downs." + std::to_string(idx), cur, curC, -1, 0, cm, attn_here());
       if (o < 0) return o;
       cur = o; curC = cm; ++idx;
       feats.push_back({cur, curC});
@@ -328,6 +375,7 @@ int build_plan(fdsr_handle h) {
       const std::string p = "downs." + std::to_string(idx);
       cur = conv_plain(p + ".conv", p, CONV3_S2, cur, curC, curC, curC, lvl, lvl + 1);
       ++lvl; ++idx;
+      now_res /= 2;
       feats.push_back({cur, curC});
     }
   }
@@ -348,7 +396,7 @@ int build_plan(fdsr_handle h) {
     for (int rb = 0; rb < c.res_blocks + 1; ++rb) {
       Feat f = feats.back();
       feats.pop_back();
-      int o = res_block("ups." + std::to_string(idx), cur, curC, f.t, f.C, cm, false);   // cat((x, skip)) unet.py:319
+      int o = res_block("ups." + std::to_string(idx), cur, curC, f.t, f.C, cm, attn_here());   // cat((x, skip)) unet.py:319
       if (o < 0) return o;
       cur = o; curC = cm; ++idx;
     }
@@ -356,6 +404,7 @@ int build_plan(fdsr_handle h) {
       const std::string p = "ups." + std::to_string(idx);
       cur = conv_plain(p + ".conv", p, CONV3_UP, cur, curC, curC, curC, lvl, lvl - 1);
       --lvl; ++idx;
+      now_res *= 2;
     }
   }
   // final_conv = Block(pre, out_channel)
@@ -389,8 +438,8 @@ int build_plan(fdsr_handle h) {
   auto take = [&](size_t n) { size_t o = off; off += align_up(n, 64); return o; };
   const size_t noise_w_off = h->noise_w_off = take((size_t)h->TE * ic);
   const size_t noise_b_off = h->noise_b_off = take((size_t)h->TE);
-  h->w_mlp[0] = h->key2w["noise_level_mlp.1.weight"]; h->w_mlp[1] = h->key2w["noise_level_mlp.1.bias"];
-  h->w_mlp[2] = h->key2w["noise_level_mlp.3.weight"]; h->w_mlp[3] = h->key2w["noise_level_mlp.3.bias"];
+  h->w_mlp[0] = h->key2w[mlp + ".1.weight"]; h->w_mlp[1] = h->key2w[mlp + ".1.bias"];
+  h->w_mlp[2] = h->key2w[mlp + ".3.weight"]; h->w_mlp[3] = h->key2w[mlp + ".3.bias"];
   for (auto& w : h->weights) {
     if (!w.live) continue;
     switch (w.sink) {
@@ -400,8 +449,19 @@ int build_plan(fdsr_handle h) {
       case WeightEntry::NOISE_B: w.dev_off = noise_b_off + (size_t)w.row_off; break;
     }
   }
+  h->n_schema = (int)h->weights.size();
+  if (h->max_qkv) {   // zeros standing in for the missing bias of attn.qkv (Conv2d(bias=False))
+    WeightEntry z;
+    z.key = "__zero_bias";
+    z.shape = {h->max_qkv};
+    z.live = false;
+    z.loaded = true;
+    z.dev_off = take(h->max_qkv);
+    h->weights.push_back(z);
+    h->w_zero_bias = (int)h->weights.size() - 1;
+  }
   // positional-encoding frequency table (not a checkpoint tensor): filled at device init
-  {
+  if (!h->sr3) {
     WeightEntry f;
     f.key = "__posenc_freq";
     f.shape = {ic / 2};
@@ -434,6 +494,10 @@ int build_plan(fdsr_handle h) {
     const Op& op = h->ops[i];
     auto use = [&](int t) { if (t >= 0) h->tensors[t].last_use = (int)i; };
     use(op.src0); use(op.src1); use(op.res);
+    if (op.aux >= 0) {
+      if (h->tensors[op.aux].first_def < 0) h->tensors[op.aux].first_def = (int)i;
+      h->tensors[op.aux].last_use = (int)i;
+    }
     if (op.dst >= 0) {
       if (h->tensors[op.dst].first_def < 0) h->tensors[op.dst].first_def = (int)i;
       h->tensors[op.dst].last_use = std::max(h->tensors[op.dst].last_use, (int)i);
@@ -449,14 +513,16 @@ int ensure_device(fdsr_handle h) {
     return fail(h, FDSR_E_HIP, "no HIP device visible: the FastDiffSR engine has no CPU fallback");
   HIPCHK(h, hipMalloc((void**)&h->d_params, h->param_floats * sizeof(float)));
   HIPCHK(h, hipMemset(h->d_params, 0, h->param_floats * sizeof(float)));
+  if (!h->sr3) {
   // unet.py:27-31: step = arange(count)/count ; exp(-ln(1e4) * step), in fp32
-  const int half = h->cfg.inner_channel / 2;
-  std::vector<float> fr(half);
-  for (int k = 0; k < half; ++k) {
-    const float step = (float)k / (float)half;
-    fr[k] = expf((float)(-std::log(1e4)) * step);
+    const int half = h->cfg.inner_channel / 2;
+    std::vector<float> fr(half);
+    for (int k = 0; k < half; ++k) {
+      const float step = (float)k / (float)half;
+      fr[k] = expf((float)(-std::log(1e4)) * step);
+    }
+    HIPCHK(h, hipMemcpy(h->d_params + h->weights[h->w_freq].dev_off, fr.data(), half * sizeof(float), hipMemcpyHostToDevice));
   }
-  HIPCHK(h, hipMemcpy(h->d_params + h->weights[h->w_freq].dev_off, fr.data(), half * sizeof(float), hipMemcpyHostToDevice));
   if (h->wq_bytes) {
     HIPCHK(h, hipMalloc((void**)&h->d_wq, h->wq_bytes));
     HIPCHK(h, hipMemset(h->d_wq, 0, h->wq_bytes));
@@ -491,7 +557,9 @@ int make_shape_plan(fdsr_handle h, int N, int H, int W, ShapePlan* sp) {
   sp->part_off.assign(h->tensors.size(), 0);
   sp->tensor_nt.assign(h->tensors.size(), 0);
   auto act_bytes = [&](const TensorDesc& t) {
-    return align_up((size_t)N * (H >> t.level) * (W >> t.level) * t.C * sizeof(float), 256);
+    const size_t hw = (size_t)(H >> t.level) * (W >> t.level);
+    if (t.C < 0) return align_up(attn_scratch_floats(N, (int)hw) * sizeof(float), 256);   // attention scores
+    return align_up((size_t)N * hw * t.C * sizeof(float), 256);
   };
   auto part_bytes = [&](const TensorDesc& t) -> size_t {
     if (!t.need_part) return 0;
@@ -536,6 +604,7 @@ int make_shape_plan(fdsr_handle h, int N, int H, int W, ShapePlan* sp) {
     if (h->tensors[t].persistent) sp->tensor_off[t] = alloc(tbytes(h->tensors[t]));
   for (size_t i = 0; i < h->ops.size(); ++i) {
     const Op& op = h->ops[i];
+    if (op.aux >= 0 && h->tensors[op.aux].first_def == (int)i) sp->tensor_off[op.aux] = alloc(tbytes(h->tensors[op.aux]));
     if (op.dst >= 0 && !h->tensors[op.dst].persistent && h->tensors[op.dst].first_def == (int)i)
       sp->tensor_off[op.dst] = alloc(tbytes(h->tensors[op.dst]));
     if (!h->debug)
@@ -591,6 +660,7 @@ int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, 
     tp.inner = h->cfg.inner_channel;
     tp.TE = h->TE;
     tp.N = N;
+    tp.swish_block = h->sr3 ? 1 : 0;
     HIPCHK(h, launch_temb(tp, st));
   }
   for (const Op& op : h->ops) {
@@ -615,7 +685,7 @@ int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, 
         p.x0 = TP(op.src0);
         p.x1 = TP(op.src1);
         p.w = P(op.w);
-        p.bias = P(op.b);
+        p.bias = op.b == -2 ? P(h->w_zero_bias) : P(op.b);
         p.temb = op.temb_off >= 0 ? temb : nullptr;
         p.temb_stride = h->TE;
         p.temb_off = op.temb_off >= 0 ? op.temb_off : 0;
@@ -624,8 +694,9 @@ int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, 
         if (op.gn_slot >= 0) {
           p.gn_scale = reinterpret_cast<const float*>(ws + sp.gn_off[op.gn_slot]);
           p.gn_shift = p.gn_scale + (size_t)N * (op.C0 + op.C1);
+          p.gn_plain = op.b == -2 ? 1 : 0;   // attn.qkv: SelfAttention.norm has no Swish
         }
-        p.part_out = op.ck == CONV1 ? nullptr : PART(op.dst);   // res_conv output is overwritten in place by block2
+        p.part_out = op.no_part ? nullptr : PART(op.dst);   // res_conv output is overwritten in place by block2
         int nt = 0;
         p.N = N; p.Hin = Hi; p.Win = Wi;
         p.Hout = H >> op.lvl_out; p.Wout = W >> op.lvl_out;
@@ -663,6 +734,10 @@ int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, 
           // algorithmic bytes: input read once + output written once
           h->prof_bytes += 4.0 * N * ((double)Hi * Wi * (op.C0 + op.C1) + (double)p.Hout * p.Wout * op.Cout);
         }
+        break;
+      }
+      case Op::ATTN: {
+        HIPCHK(h, launch_self_attention(TP(op.src0), TP(op.aux), TP(op.dst), N, Hi * Wi, op.C0, st));
         break;
       }
       case Op::CLAM:
@@ -815,7 +890,8 @@ int sample_body(fdsr_handle h, const float* cond, const float* noise, float* out
   HIPCHK(h, launch_nchw_to_nhwc(noise, xin, N, 3, H, W, h->CP, 3, 0, st));
   for (int k = 0; k < h->T; ++k) {                                        // for i in reversed(range(T))  :209
     const int t = h->T - 1 - k;
-    int rc = run_unet(h, N, H, W, ws, nullptr, h->s_nl[t], st);
+    // FastDiffSR: the network sees the noise level sqrt(alpha_bar) (:169-170); SR3: the integer time
+    int rc = run_unet(h, N, H, W, ws, nullptr, h->sr3 ? (float)t : h->s_nl[t], st);
     if (rc) return rc;
     PosteriorParams pp{};
     pp.eps = eps;
@@ -826,6 +902,7 @@ int sample_body(fdsr_handle h, const float* cond, const float* noise, float* out
     pp.N = N; pp.HW = H * W; pp.CP = h->CP;
     pp.c_recip = h->s_recip[t]; pp.c_recipm1 = h->s_recipm1[t];
     pp.coef1 = h->s_c1[t]; pp.coef2 = h->s_c2[t]; pp.sigma = h->s_sigma[t];
+    pp.plain_out = h->sr3 ? 1 : 0;                                        // ddpm_modules: ret_img[-1] is x_0 itself
     HIPCHK(h, launch_posterior(pp, st));
   }
   return FDSR_OK;
@@ -867,7 +944,7 @@ void fdsr_destroy(fdsr_handle h) {
 
 int fdsr_num_weights(fdsr_handle h) {
   if (!h) return FDSR_E_INVALID;
-  return (int)h->weights.size() - 1;   // without the synthetic frequency table
+  return h->n_schema;   // without the synthetic entries (frequency table, zero bias)
 }
 
 int fdsr_weight_info(fdsr_handle h, int idx, char* key, int key_cap, int64_t shape[4], int* ndim, int* live) {

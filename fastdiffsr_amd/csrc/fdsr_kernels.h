@@ -21,6 +21,7 @@ struct ConvParams {
   float* out;            // [N,Hout,Wout,Cout]
   const float* gn_scale;   // [N][C0+C1] per-channel GroupNorm scale = rstd*gamma (null: no GN+Swish)
   const float* gn_shift;   // [N][C0+C1] beta - mean*scale        (gn_finalize_kernel writes both)
+  int gn_plain;            // 1: GroupNorm only (SelfAttention.norm); 0: GroupNorm + Swish (Block)
   float* part_out;         // optional [N][tiles][Cout][2]: per-tile (sum, sumsq) of OUT per channel,
                            // the GroupNorm statistics of the next Block, fused into this epilogue
   int N, Hin, Win;       // source tensor dims (before upsample)
@@ -86,6 +87,7 @@ struct TembParams {
   float nl_scalar;
   float* temb;        // [N][TE]
   int inner, TE, N;
+  int swish_block;    // SR3 variant: per-block Linear applied to Swish(t)
 };
 hipError_t launch_temb(const TembParams& p, hipStream_t s);
 
@@ -102,6 +104,11 @@ hipError_t launch_nchw_to_nhwc(const float* src, float* dst, int N, int Csrc, in
                                int Cdst, int c_off, int zero_rest, hipStream_t s);
 hipError_t launch_nhwc_to_nchw(const float* src, float* dst, int N, int C, int H, int W,
                                int Csrc_stride, hipStream_t s);
+
+// SelfAttention (n_head = 1) of the SR3 sibling on the NHWC qkv tensor [N][HW][3C]:
+// S (scratch [N][HW][HW]) = softmax(Q K^T / sqrt(C)), O [N][HW][C] = S V.
+hipError_t launch_self_attention(const float* qkv, float* S, float* O, int N, int HW, int C, hipStream_t s);
+size_t attn_scratch_floats(int N, int HW);
 
 // tensor2img of the val loop (core/metrics.py:16-42): NCHW fp32 -> HWC uint8
 hipError_t launch_tensor2img_u8(const float* src, unsigned char* dst, int N, int C, int H, int W, float lo, float hi,
@@ -122,6 +129,7 @@ struct PosteriorParams {
   float* out;          // [N,3,H,W] NCHW or null: res2img(x_0, cond) at the last step
   int N, HW, CP;
   float c_recip, c_recipm1, coef1, coef2, sigma;
+  int plain_out;       // SR3 variant: out = x_0 itself (no res2img)
 };
 hipError_t launch_posterior(const PosteriorParams& p, hipStream_t s);
 

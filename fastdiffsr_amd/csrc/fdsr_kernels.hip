@@ -151,7 +151,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_f32_kernel(const ConvParams 
       f32x4 v = rin[i];
       if (gn && in_pix[i] >= 0) {   // conv zero-pads the ACTIVATED tensor
         v = v * sc + sh;
-        v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w);
+        if (!p.gn_plain) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
       }
       *reinterpret_cast<f32x4*>(sIn + (row0 + i * RPP) * S + q * 4) = v;
     }
@@ -436,9 +436,9 @@ __global__ void __launch_bounds__(256) temb_kernel(const TembParams p) {
   float* enc = st;
   float* hbuf = st + inner;
   float* tv = hbuf + hid;
-  const float nl = p.nl_dev ? p.nl_dev[n] : p.nl_scalar;
+  const float nl = p.nl_dev ? p.nl_dev[n] : p.nl_scalar;   // noise level, or the integer time (SR3 variant)
   const int half = inner / 2;
-  for (int k = tid; k < half; k += 256) {   // unet.py:27-35: cat([sin, cos], -1)
+  for (int k = tid; k < half; k += 256) {   // unet.py:27-35 / ddpm_modules TimeEmbedding: cat([sin, cos], -1)
     const float e = nl * p.freq[k];
     enc[k] = sinf(e);
     enc[half + k] = cosf(e);
@@ -455,7 +455,8 @@ __global__ void __launch_bounds__(256) temb_kernel(const TembParams p) {
     float a = p.b2[j];
     const float* w = p.w2 + (size_t)j * hid;
     for (int k = 0; k < hid; ++k) a = fmaf(w[k], hbuf[k], a);
-    tv[j] = a;
+    // SR3 variant (ddpm_modules/unet.py:81-84): the per-block Linear is applied to Swish(t)
+    tv[j] = p.swish_block ? a / (1.0f + expf(-a)) : a;
   }
   __syncthreads();
   for (int o = tid; o < p.TE; o += 256) {
@@ -679,7 +680,7 @@ __global__ void __launch_bounds__(256) posterior_kernel(const PosteriorParams p)
     if (p.noise) xn = __fadd_rn(mean, __fmul_rn(p.noise[o], p.sigma));       // :189-190
     xs[3 + c] = xn;
     if (p.traj) p.traj[o] = xn;
-    if (p.out) p.out[o] = fminf(fmaxf(xn, -1.f), 1.f) / 2.0f + xs[c];        // res2img :275-281
+    if (p.out) p.out[o] = p.plain_out ? xn : fminf(fmaxf(xn, -1.f), 1.f) / 2.0f + xs[c];   // res2img :275-281 (SR3: the image itself)
   }
 }
 
@@ -784,6 +785,88 @@ hipError_t launch_resize_bicubic_u8(const unsigned char* src, unsigned char* tmp
                      W, t1);
   hipLaunchKernelGGL(resize_v_u8_kernel, dim3((unsigned)((t2 + 255) / 256)), dim3(256), 0, s, tmp, dst_u8, dst_f32, bounds_y, kk_y,
                      ksize_y, h, H, W, t2);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// SelfAttention of the SR3 sibling (ddpm_modules/unet.py:99-127, n_head = 1) on the exact-fp32 matrix
+// instruction: S = Q K^T / sqrt(C) -> row softmax -> O = P V.  q/k/v are channel slices of the
+// NHWC qkv tensor [N][HW][3C]; one wave per 32x32 output tile (the whole op is <1 % of a forward).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) attn_scores_kernel(const float* __restrict__ qkv, float* __restrict__ S, int HW, int HWp,
+                                                         int C, float inv_div) {
+  const int lane = threadIdx.x, r31 = lane & 31, h = lane >> 5;
+  const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32, b = blockIdx.z;
+  const float* base = qkv + (size_t)b * HW * 3 * C;
+  const float* qrow = base + (size_t)min(m0 + r31, HW - 1) * 3 * C + 4 * h;          // A[i = query][k = channel]
+  const float* krow = base + (size_t)min(n0 + r31, HW - 1) * 3 * C + C + 4 * h;      // B[k][j = key] = K[j][k]
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  for (int k = 0; k < C; k += 8) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(qrow + k);
+    const f32x4 bb = *reinterpret_cast<const f32x4*>(krow + k);
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s2], bb[s2], acc, 0, 0, 0);
+  }
+  const int col = n0 + r31;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int row = m0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+    if (row < HW && col < HW) S[((size_t)b * HW + row) * HWp + col] = acc[i] * inv_div;
+  }
+}
+
+// rows of pitch HWp >= HW (multiple of 8); the pad columns are written as exact zeros
+__global__ void __launch_bounds__(256) softmax_rows_kernel(float* __restrict__ S, int HW, int HWp, size_t rows) {
+  const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  float* r = S + row * HWp;
+  float m = -INFINITY;
+  for (int i = lane; i < HW; i += 64) m = fmaxf(m, r[i]);
+  m = wave_max(m);
+  float sum = 0.f;
+  for (int i = lane; i < HW; i += 64) { const float e = expf(r[i] - m); r[i] = e; sum += e; }
+  sum = wave_sum(sum);
+  for (int i = lane; i < HWp; i += 64) r[i] = i < HW ? r[i] / sum : 0.f;
+}
+
+__global__ void __launch_bounds__(64) attn_pv_kernel(const float* __restrict__ P, const float* __restrict__ qkv,
+                                                     float* __restrict__ O, int HW, int HWp, int C) {
+  const int lane = threadIdx.x, r31 = lane & 31, h = lane >> 5;
+  const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32, b = blockIdx.z;   // n: channel, m: query
+  const float* prow = P + ((size_t)b * HW + min(m0 + r31, HW - 1)) * HWp + 4 * h;   // A[i = query][k = key]
+  const float* vcol = qkv + (size_t)b * HW * 3 * C + 2 * C + n0 + r31;               // B[k = key][j = channel]
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  for (int k = 0; k < HWp; k += 8) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(prow + k);
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) {
+      const float bv = vcol[(size_t)min(k + 4 * h + s2, HW - 1) * 3 * C];   // pad keys carry P == 0
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s2], bv, acc, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int row = m0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+    if (row < HW) O[((size_t)b * HW + row) * C + n0 + r31] = acc[i];
+  }
+}
+
+// S: scratch of attn_scratch_floats(N, HW) floats
+size_t attn_scratch_floats(int N, int HW) { return (size_t)N * HW * ((HW + 7) / 8 * 8); }
+
+hipError_t launch_self_attention(const float* qkv, float* S, float* O, int N, int HW, int C, hipStream_t s) {
+  if (C % 32) return hipErrorInvalidValue;
+  const int HWp = (HW + 7) / 8 * 8;
+  const float inv_div = 1.0f / sqrtf((float)C);
+  hipLaunchKernelGGL(attn_scores_kernel, dim3((HW + 31) / 32, (HW + 31) / 32, N), dim3(64), 0, s, qkv, S, HW, HWp, C, inv_div);
+  const size_t rows = (size_t)N * HW;
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, S, HW, HWp, rows);
+  hipLaunchKernelGGL(attn_pv_kernel, dim3(C / 32, (HW + 31) / 32, N), dim3(64), 0, s, S, qkv, O, HW, HWp, C);
   return hipGetLastError();
 }
 

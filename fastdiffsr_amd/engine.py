@@ -26,6 +26,10 @@ class Engine:
         for i, m in enumerate(cfg.channel_mults):
             c.channel_mults[i] = int(m)
         c.res_blocks, c.dropout, c.image_size = cfg.res_blocks, float(cfg.dropout), int(cfg.image_size)
+        c.variant = 1 if cfg.variant == 'ddpm' else 0
+        c.n_attn_res = min(len(cfg.attn_res), _lib.FDSR_MAX_MULTS)
+        for i, r in enumerate(cfg.attn_res[:_lib.FDSR_MAX_MULTS]):
+            c.attn_res[i] = int(r)
         h = C.c_void_p()
         rc = self.lib.fdsr_create(C.byref(c), C.byref(h))
         if rc != 0:
@@ -125,8 +129,9 @@ class Engine:
         cond = self._check_input(cond, 'cond')
         noise = self._check_input(noise, 'noise')
         B, _, H, W = cond.shape
-        if tuple(noise.shape) != (self.T, B, 3, H, W):
-            raise ValueError(f'noise must be [{self.T},{B},3,{H},{W}], got {tuple(noise.shape)}')
+        nT = self.T + (1 if self.cfg.variant == 'ddpm' else 0)     # SR3 draws noise at t = 0 too
+        if tuple(noise.shape) != (nT, B, 3, H, W):
+            raise ValueError(f'noise must be [{nT},{B},3,{H},{W}], got {tuple(noise.shape)}')
         ws = self._workspace(B, H, W, cond.device)
         if out is None:
             out = torch.empty(B, 3, H, W, device=cond.device, dtype=torch.float32)

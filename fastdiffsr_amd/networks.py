@@ -1,13 +1,14 @@
 """`define_G`: the reference's generator factory (FastDiffSR/model/networks.py:82-119)
 for `which_model_G == 'fastdiffsr'`, building the HIP-backed modules."""
-from . import diffusion, unet
-
-
 def define_G(opt):
     model_opt = opt['model']
     which = model_opt['which_model_G']
-    if which not in ('fastdiffsr', 'fastdiffsr_hip'):
-        raise NotImplementedError(f"fastdiffsr_amd only provides which_model_G='fastdiffsr' (got {which!r})")
+    if which == 'ddpm':                     # networks.py:84-85: the SR3 sibling
+        from .sr3 import diffusion, unet
+    elif which in ('fastdiffsr', 'fastdiffsr_hip'):
+        from . import diffusion, unet
+    else:
+        raise NotImplementedError(f"fastdiffsr_amd provides which_model_G in ('fastdiffsr', 'ddpm') (got {which!r})")
     if ('norm_groups' not in model_opt['unet']) or model_opt['unet']['norm_groups'] is None:
         model_opt['unet']['norm_groups'] = 32
     u = model_opt['unet']
@@ -18,5 +19,6 @@ def define_G(opt):
                                        channels=model_opt['diffusion']['channels'], loss_type='l1',
                                        conditional=model_opt['diffusion']['conditional'],
                                        schedule_opt=model_opt['beta_schedule']['train'],
-                                       scale=int(256 / int(opt['datasets']['train']['l_resolution'])))
+                                       **({} if which == 'ddpm' else
+                                          {'scale': int(256 / int(opt['datasets']['train']['l_resolution']))}))
     return netG

@@ -33,19 +33,25 @@ def _holder_path(root, parts):
 
 
 class UNet(nn.Module):
+    _variant = 'fastdiffsr'
+
     def __init__(self, in_channel=6, out_channel=3, inner_channel=32, norm_groups=32, channel_mults=(1, 2, 4, 4),
                  attn_res=(8), res_blocks=3, dropout=0, with_noise_level_emb=True, image_size=256):
         super().__init__()
         if not with_noise_level_emb:
-            raise NotImplementedError('the HIP engine implements the noise-level-conditioned UNet only')
+            raise NotImplementedError('the HIP engine implements the noise-level / time conditioned UNet only')
         self.cfg = UNetConfig(in_channel=in_channel, out_channel=out_channel, inner_channel=inner_channel,
                               norm_groups=norm_groups, channel_mults=tuple(channel_mults), attn_res=attn_res,
-                              res_blocks=res_blocks, dropout=dropout, image_size=image_size)
+                              res_blocks=res_blocks, dropout=dropout, image_size=image_size, variant=self._variant)
         self._schema = param_schema(self.cfg)
         for key, shape in self._schema.items():
             parts = key.split('.')
             holder = _holder_path(self, parts[:-1])
-            holder.register_parameter(parts[-1], nn.Parameter(self._default_init(parts[-1], shape, key)))
+            if parts[-1] == 'inv_freq':      # TimeEmbedding's registered buffer (ddpm_modules/unet.py:22-27)
+                from .synth import synth_tensor
+                holder.register_buffer('inv_freq', torch.from_numpy(synth_tensor(key, shape)))
+            else:
+                holder.register_parameter(parts[-1], nn.Parameter(self._default_init(parts[-1], shape, key)))
         self._engine = None
         self._uploaded_version = None
 
@@ -53,12 +59,15 @@ class UNet(nn.Module):
         """PyTorch's default initialisers (Conv2d/Linear: kaiming_uniform(a=sqrt 5) and
         bias ~ U(+-1/sqrt(fan_in)); GroupNorm: weight 1, bias 0)."""
         t = torch.empty(shape)
-        if '.block.0.' in key:          # GroupNorm
+        if '.block.0.' in key or '.attn.norm.' in key:          # GroupNorm
             return t.fill_(1.0 if leaf == 'weight' else 0.0)
         if leaf == 'weight':
             nn.init.kaiming_uniform_(t, a=math.sqrt(5))
             return t
-        wshape = self._schema[key[:-len('bias')] + 'weight']
+        wkey = key[:-len('bias')] + 'weight'
+        if wkey not in self._schema:
+            return t.zero_()
+        wshape = self._schema[wkey]
         fan_in = 1
         for d in wshape[1:]:
             fan_in *= d
@@ -73,7 +82,8 @@ class UNet(nn.Module):
         return self._engine
 
     def _param_version(self):
-        return tuple(p._version for p in self.parameters()) + tuple(id(p.data) for p in self.parameters())
+        ts = list(self.parameters()) + list(self.buffers())
+        return tuple(p._version for p in ts) + tuple(id(p.data) for p in ts)
 
     def sync_weights(self, force=False):
         """Upload parameters to the engine if they changed since the last upload."""

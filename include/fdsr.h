@@ -56,8 +56,14 @@ typedef struct fdsr_config {
   int32_t channel_mults[FDSR_MAX_MULTS]; /* {1,2,4,4}                      */
   int32_t res_blocks;    /* 2                                              */
   float dropout;         /* 0.2; identity in eval (sampling) mode          */
-  int32_t image_size;    /* informational; the UNet is fully convolutional */
+  int32_t image_size;    /* FastDiffSR: informational.  SR3 variant: attention is placed where the
+                            resolution (image_size halved per level) is in attn_res (ddpm_modules/unet.py:183) */
+  int32_t variant;       /* FDSR_VARIANT_FASTDIFFSR (model/fastdiffsr_modules) or FDSR_VARIANT_SR3 (model/ddpm_modules) */
+  int32_t n_attn_res;
+  int32_t attn_res[FDSR_MAX_MULTS];
 } fdsr_config;
+#define FDSR_VARIANT_FASTDIFFSR 0
+#define FDSR_VARIANT_SR3 1
 
 /* Per-timestep scalars the reverse process reads (diffusion.py:109-155; only
  * these five buffers + the fp64 sqrt_alphas_cumprod_prev list are used by
@@ -107,7 +113,10 @@ int fdsr_unet_forward(fdsr_handle h, const float* x_nchw, const float* noise_lev
                       float* eps_nchw, int batch, int height, int width,
                       void* workspace, size_t workspace_bytes, void* hip_stream);
 
-/* GaussianDiffusion.p_sample_loop, conditional branch (diffusion.py:192-221),
+/* SR3 variant: same entry point; noise is [T+1,B,3,H,W] (a draw exists for t = 0 too and is masked, ddpm_modules/
+ * diffusion.py:189-196), the network sees the integer time, and out is x_0 itself (no res2img, :226-227).
+ *
+ * GaussianDiffusion.p_sample_loop, conditional branch (diffusion.py:192-221),
  * batched as B independent B=1 runs (the reference crashes for B>=2, :215-216).
  *   cond_nchw [B,3,H,W]        the bicubic-upsampled LR image (x_in)
  *   noise     [T,B,3,H,W]      noise[0] = x_T (`randn(shape)` :207), noise[k] =
