@@ -106,6 +106,12 @@ struct fdsr_engine {
   int w_mlp[4] = {-1, -1, -1, -1};
   float* d_params = nullptr;
   unsigned char* d_wq = nullptr;
+  // Sampling feeds every image of a batch the same noise level, and only T distinct ones ever
+  // occur (diffusion.py:169-170), so the whole embedding table [T][TE] is evaluated once per
+  // (weights, schedule) and the conv epilogues index it with batch stride 0.
+  float* d_temb_table = nullptr;
+  float* d_nl = nullptr;
+  bool temb_table_valid = false;
   size_t wq_bytes = 0;
   int prec = PREC_F32;
   bool kernels_ready = false;
@@ -636,32 +642,21 @@ double conv_flops(const Op& op, int N, int H, int W) {
 }
 
 // One UNet forward over the plan; input already packed in tensor t_in.
-int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, float nl_scalar, hipStream_t st) {
+int fill_temb(fdsr_handle h, float* temb, int N, const float* nl_dev, float nl_scalar, hipStream_t st);
+
+int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, float nl_scalar, hipStream_t st,
+             const float* temb_row = nullptr) {
   ShapePlan& sp = h->plan;
   const int G = h->cfg.norm_groups;
-  float* temb = reinterpret_cast<float*>(ws + sp.off_temb);
+  const float* temb = temb_row ? temb_row : reinterpret_cast<const float*>(ws + sp.off_temb);
   float* gate = reinterpret_cast<float*>(ws + sp.off_gate);
   auto P = [&](int widx) -> const float* { return widx >= 0 ? h->d_params + h->weights[widx].dev_off : nullptr; };
   auto TP = [&](int t) -> float* { return t >= 0 ? reinterpret_cast<float*>(ws + sp.tensor_off[t]) : nullptr; };
 
   auto PART = [&](int t) -> float* { return (t >= 0 && sp.part_off[t]) ? reinterpret_cast<float*>(ws + sp.part_off[t]) : nullptr; };
-  {
-    TembParams tp;
-    tp.freq = P(h->w_freq);
-    tp.w1 = P(h->w_mlp[0]);
-    tp.b1 = P(h->w_mlp[1]);
-    tp.w2 = P(h->w_mlp[2]);
-    tp.b2 = P(h->w_mlp[3]);
-    tp.wn = h->d_params + h->noise_w_off;   // all 22 noise_func Linear layers, concatenated by rows
-    tp.bn = h->d_params + h->noise_b_off;
-    tp.nl_dev = nl_dev;
-    tp.nl_scalar = nl_scalar;
-    tp.temb = temb;
-    tp.inner = h->cfg.inner_channel;
-    tp.TE = h->TE;
-    tp.N = N;
-    tp.swish_block = h->sr3 ? 1 : 0;
-    HIPCHK(h, launch_temb(tp, st));
+  if (!temb_row) {
+    int rc = fill_temb(h, reinterpret_cast<float*>(ws + sp.off_temb), N, nl_dev, nl_scalar, st);
+    if (rc) return rc;
   }
   for (const Op& op : h->ops) {
     const int Hi = H >> op.lvl_in, Wi = W >> op.lvl_in;
@@ -687,7 +682,7 @@ int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, 
         p.w = P(op.w);
         p.bias = op.b == -2 ? P(h->w_zero_bias) : P(op.b);
         p.temb = op.temb_off >= 0 ? temb : nullptr;
-        p.temb_stride = h->TE;
+        p.temb_stride = temb_row ? 0 : h->TE;
         p.temb_off = op.temb_off >= 0 ? op.temb_off : 0;
         p.res = TP(op.res);
         p.out = TP(op.dst);
@@ -867,6 +862,45 @@ int pack_weights_h(fdsr_handle h, WeightEntry& w, const float* host) {
   return FDSR_OK;
 }
 
+int fill_temb(fdsr_handle h, float* temb, int N, const float* nl_dev, float nl_scalar, hipStream_t st) {
+  auto P = [&](int widx) -> const float* { return widx >= 0 ? h->d_params + h->weights[widx].dev_off : nullptr; };
+  TembParams tp;
+  tp.freq = P(h->w_freq);
+  tp.w1 = P(h->w_mlp[0]);
+  tp.b1 = P(h->w_mlp[1]);
+  tp.w2 = P(h->w_mlp[2]);
+  tp.b2 = P(h->w_mlp[3]);
+  tp.wn = h->d_params + h->noise_w_off;   // all 22 noise_func Linear layers, concatenated by rows
+  tp.bn = h->d_params + h->noise_b_off;
+  tp.nl_dev = nl_dev;
+  tp.nl_scalar = nl_scalar;
+  tp.temb = temb;
+  tp.inner = h->cfg.inner_channel;
+  tp.TE = h->TE;
+  tp.N = N;
+  tp.swish_block = h->sr3 ? 1 : 0;
+  HIPCHK(h, launch_temb(tp, st));
+  return FDSR_OK;
+}
+
+// Row t of the table is what the per-step kernel would produce for noise level t: same kernel,
+// same arithmetic, evaluated for all T levels in one launch.
+int ensure_temb_table(fdsr_handle h, hipStream_t st) {
+  if (h->temb_table_valid) return FDSR_OK;
+  if (h->d_temb_table) { (void)hipFree(h->d_temb_table); h->d_temb_table = nullptr; }
+  if (h->d_nl) { (void)hipFree(h->d_nl); h->d_nl = nullptr; }
+  HIPCHK(h, hipMalloc(&h->d_temb_table, (size_t)h->T * h->TE * sizeof(float)));
+  HIPCHK(h, hipMalloc(&h->d_nl, (size_t)h->T * sizeof(float)));
+  std::vector<float> nl(h->T);
+  for (int t = 0; t < h->T; ++t) nl[t] = h->sr3 ? (float)t : h->s_nl[t];
+  HIPCHK(h, hipMemcpy(h->d_nl, nl.data(), nl.size() * sizeof(float), hipMemcpyHostToDevice));
+  int rc = fill_temb(h, h->d_temb_table, h->T, h->d_nl, 0.f, st);
+  if (rc) return rc;
+  HIPCHK(h, hipStreamSynchronize(st));
+  h->temb_table_valid = true;
+  return FDSR_OK;
+}
+
 int check_ready(fdsr_handle h, bool need_schedule) {
   for (const auto& w : h->weights)
     if (w.live && !w.loaded) return fail(h, FDSR_E_STATE, "weight '%s' has not been loaded", w.key.c_str());
@@ -891,7 +925,7 @@ int sample_body(fdsr_handle h, const float* cond, const float* noise, float* out
   for (int k = 0; k < h->T; ++k) {                                        // for i in reversed(range(T))  :209
     const int t = h->T - 1 - k;
     // FastDiffSR: the network sees the noise level sqrt(alpha_bar) (:169-170); SR3: the integer time
-    int rc = run_unet(h, N, H, W, ws, nullptr, h->sr3 ? (float)t : h->s_nl[t], st);
+    int rc = run_unet(h, N, H, W, ws, nullptr, 0.f, st, h->d_temb_table + (size_t)t * h->TE);
     if (rc) return rc;
     PosteriorParams pp{};
     pp.eps = eps;
@@ -939,6 +973,8 @@ void fdsr_destroy(fdsr_handle h) {
   for (auto e : h->ev_pool) (void)hipEventDestroy(e);
   if (h->d_params) (void)hipFree(h->d_params);
   if (h->d_wq) (void)hipFree(h->d_wq);
+  if (h->d_temb_table) (void)hipFree(h->d_temb_table);
+  if (h->d_nl) (void)hipFree(h->d_nl);
   delete h;
 }
 
@@ -988,6 +1024,7 @@ int fdsr_load_weight(fdsr_handle h, const char* key, const float* host, const in
     HIPCHK(h, hipMemcpy(dst, host, numel(w.shape) * sizeof(float), hipMemcpyHostToDevice));
   }
   w.loaded = true;
+  h->temb_table_valid = false;
   for (auto& g : h->graphs) (void)hipGraphExecDestroy(g.exec);   // weights are baked by address only, but be safe
   h->graphs.clear();
   return FDSR_OK;
@@ -1007,6 +1044,7 @@ int fdsr_set_schedule(fdsr_handle h, const fdsr_schedule* s) {
   auto cp = [&](std::vector<float>& v, const float* p) { v.assign(p, p + s->n_timestep); };
   cp(h->s_nl, s->noise_level); cp(h->s_recip, s->sqrt_recip); cp(h->s_recipm1, s->sqrt_recipm1);
   cp(h->s_c1, s->coef1); cp(h->s_c2, s->coef2); cp(h->s_sigma, s->sigma);
+  h->temb_table_valid = false;
   for (auto& g : h->graphs) (void)hipGraphExecDestroy(g.exec);
   h->graphs.clear();
   return FDSR_OK;
@@ -1049,6 +1087,7 @@ int fdsr_sample(fdsr_handle h, const float* cond_nchw, const float* noise, float
   if ((rc = check_ws(h, workspace, workspace_bytes))) return rc;
   hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
   char* ws = reinterpret_cast<char*>(workspace);
+  if ((rc = ensure_temb_table(h, st))) return rc;
   const bool use_graph = (flags & FDSR_SAMPLE_GRAPH) && !h->profiling && st != nullptr;
   if (!use_graph) return sample_body(h, cond_nchw, noise, out_nchw, traj_nchw, batch, height, width, ws, st);
 
