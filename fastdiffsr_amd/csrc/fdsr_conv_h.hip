@@ -23,6 +23,7 @@
 //   * epilogue as in the fp32 kernel (bias + noise-embedding shift + residual, NHWC stores)
 #include "fdsr_kernels.h"
 
+#include <algorithm>
 #include <cstdlib>
 
 namespace fdsr {
@@ -81,6 +82,9 @@ __global__ void __launch_bounds__(512, 2) conv_mfma_h_kernel(const ConvParams p)
     const int q8 = nwg >> 3, r8 = nwg & 7, xcd = b & 7, k = b >> 3;
     bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
   }
+  const int SK = p.ksplit > 1 ? p.ksplit : 1;
+  const int ksi = bid % SK;   // K slice of this workgroup
+  bid /= SK;
   const int cot = bid % nco;
   int pt = bid / nco;
   const int tx = pt % tilesX;
@@ -183,11 +187,12 @@ __global__ void __launch_bounds__(512, 2) conv_mfma_h_kernel(const ConvParams p)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[mb][i] = 0.f;
 
+  const int kc0 = ksi * nk / SK, kc1 = (ksi + 1) * nk / SK;   // this slice's chunks
 #pragma unroll
-  for (int tap = 0; tap < T; ++tap) load_b_tap(0, tap);
-  prefetch(0);
-  stage(0, sBuf0);
-  if (nk > 1) prefetch(1);
+  for (int tap = 0; tap < T; ++tap) load_b_tap(kc0, tap);
+  prefetch(kc0);
+  stage(kc0, sBuf0);
+  if (kc0 + 1 < kc1) prefetch(kc0 + 1);
   __syncthreads();
 
   // A fragments are double-buffered over taps: the reads of tap t+1 are issued before the MFMAs
@@ -205,10 +210,10 @@ __global__ void __launch_bounds__(512, 2) conv_mfma_h_kernel(const ConvParams p)
         Af[slot][mb][pl] = *reinterpret_cast<const uint4*>(arow[mb] + aoff + 32 * pl);
   };
 
-  for (int kc = 0; kc < nk; ++kc) {
-    unsigned char* cur = (kc & 1) ? sBuf1 : sBuf0;
-    unsigned char* nxt = (kc & 1) ? sBuf0 : sBuf1;
-    const bool more = kc + 1 < nk;
+  for (int kc = kc0; kc < kc1; ++kc) {
+    unsigned char* cur = ((kc - kc0) & 1) ? sBuf1 : sBuf0;
+    unsigned char* nxt = ((kc - kc0) & 1) ? sBuf0 : sBuf1;
+    const bool more = kc + 1 < kc1;
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) arow[mb] = cur + abase[mb];
     load_a(0, 0);
@@ -230,7 +235,7 @@ __global__ void __launch_bounds__(512, 2) conv_mfma_h_kernel(const ConvParams p)
       if (more) load_b_tap(kc + 1, tap);             // same registers, next chunk
       if (tap == T / 2 && more) {                    // mid-chunk: fill the other halo buffer
         stage(kc + 1, nxt);
-        if (kc + 2 < nk) prefetch(kc + 2);
+        if (kc + 2 < kc1) prefetch(kc + 2);
       }
     }
     __syncthreads();
@@ -248,6 +253,26 @@ __global__ void __launch_bounds__(512, 2) conv_mfma_h_kernel(const ConvParams p)
   }
   float s1 = 0.f, s2 = 0.f;
   const bool interior = (oy0 + TH <= p.Hout) && (ox0 + TW <= p.Wout) && (co0 + BN <= p.Cout);
+  if (SK > 1) {   // raw partial accumulators; bias, shift, residual and statistics happen in the reduce
+    float* sb = p.kscratch + (size_t)ksi * p.N * p.Hout * p.Wout * p.Cout;
+    if (interior) {
+      float* obase = sb + ((size_t)(n * p.Hout + oy0 + wm) * p.Wout + ox0 + 4 * h) * p.Cout + co;
+      const size_t rstride = (size_t)WM * p.Wout * p.Cout;
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) obase[mb * rstride + (size_t)((i & 3) + 8 * (i >> 2)) * p.Cout] = acc[mb][i];
+    } else {
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int oy = oy0 + wm + mb * WM, ox = ox0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+          if (cok && oy < p.Hout && ox < p.Wout) sb[((size_t)(n * p.Hout + oy) * p.Wout + ox) * p.Cout + co] = acc[mb][i];
+        }
+    }
+    return;
+  }
   if (interior) {
     float* obase = p.out + ((size_t)(n * p.Hout + oy0 + wm) * p.Wout + ox0 + 4 * h) * p.Cout + co;
     const size_t rstride = (size_t)WM * p.Wout * p.Cout;
@@ -320,6 +345,54 @@ __global__ void __launch_bounds__(512, 2) conv_mfma_h_kernel(const ConvParams p)
   }
 }
 
+// Split-K second phase: sums the ksplit partial outputs in slice order, applies bias + noise-embedding
+// shift + residual, stores NHWC and emits the per-tile channel statistics.  One workgroup per
+// 2 x 32 output pixels (the smallest conv tile, so the partials fit the same appendix) x cb channels.
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const ConvParams p, const int cb) {
+  __shared__ float sred[256 * 8];
+  const int tilesX = (p.Wout + 31) / 32;
+  const int tile = blockIdx.x, n = blockIdx.y;
+  const int tx = tile % tilesX, ty = tile / tilesX;
+  const int cq = cb >> 2, groups = 256 / cq, cbase = blockIdx.z * cb;
+  const int tid = threadIdx.x, c4 = tid % cq, g = tid / cq;
+  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+  if (g < groups) {
+    f32x4 add = *reinterpret_cast<const f32x4*>(p.bias + cbase + c4 * 4);
+    if (p.temb) add += *reinterpret_cast<const f32x4*>(p.temb + (size_t)n * p.temb_stride + p.temb_off + cbase + c4 * 4);
+    const size_t slice = (size_t)p.N * p.Hout * p.Wout * p.Cout;
+    for (int px = g; px < 64; px += groups) {
+      const int oy = ty * 2 + (px >> 5), ox = tx * 32 + (px & 31);
+      if (oy >= p.Hout || ox >= p.Wout) continue;
+      const size_t o = ((size_t)(n * p.Hout + oy) * p.Wout + ox) * p.Cout + cbase + c4 * 4;
+      f32x4 a = *reinterpret_cast<const f32x4*>(p.kscratch + o);
+#pragma unroll 4
+      for (int s = 1; s < p.ksplit; ++s) a += *reinterpret_cast<const f32x4*>(p.kscratch + s * slice + o);
+      a = a * p.w_inv_scale + add;
+      if (p.res) a += *reinterpret_cast<const f32x4*>(p.res + o);
+      *reinterpret_cast<f32x4*>(p.out + o) = a;
+      s1 += a;
+      s2 += a * a;
+    }
+  }
+  if (p.part_out) {
+    if (g < groups) {
+      *reinterpret_cast<f32x4*>(sred + (g * cq + c4) * 8) = s1;
+      *reinterpret_cast<f32x4*>(sred + (g * cq + c4) * 8 + 4) = s2;
+    }
+    __syncthreads();
+    if (tid < cq) {
+      f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
+      for (int gg = 0; gg < groups; ++gg) {
+        a += *reinterpret_cast<const f32x4*>(sred + (gg * cq + tid) * 8);
+        b += *reinterpret_cast<const f32x4*>(sred + (gg * cq + tid) * 8 + 4);
+      }
+      float* dst = p.part_out + (((size_t)n * gridDim.x + tile) * p.Cout + cbase + tid * 4) * 2;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { dst[2 * e] = a[e]; dst[2 * e + 1] = b[e]; }
+    }
+  }
+}
+
 template <int KS, int STRIDE, bool UP, int TH, int WN, int PREC, int KSUB>
 static hipError_t launch_h_t(const ConvParams& p, hipStream_t s, int* tiles) {
   using Cfg = ConvHCfg<KS, STRIDE, UP, TH, WN, PREC, KSUB>;
@@ -327,8 +400,15 @@ static hipError_t launch_h_t(const ConvParams& p, hipStream_t s, int* tiles) {
   const size_t lds = (size_t)2 * Cfg::BUF_BYTES;
   const int tilesX = (p.Wout + Cfg::TW - 1) / Cfg::TW, tilesY = (p.Hout + TH - 1) / TH;
   if (tiles) *tiles = tilesX * tilesY;
-  const int nwg = p.N * tilesX * tilesY * (p.Cout_pad / Cfg::BN);
+  const int sk = p.ksplit > 1 ? p.ksplit : 1;
+  const int nwg = p.N * tilesX * tilesY * (p.Cout_pad / Cfg::BN) * sk;
   hipLaunchKernelGGL(kfn, dim3(nwg), dim3(Cfg::NT), lds, s, p);
+  if (sk > 1) {
+    const int rt = ((p.Wout + 31) / 32) * ((p.Hout + 1) / 2);
+    if (tiles) *tiles = rt;
+    const int cb = p.Cout % 32 == 0 ? 32 : p.Cout;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rt, p.N, p.Cout / cb), dim3(256), 0, s, p, cb);
+  }
   return hipGetLastError();
 }
 
@@ -375,6 +455,24 @@ static int pick_th(ConvKind kind, int WN, int ksub, const ConvParams& p) {
     if (wgs >= 512) break;
   }
   return best;
+}
+
+int conv_h_ksplit(ConvKind kind, int N, int Hout, int Wout, int Cout, int Cout_pad, int Cin_pad, int C0, int C1) {
+  static const bool off = getenv("FDSR_NO_SPLITK") != nullptr;
+  if (off || kind == CONV3_UP || (Cout & 3) || Cout > 1024) return 1;
+  int TH, WN;
+  conv_h_config(kind, Cout, &TH, &WN);
+  const int ksub = (kind == CONV1 && Cin_pad % 64 == 0 && (C1 == 0 || C0 % 64 == 0)) ? 4 : 1;
+  ConvParams p{};
+  p.N = N; p.Hout = Hout; p.Wout = Wout; p.Cout_pad = Cout_pad;
+  TH = pick_th(kind, WN, ksub, p);
+  const long wgs = (long)N * ((Wout + 31) / 32) * ((Hout + TH - 1) / TH) * (Cout_pad / (32 * WN));
+  const int nk = Cin_pad / (16 * ksub);
+  static const int target = getenv("FDSR_SK_TARGET") ? atoi(getenv("FDSR_SK_TARGET")) : 256;
+  if (wgs >= target) return 1;
+  // enough slices to give every CU a workgroup, at least two chunks per slice
+  const int sk = (int)std::min<long>(std::min(16, nk / 2), (target + wgs - 1) / wgs);
+  return sk >= 2 ? sk : 1;
 }
 
 hipError_t launch_conv_h(ConvKind kind, int prec, const ConvParams& p, hipStream_t s, int* tiles) {

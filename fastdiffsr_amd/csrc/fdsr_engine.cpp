@@ -73,7 +73,8 @@ struct ShapePlan {
   int N = 0, H = 0, W = 0;
   bool debug = false;
   size_t bytes = 0;
-  size_t off_temb = 0, off_gate = 0;
+  size_t off_temb = 0, off_gate = 0, off_splitk = 0;
+  std::vector<int> op_ksplit;      // per op: K-loop split factor of a 16-bit conv at this shape (1 = none)
   std::vector<size_t> tensor_off;
   std::vector<size_t> part_off;    // per tensor: per-tile channel sums [N][max_tiles][C][2] (0 = none)
   std::vector<size_t> gn_off;      // per GroupNorm slot: scale [N][C] then shift [N][C]
@@ -558,6 +559,19 @@ int make_shape_plan(fdsr_handle h, int N, int H, int W, ShapePlan* sp) {
     }
   sp->off_temb = off;  off += align_up((size_t)N * h->TE * sizeof(float), 256);
   sp->off_gate = off;  off += align_up((size_t)N * std::max(h->Cmid, 1) * sizeof(float), 256);
+  // small grids split the K loop over workgroups; the slices meet in a scratch region
+  sp->op_ksplit.assign(h->ops.size(), 1);
+  size_t sk_bytes = 0;
+  for (size_t i = 0; i < h->ops.size(); ++i) {
+    const Op& op = h->ops[i];
+    if (op.kind != Op::CONV || !h->weights[op.w].h_ok) continue;
+    const WeightEntry& w = h->weights[op.w];
+    const int Ho = H >> op.lvl_out, Wo = W >> op.lvl_out;
+    const int sk = conv_h_ksplit(op.ck, N, Ho, Wo, op.Cout, w.h_cout_pad, w.h_cin_pad, op.C0, op.C1);
+    sp->op_ksplit[i] = sk;
+    if (sk > 1) sk_bytes = std::max(sk_bytes, (size_t)sk * N * Ho * Wo * op.Cout * sizeof(float));
+  }
+  sp->off_splitk = off;  off += align_up(sk_bytes, 256);
   const size_t arena0 = off;
   sp->tensor_off.assign(h->tensors.size(), 0);
   sp->part_off.assign(h->tensors.size(), 0);
@@ -658,7 +672,8 @@ int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, 
     int rc = fill_temb(h, reinterpret_cast<float*>(ws + sp.off_temb), N, nl_dev, nl_scalar, st);
     if (rc) return rc;
   }
-  for (const Op& op : h->ops) {
+  for (size_t oi = 0; oi < h->ops.size(); ++oi) {
+    const Op& op = h->ops[oi];
     const int Hi = H >> op.lvl_in, Wi = W >> op.lvl_in;
     switch (op.kind) {
       case Op::GN_FINALIZE: {
@@ -715,6 +730,8 @@ int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, 
             p.w_inv_scale = w.up2_inv_scale[h->prec];
             HIPCHK(h, launch_conv_up2_h(h->prec, p, st, &nt));
           } else {
+            p.ksplit = (op.ck == CONV3_UP) ? 1 : sp.op_ksplit[oi];
+            p.kscratch = reinterpret_cast<float*>(ws + sp.off_splitk);
             HIPCHK(h, launch_conv_h(op.ck, h->prec, p, st, &nt));
           }
         } else {

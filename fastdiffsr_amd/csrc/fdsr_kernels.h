@@ -32,6 +32,10 @@ struct ConvParams {
   // 16-bit MFMA path (fdsr_conv_h.hip): weights in MFMA-fragment order, see pack_weights_h()
   const void* wq;
   float w_inv_scale;     // accumulator un-scaling (weights are stored multiplied by a power of two)
+  // split-K (small grids only, see conv_h_ksplit): slice s of the K loop writes its raw accumulators
+  // to kscratch[s][N,Hout,Wout,Cout]; splitk_reduce_kernel sums the slices in order and applies the epilogue
+  int ksplit;            // <= 1: off
+  float* kscratch;
 };
 
 enum Precision { PREC_F32 = 0, PREC_F16X3 = 1, PREC_BF16 = 2 };
@@ -49,6 +53,9 @@ hipError_t kernels_init();
 // 16-bit-operand MFMA convolutions (fp32-grade f16x3 split, or plain bf16).
 void conv_h_config(ConvKind kind, int Cout, int* TH, int* WN);   // BN = 32*WN, K-chunk = 16
 hipError_t launch_conv_h(ConvKind kind, int prec, const ConvParams& p, hipStream_t s, int* tiles_per_image);
+// K-loop split factor of a 16-bit conv launch (1 = none): a pure function of the shape, so the
+// workspace planner and the launcher agree.  Only grids that would leave most of the 256 CUs idle split.
+int conv_h_ksplit(ConvKind kind, int N, int Hout, int Wout, int Cout, int Cout_pad, int Cin_pad, int C0, int C1);
 hipError_t kernels_h_init();
 // Upsample(nearest x2)+Conv3x3 in sub-pixel form (fdsr_conv_up2.hip): four 2x2 convs on the source grid
 // with pre-summed weights packed [cot][kc][wn][py][px*4+a*2+b][plane][lane] x 16 B.

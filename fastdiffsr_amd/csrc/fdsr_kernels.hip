@@ -363,27 +363,24 @@ hipError_t launch_conv(ConvKind kind, const ConvParams& p, hipStream_t s, int* t
 // ---------------------------------------------------------------------------
 // GroupNorm finalisation from the producers' per-tile partial sums
 // ---------------------------------------------------------------------------
-// grid = (N, G / GPW): one workgroup finalises GPW = 4 groups of one image.  Thread (ch, slice):
-// channel ch of the workgroup's 4*cpg channels, tiles t = slice, slice + S, ... in order; the S slice
-// sums are then combined in a fixed order (bitwise reproducible, no atomics).
-#define FDSR_GN_GPW 4
+// grid = (N, G): one workgroup finalises one group of one image.  Thread (ch, slice): channel ch of
+// the group's cpg channels, tiles t = slice, slice + S, ... in order; the 256 slot sums are then
+// folded by one wave in a fixed order (bitwise reproducible, no atomics).
 __global__ void __launch_bounds__(256) gn_finalize_kernel(const GnFinalizeParams p) {
   __shared__ double sd[256][2];
-  __shared__ double gs[FDSR_GN_GPW][2];
-  const int C = p.C0 + p.C1, tid = threadIdx.x, n = blockIdx.x;
-  const int cpg = C / p.G;
-  const int g0 = blockIdx.y * FDSR_GN_GPW;
-  const int ng = min(FDSR_GN_GPW, p.G - g0);
-  const int nch = ng * cpg;                 // <= 256 (launcher checks cpg <= 64)
-  const int S = 256 / nch;                  // tile slices per channel
-  const int ch = tid % nch, slice = tid / nch;
-  const int c = g0 * cpg + ch;
+  __shared__ double gs[2];
+  const int C = p.C0 + p.C1, tid = threadIdx.x, n = blockIdx.x, g = blockIdx.y;
+  const int cpg = C / p.G;                  // <= 64 (launcher checks)
+  const int S = 256 / cpg;                  // tile slices per channel
+  const int ch = tid % cpg, slice = tid / cpg;
+  const int c = g * cpg + ch;
   double a = 0.0, b = 0.0;
   if (slice < S) {
     const float* part;
     int nt, Cs, cc;
     if (c < p.C0) { part = p.part0; nt = p.nt0; Cs = p.C0; cc = c; } else { part = p.part1; nt = p.nt1; Cs = p.C1; cc = c - p.C0; }
     const float* src = part + ((size_t)n * nt * Cs + cc) * 2;
+#pragma unroll 4
     for (int t = slice; t < nt; t += S) {
       const float2 v = *reinterpret_cast<const float2*>(src + (size_t)t * Cs * 2);
       a += (double)v.x;
@@ -393,31 +390,34 @@ __global__ void __launch_bounds__(256) gn_finalize_kernel(const GnFinalizeParams
   sd[tid][0] = a;
   sd[tid][1] = b;
   __syncthreads();
-  if (tid < ng) {
+  if (tid < 64) {   // one wave folds the 256 slots: four strided adds, then a butterfly (same order every run)
     double ga = 0.0, gb = 0.0;
-    for (int k = 0; k < cpg; ++k)
-      for (int sl = 0; sl < S; ++sl) { ga += sd[sl * nch + tid * cpg + k][0]; gb += sd[sl * nch + tid * cpg + k][1]; }
-    const double inv = 1.0 / ((double)cpg * (double)p.HW);
-    const double mean = ga * inv;
-    double var = gb * inv - mean * mean;
-    var = var < 0.0 ? 0.0 : var;
-    gs[tid][0] = mean;
-    gs[tid][1] = 1.0 / sqrt(var + (double)p.eps);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { ga += sd[tid + 64 * k][0]; gb += sd[tid + 64 * k][1]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { ga += __shfl_xor(ga, o, 64); gb += __shfl_xor(gb, o, 64); }
+    if (tid == 0) {
+      const double inv = 1.0 / ((double)cpg * (double)p.HW);
+      const double mean = ga * inv;
+      double var = gb * inv - mean * mean;
+      var = var < 0.0 ? 0.0 : var;
+      gs[0] = mean;
+      gs[1] = 1.0 / sqrt(var + (double)p.eps);
+    }
   }
   __syncthreads();
-  if (tid < nch) {
-    const int g = tid / cpg;
-    const int cc = g0 * cpg + tid;
-    const float sc = (float)gs[g][1] * p.gamma[cc];
+  if (tid < cpg) {
+    const int cc = g * cpg + tid;
+    const float sc = (float)gs[1] * p.gamma[cc];
     p.scale[(size_t)n * C + cc] = sc;
-    p.shift[(size_t)n * C + cc] = p.beta[cc] - (float)gs[g][0] * sc;
+    p.shift[(size_t)n * C + cc] = p.beta[cc] - (float)gs[0] * sc;
   }
 }
 
 hipError_t launch_gn_finalize(const GnFinalizeParams& p, hipStream_t s) {
   const int C = p.C0 + p.C1;
   if (C % p.G || C / p.G > 64) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(p.N, (p.G + FDSR_GN_GPW - 1) / FDSR_GN_GPW), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(p.N, p.G), dim3(256), 0, s, p);
   return hipGetLastError();
 }
 
