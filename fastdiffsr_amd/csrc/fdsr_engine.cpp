@@ -558,7 +558,13 @@ int make_shape_plan(fdsr_handle h, int N, int H, int W, ShapePlan* sp) {
       off += align_up((size_t)2 * N * (op.C0 + op.C1) * sizeof(float), 256);
     }
   sp->off_temb = off;  off += align_up((size_t)N * h->TE * sizeof(float), 256);
-  sp->off_gate = off;  off += align_up((size_t)N * std::max(h->Cmid, 1) * sizeof(float), 256);
+  {
+    size_t gate_floats = 1;
+    for (const Op& op : h->ops)
+      if (op.kind == Op::CLAM)
+        gate_floats = std::max(gate_floats, clam_slam_scratch_floats(N, (H >> op.lvl_in) * (W >> op.lvl_in), op.C0));
+    sp->off_gate = off;  off += align_up(gate_floats * sizeof(float), 256);
+  }
   // small grids split the K loop over workgroups; the slices meet in a scratch region
   sp->op_ksplit.assign(h->ops.size(), 1);
   size_t sk_bytes = 0;
@@ -583,7 +589,7 @@ int make_shape_plan(fdsr_handle h, int N, int H, int W, ShapePlan* sp) {
   };
   auto part_bytes = [&](const TensorDesc& t) -> size_t {
     if (!t.need_part) return 0;
-    const int mt = std::max(conv_max_tiles(H >> t.level, W >> t.level), FDSR_SLAM_PARTS);
+    const int mt = conv_max_tiles(H >> t.level, W >> t.level);
     return align_up((size_t)N * mt * t.C * 2 * sizeof(float), 256);
   };
   auto tbytes = [&](const TensorDesc& t) { return act_bytes(t) + part_bytes(t); };
@@ -755,10 +761,12 @@ int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, 
       case Op::CLAM:
         HIPCHK(h, launch_clam_gate(TP(op.src0), N, Hi * Wi, op.C0, P(op.fc1), P(op.fc2), op.C0 / 16, gate, st));
         break;
-      case Op::SLAM:
-        HIPCHK(h, launch_slam(TP(op.src0), gate, P(op.w), N, Hi, Wi, op.C0, TP(op.dst), PART(op.dst), st));
-        sp.tensor_nt[op.dst] = FDSR_SLAM_PARTS;
+      case Op::SLAM: {
+        int nt = 0;
+        HIPCHK(h, launch_slam(TP(op.src0), gate, P(op.w), N, Hi, Wi, op.C0, TP(op.dst), PART(op.dst), st, &nt));
+        sp.tensor_nt[op.dst] = nt;
         break;
+      }
     }
   }
   return FDSR_OK;

@@ -76,7 +76,6 @@ struct GnFinalizeParams {
 hipError_t launch_gn_finalize(const GnFinalizeParams& p, hipStream_t s);
 // upper bound of tiles_per_image over every conv kernel variant (sizes the partial buffers)
 int conv_max_tiles(int H, int W);
-#define FDSR_SLAM_PARTS 16
 
 // noise-level embedding: PositionalEncoding -> Linear -> Swish -> Linear
 // (unet.py:22-35, :242-248) and the per-ResnetBlock shift Linear(inner -> Cout)
@@ -98,13 +97,17 @@ struct TembParams {
 };
 hipError_t launch_temb(const TembParams& p, hipStream_t s);
 
-// CLAM (unet.py:123-149): gate[N][C] = sigmoid(fc2(relu(fc1(avg))) + fc2(relu(fc1(max))))
+// CLAM (unet.py:123-149): gate[N][C] = sigmoid(fc2(relu(fc1(avg))) + fc2(relu(fc1(max)))), pooled in
+// FDSR_CLAM_SLICES pixel slices per image (phase 1) that phase 2 folds in order.
+// scratch (clam_slam_scratch_floats): gate [N][C] | pool [N][SLICES][C][2] | map [N][2][HW]
+#define FDSR_CLAM_SLICES 32
+size_t clam_slam_scratch_floats(int N, int HW, int C);
 hipError_t launch_clam_gate(const float* x, int N, int HW, int C, const float* fc1 /*[C/16][C]*/,
-                            const float* fc2 /*[C][C/16]*/, int Cr, float* gate, hipStream_t s);
+                            const float* fc2 /*[C][C/16]*/, int Cr, float* scratch, hipStream_t s);
 // SLAM applied to (x * gate) (unet.py:151-173): out = y * sigmoid(conv7x7([mean_c y, max_c y]))
-// part_out (optional): [N][FDSR_SLAM_PARTS][C][2] per-wave partial (sum, sumsq) of out per channel.
-hipError_t launch_slam(const float* x, const float* gate, const float* w7 /*[2][7][7]*/,
-                       int N, int H, int W, int C, float* out, float* part_out, hipStream_t s);
+// part_out (optional): [N][tiles][C][2] per-tile (2 x 32 pixels) partial (sum, sumsq) of out per channel.
+hipError_t launch_slam(const float* x, float* scratch, const float* w7 /*[2][7][7]*/,
+                       int N, int H, int W, int C, float* out, float* part_out, hipStream_t s, int* tiles_per_image);
 
 // layout changes at the boundary
 hipError_t launch_nchw_to_nhwc(const float* src, float* dst, int N, int Csrc, int H, int W,

@@ -486,39 +486,63 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-__global__ void __launch_bounds__(1024) clam_gate_kernel(const float* __restrict__ x, int HW, int C, const float* __restrict__ fc1,
-                                                         const float* __restrict__ fc2, int Cr, float* gate) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];   // psum[rows][C] | pmax[rows][C] | avg[C] | mx[C] | ha[Cr] | hm[Cr]
+// Phase 1, grid (FDSR_CLAM_SLICES, N): per-channel sum and maximum of one pixel slice.
+__global__ void __launch_bounds__(256) clam_pool_kernel(const float* __restrict__ x, int HW, int C, float* __restrict__ pool) {
+  __shared__ __attribute__((aligned(16))) float ps[256 * 8];
+  const int tid = threadIdx.x, sl = blockIdx.x, n = blockIdx.y;
+  const int cq = C >> 2, rows = 256 / cq, c4 = tid % cq, r = tid / cq;
+  const int p0 = (int)((long)sl * HW / FDSR_CLAM_SLICES), p1 = (int)((long)(sl + 1) * HW / FDSR_CLAM_SLICES);
+  f32x4 s = {0.f, 0.f, 0.f, 0.f}, m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  if (r < rows) {
+    const float* base = x + (size_t)n * HW * C + c4 * 4;
+    for (int pix = p0 + r; pix < p1; pix += rows) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(base + (size_t)pix * C);
+      s += v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], v[e]);
+    }
+    *reinterpret_cast<f32x4*>(ps + (r * cq + c4) * 8) = s;
+    *reinterpret_cast<f32x4*>(ps + (r * cq + c4) * 8 + 4) = m;
+  }
+  __syncthreads();
+  if (tid < cq) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(ps + tid * 8), b = *reinterpret_cast<const f32x4*>(ps + tid * 8 + 4);
+    for (int rr = 1; rr < rows; ++rr) {
+      a += *reinterpret_cast<const f32x4*>(ps + (rr * cq + tid) * 8);
+      const f32x4 q = *reinterpret_cast<const f32x4*>(ps + (rr * cq + tid) * 8 + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) b[e] = fmaxf(b[e], q[e]);
+    }
+    float* dst = pool + (((size_t)n * FDSR_CLAM_SLICES + sl) * C + tid * 4) * 2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { dst[2 * e] = a[e]; dst[2 * e + 1] = b[e]; }
+  }
+}
+
+// Phase 2, grid (N): fold the slices in order, then the shared MLP on both pooled vectors.
+__global__ void __launch_bounds__(256) clam_gate_kernel(const float* __restrict__ pool, int HW, int C, const float* __restrict__ fc1,
+                                                        const float* __restrict__ fc2, int Cr, float* gate) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // avg[C] | mx[C] | ha[Cr] | hm[Cr]
   const int tid = threadIdx.x, n = blockIdx.x;
-  const int rows = max(1, 1024 / C);
-  float* psum = sm;
-  float* pmax = psum + rows * C;
-  float* avg = pmax + rows * C;
+  float* avg = sm;
   float* mx = avg + C;
   float* ha = mx + C;
   float* hm = ha + Cr;
-  const int c = tid % C, r = tid / C;
-  if (r < rows && tid < rows * C) {
-    const float* base = x + (size_t)n * HW * C + c;
+  for (int cc = tid; cc < C; cc += 256) {
     float s = 0.f, m = -INFINITY;
-    for (int pix = r; pix < HW; pix += rows) {
-      const float v = base[(size_t)pix * C];
-      s += v;
-      m = fmaxf(m, v);
+    const float* src = pool + ((size_t)n * FDSR_CLAM_SLICES * C + cc) * 2;
+#pragma unroll 8
+    for (int sl = 0; sl < FDSR_CLAM_SLICES; ++sl) {
+      const float2 v = *reinterpret_cast<const float2*>(src + (size_t)sl * C * 2);
+      s += v.x;
+      m = fmaxf(m, v.y);
     }
-    psum[r * C + c] = s;
-    pmax[r * C + c] = m;
-  }
-  __syncthreads();
-  for (int cc = tid; cc < C; cc += 1024) {
-    float s = 0.f, m = -INFINITY;
-    for (int rr = 0; rr < rows; ++rr) { s += psum[rr * C + cc]; m = fmaxf(m, pmax[rr * C + cc]); }
     avg[cc] = s / (float)HW;
     mx[cc] = m;
   }
   __syncthreads();
-  const int wave = tid >> 6, lane = tid & 63, nwave = 16;
-  for (int j = wave; j < 2 * Cr; j += nwave) {   // fc1 + ReLU on both pooled vectors
+  const int wave = tid >> 6, lane = tid & 63;
+  for (int j = wave; j < 2 * Cr; j += 4) {   // fc1 + ReLU on both pooled vectors
     const int jj = j % Cr;
     const float* v = j < Cr ? avg : mx;
     float a = 0.f;
@@ -527,7 +551,7 @@ __global__ void __launch_bounds__(1024) clam_gate_kernel(const float* __restrict
     if (lane == 0) (j < Cr ? ha : hm)[jj] = fmaxf(a, 0.f);
   }
   __syncthreads();
-  for (int cc = tid; cc < C; cc += 1024) {
+  for (int cc = tid; cc < C; cc += 256) {
     float a = 0.f, b = 0.f;
     for (int j = 0; j < Cr; ++j) { a = fmaf(fc2[(size_t)cc * Cr + j], ha[j], a); b = fmaf(fc2[(size_t)cc * Cr + j], hm[j], b); }
     const float o = a + b;
@@ -535,31 +559,34 @@ __global__ void __launch_bounds__(1024) clam_gate_kernel(const float* __restrict
   }
 }
 
+size_t clam_slam_scratch_floats(int N, int HW, int C) {
+  return (size_t)N * C + (size_t)N * FDSR_CLAM_SLICES * C * 2 + (size_t)N * 2 * HW;
+}
+
 hipError_t launch_clam_gate(const float* x, int N, int HW, int C, const float* fc1, const float* fc2, int Cr,
-                            float* gate, hipStream_t s) {
-  if (C > 1024) return hipErrorInvalidValue;
-  const int rows = 1024 / C > 0 ? 1024 / C : 1;
-  const size_t lds = (size_t)(2 * rows * C + 2 * C + 2 * Cr) * sizeof(float);
-  hipLaunchKernelGGL(clam_gate_kernel, dim3(N), dim3(1024), lds, s, x, HW, C, fc1, fc2, Cr, gate);
+                            float* scratch, hipStream_t s) {
+  if (C > 1024 || (C & 3)) return hipErrorInvalidValue;
+  float* gate = scratch;
+  float* pool = scratch + (size_t)N * C;
+  hipLaunchKernelGGL(clam_pool_kernel, dim3(FDSR_CLAM_SLICES, N), dim3(256), 0, s, x, HW, C, pool);
+  const size_t lds = (size_t)(2 * C + 2 * Cr) * sizeof(float);
+  hipLaunchKernelGGL(clam_gate_kernel, dim3(N), dim3(256), lds, s, pool, HW, C, fc1, fc2, Cr, gate);
   return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------
 // SLAM on y = x*gate: channel mean/max -> 7x7 conv -> sigmoid -> scale   (unet.py:151-173)
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) slam_kernel(const float* __restrict__ x, const float* __restrict__ gate,
-                                                    const float* __restrict__ w7, int H, int W, int C, float* out,
-                                                    float* part_out) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];   // map[2][HW] | sig[HW] | w[98]
-  const int HW = H * W, tid = threadIdx.x, n = blockIdx.x;
-  float* mp = sm;
-  float* sig = sm + 2 * HW;
-  float* wk = sig + HW;
-  const int wave = tid >> 6, lane = tid & 63;
-  if (tid < 98) wk[tid] = w7[tid];
+// Phase 1, grid (ceil(HW/16), N): one wave per pixel, map[n][0] = mean_c y, map[n][1] = max_c y.
+__global__ void __launch_bounds__(256) slam_map_kernel(const float* __restrict__ x, const float* __restrict__ gate, int HW, int C,
+                                                       float* __restrict__ map) {
+  const int tid = threadIdx.x, n = blockIdx.y, wave = tid >> 6, lane = tid & 63;
   const float* xb = x + (size_t)n * HW * C;
   const float* gb = gate + (size_t)n * C;
-  for (int pix = wave; pix < HW; pix += 16) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int pix = blockIdx.x * 16 + wave * 4 + i;
+    if (pix >= HW) break;
     float s = 0.f, m = -INFINITY;
     for (int c = lane * 4; c < C; c += 256) {
       const f32x4 v = *reinterpret_cast<const f32x4*>(xb + (size_t)pix * C + c);
@@ -570,51 +597,85 @@ __global__ void __launch_bounds__(1024) slam_kernel(const float* __restrict__ x,
     }
     s = wave_sum(s);
     m = wave_max(m);
-    if (lane == 0) { mp[pix] = s / (float)C; mp[HW + pix] = m; }
+    if (lane == 0) { map[(size_t)n * 2 * HW + pix] = s / (float)C; map[(size_t)n * 2 * HW + HW + pix] = m; }
   }
+}
+
+// Phase 2, grid (tiles of 2 x 32 pixels, N): 7x7 conv + sigmoid on the map, out = sig * (gate * x), and the
+// per-tile channel statistics of out (GroupNorm input of the next block, mid.1.block1).
+__global__ void __launch_bounds__(256) slam_apply_kernel(const float* __restrict__ x, const float* __restrict__ gate,
+                                                         const float* __restrict__ map, const float* __restrict__ w7, int H, int W,
+                                                         int C, float* out, float* part_out) {
+  __shared__ __attribute__((aligned(16))) float red[256 * 8];
+  __shared__ float sig[64];
+  __shared__ float wk[98];
+  const int HW = H * W, tid = threadIdx.x, tile = blockIdx.x, n = blockIdx.y;
+  const int tilesX = (W + 31) / 32, tx = tile % tilesX, ty = tile / tilesX;
+  if (tid < 98) wk[tid] = w7[tid];
   __syncthreads();
-  for (int pix = tid; pix < HW; pix += 1024) {
-    const int y = pix / W, xx = pix % W;
+  if (tid < 64) {
+    const int y = ty * 2 + (tid >> 5), xx = tx * 32 + (tid & 31);
     float a = 0.f;
-    for (int ch = 0; ch < 2; ++ch)
-      for (int ky = 0; ky < 7; ++ky) {
-        const int iy = y + ky - 3;
-        if (iy < 0 || iy >= H) continue;
-        for (int kx = 0; kx < 7; ++kx) {
-          const int ix = xx + kx - 3;
-          if (ix < 0 || ix >= W) continue;
-          a = fmaf(wk[(ch * 7 + ky) * 7 + kx], mp[ch * HW + iy * W + ix], a);
+    if (y < H && xx < W) {
+      const float* mp = map + (size_t)n * 2 * HW;
+      for (int ch = 0; ch < 2; ++ch)
+        for (int ky = 0; ky < 7; ++ky) {
+          const int iy = y + ky - 3;
+          if (iy < 0 || iy >= H) continue;
+          for (int kx = 0; kx < 7; ++kx) {
+            const int ix = xx + kx - 3;
+            if (ix < 0 || ix >= W) continue;
+            a = fmaf(wk[(ch * 7 + ky) * 7 + kx], mp[ch * HW + iy * W + ix], a);
+          }
         }
-      }
-    sig[pix] = 1.0f / (1.0f + expf(-a));
+    }
+    sig[tid] = 1.0f / (1.0f + expf(-a));
   }
   __syncthreads();
-  float* ob = out + (size_t)n * HW * C;
-  // channel chunk outermost so each lane keeps one (sum, sumsq) pair per channel quad: the
-  // per-wave partials are the GroupNorm statistics input of the next block (mid.1.block1)
-  for (int c = lane * 4; c < C; c += 256) {
-    const f32x4 g = *reinterpret_cast<const f32x4*>(gb + c);
-    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
-    for (int pix = wave; pix < HW; pix += 16) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(xb + (size_t)pix * C + c);
-      const f32x4 o = sig[pix] * (g * v);
-      *reinterpret_cast<f32x4*>(ob + (size_t)pix * C + c) = o;
-      a += o;
-      b += o * o;
+  const int cq = C >> 2, groups = 256 / cq, c4 = tid % cq, g = tid / cq;
+  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+  if (g < groups) {
+    const f32x4 gv = *reinterpret_cast<const f32x4*>(gate + (size_t)n * C + c4 * 4);
+    for (int px = g; px < 64; px += groups) {
+      const int y = ty * 2 + (px >> 5), xx = tx * 32 + (px & 31);
+      if (y >= H || xx >= W) continue;
+      const size_t o = ((size_t)n * HW + (size_t)y * W + xx) * C + c4 * 4;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(x + o);
+      const f32x4 r = sig[px] * (gv * v);
+      *reinterpret_cast<f32x4*>(out + o) = r;
+      s1 += r;
+      s2 += r * r;
     }
-    if (part_out) {
-      float* dst = part_out + (((size_t)n * FDSR_SLAM_PARTS + wave) * C + c) * 2;
+  }
+  if (part_out) {
+    if (g < groups) {
+      *reinterpret_cast<f32x4*>(red + (g * cq + c4) * 8) = s1;
+      *reinterpret_cast<f32x4*>(red + (g * cq + c4) * 8 + 4) = s2;
+    }
+    __syncthreads();
+    if (tid < cq) {
+      f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
+      for (int gg = 0; gg < groups; ++gg) {
+        a += *reinterpret_cast<const f32x4*>(red + (gg * cq + tid) * 8);
+        b += *reinterpret_cast<const f32x4*>(red + (gg * cq + tid) * 8 + 4);
+      }
+      float* dst = part_out + (((size_t)n * gridDim.x + tile) * C + tid * 4) * 2;
 #pragma unroll
       for (int e = 0; e < 4; ++e) { dst[2 * e] = a[e]; dst[2 * e + 1] = b[e]; }
     }
   }
 }
 
-hipError_t launch_slam(const float* x, const float* gate, const float* w7, int N, int H, int W, int C, float* out,
-                       float* part_out, hipStream_t s) {
-  const size_t lds = (size_t)(3 * H * W + 128) * sizeof(float);
-  if (lds > 150 * 1024 || C % 4) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(slam_kernel, dim3(N), dim3(1024), lds, s, x, gate, w7, H, W, C, out, part_out);
+hipError_t launch_slam(const float* x, float* scratch, const float* w7, int N, int H, int W, int C, float* out,
+                       float* part_out, hipStream_t s, int* tiles) {
+  if (C > 1024 || (C & 3)) return hipErrorInvalidValue;
+  const int HW = H * W;
+  const float* gate = scratch;
+  float* map = scratch + (size_t)N * C + (size_t)N * FDSR_CLAM_SLICES * C * 2;
+  hipLaunchKernelGGL(slam_map_kernel, dim3((HW + 15) / 16, N), dim3(256), 0, s, x, gate, HW, C, map);
+  const int nt = ((W + 31) / 32) * ((H + 1) / 2);
+  if (tiles) *tiles = nt;
+  hipLaunchKernelGGL(slam_apply_kernel, dim3(nt, N), dim3(256), 0, s, x, gate, map, w7, H, W, C, out, part_out);
   return hipGetLastError();
 }
 
@@ -876,7 +937,7 @@ hipError_t kernels_init() {
   if ((e = init_conv_t<KS_, ST_, UP_, KC_, BN_, WM_>()) != hipSuccess) return e;
   FDSR_CONV_INSTANCES(X)
 #undef X
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(slam_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  return hipSuccess;
 }
 
 }  // namespace fdsr
