@@ -126,3 +126,32 @@ def test_gpu_bicubic_lr_to_sr_bit_exact(golden_dir):
         np.testing.assert_array_equal(u8[0].cpu().numpy(), sr)
         np.testing.assert_array_equal(u8[1].cpu().numpy(), PB.resize_bicubic_u8(lr[::-1].copy(), sr.shape[0], sr.shape[1]))
         assert torch.equal(cond[0].cpu(), PB.u8_to_model_tensor(sr))
+
+
+def test_p_losses_forward_matches_reference_golden(golden_dir):
+    """GaussianDiffusion.forward == p_losses (diffusion.py:242-273): forward value of the L1(sum)
+    loss through the HIP UNet with per-sample continuous noise levels, against the loss the
+    reference itself produced for the same inputs and draws (tests/golden/train_loss.npz)."""
+    import os
+    from unittest import mock
+    from fastdiffsr_amd import networks
+    g = np.load(os.path.join(golden_dir, 'train_loss.npz'))
+    opt = _opt()
+    device = torch.device('cuda')
+    netG = networks.define_G(opt).to(device)
+    netG.set_loss(device)
+    netG.set_new_noise_schedule(opt['model']['beta_schedule']['val'], device)
+    sd_np = synth_state_dict(netG.denoise_fn.cfg, 0, prefix='denoise_fn.')
+    ckpt = {k: torch.from_numpy(v) for k, v in sd_np.items()}
+    for k, v in netG.state_dict().items():
+        if not k.startswith('denoise_fn.'):
+            ckpt[k] = v.cpu()
+    netG.load_state_dict(ckpt, strict=True)
+    netG.eval()
+    hr, sr, nz = (torch.from_numpy(g[k]).to(device) for k in ('hr', 'sr', 'noise'))
+    gam = g['gamma']
+    with mock.patch.object(np.random, 'randint', lambda a, b: 7), \
+            mock.patch.object(np.random, 'uniform', lambda a, b, size: gam):
+        loss = netG({'HR': hr, 'SR': sr}, noise=nz)
+    ref = float(g['loss'])
+    assert abs(loss.item() - ref) <= 1e-5 * abs(ref), (loss.item(), ref)
