@@ -974,7 +974,7 @@ int sample_body(fdsr_handle h, const float* cond, const float* noise, float* out
 // ---------------------------------------------------------------------------
 extern "C" {
 
-const char* fdsr_version(void) { return "fdsr-hip 0.1 (gfx950, f32 MFMA 32x32x2 implicit-GEMM conv, NHWC)"; }
+const char* fdsr_version(void) { return "fdsr-hip 0.3 (gfx950; NHWC implicit-GEMM MFMA convolutions: f16x3 / f32 / bf16)"; }
 
 const char* fdsr_last_error(fdsr_handle h) { return h ? h->err.c_str() : g_global_error.c_str(); }
 
