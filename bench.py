@@ -91,6 +91,9 @@ def main():
     ap.add_argument('--precision', default='f16x3', choices=['f32', 'f16x3', 'bf16'],
                     help='conv arithmetic: exact fp32 MFMA, fp32-grade split-f16 MFMA, or bf16')
     ap.add_argument('--graph', action='store_true', help='replay the 20-step loop as a hipGraph')
+    ap.add_argument('--noise', default='engine', choices=['engine', 'tensor'],
+                    help="engine: N(0,1) drawn inside the timed loop by the engine (Philox), as the reference draws "
+                         "randn_like per step; tensor: a pre-drawn [T,B,3,H,W] tensor resident in HBM (the parity-run form)")
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -126,8 +129,13 @@ def main():
 
     B, S = args.batch, args.size
     # independent per-GPU batch (weak scaling): rank r samples its own B images
-    cond, noise = synth_inputs(B, S, S, 20, cond_seed=1234 + rank, noise_seed=4321 + rank)
-    cond, noise = cond.to(dev), noise.to(dev)
+    if args.noise == 'tensor':
+        cond, noise = synth_inputs(B, S, S, 20, cond_seed=1234 + rank, noise_seed=4321 + rank)
+        cond, noise = cond.to(dev), noise.to(dev)
+    else:   # the engine draws x_T and the 19 per-step planes inside the timed loop (seed per rank)
+        cond, _ = synth_inputs(B, S, S, 1, cond_seed=1234 + rank)
+        cond, noise = cond.to(dev), None
+        eng.set_seed(4321 + rank)
     out = torch.empty(B, 3, S, S, device=dev)
 
     def sync():
@@ -162,9 +170,14 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.precision, 'data': 'synthetic',
             'config': {'workload': f'x4 64->256, batch={B}/GPU, T=20, random-init FastDiffSR UNet (inner 64, mults 1-2-4-4), '
                                    f'{S}x{S}, conv arithmetic {args.precision} (BASELINE configs[1])',
-                       'batch_per_gpu': B, 'global_batch': B * world, 'timesteps': 20, 'hipgraph': bool(args.graph),
+                       'batch_per_gpu': B, 'global_batch': B * world, 'timesteps': 20, 'noise': ('drawn in the loop by the engine (Philox4x32-10)' if args.noise == 'engine'
+                                                  else 'pre-drawn tensor in HBM'), 'hipgraph': bool(args.graph),
                        'parallelism': f'dp{world} (independent batches, weights broadcast once)'},
             'whole_path_tflops': ips / world * FLOPS_PER_IMAGE / 1e12,
+            # the whole path against both roofs, per GPU (ideal-fused fp32 traffic 32.85 GB / image)
+            'whole_path': {'frac_mfma_peak': ips / world * FLOPS_PER_IMAGE / 1e12 / (PEAK_F32_MFMA if args.precision == 'f32' else PEAK_16BIT_MFMA),
+                           'ideal_fused_gbytes_per_s': ips / world * 32.85,
+                           'frac_hbm_peak': ips / world * 32.85 / 8000.0},
         }
         if prof and prof['conv_ms'] > 0:
             ach = prof['conv_flops'] / (prof['conv_ms'] * 1e-3) / 1e12

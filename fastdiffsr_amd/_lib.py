@@ -49,6 +49,8 @@ SYMBOLS = {
     'fdsr_sample': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                               C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]),
     'fdsr_set_precision': (C.c_int, [C.c_void_p, C.c_int]),
+    'fdsr_set_seed': (C.c_int, [C.c_void_p, C.c_uint64]),
+    'fdsr_randn': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'fdsr_resize_bicubic_u8': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p]),
     'fdsr_tensor2img_u8': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,

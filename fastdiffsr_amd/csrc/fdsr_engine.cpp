@@ -110,6 +110,8 @@ struct fdsr_engine {
   // Sampling feeds every image of a batch the same noise level, and only T distinct ones ever
   // occur (diffusion.py:169-170), so the whole embedding table [T][TE] is evaluated once per
   // (weights, schedule) and the conv epilogues index it with batch stride 0.
+  unsigned long long* d_rng = nullptr;   // {seed, call counter}: noise drawn by the engine (fdsr_sample, noise == NULL)
+  unsigned long long rng_seed = 0;
   float* d_temb_table = nullptr;
   float* d_nl = nullptr;
   bool temb_table_valid = false;
@@ -939,6 +941,14 @@ int check_ws(fdsr_handle h, void* ws, size_t bytes) {
   return FDSR_OK;
 }
 
+int ensure_rng(fdsr_handle h) {
+  if (h->d_rng) return FDSR_OK;
+  HIPCHK(h, hipMalloc(&h->d_rng, 2 * sizeof(unsigned long long)));
+  const unsigned long long init[2] = {h->rng_seed, 0ull};
+  HIPCHK(h, hipMemcpy(h->d_rng, init, sizeof(init), hipMemcpyHostToDevice));
+  return FDSR_OK;
+}
+
 int sample_body(fdsr_handle h, const float* cond, const float* noise, float* out, float* traj, int N, int H, int W,
                 char* ws, hipStream_t st) {
   float* xin = reinterpret_cast<float*>(ws + h->plan.tensor_off[h->t_in]);
@@ -946,7 +956,12 @@ int sample_body(fdsr_handle h, const float* cond, const float* noise, float* out
   const size_t img = (size_t)N * 3 * H * W;
   // x_in = cond, img = randn(shape)                                       diffusion.py:204-208
   HIPCHK(h, launch_nchw_to_nhwc(cond, xin, N, 3, H, W, h->CP, 0, 1, st));
-  HIPCHK(h, launch_nchw_to_nhwc(noise, xin, N, 3, H, W, h->CP, 3, 0, st));
+  if (noise) {
+    HIPCHK(h, launch_nchw_to_nhwc(noise, xin, N, 3, H, W, h->CP, 3, 0, st));
+  } else {   // the engine draws: a new call counter per sample (also under graph replay), plane 0 = x_T
+    HIPCHK(h, launch_rng_advance(h->d_rng, st));
+    HIPCHK(h, launch_randn_xin(h->d_rng, xin, N, H * W, h->CP, st));
+  }
   for (int k = 0; k < h->T; ++k) {                                        // for i in reversed(range(T))  :209
     const int t = h->T - 1 - k;
     // FastDiffSR: the network sees the noise level sqrt(alpha_bar) (:169-170); SR3: the integer time
@@ -955,7 +970,9 @@ int sample_body(fdsr_handle h, const float* cond, const float* noise, float* out
     PosteriorParams pp{};
     pp.eps = eps;
     pp.xin = xin;
-    pp.noise = t > 0 ? noise + (size_t)(k + 1) * img : nullptr;           // zeros at t == 0  :189
+    pp.noise = (t > 0 && noise) ? noise + (size_t)(k + 1) * img : nullptr;   // zeros at t == 0  :189
+    pp.rng = (t > 0 && !noise) ? h->d_rng : nullptr;
+    pp.rng_plane = k + 1;
     pp.traj = traj ? traj + (size_t)k * img : nullptr;
     pp.out = t == 0 ? out : nullptr;
     pp.N = N; pp.HW = H * W; pp.CP = h->CP;
@@ -1000,6 +1017,7 @@ void fdsr_destroy(fdsr_handle h) {
   if (h->d_wq) (void)hipFree(h->d_wq);
   if (h->d_temb_table) (void)hipFree(h->d_temb_table);
   if (h->d_nl) (void)hipFree(h->d_nl);
+  if (h->d_rng) (void)hipFree(h->d_rng);
   delete h;
 }
 
@@ -1103,7 +1121,7 @@ int fdsr_unet_forward(fdsr_handle h, const float* x_nchw, const float* noise_lev
 
 int fdsr_sample(fdsr_handle h, const float* cond_nchw, const float* noise, float* out_nchw, float* traj_nchw, int batch,
                 int height, int width, void* workspace, size_t workspace_bytes, void* hip_stream, int flags) {
-  if (!h || !cond_nchw || !noise || !out_nchw) return fail(h, FDSR_E_INVALID, "null argument");
+  if (!h || !cond_nchw || !out_nchw) return fail(h, FDSR_E_INVALID, "null argument");
   if (h->cfg.in_channel != 6 || h->cfg.out_channel != 3)
     return fail(h, FDSR_E_INVALID, "conditional sampling needs in_channel=6, out_channel=3");
   int rc = check_ready(h, true);
@@ -1113,6 +1131,7 @@ int fdsr_sample(fdsr_handle h, const float* cond_nchw, const float* noise, float
   hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
   char* ws = reinterpret_cast<char*>(workspace);
   if ((rc = ensure_temb_table(h, st))) return rc;
+  if (!noise && (rc = ensure_rng(h))) return rc;
   const bool use_graph = (flags & FDSR_SAMPLE_GRAPH) && !h->profiling && st != nullptr;
   if (!use_graph) return sample_body(h, cond_nchw, noise, out_nchw, traj_nchw, batch, height, width, ws, st);
 
@@ -1136,6 +1155,24 @@ int fdsr_sample(fdsr_handle h, const float* cond_nchw, const float* noise, float
   if (h->graphs.size() >= 8) { (void)hipGraphExecDestroy(h->graphs.front().exec); h->graphs.erase(h->graphs.begin()); }
   h->graphs.push_back(ge);
   HIPCHK(h, hipGraphLaunch(ge.exec, st));
+  return FDSR_OK;
+}
+
+int fdsr_set_seed(fdsr_handle h, uint64_t seed) {
+  if (!h) return FDSR_E_INVALID;
+  h->rng_seed = seed;
+  if (h->d_rng) {
+    const unsigned long long init[2] = {seed, 0ull};
+    HIPCHK(h, hipMemcpy(h->d_rng, init, sizeof(init), hipMemcpyHostToDevice));
+  }
+  return FDSR_OK;
+}
+
+int fdsr_randn(fdsr_handle h, float* dst_nchw, int batch, int height, int width, int plane, void* hip_stream) {
+  if (!h || !dst_nchw || batch < 1 || height < 1 || width < 1 || plane < 0) return fail(h, FDSR_E_INVALID, "bad fdsr_randn arguments");
+  int rc = ensure_rng(h);
+  if (rc) return rc;
+  HIPCHK(h, launch_randn_plane(h->d_rng, dst_nchw, batch, height * width, plane, reinterpret_cast<hipStream_t>(hip_stream)));
   return FDSR_OK;
 }
 

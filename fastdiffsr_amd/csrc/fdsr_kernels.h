@@ -134,7 +134,9 @@ hipError_t launch_resize_bicubic_u8(const unsigned char* src, unsigned char* tmp
 struct PosteriorParams {
   const float* eps;    // [N,H,W,3]
   float* xin;          // [N,H,W,CP]
-  const float* noise;  // [N,3,H,W] NCHW or null (t == 0)
+  const float* noise;  // [N,3,H,W] NCHW or null (t == 0, or engine RNG)
+  const unsigned long long* rng;   // device {seed, call counter} or null: draw N(0,1) in the kernel (Philox4x32-10)
+  int rng_plane;                   // which of the T noise planes this step draws (the k of noise[k])
   float* traj;         // [N,3,H,W] NCHW or null: x_{t-1}
   float* out;          // [N,3,H,W] NCHW or null: res2img(x_0, cond) at the last step
   int N, HW, CP;
@@ -142,5 +144,13 @@ struct PosteriorParams {
   int plain_out;       // SR3 variant: out = x_0 itself (no res2img)
 };
 hipError_t launch_posterior(const PosteriorParams& p, hipStream_t s);
+
+// Engine-side noise (fdsr_sample with noise == NULL): counter-based Philox4x32-10 + Box-Muller, keyed by
+// (seed, call counter) and indexed by (plane, pixel): the values do not depend on the launch geometry.
+hipError_t launch_rng_advance(unsigned long long* rng, hipStream_t s);                      // ++call counter
+// plane `plane` of the noise the engine would use, as [N,3,H,W] fp32 (tests) ...
+hipError_t launch_randn_plane(const unsigned long long* rng, float* dst_nchw, int N, int HW, int plane, hipStream_t s);
+// ... and x_T = plane 0 written straight into channels 3..5 of the packed UNet input
+hipError_t launch_randn_xin(const unsigned long long* rng, float* xin, int N, int HW, int CP, hipStream_t s);
 
 }  // namespace fdsr

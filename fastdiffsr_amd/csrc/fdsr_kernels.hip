@@ -718,6 +718,73 @@ hipError_t launch_nhwc_to_nchw(const float* src, float* dst, int N, int C, int H
 }
 
 // ---------------------------------------------------------------------------
+// engine-side N(0,1): Philox4x32-10 (Salmon et al., SC'11) + Box-Muller
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void philox_round(unsigned& c0, unsigned& c1, unsigned& c2, unsigned& c3, unsigned k0, unsigned k1) {
+  const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+  const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
+  const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+  c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+}
+// three standard normals for pixel `i` of noise plane `plane` under {seed, calls}
+__device__ __forceinline__ void randn3(const unsigned long long* rng, int plane, size_t i, float out[3]) {
+  const unsigned long long seed = rng[0], calls = rng[1];
+  unsigned c0 = (unsigned)i, c1 = (unsigned)(i >> 32), c2 = (unsigned)plane, c3 = (unsigned)calls;
+  unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32) ^ (unsigned)(calls >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c0, c1, c2, c3, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  // 24-bit uniforms in (0,1); Box-Muller on two pairs (the fourth normal is not used)
+  const float u0 = ((float)(c0 >> 8) + 0.5f) * 5.9604644775390625e-8f, u1 = ((float)(c1 >> 8) + 0.5f) * 5.9604644775390625e-8f;
+  const float u2 = ((float)(c2 >> 8) + 0.5f) * 5.9604644775390625e-8f, u3 = ((float)(c3 >> 8) + 0.5f) * 5.9604644775390625e-8f;
+  const float r0 = sqrtf(-2.0f * logf(u0)), r1 = sqrtf(-2.0f * logf(u2));
+  float s0, cs0, s1, cs1;
+  sincospif(2.0f * u1, &s0, &cs0);
+  sincospif(2.0f * u3, &s1, &cs1);
+  out[0] = r0 * cs0;
+  out[1] = r0 * s0;
+  out[2] = r1 * cs1;
+  (void)s1;
+}
+
+__global__ void rng_advance_kernel(unsigned long long* rng) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) rng[1] += 1ull;
+}
+hipError_t launch_rng_advance(unsigned long long* rng, hipStream_t s) {
+  hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(64), 0, s, rng);
+  return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256) randn_plane_kernel(const unsigned long long* __restrict__ rng, float* __restrict__ dst, int HW,
+                                                          int CP, int c_off, int plane, size_t total) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  float z[3];
+  randn3(rng, plane, i, z);
+  if (CP) {   // NHWC, channels c_off..c_off+2 of the packed input
+#pragma unroll
+    for (int c = 0; c < 3; ++c) dst[i * CP + c_off + c] = z[c];
+  } else {    // NCHW [N,3,H,W]
+    const size_t n = i / HW, pix = i % HW;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) dst[(n * 3 + c) * HW + pix] = z[c];
+  }
+}
+hipError_t launch_randn_plane(const unsigned long long* rng, float* dst, int N, int HW, int plane, hipStream_t s) {
+  const size_t total = (size_t)N * HW;
+  hipLaunchKernelGGL(randn_plane_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, rng, dst, HW, 0, 0, plane, total);
+  return hipGetLastError();
+}
+hipError_t launch_randn_xin(const unsigned long long* rng, float* xin, int N, int HW, int CP, hipStream_t s) {
+  const size_t total = (size_t)N * HW;
+  hipLaunchKernelGGL(randn_plane_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, rng, xin, HW, CP, 3, 0, total);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // reverse-diffusion update                                   (diffusion.py:157-190)
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) posterior_kernel(const PosteriorParams p) {
@@ -726,6 +793,8 @@ __global__ void __launch_bounds__(256) posterior_kernel(const PosteriorParams p)
   if (i >= total) return;
   const size_t n = i / p.HW, pix = i % p.HW;
   float* xs = p.xin + i * p.CP;
+  float z[3] = {0.f, 0.f, 0.f};
+  if (p.rng) randn3(p.rng, p.rng_plane, i, z);
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     const float x = xs[3 + c];
@@ -739,6 +808,7 @@ __global__ void __launch_bounds__(256) posterior_kernel(const PosteriorParams p)
     float xn = mean;
     const size_t o = (n * 3 + c) * p.HW + pix;
     if (p.noise) xn = __fadd_rn(mean, __fmul_rn(p.noise[o], p.sigma));       // :189-190
+    else if (p.rng) xn = __fadd_rn(mean, __fmul_rn(z[c], p.sigma));
     xs[3 + c] = xn;
     if (p.traj) p.traj[o] = xn;
     if (p.out) p.out[o] = p.plain_out ? xn : fminf(fmaxf(xn, -1.f), 1.f) / 2.0f + xs[c];   // res2img :275-281 (SR3: the image itself)

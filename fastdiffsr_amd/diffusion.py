@@ -25,6 +25,10 @@ class GaussianDiffusion(nn.Module):
         # conv arithmetic of the HIP engine: 'f16x3' (fp32-grade split-f16 MFMA, default), 'f32' (exact
         # fp32 MFMA) or 'bf16' (PSNR-grade); see include/fdsr.h
         self.precision = 'f16x3'
+        # where the sampling noise comes from when the caller passes none: 'torch' = torch.randn on the
+        # device in the reference's order (reproducible with torch.manual_seed, like the reference);
+        # 'engine' = drawn inside the HIP loop (Philox, denoise_fn.engine.set_seed)
+        self.rng = 'torch'
         # like the reference (:96-98) the schedule is NOT set here; DDPM calls set_new_noise_schedule
 
     def set_loss(self, device):                                   # :101-107
@@ -51,7 +55,9 @@ class GaussianDiffusion(nn.Module):
         device = self.betas.device
         x = x_in.to(device=device, dtype=torch.float32).contiguous()
         T = self.num_timesteps
-        if noise is None:
+        if noise is None and getattr(self, 'rng', 'torch') == 'engine':
+            pass    # the engine draws inside the loop (Philox; Engine.set_seed): the throughput form
+        elif noise is None:
             # same draws, same order as the reference: randn(shape) then randn_like per step t>0 (:207, :189)
             noise = torch.empty((T,) + tuple(x.shape), device=device, dtype=torch.float32)
             noise[0] = torch.randn(x.shape, device=device)

@@ -125,13 +125,16 @@ class Engine:
         self._keep = (x, nl)
         return out
 
-    def sample(self, cond, noise, want_traj=False, graph=False, out=None, traj=None):
+    def sample(self, cond, noise=None, want_traj=False, graph=False, out=None, traj=None):
+        """noise: [T,B,3,H,W] (parity runs: the reference's draws), or None: the engine draws
+        inside the loop (Philox, see set_seed) like the reference's in-loop randn_like."""
         cond = self._check_input(cond, 'cond')
-        noise = self._check_input(noise, 'noise')
         B, _, H, W = cond.shape
-        nT = self.T + (1 if self.cfg.variant == 'ddpm' else 0)     # SR3 draws noise at t = 0 too
-        if tuple(noise.shape) != (nT, B, 3, H, W):
-            raise ValueError(f'noise must be [{nT},{B},3,{H},{W}], got {tuple(noise.shape)}')
+        if noise is not None:
+            noise = self._check_input(noise, 'noise')
+            nT = self.T + (1 if self.cfg.variant == 'ddpm' else 0)     # SR3 draws noise at t = 0 too
+            if tuple(noise.shape) != (nT, B, 3, H, W):
+                raise ValueError(f'noise must be [{nT},{B},3,{H},{W}], got {tuple(noise.shape)}')
         ws = self._workspace(B, H, W, cond.device)
         if out is None:
             out = torch.empty(B, 3, H, W, device=cond.device, dtype=torch.float32)
@@ -143,6 +146,17 @@ class Engine:
                                                 B, H, W, _ptr(ws), ws.numel(), C.c_void_p(st), flags))
         self._keep = (cond, noise, out, traj)
         return (out, traj) if want_traj else out
+
+    def set_seed(self, seed):
+        """Seed of the engine-side noise; also resets its per-call counter."""
+        _lib.check(self.h, self.lib.fdsr_set_seed(self.h, C.c_uint64(int(seed) & (2 ** 64 - 1))))
+
+    def randn(self, B, H, W, plane, device='cuda'):
+        """Noise plane `plane` under the current call counter, [B,3,H,W] (generator tests)."""
+        dst = torch.empty(B, 3, H, W, device=device, dtype=torch.float32)
+        st = torch.cuda.current_stream(dst.device).cuda_stream
+        _lib.check(self.h, self.lib.fdsr_randn(self.h, _ptr(dst), B, H, W, int(plane), C.c_void_p(st)))
+        return dst
 
     def set_precision(self, mode):
         """'f32' (exact fp32 MFMA), 'f16x3' (fp32-grade split-f16 MFMA) or 'bf16'."""

@@ -120,7 +120,10 @@ int fdsr_unet_forward(fdsr_handle h, const float* x_nchw, const float* noise_lev
  * batched as B independent B=1 runs (the reference crashes for B>=2, :215-216).
  *   cond_nchw [B,3,H,W]        the bicubic-upsampled LR image (x_in)
  *   noise     [T,B,3,H,W]      noise[0] = x_T (`randn(shape)` :207), noise[k] =
- *                              the `randn_like` of step t = T-k (:189), k=1..T-1
+ *                              the `randn_like` of step t = T-k (:189), k=1..T-1;
+ *                              or NULL: the engine draws the same planes itself inside the
+ *                              loop (Philox4x32-10 + Box-Muller keyed by fdsr_set_seed and a
+ *                              per-call counter) -- the throughput mode; parity runs pass noise
  *   out_nchw  [B,3,H,W]        res2img(x_0, cond) (:214, :275-281) == ret_img[-1]
  *   traj_nchw [T,B,3,H,W] or NULL: x_t after every step (t = T-1..0), for
  *                              continous=True frames and parity tests.
@@ -129,6 +132,15 @@ int fdsr_unet_forward(fdsr_handle h, const float* x_nchw, const float* noise_lev
 int fdsr_sample(fdsr_handle h, const float* cond_nchw, const float* noise,
                 float* out_nchw, float* traj_nchw, int batch, int height, int width,
                 void* workspace, size_t workspace_bytes, void* hip_stream, int flags);
+
+/* Seed of the engine-side noise (resets the per-call counter): the same seed and call order give
+ * the same images, whatever the batch split or launch geometry.  The reference draws from torch's
+ * global generator (diffusion.py:189, :207); its stream is not reproduced, so parity is defined on
+ * explicit noise only. */
+int fdsr_set_seed(fdsr_handle h, uint64_t seed);
+/* Plane `plane` ([B,3,H,W] fp32, device) of the noise drawn under the current call counter
+ * (plane 0 = x_T, plane k = step t = T-k).  For tests of the generator. */
+int fdsr_randn(fdsr_handle h, float* dst_nchw, int batch, int height, int width, int plane, void* hip_stream);
 
 /* Arithmetic of the convolutions (everything else is fp32 in every mode):
  *   FDSR_PREC_F32    exact fp32 on v_mfma_f32_32x32x2_f32 (default)
