@@ -23,8 +23,45 @@ def parse_json_with_comments(text):
     return json.loads(''.join(lines), object_pairs_hook=OrderedDict)
 
 
-def load_config(path, phase='val'):
+def load_config(path, phase='val', gpu_ids=None, debug=False, enable_wandb=False, log_wandb_ckpt=False,
+                log_eval=False, log_infer=False, timestamp=None):
+    """`core.logger.parse(args)` (logger.py:21-94) without its side effects: the experiment directories are
+    named but not created and CUDA_VISIBLE_DEVICES is left alone.  Everything else follows the reference,
+    including `distributed = len(gpu_list) > 1` on the comma-joined STRING (:52-56) and the `-debug`
+    rewrites (:59-68).  Checked against the reference's own parser on its configs (tests/golden/configs.json)."""
+    import os
+    from datetime import datetime
     with open(path, 'r') as f:
         opt = parse_json_with_comments(f.read())
+    if debug:
+        opt['name'] = 'debug_{}'.format(opt['name'])
+    stamp = timestamp or datetime.now().strftime('%y%m%d_%H%M%S')
+    root = os.path.join('experiments', '{}_{}'.format(opt['name'], stamp))
+    if 'path' in opt:
+        opt['path']['experiments_root'] = root
+        for key, sub in list(opt['path'].items()):
+            if 'resume' not in key and 'experiments' not in key:
+                opt['path'][key] = os.path.join(root, sub)
     opt['phase'] = phase
+    if gpu_ids is not None:
+        opt['gpu_ids'] = [int(i) for i in gpu_ids.split(',')]
+        gpu_list = gpu_ids
+    else:
+        gpu_list = ','.join(str(x) for x in opt['gpu_ids'])
+    opt['distributed'] = len(gpu_list) > 1
+    if 'debug' in opt['name']:
+        opt['train']['val_freq'] = 2
+        opt['train']['print_freq'] = 2
+        opt['train']['save_checkpoint_freq'] = 3
+        opt['datasets']['train']['batch_size'] = 2
+        opt['model']['beta_schedule']['train']['n_timestep'] = 10
+        opt['model']['beta_schedule']['val']['n_timestep'] = 10
+        opt['datasets']['train']['data_len'] = 6
+        opt['datasets']['val']['data_len'] = 3
+    if phase == 'train':
+        opt['datasets']['val']['data_len'] = 13
+    opt['log_wandb_ckpt'] = log_wandb_ckpt
+    opt['log_eval'] = log_eval
+    opt['log_infer'] = log_infer
+    opt['enable_wandb'] = enable_wandb
     return dict_to_nonedict(opt)

@@ -283,5 +283,48 @@ def main():
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
 
+
+def config_goldens():
+    """(ix) the reference's own option parser (core/logger.py:21-94) on its ten fastdiffsr / ddpm configs:
+    what `parse` returns, minus the timestamped `path` subtree.  Pins fastdiffsr_amd.config.load_config."""
+    import argparse
+    import json
+    import tempfile
+    import_reference()
+    from core import logger as ref_logger
+    out = {}
+    cfg_dir = os.path.join(REF, 'config')
+    cases = []
+    for fam in ('fastdiffsr', 'ddpm'):
+        for stem, phase in (('test_64_256', 'val'), ('test_32_256', 'val'), ('train_64_256', 'train'),
+                            ('train_32_256', 'train'), ('infer_x4', 'val')):
+            cases.append((f'sr_{fam}_{stem}.json', phase, None, False))
+    cases.append(('sr_fastdiffsr_train_64_256.json', 'train', '0,1', True))    # -debug and a gpu list
+    cwd, env = os.getcwd(), os.environ.get('CUDA_VISIBLE_DEVICES')
+    with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)                      # parse() creates experiment directories relative to the cwd
+        try:
+            for name, phase, gpu_ids, debug in cases:
+                args = argparse.Namespace(config=os.path.join(cfg_dir, name), phase=phase, gpu_ids=gpu_ids, debug=debug,
+                                          enable_wandb=False, log_wandb_ckpt=False, log_eval=False, log_infer=False)
+                opt = ref_logger.parse(args)
+                opt = json.loads(json.dumps(opt))
+                opt.pop('path', None)
+                out[f'{name}|{phase}|{gpu_ids}|{int(debug)}'] = opt
+        finally:
+            os.chdir(cwd)
+            if env is None:
+                os.environ.pop('CUDA_VISIBLE_DEVICES', None)
+            else:
+                os.environ['CUDA_VISIBLE_DEVICES'] = env
+    with open(os.path.join(OUT, 'configs.json'), 'w') as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print('wrote configs.json with', len(out), 'cases')
+
+
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == 'configs':
+        config_goldens()          # only tests/golden/configs.json
+    else:
+        main()
+        config_goldens()
