@@ -74,9 +74,37 @@ def cpu_baseline(cfg, sd, budget_s=20.0):
                 break
         dt = time.perf_counter() - t0
     step = dt / k
-    return {'value': 1.0 / (20 * step), 'unit': 'images/s', 'cores': threads, 'kind': 'port',
-            'sample': f'{k} of 20 reverse steps of 1 image, 256x256, fp32, PyTorch-CPU restatement (oracle/), '
-                      f'{dt:.1f} s after 1 warm-up forward, {threads} threads (host reports {cores} usable)'}
+    res = {'value': 1.0 / (20 * step), 'unit': 'images/s', 'cores': threads, 'kind': 'port',
+           'sample': f'{k} of 20 reverse steps of 1 image, 256x256, fp32, PyTorch-CPU restatement (oracle/), '
+                     f'{dt:.1f} s after 1 warm-up forward, {threads} threads (host reports {cores} usable)'}
+    return res, {'cond': cond, 'noise': noise, 'k': k, 'x_k': img}
+
+
+def parity_check(eng, dev, ref):
+    """The image the CPU baseline leg just produced is also the checker: the same cond / noise through the
+    HIP engine (B=1, explicit noise), compared after the k steps the oracle got through.  PSNR is taken the
+    reference's way (tensor2img -> uint8, core/metrics.py:16-42, :94-101) against a synthetic HR
+    (cond + a smooth residual) and only when all 20 steps ran."""
+    import math
+    from fastdiffsr_amd.metrics import tensor2img, calculate_psnr
+    cond, noise, k = ref['cond'].to(dev), ref['noise'].to(dev), ref['k']
+    out, traj = eng.sample(cond, noise, want_traj=True)
+    got = traj[k - 1].cpu()
+    res = {'vs': f'oracle state after {k} of 20 steps, 1 image 256x256, same cond and noise',
+           'max_abs_diff_x_t': float((got - ref['x_k']).abs().max())}
+    if k == 20:
+        c = ref['cond']
+        yy, xx = torch.meshgrid(torch.arange(256.), torch.arange(256.), indexing='ij')
+        r = torch.stack([torch.sin(2 * math.pi * (yy / 64 + ch / 3)) * torch.cos(2 * math.pi * xx / 48) for ch in range(3)])[None]
+        hr = (c + 0.5 * r).clamp(-1, 1)
+        ref_img = ref['x_k'].clamp(-1, 1) / 2.0 + c                    # res2img (diffusion.py:275-281)
+        diff_img = float((out.cpu() - ref_img).abs().max())
+        hr_u8 = tensor2img(hr[0].clone())                            # tensor2img clamps in place, like the reference's
+        p_ref = calculate_psnr(tensor2img(ref_img[0].clone()), hr_u8)
+        p_got = calculate_psnr(tensor2img(out[0].cpu()), hr_u8)
+        res.update({'max_abs_diff_image': diff_img,
+                    'psnr_db': p_got, 'psnr_oracle_db': p_ref, 'psnr_delta_db': p_got - p_ref})
+    return res
 
 
 def main():
@@ -208,7 +236,8 @@ def main():
                                'timed_steps_of_20': len(range(0, 20, 4)),
                                'conv_time_share': prof['conv_ms'] * 1e-3 * (20 / len(range(0, 20, 4))) / dt}
         if world == 1 and not args.no_cpu_baseline:
-            res['cpu_baseline'] = cpu_baseline(cfg, sd)
+            res['cpu_baseline'], ref = cpu_baseline(cfg, sd)
+            res['parity_check'] = parity_check(eng, dev, ref)
         print(json.dumps(res), flush=True)
     if distributed:
         dist.destroy_process_group()
