@@ -47,5 +47,27 @@ def build(force=False, verbose=True):
     return LIB
 
 
+DEMO_SRC = os.path.join(os.path.dirname(CSRC), '..', 'examples', 'fdsr_demo.c')
+DEMO = os.path.join(os.path.dirname(CSRC), '..', 'examples', 'fdsr_demo')
+
+
+def build_demo(force=False, verbose=True):
+    """examples/fdsr_demo: the C ABI driven from plain C99 (gcc, no torch), linked against the in-tree library."""
+    src, out = os.path.normpath(DEMO_SRC), os.path.normpath(DEMO)
+    if not os.path.exists(src):
+        return None
+    if not force and os.path.exists(out) and os.path.getmtime(out) >= max(os.path.getmtime(src), os.path.getmtime(LIB)):
+        return out
+    inc = os.path.normpath(os.path.join(os.path.dirname(CSRC), '..', 'include'))
+    cmd = ['gcc', '-std=c99', '-O2', '-Wall', '-D__HIP_PLATFORM_AMD__', '-I' + inc, '-I/opt/rocm/include', src,
+           '-L' + CSRC, '-lfdsr_hip', '-L/opt/rocm/lib', '-lamdhip64', '-Wl,-rpath,$ORIGIN/../fastdiffsr_amd/csrc',
+           '-Wl,-rpath,/opt/rocm/lib', '-o', out]
+    if verbose:
+        print(' '.join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return out
+
+
 if __name__ == '__main__':
     build(force='--force' in sys.argv)
+    build_demo(force='--force' in sys.argv)

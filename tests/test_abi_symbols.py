@@ -42,3 +42,25 @@ def test_product_never_imports_oracle():
             if f.endswith(('.py', '.cpp', '.hip', '.h')):
                 src = open(os.path.join(dp, f)).read()
                 assert 'import oracle' not in src and 'from oracle' not in src, f
+
+
+def test_header_is_plain_c99_and_demo_links(tmp_path):
+    """include/fdsr.h must compile as C (no C++ or torch types at the boundary), and the plain-C host in
+    examples/ must link against the in-tree library with nothing but the HIP runtime."""
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gcc = shutil.which('gcc')
+    if gcc is None:
+        import pytest
+        pytest.skip('no gcc')
+    src = tmp_path / 'hdr.c'
+    src.write_text('#include "fdsr.h"\nint main(void) { fdsr_config c; (void)c; return sizeof(fdsr_schedule) ? 0 : 1; }\n')
+    subprocess.check_call([gcc, '-std=c99', '-pedantic', '-Wall', '-Werror', '-I' + os.path.join(root, 'include'),
+                           '-fsyntax-only', str(src)])
+    from fastdiffsr_amd import build as b
+    demo = b.build_demo(force=True, verbose=False)
+    out = subprocess.run(['ldd', demo], capture_output=True, text=True).stdout
+    assert 'libfdsr_hip.so' in out and 'not found' not in out.split('libfdsr_hip.so')[1].split('\n')[0]
+    assert 'torch' not in out and 'python' not in out
