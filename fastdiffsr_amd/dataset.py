@@ -1,0 +1,78 @@
+"""The reference's image-folder dataset (FastDiffSR/data/LRHR_dataset.py, data/util.py, data/__init__.py)
+for the val path: `{dataroot}/hr_{r}`, `sr_{l}_{r}` (the bicubic conditioning image), `lr_{l}`, files
+paired by sorted order.  Tensors are what `transform_augment(split='val', min_max=(-1, 1))` gives:
+ToTensor (uint8 / 255, CHW) * 2 - 1.  Training-time flips (util.py:66-75) and the lmdb container are not
+needed on the sampling path: lmdb raises, like the reference does for unknown datatypes.
+
+`cond_from_lr=True` builds SR on the GPU from the LR image instead of reading `sr_*` (bit-identical to the
+reference's offline PIL bicubic, see data.lr_to_sr): the val loop then needs only LR + HR folders."""
+import os
+
+import numpy as np
+import torch
+from torch.utils.data import Dataset
+
+IMG_EXTENSIONS = ['.jpg', '.JPG', '.jpeg', '.JPEG', '.png', '.PNG', '.ppm', '.PPM', '.bmp', '.BMP', 'tif']
+
+
+def is_image_file(filename):                                   # util.py:12-13 (note: 'tif' has no dot there either)
+    return any(filename.endswith(ext) for ext in IMG_EXTENSIONS)
+
+
+def get_paths_from_images(path):                               # util.py:16-25
+    assert os.path.isdir(path), '{:s} is not a valid directory'.format(path)
+    images = []
+    for dirpath, _, fnames in sorted(os.walk(path)):
+        for fname in sorted(fnames):
+            if is_image_file(fname):
+                images.append(os.path.join(dirpath, fname))
+    assert images, '{:s} has no valid image file'.format(path)
+    return sorted(images)
+
+
+def to_tensor(pil_img, min_max=(-1, 1)):
+    """torchvision ToTensor() then `img * (max - min) + min` (util.py:64-75), for 8-bit RGB images."""
+    a = np.asarray(pil_img, dtype=np.uint8)
+    if a.ndim == 2:
+        a = a[:, :, None]
+    t = torch.from_numpy(np.ascontiguousarray(a.transpose(2, 0, 1))).to(torch.float32).div(255)
+    return t * (min_max[1] - min_max[0]) + min_max[0]
+
+
+class LRHRDataset(Dataset):
+    def __init__(self, dataroot, datatype='img', l_resolution=64, r_resolution=256, split='val', data_len=-1,
+                 need_LR=False, img_mask='no', cond_from_lr=False):
+        if datatype != 'img':
+            raise NotImplementedError('data_type [{:s}] is not recognized.'.format(str(datatype)))
+        if split == 'train':
+            raise NotImplementedError('training-time augmentation is SURVEY 8f-3; this dataset serves the val path')
+        self.l_res, self.r_res, self.split = l_resolution, r_resolution, split
+        self.need_LR = need_LR or cond_from_lr
+        self.cond_from_lr = cond_from_lr
+        self.hr_path = get_paths_from_images('{}/hr_{}'.format(dataroot, r_resolution))
+        self.sr_path = None if cond_from_lr else get_paths_from_images('{}/sr_{}_{}'.format(dataroot, l_resolution, r_resolution))
+        self.lr_path = get_paths_from_images('{}/lr_{}'.format(dataroot, l_resolution)) if self.need_LR else None
+        self.dataset_len = len(self.hr_path)
+        self.data_len = self.dataset_len if data_len is None or data_len <= 0 else min(data_len, self.dataset_len)
+
+    def __len__(self):
+        return self.data_len
+
+    def __getitem__(self, index):
+        from PIL import Image
+        out = {'HR': to_tensor(Image.open(self.hr_path[index]).convert('RGB')), 'Index': index}
+        if self.sr_path is not None:
+            out['SR'] = to_tensor(Image.open(self.sr_path[index]).convert('RGB'))
+        if self.need_LR:
+            lr = Image.open(self.lr_path[index]).convert('RGB')
+            out['LR'] = to_tensor(lr)
+            if self.cond_from_lr:
+                out['LR_u8'] = torch.from_numpy(np.array(lr, dtype=np.uint8))
+        return out
+
+
+def create_dataset(dataset_opt, phase, cond_from_lr=False):     # data/__init__.py:24-40
+    return LRHRDataset(dataroot=dataset_opt['dataroot'], datatype=dataset_opt['datatype'],
+                       l_resolution=dataset_opt['l_resolution'], r_resolution=dataset_opt['r_resolution'],
+                       split=phase, data_len=dataset_opt['data_len'], need_LR=(dataset_opt['mode'] == 'LRHR'),
+                       img_mask=dataset_opt.get('img_mask', 'no') or 'no', cond_from_lr=cond_from_lr)

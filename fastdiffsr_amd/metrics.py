@@ -100,3 +100,35 @@ def calculate_ergas(img1, img2, scale=4):            # metrics.py:147-152
     mse = calculate_mse(img1, img2)
     mean2 = np.mean(img1, dtype=np.float64) ** 2
     return float(100.0 * np.sqrt(mse / mean2 / channel) / scale)
+
+
+# --- what sr_mfe.py's val loop actually calls for MSE / PSNR / SSIM (sr_mfe.py:313-333): the
+# skimage.measure functions of skimage 0.16 with their defaults.  skimage is not in this image, so these are
+# restated from its published algorithm (compare_ssim: uniform 7x7 window via scipy.ndimage.uniform_filter,
+# sample covariance, K1 = 0.01, K2 = 0.03, data range of the dtype, borders cropped, mean over channels) and
+# are unpinned.
+def compare_mse(im1, im2):
+    return float(np.mean(np.square(im1.astype(np.float64) - im2.astype(np.float64)), dtype=np.float64))
+
+
+def compare_psnr(im_true, im_test):
+    err = compare_mse(im_true, im_test)
+    return float('inf') if err == 0 else 10 * math.log10((255.0 ** 2) / err)
+
+
+def compare_ssim(X, Y, multichannel=True, win_size=7):
+    from scipy.ndimage import uniform_filter
+    if multichannel:
+        return float(np.mean([compare_ssim(X[..., c], Y[..., c], multichannel=False, win_size=win_size)
+                              for c in range(X.shape[-1])]))
+    K1, K2, R = 0.01, 0.03, 255.0
+    X, Y = X.astype(np.float64), Y.astype(np.float64)
+    NP = win_size ** X.ndim
+    cov_norm = NP / (NP - 1)
+    ux, uy = uniform_filter(X, size=win_size), uniform_filter(Y, size=win_size)
+    uxx, uyy, uxy = uniform_filter(X * X, size=win_size), uniform_filter(Y * Y, size=win_size), uniform_filter(X * Y, size=win_size)
+    vx, vy, vxy = cov_norm * (uxx - ux * ux), cov_norm * (uyy - uy * uy), cov_norm * (uxy - ux * uy)
+    C1, C2 = (K1 * R) ** 2, (K2 * R) ** 2
+    S = ((2 * ux * uy + C1) * (2 * vxy + C2)) / ((ux ** 2 + uy ** 2 + C1) * (vx + vy + C2))
+    pad = (win_size - 1) // 2
+    return float(S[pad:-pad, pad:-pad].mean())

@@ -1,0 +1,71 @@
+"""`python -m fastdiffsr_amd.val -c <reference-style config>` end to end on the GPU: config file -> folders ->
+DDPM wrapper -> HIP sampler -> uint8 images, metrics, log lines (the reference's sr_mfe.py val phase)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from fastdiffsr_amd import metrics as M
+from fastdiffsr_amd.arch import FASTDIFFSR_SCHEDULE_VAL
+
+pytestmark = pytest.mark.gpu
+
+
+def test_val_cli_end_to_end(tmp_path):
+    from PIL import Image
+    from fastdiffsr_amd import val
+    from test_val_host import make_dataset
+    root = make_dataset(str(tmp_path / 'data'), n=3, l=64, r=256, seed=3)
+    # the config goes through the comment-stripping reader exactly as a reference file would
+    text = json.dumps(_config_plain(root), indent=1).replace('"phase": "val",', '"phase": "val", // a comment')
+    cpath = tmp_path / 'cfg.json'
+    cpath.write_text(text)
+    lines = []
+    torch.manual_seed(11)
+    r1 = val.run(_load(cpath), batch=2, results=str(tmp_path / 'out1'), log=lines.append)
+    assert r1['images'] == 3 and len(lines) == 2 and lines[0].startswith('<epoch:  0, iter:       0> bic_mse:')
+    files = sorted(os.listdir(tmp_path / 'out1'))
+    assert files == ['0_1_sr.tif', '0_2_sr.tif', '0_3_sr.tif']
+    # metrics recomputed independently from the saved images and the dataset folders
+    hr = [np.asarray(Image.open(os.path.join(root, 'hr_256', '%05d.png' % (i + 1)))) for i in range(3)]
+    bic = [np.asarray(Image.open(os.path.join(root, 'sr_64_256', '%05d.png' % (i + 1)))) for i in range(3)]
+    sr = [np.asarray(Image.open(tmp_path / 'out1' / f)) for f in files]
+    assert abs(r1['bic_psnr'] - np.mean([M.compare_psnr(b, h) for b, h in zip(bic, hr)])) < 1e-9
+    assert abs(r1['sr_psnr'] - np.mean([M.compare_psnr(s, h) for s, h in zip(sr, hr)])) < 1e-9
+    assert abs(r1['sr_ssim'] - np.mean([M.compare_ssim(s, h) for s, h in zip(sr, hr)])) < 1e-9
+    assert abs(r1['bic_ergas'] - np.mean([M.calculate_ergas(b, h, scale=4) for b, h in zip(bic, hr)])) < 1e-9
+    # conditioning resized from LR on the GPU == the offline PIL bicubic folder: same noise -> same images
+    torch.manual_seed(11)
+    r2 = val.run(_load(cpath), batch=2, cond_from_lr=True, results=str(tmp_path / 'out2'), log=lines.append)
+    for f in files:
+        assert np.array_equal(np.asarray(Image.open(tmp_path / 'out1' / f)), np.asarray(Image.open(tmp_path / 'out2' / f)))
+    assert r2['sr_psnr'] == r1['sr_psnr'] and r2['bic_psnr'] == r1['bic_psnr']
+    # the CLI entry itself (batch 1, nothing saved)
+    r3 = val.main(['-c', str(cpath), '--max-images', '1', '--no-save'])
+    assert r3['images'] == 1
+
+
+def _config_plain(root):
+    return {
+        "name": "sr_fastdiffsr_test", "phase": "val", "gpu_ids": [0],
+        "path": {"log": "logs", "tb_logger": "tb_logger", "results": "results", "checkpoint": "checkpoint", "resume_state": None},
+        "datasets": {"train": {"name": "t", "mode": "HR", "dataroot": root, "datatype": "img", "l_resolution": 64,
+                               "r_resolution": 256, "batch_size": 8, "num_workers": 1, "use_shuffle": True, "data_len": -1},
+                     "val": {"name": "v", "mode": "LRHR", "dataroot": root, "datatype": "img", "l_resolution": 64,
+                             "r_resolution": 256, "data_len": -1}},
+        "model": {"which_model_G": "fastdiffsr", "finetune_norm": False,
+                  "unet": {"in_channel": 6, "out_channel": 3, "inner_channel": 64, "channel_multiplier": [1, 2, 4, 4],
+                           "attn_res": [16], "res_blocks": 2, "dropout": 0.2},
+                  "beta_schedule": {"train": dict(FASTDIFFSR_SCHEDULE_VAL), "val": dict(FASTDIFFSR_SCHEDULE_VAL)},
+                  "diffusion": {"image_size": 256, "channels": 3, "conditional": True}},
+        "train": {"n_iter": 10, "val_freq": 5, "save_checkpoint_freq": 5, "print_freq": 1,
+                  "optimizer": {"type": "adam", "lr": 1e-4},
+                  "ema_scheduler": {"step_start_ema": 5000, "update_ema_every": 1, "ema_decay": 0.9999}},
+        "wandb": {"project": "x"}}
+
+
+def _load(cpath):
+    from fastdiffsr_amd.config import load_config
+    return load_config(str(cpath), phase='val')
