@@ -2,6 +2,7 @@
 FastDiffSR/sr_mfe.py:257-378) on the HIP engine:
 
     python -m fastdiffsr_amd.val -c config/sr_fastdiffsr_test_64_256.json [--batch 16] [--cond-from-lr]
+    python -m fastdiffsr_amd.val -c config/sr_fastdiffsr_infer_x4.json --infer        # infer.py
 
 Same config files, same dataset folders, same per-image metrics and log lines (MSE / PSNR / SSIM as
 skimage.measure computes them, ERGAS as core/metrics.py:147-152; LPIPS needs AlexNet weights and is left out),
@@ -38,7 +39,8 @@ def _collate(items):
 
 
 def run(opt, batch=1, cond_from_lr=False, precision='f16x3', results=None, max_images=None, rank=0, world=1,
-        save_images=True, log=print):
+        save_images=True, log=print, infer=False):
+    """infer=True is the reference's infer.py (:62-110): the same loop, `{step}_{idx}_sr.png` outputs, timing, no metrics."""
     val_opt = opt['datasets']['val']
     dataset = create_dataset(val_opt, 'val', cond_from_lr=cond_from_lr)
     n_total = len(dataset) if max_images is None else min(len(dataset), max_images)
@@ -72,7 +74,10 @@ def run(opt, batch=1, cond_from_lr=False, precision='f16x3', results=None, max_i
             sr_img = M.tensor2img(diffusion.SR[j])
             if save_images:
                 from PIL import Image
-                Image.fromarray(sr_img).save('{}/{}_{}_sr.tif'.format(result_path, current_step, idx))
+                Image.fromarray(sr_img).save('{}/{}_{}_sr.{}'.format(result_path, current_step, idx, 'png' if infer else 'tif'))
+            if infer:
+                sums[8] += 1.0
+                continue
             sums += np.array([M.compare_mse(fake_img, hr_img), M.compare_psnr(fake_img, hr_img), M.compare_ssim(fake_img, hr_img),
                               M.calculate_ergas(fake_img, hr_img, scale=scale),
                               M.compare_mse(sr_img, hr_img), M.compare_psnr(sr_img, hr_img), M.compare_ssim(sr_img, hr_img),
@@ -87,7 +92,9 @@ def run(opt, batch=1, cond_from_lr=False, precision='f16x3', results=None, max_i
     res = dict(images=int(sums[8]), bic_mse=avg[0], bic_psnr=avg[1], bic_ssim=avg[2], bic_ergas=avg[3],
                sr_mse=avg[4], sr_psnr=avg[5], sr_ssim=avg[6], sr_ergas=avg[7],
                sample_seconds_this_rank=t_sample, result_path=result_path)
-    if rank == 0:
+    if rank == 0 and infer:
+        log('inference: {} images, {:.4f} s per image on this rank (batch {})'.format(int(sums[8]), t_sample / max(hi - lo, 1), batch))
+    elif rank == 0:
         log('<epoch:{:3d}, iter:{:8,d}> bic_mse: {:.5e}, bic_psnr: {:.5e}, bic_ssim: {:.5e}, bic_ergas: {:.5e}'.format(
             current_epoch, current_step, *avg[:4]))
         log('<epoch:{:3d}, iter:{:8,d}> sr_mse: {:.5e}, sr_psnr: {:.5e}, sr_ssim: {:.5e}, sr_ergas: {:.5e}'.format(
@@ -107,6 +114,7 @@ def main(argv=None):
     ap.add_argument('--results', default=None)
     ap.add_argument('--max-images', type=int, default=None)
     ap.add_argument('--no-save', action='store_true')
+    ap.add_argument('--infer', action='store_true', help="the reference's infer.py: png outputs and timing, no metrics")
     a = ap.parse_args(argv)
     rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
     if world > 1:
@@ -116,7 +124,7 @@ def main(argv=None):
         dist.init_process_group('nccl')
     opt = load_config(a.config, phase=a.phase, gpu_ids=a.gpu_ids, debug=a.debug)
     res = run(opt, batch=a.batch, cond_from_lr=a.cond_from_lr, precision=a.precision, results=a.results,
-              max_images=a.max_images, rank=rank, world=world, save_images=not a.no_save)
+              max_images=a.max_images, rank=rank, world=world, save_images=not a.no_save, infer=a.infer)
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()

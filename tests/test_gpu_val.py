@@ -45,6 +45,9 @@ def test_val_cli_end_to_end(tmp_path):
     # the CLI entry itself (batch 1, nothing saved)
     r3 = val.main(['-c', str(cpath), '--max-images', '1', '--no-save'])
     assert r3['images'] == 1
+    # infer.py: png outputs, no metrics
+    r4 = val.main(['-c', str(cpath), '--infer', '--batch', '3', '--results', str(tmp_path / 'out4')])
+    assert r4['images'] == 3 and sorted(os.listdir(tmp_path / 'out4')) == ['0_1_sr.png', '0_2_sr.png', '0_3_sr.png']
 
 
 def _config_plain(root):
