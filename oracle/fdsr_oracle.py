@@ -264,6 +264,36 @@ def p_losses(sd, cfg: UNetConfig, hr: Tensor, sr: Tensor, gamma: Tensor, noise: 
 
 
 # --------------------------------------------------------------------------
+# f-3 (next row)  one optimisation step             FastDiffSR/model/model.py:27-57
+# --------------------------------------------------------------------------
+def train_step(sd, cfg: UNetConfig, hr: Tensor, sr: Tensor, gamma: Tensor, noise: Tensor, lr: float,
+               loss_type: str = 'l1', betas=(0.9, 0.999), eps: float = 1e-8, dropout_masks=None):
+    """DDPM.optimize_parameters (model.py:47-57) from fresh Adam state: zero_grad, l_pix = netG(data),
+    l_pix = l_pix.sum() / (b*c*h*w), backward, Adam step (torch.optim.Adam defaults, model.py:37-38).
+    Gradients come from autograd over the restated forward; tensors the forward never touches (the 44
+    dead `.conv` tensors, unet.py:212) get no gradient and are left alone by the optimiser, as in torch.
+    Returns (l_pix, grads {key: Tensor}, new_sd {key: Tensor})."""
+    leaves = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()}
+    loss = p_losses(leaves, cfg, hr, sr, gamma, noise, loss_type, dropout_masks)
+    b, c, h, w = hr.shape
+    l_pix = loss.sum() / int(b * c * h * w)
+    l_pix.backward()
+    grads = {k: v.grad for k, v in leaves.items() if v.grad is not None}
+    new_sd = {}
+    b1, b2 = betas
+    for k, w_ in sd.items():
+        g = grads.get(k)
+        if g is None:
+            new_sd[k] = w_.detach().clone()
+            continue
+        m = (1 - b1) * g                                   # exp_avg after step 1
+        v = (1 - b2) * g * g                               # exp_avg_sq after step 1
+        denom = (v.sqrt() / (1 - b2) ** 0.5) + eps         # bias_correction2 = 1 - b2
+        new_sd[k] = w_.detach() - (lr / (1 - b1)) * (m / denom)
+    return l_pix.detach(), grads, new_sd
+
+
+# --------------------------------------------------------------------------
 # f-1 (next row)  tensor2img / PSNR           FastDiffSR/core/metrics.py:16-42, :94-101
 # --------------------------------------------------------------------------
 def tensor2img_u8(t: Tensor, min_max=(-1, 1)) -> np.ndarray:

@@ -284,6 +284,59 @@ def main():
 
 
 
+def train_goldens():
+    """(x) one optimisation step of the reference itself (model.py:47-57: zero_grad, loss / (b*c*h*w), backward,
+    torch.optim.Adam step), dropout off, fixed t / gamma / noise: loss, three named gradients in full, a
+    (sum, sum of squares) pair for EVERY gradient, and the three tensors after the step.  Pins oracle.train_step."""
+    from unittest import mock
+    diffusion, unet = import_reference()
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    cfg = UNetConfig(**FASTDIFFSR_UNET)
+    sd = synth_state_dict(cfg, 0)
+    net = unet.UNet(in_channel=6, out_channel=3, norm_groups=32, inner_channel=64, channel_mults=[1, 2, 4, 4],
+                    attn_res=[16], res_blocks=2, dropout=0.2, image_size=256)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    G = diffusion.GaussianDiffusion(net, image_size=256, channels=3, loss_type='l1', conditional=True,
+                                    schedule_opt=dict(FASTDIFFSR_SCHEDULE_VAL))
+    G.set_loss('cpu')
+    G.set_new_noise_schedule(dict(FASTDIFFSR_SCHEDULE_VAL), 'cpu')
+    G.eval()                                            # dropout off; everything else as in training
+    tl = np.load(os.path.join(OUT, 'train_loss.npz'))   # same inputs / draws as the loss golden
+    hr, sr, nz = (torch.from_numpy(tl[k]) for k in ('hr', 'sr', 'noise'))
+    gam = tl['gamma']
+    lr = 1e-4                                           # config/sr_fastdiffsr_train_64_256.json: train.optimizer.lr
+    opt = torch.optim.Adam(list(G.parameters()), lr=lr)
+    opt.zero_grad()
+    with mock.patch.object(np.random, 'randint', lambda a, b: 7), \
+            mock.patch.object(np.random, 'uniform', lambda a, b, size: gam):
+        l_pix = G({'HR': hr, 'SR': sr}, noise=nz)
+    b, c, h, w = hr.shape
+    l_pix = l_pix.sum() / int(b * c * h * w)
+    l_pix.backward()
+    named = dict(G.named_parameters())
+    keys3 = ['downs.0.weight', 'mid.0.sa.conv1.weight', 'final_conv.block.3.bias']
+    out = {'l_pix': np.array(l_pix.item(), dtype=np.float64), 'lr': np.array(lr)}
+    names, stats = [], []
+    for k, p in named.items():
+        kk = k[len('denoise_fn.'):]
+        if p.grad is None:
+            continue
+        names.append(kk)
+        g64 = p.grad.double()
+        stats.append([g64.sum().item(), (g64 * g64).sum().item()])
+    out['grad_keys'] = np.array(names)
+    out['grad_stats'] = np.array(stats, dtype=np.float64)
+    for k in keys3:
+        out['grad/' + k] = named['denoise_fn.' + k].grad.numpy().copy()
+    opt.step()
+    for k in keys3:
+        out['after/' + k] = named['denoise_fn.' + k].detach().numpy().copy()
+    out['n_params_without_grad'] = np.array(sum(1 for p in named.values() if p.grad is None))
+    np.savez_compressed(os.path.join(OUT, 'train_step.npz'), **out)
+    print('wrote train_step.npz: l_pix', l_pix.item(), 'tensors with grad', len(names), 'without', int(out['n_params_without_grad']))
+
+
 def config_goldens():
     """(ix) the reference's own option parser (core/logger.py:21-94) on its ten fastdiffsr / ddpm configs:
     what `parse` returns, minus the timestamped `path` subtree.  Pins fastdiffsr_amd.config.load_config."""
@@ -325,6 +378,9 @@ def config_goldens():
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'configs':
         config_goldens()          # only tests/golden/configs.json
+    elif len(sys.argv) > 1 and sys.argv[1] == 'train':
+        train_goldens()           # only tests/golden/train_step.npz (reads train_loss.npz)
     else:
         main()
         config_goldens()
+        train_goldens()

@@ -220,3 +220,35 @@ def test_sr3_sibling_vs_reference_goldens(golden_dir):
     assert ref.shape[0] == 2 + 12 * 2
     assert np.abs(torch.cat([cond] + traj).numpy() - ref).max() <= 2e-5
     assert np.abs(out.numpy() - ref[-2:]).max() <= 2e-5
+
+
+def test_training_step_matches_reference(full, golden_dir):
+    """oracle.train_step vs one optimisation step of the reference itself (model.py:47-57; golden made by
+    oracle/make_goldens.py train): loss, every gradient (sum / sum of squares per tensor + three tensors in
+    full), the Adam update.  This is the oracle of SURVEY 8f-3; the HIP backward kernels are not built yet."""
+    cfg, sd, _ = full
+    g = _load(golden_dir, 'train_step.npz')
+    tl = _load(golden_dir, 'train_loss.npz')
+    hr, sr, nz = (torch.from_numpy(tl[k]) for k in ('hr', 'sr', 'noise'))
+    gamma = torch.FloatTensor(tl['gamma'])
+    l_pix, grads, new_sd = O.train_step(sd, cfg, hr, sr, gamma, nz, lr=float(g['lr']))
+    assert abs(l_pix.item() - float(g['l_pix'])) <= 1e-6 * abs(float(g['l_pix']))
+    keys = [str(k) for k in g['grad_keys']]
+    assert sorted(keys) == sorted(grads.keys()) and len(keys) == 273          # the 44 dead tensors get none
+    assert int(g['n_params_without_grad']) == 44 == len(sd) - len(grads)
+    for k, (s1, s2) in zip(keys, g['grad_stats']):
+        g64 = grads[k].double()
+        scale = max(np.sqrt(s2), 1e-12)
+        assert abs(g64.sum().item() - s1) <= 2e-4 * scale + 1e-9, k
+        assert abs((g64 * g64).sum().item() - s2) <= 2e-4 * s2 + 1e-18, k
+    for k in ('downs.0.weight', 'mid.0.sa.conv1.weight', 'final_conv.block.3.bias'):
+        ref = g['grad/' + k]
+        assert np.abs(grads[k].numpy() - ref).max() <= 2e-4 * np.abs(ref).max() + 1e-9, k
+        # Adam's first step moves every weight by ~lr * sign(g): compare where the reference's |g| is not tiny
+        aft, ref_aft = new_sd[k].numpy(), g['after/' + k]
+        mask = np.abs(ref) > 1e-3 * np.abs(ref).max()
+        assert np.abs(aft - ref_aft)[mask].max() <= 2e-7, k
+        assert np.abs(aft - ref_aft).max() <= 2.1 * float(g['lr']), k
+    for k in sd:
+        if k not in grads:
+            assert torch.equal(new_sd[k], sd[k])
