@@ -200,6 +200,13 @@ def test_batch16_properties(full):
     # no atomics anywhere on the path (GroupNorm statistics are per-tile partials summed in a fixed
     # order): a rerun is bitwise identical, like the reference's CPU loop (SURVEY 8c noise floor)
     assert d_rep == 0.0 and d_b <= TOL_LOOP / 4
+    # and the last image of the batch against the oracle directly (its own cond and noise)
+    from oracle import fdsr_oracle as O
+    tab = O.schedule_tables(FASTDIFFSR_SCHEDULE_VAL)
+    ref = O.p_sample_loop(O.to_torch_sd(sd), cfg, tab, cond[15:16], noise[:, 15:16])
+    d_o = (out[15:16].cpu() - ref).abs().max().item()
+    report(f'B=16 256x256: image 15 of the batch vs oracle max|d|={d_o:.3e}')
+    assert d_o <= TOL_LOOP
 
 
 @pytest.mark.parametrize('prec,tol_fwd,tol_loop', [('f16x3', 1e-4, 1e-3), ('bf16', 0.25, None)])
