@@ -50,6 +50,7 @@ SYMBOLS = {
                               C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]),
     'fdsr_set_precision': (C.c_int, [C.c_void_p, C.c_int]),
     'fdsr_set_seed': (C.c_int, [C.c_void_p, C.c_uint64]),
+    'fdsr_debug_tensor_elem_bytes': (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p]),
     'fdsr_randn': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'fdsr_resize_bicubic_u8': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p]),

@@ -1,0 +1,42 @@
+// Device-side activation I/O shared by the 16-bit kernels: activations live in HBM as fp32 (f32 / f16x3
+// modes) or as bf16 (bf16 mode: half the traffic); everything in registers is fp32.
+#pragma once
+#include "fdsr_kernels.h"
+
+namespace fdsr {
+
+typedef float f32x4_io __attribute__((ext_vector_type(4)));
+
+// activations in HBM: fp32 (f32 / f16x3 modes) or bf16 (bf16 mode)
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned v) { return __builtin_bit_cast(float, v << 16); }
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float v) { return __builtin_bit_cast(unsigned short, (__bf16)v); }
+template <int PREC> struct ActIO;
+template <> struct ActIO<PREC_F16X3> {
+  typedef f32x4_io Quad;   // four consecutive channels as loaded
+  static constexpr int ESZ = 4;
+  static __device__ __forceinline__ Quad load4(const float* base, size_t idx) { return *reinterpret_cast<const f32x4_io*>(base + idx); }
+  static __device__ __forceinline__ f32x4_io widen(Quad q) { return q; }
+  static __device__ __forceinline__ float load1(const float* base, size_t idx) { return base[idx]; }
+  static __device__ __forceinline__ void store1(float* base, size_t idx, float v) { base[idx] = v; }
+};
+template <> struct ActIO<PREC_BF16> {
+  typedef uint2 Quad;
+  static constexpr int ESZ = 2;
+  static __device__ __forceinline__ Quad load4(const float* base, size_t idx) {
+    return *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + idx);
+  }
+  static __device__ __forceinline__ f32x4_io widen(Quad q) {
+    f32x4_io r = {__builtin_bit_cast(float, q.x << 16), __builtin_bit_cast(float, q.x & 0xffff0000u),
+               __builtin_bit_cast(float, q.y << 16), __builtin_bit_cast(float, q.y & 0xffff0000u)};
+    return r;
+  }
+  static __device__ __forceinline__ float load1(const float* base, size_t idx) {
+    return bf16_bits_to_f32(reinterpret_cast<const unsigned short*>(base)[idx]);
+  }
+  static __device__ __forceinline__ void store1(float* base, size_t idx, float v) {
+    reinterpret_cast<unsigned short*>(base)[idx] = f32_to_bf16_bits(v);
+  }
+};
+
+
+}  // namespace fdsr

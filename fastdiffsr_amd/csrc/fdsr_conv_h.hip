@@ -22,9 +22,11 @@
 //     multiplied; one barrier per chunk
 //   * epilogue as in the fp32 kernel (bias + noise-embedding shift + residual, NHWC stores)
 #include "fdsr_kernels.h"
+#include "fdsr_act_io.h"
 
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 namespace fdsr {
 
@@ -116,7 +118,8 @@ __global__ void __launch_bounds__(512, 2) conv_mfma_h_kernel(const ConvParams p)
     in_pix[i] = v;
   }
 
-  f32x4 rin[NIN];
+  using IO = ActIO<PREC>;
+  typename IO::Quad rin[NIN];
   f32x4 rsc = {1.f, 1.f, 1.f, 1.f}, rsh = {0.f, 0.f, 0.f, 0.f};
   auto prefetch = [&](int kc) {
     const int cbase = kc * KC;
@@ -130,14 +133,14 @@ __global__ void __launch_bounds__(512, 2) conv_mfma_h_kernel(const ConvParams p)
     }
 #pragma unroll
     for (int i = 0; i < NIN; ++i)   // branch-free: padding / unused rows read pixel 0 and are zeroed in stage()
-      rin[i] = *reinterpret_cast<const f32x4*>(base + (size_t)(in_pix[i] < 0 ? 0 : in_pix[i]) * Cs + cc);
+      rin[i] = IO::load4(base, (size_t)(in_pix[i] < 0 ? 0 : in_pix[i]) * Cs + cc);
   };
   auto stage = [&](int kc, unsigned char* buf) {
     const f32x4 sc = rsc, sh = rsh;
 #pragma unroll
     for (int i = 0; i < NIN; ++i) {
       if (NIN * RPP > NPIX && i == NIN - 1 && row0 + i * RPP >= NPIX) continue;   // only the last pass can overrun
-      f32x4 v = rin[i];
+      f32x4 v = IO::widen(rin[i]);
       if (gn) {
         v = v * sc + sh;
         if (!p.gn_plain) { v.x = silu_h(v.x); v.y = silu_h(v.y); v.z = silu_h(v.z); v.w = silu_h(v.w); }
@@ -273,57 +276,66 @@ __global__ void __launch_bounds__(512, 2) conv_mfma_h_kernel(const ConvParams p)
     }
     return;
   }
-  if (interior) {
-    float* obase = p.out + ((size_t)(n * p.Hout + oy0 + wm) * p.Wout + ox0 + 4 * h) * p.Cout + co;
-    const size_t rstride = (size_t)WM * p.Wout * p.Cout;
-    float rv[MB][16];
-    if (p.res) {
-      const float* rbase = p.res + (obase - p.out);
+  // OUT16: this launch stores bf16 (bf16 mode, every conv but the last); residuals follow the activation type
+  auto epilogue = [&](auto out16_tag) {
+    constexpr bool OUT16 = decltype(out16_tag)::value;
+    auto put = [&](size_t idx, float v) {
+      if (OUT16) reinterpret_cast<unsigned short*>(p.out)[idx] = f32_to_bf16_bits(v);
+      else p.out[idx] = v;
+    };
+    if (interior) {
+      const size_t obase = ((size_t)(n * p.Hout + oy0 + wm) * p.Wout + ox0 + 4 * h) * p.Cout + co;
+      const size_t rstride = (size_t)WM * p.Wout * p.Cout;
+      float rv[MB][16];
+      if (p.res) {
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb)
+        for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) rv[mb][i] = rbase[mb * rstride + (size_t)((i & 3) + 8 * (i >> 2)) * p.Cout];
-    } else {
+          for (int i = 0; i < 16; ++i) rv[mb][i] = IO::load1(p.res, obase + mb * rstride + (size_t)((i & 3) + 8 * (i >> 2)) * p.Cout);
+      } else {
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb)
+        for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) rv[mb][i] = 0.f;
-    }
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const float v = acc[mb][i] * p.w_inv_scale + add + rv[mb][i];
-        obase[mb * rstride + (size_t)((i & 3) + 8 * (i >> 2)) * p.Cout] = v;
-        s1 += v;
-        s2 += v * v;
+          for (int i = 0; i < 16; ++i) rv[mb][i] = 0.f;
       }
-  } else {
-    float rv[MB][16];
-    if (p.res) {
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float v = acc[mb][i] * p.w_inv_scale + add + rv[mb][i];
+          put(obase + mb * rstride + (size_t)((i & 3) + 8 * (i >> 2)) * p.Cout, v);
+          s1 += v;
+          s2 += v * v;
+        }
+    } else {
+      float rv[MB][16];
+      if (p.res) {
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int oy = oy0 + wm + mb * WM, ox = ox0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            const bool ok = cok && oy < p.Hout && ox < p.Wout;
+            rv[mb][i] = ok ? IO::load1(p.res, ((size_t)(n * p.Hout + oy) * p.Wout + ox) * p.Cout + co) : 0.f;
+          }
+      }
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int oy = oy0 + wm + mb * WM, ox = ox0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-          const bool ok = cok && oy < p.Hout && ox < p.Wout;
-          rv[mb][i] = ok ? p.res[((size_t)(n * p.Hout + oy) * p.Wout + ox) * p.Cout + co] : 0.f;
+          if (cok && oy < p.Hout && ox < p.Wout) {
+            float v = acc[mb][i] * p.w_inv_scale + add;
+            if (p.res) v += rv[mb][i];
+            put(((size_t)(n * p.Hout + oy) * p.Wout + ox) * p.Cout + co, v);
+            s1 += v;
+            s2 += v * v;
+          }
         }
     }
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int oy = oy0 + wm + mb * WM, ox = ox0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-        if (cok && oy < p.Hout && ox < p.Wout) {
-          float v = acc[mb][i] * p.w_inv_scale + add;
-          if (p.res) v += rv[mb][i];
-          p.out[((size_t)(n * p.Hout + oy) * p.Wout + ox) * p.Cout + co] = v;
-          s1 += v;
-          s2 += v * v;
-        }
-      }
-  }
+  };
+  if (PREC == PREC_BF16 && !p.out_f32) epilogue(std::true_type{});
+  else epilogue(std::false_type{});
   if (p.part_out) {
     // the main loop ended with a barrier: the halo buffers are free
     float* sp = reinterpret_cast<float*>(smem_h);   // [WM][BN][2]
@@ -368,8 +380,16 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const ConvParams p, 
 #pragma unroll 4
       for (int s = 1; s < p.ksplit; ++s) a += *reinterpret_cast<const f32x4*>(p.kscratch + s * slice + o);
       a = a * p.w_inv_scale + add;
-      if (p.res) a += *reinterpret_cast<const f32x4*>(p.res + o);
-      *reinterpret_cast<f32x4*>(p.out + o) = a;
+      if (p.out_bf16) {   // bf16 mode: residual and output are bf16 tensors
+        if (p.res) a += ActIO<PREC_BF16>::widen(ActIO<PREC_BF16>::load4(p.res, o));
+        uint2 pk;
+        pk.x = (unsigned)f32_to_bf16_bits(a[0]) | ((unsigned)f32_to_bf16_bits(a[1]) << 16);
+        pk.y = (unsigned)f32_to_bf16_bits(a[2]) | ((unsigned)f32_to_bf16_bits(a[3]) << 16);
+        *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p.out) + o) = pk;
+      } else {
+        if (p.res) a += *reinterpret_cast<const f32x4*>(p.res + o);
+        *reinterpret_cast<f32x4*>(p.out + o) = a;
+      }
       s1 += a;
       s2 += a * a;
     }
@@ -402,12 +422,14 @@ static hipError_t launch_h_t(const ConvParams& p, hipStream_t s, int* tiles) {
   if (tiles) *tiles = tilesX * tilesY;
   const int sk = p.ksplit > 1 ? p.ksplit : 1;
   const int nwg = p.N * tilesX * tilesY * (p.Cout_pad / Cfg::BN) * sk;
-  hipLaunchKernelGGL(kfn, dim3(nwg), dim3(Cfg::NT), lds, s, p);
+  ConvParams q = p;
+  q.out_bf16 = (PREC == PREC_BF16 && !p.out_f32) ? 1 : 0;
+  hipLaunchKernelGGL(kfn, dim3(nwg), dim3(Cfg::NT), lds, s, q);
   if (sk > 1) {
     const int rt = ((p.Wout + 31) / 32) * ((p.Hout + 1) / 2);
     if (tiles) *tiles = rt;
     const int cb = p.Cout % 32 == 0 ? 32 : p.Cout;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rt, p.N, p.Cout / cb), dim3(256), 0, s, p, cb);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rt, p.N, p.Cout / cb), dim3(256), 0, s, q, cb);
   }
   return hipGetLastError();
 }

@@ -15,6 +15,7 @@
 // current 16-channel chunk (hi|lo) in 64 VGPRs; per source row it reads 6 A fragments (2 rows x 3
 // column shifts) that feed the 8 tap-products; accumulators: [row][px].
 #include "fdsr_kernels.h"
+#include "fdsr_act_io.h"
 
 namespace fdsr {
 
@@ -81,18 +82,19 @@ __global__ void __launch_bounds__(512, 2) conv_up2_h_kernel(const ConvParams p) 
     const bool ok = pix < NPIX && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
     in_pix[i] = ok ? (n * p.Hin + iy) * p.Win + ix : -1;
   }
-  f32x4 rin[NIN];
+  using IO = ActIO<PREC>;
+  typename IO::Quad rin[NIN];
   auto prefetch = [&](int kc) {
-    const float* base = p.x0 + kc * KC + q * 4;
+    const size_t coff = (size_t)kc * KC + q * 4;
 #pragma unroll
     for (int i = 0; i < NIN; ++i)
-      rin[i] = *reinterpret_cast<const f32x4*>(base + (size_t)(in_pix[i] < 0 ? 0 : in_pix[i]) * p.C0);
+      rin[i] = IO::load4(p.x0, (size_t)(in_pix[i] < 0 ? 0 : in_pix[i]) * p.C0 + coff);
   };
   auto stage = [&](unsigned char* buf) {
 #pragma unroll
     for (int i = 0; i < NIN; ++i) {
       if (NIN * RPP > NPIX && i == NIN - 1 && row0 + i * RPP >= NPIX) continue;
-      f32x4 v = rin[i];
+      f32x4 v = IO::widen(rin[i]);
       const float keep = in_pix[i] >= 0 ? 1.f : 0.f;
       unsigned char* dst = buf + (row0 + i * RPP) * ROWB + q * 8;
       if (PREC == PREC_F16X3) {
@@ -194,13 +196,13 @@ __global__ void __launch_bounds__(512, 2) conv_up2_h_kernel(const ConvParams p) 
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
       const int Y = 2 * (oy0 + wm + mb * WM) + py;
-      float* rowp = p.out + ((size_t)(n * p.Hout + Y) * p.Wout + 2 * (ox0 + 4 * h)) * p.Cout + co;
+      const size_t rowp = ((size_t)(n * p.Hout + Y) * p.Wout + 2 * (ox0 + 4 * h)) * p.Cout + co;
 #pragma unroll
       for (int px = 0; px < 2; ++px)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const float v = acc[mb][px][i] * p.w_inv_scale + add;
-          rowp[(size_t)(2 * ((i & 3) + 8 * (i >> 2)) + px) * p.Cout] = v;
+          IO::store1(p.out, rowp + (size_t)(2 * ((i & 3) + 8 * (i >> 2)) + px) * p.Cout, v);   // bf16 mode: bf16 activation
           s1 += v;
           s2 += v * v;
         }
@@ -215,7 +217,7 @@ __global__ void __launch_bounds__(512, 2) conv_up2_h_kernel(const ConvParams p) 
           const int sy = oy0 + wm + mb * WM, sx = ox0 + (i & 3) + 8 * (i >> 2) + 4 * h;
           if (cok && sy < p.Hin && sx < p.Win) {
             const float v = acc[mb][px][i] * p.w_inv_scale + add;
-            p.out[((size_t)(n * p.Hout + 2 * sy + py) * p.Wout + 2 * sx + px) * p.Cout + co] = v;
+            IO::store1(p.out, ((size_t)(n * p.Hout + 2 * sy + py) * p.Wout + 2 * sx + px) * p.Cout + co, v);
             s1 += v;
             s2 += v * v;
           }

@@ -716,6 +716,9 @@ int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, 
           p.gn_plain = op.b == -2 ? 1 : 0;   // attn.qkv: SelfAttention.norm has no Swish
         }
         p.part_out = op.no_part ? nullptr : PART(op.dst);   // res_conv output is overwritten in place by block2
+        // bf16 mode keeps every activation but the packed input and eps as bf16 in HBM
+        p.out_f32 = (op.dst == h->t_eps) ? 1 : 0;
+        p.out_bf16 = (h->prec == PREC_BF16 && op.dst != h->t_eps) ? 1 : 0;
         int nt = 0;
         p.N = N; p.Hin = Hi; p.Win = Wi;
         p.Hout = H >> op.lvl_out; p.Wout = W >> op.lvl_out;
@@ -762,11 +765,13 @@ int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, 
         break;
       }
       case Op::CLAM:
-        HIPCHK(h, launch_clam_gate(TP(op.src0), N, Hi * Wi, op.C0, P(op.fc1), P(op.fc2), op.C0 / 16, gate, st));
+        HIPCHK(h, launch_clam_gate(TP(op.src0), N, Hi * Wi, op.C0, P(op.fc1), P(op.fc2), op.C0 / 16, gate, st,
+                                   h->prec == PREC_BF16));
         break;
       case Op::SLAM: {
         int nt = 0;
-        HIPCHK(h, launch_slam(TP(op.src0), gate, P(op.w), N, Hi, Wi, op.C0, TP(op.dst), PART(op.dst), st, &nt));
+        HIPCHK(h, launch_slam(TP(op.src0), gate, P(op.w), N, Hi, Wi, op.C0, TP(op.dst), PART(op.dst), st, &nt,
+                              h->prec == PREC_BF16));
         sp.tensor_nt[op.dst] = nt;
         break;
       }
@@ -1251,6 +1256,15 @@ int fdsr_resize_bicubic_u8(fdsr_handle h, const uint8_t* src_nhwc, int batch, in
 
 int fdsr_set_precision(fdsr_handle h, int mode) {
   if (!h || mode < 0 || mode > 2) return fail(h, FDSR_E_INVALID, "precision mode must be 0 (f32), 1 (f16x3) or 2 (bf16)");
+  if (mode == PREC_BF16) {
+    // bf16 mode stores activations as bf16: every conv but the packed-input one must run on the 16-bit
+    // kernels, and the attention kernels of the SR3 variant read fp32
+    for (const Op& op : h->ops) {
+      if (op.kind == Op::ATTN) return fail(h, FDSR_E_INVALID, "bf16 mode is not available for the SR3 variant (fp32 attention kernels)");
+      if (op.kind == Op::CONV && !h->weights[op.w].h_ok && op.src0 != h->t_in)
+        return fail(h, FDSR_E_INVALID, "bf16 mode needs channel counts that are multiples of 16 (layer %s)", op.name.c_str());
+    }
+  }
   if (h->prec != mode) {
     for (auto& g : h->graphs) (void)hipGraphExecDestroy(g.exec);
     h->graphs.clear();
@@ -1275,6 +1289,16 @@ int fdsr_debug_tensor(fdsr_handle h, const char* name, const float** dev_ptr, in
       if (hgt) *hgt = h->plan.H >> h->tensors[t].level;
       if (wid) *wid = h->plan.W >> h->tensors[t].level;
       if (ch) *ch = h->tensors[t].C;
+      return FDSR_OK;
+    }
+  return fail(h, FDSR_E_KEY, "no tensor named '%s'", name);
+}
+
+int fdsr_debug_tensor_elem_bytes(fdsr_handle h, const char* name, int* bytes) {
+  if (!h || !name || !bytes) return fail(h, FDSR_E_INVALID, "null argument");
+  for (size_t t = 0; t < h->tensors.size(); ++t)
+    if (h->tensors[t].name == name) {
+      *bytes = (h->prec == PREC_BF16 && (int)t != h->t_in && (int)t != h->t_eps) ? 2 : 4;
       return FDSR_OK;
     }
   return fail(h, FDSR_E_KEY, "no tensor named '%s'", name);

@@ -36,6 +36,11 @@ struct ConvParams {
   // to kscratch[s][N,Hout,Wout,Cout]; splitk_reduce_kernel sums the slices in order and applies the epilogue
   int ksplit;            // <= 1: off
   float* kscratch;
+  // PREC_BF16 keeps activations in HBM as bf16 (half the traffic): the 16-bit kernels then read x0/x1/res
+  // and write out as bf16 through the same pointers.  out_f32: this launch still writes fp32 (the final
+  // conv: eps feeds the fp32 posterior update); the fp32 kernel sets out_bf16 for the 6-channel input conv.
+  int out_f32;
+  int out_bf16;
 };
 
 enum Precision { PREC_F32 = 0, PREC_F16X3 = 1, PREC_BF16 = 2 };
@@ -103,11 +108,12 @@ hipError_t launch_temb(const TembParams& p, hipStream_t s);
 #define FDSR_CLAM_SLICES 32
 size_t clam_slam_scratch_floats(int N, int HW, int C);
 hipError_t launch_clam_gate(const float* x, int N, int HW, int C, const float* fc1 /*[C/16][C]*/,
-                            const float* fc2 /*[C][C/16]*/, int Cr, float* scratch, hipStream_t s);
+                            const float* fc2 /*[C][C/16]*/, int Cr, float* scratch, hipStream_t s, int act_bf16);
 // SLAM applied to (x * gate) (unet.py:151-173): out = y * sigmoid(conv7x7([mean_c y, max_c y]))
 // part_out (optional): [N][tiles][C][2] per-tile (2 x 32 pixels) partial (sum, sumsq) of out per channel.
 hipError_t launch_slam(const float* x, float* scratch, const float* w7 /*[2][7][7]*/,
-                       int N, int H, int W, int C, float* out, float* part_out, hipStream_t s, int* tiles_per_image);
+                       int N, int H, int W, int C, float* out, float* part_out, hipStream_t s, int* tiles_per_image,
+                       int act_bf16 /* x and out are bf16 tensors (bf16 mode) */);
 
 // layout changes at the boundary
 hipError_t launch_nchw_to_nhwc(const float* src, float* dst, int N, int Csrc, int H, int W,

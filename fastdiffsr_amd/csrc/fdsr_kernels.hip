@@ -221,7 +221,8 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_f32_kernel(const ConvParams 
   float s1[NB], s2[NB];
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) s1[nb] = s2[nb] = 0.f;
-  if ((oy0 + TH <= p.Hout) && (ox0 + TW <= p.Wout) && (co0 + BN <= p.Cout)) {
+  // out_bf16 (bf16 mode, the 6-channel input conv only): bf16 stores through the bounds-checked path
+  if ((oy0 + TH <= p.Hout) && (ox0 + TW <= p.Wout) && (co0 + BN <= p.Cout) && !p.out_bf16) {
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
       const int co = co0 + (wn * NB + nb) * 32 + r31;
@@ -280,7 +281,8 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_f32_kernel(const ConvParams 
             const size_t off = ((size_t)(n * p.Hout + oy) * p.Wout + ox) * p.Cout + co;
             float v = acc[mb][nb][i] + add;
             if (p.res) v += rv[mb][i];
-            p.out[off] = v;
+            if (p.out_bf16) reinterpret_cast<unsigned short*>(p.out)[off] = __builtin_bit_cast(unsigned short, (__bf16)v);
+            else p.out[off] = v;
             s1[nb] += v;
             s2[nb] += v * v;
           }
@@ -486,7 +488,31 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// four consecutive channels of an activation tensor kept as fp32 (BF = false) or bf16 (BF = true, bf16 mode)
+template <bool BF>
+__device__ __forceinline__ f32x4 ldq(const float* base, size_t idx) {
+  if (BF) {
+    const uint2 q = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + idx);
+    f32x4 r = {__builtin_bit_cast(float, q.x << 16), __builtin_bit_cast(float, q.x & 0xffff0000u),
+               __builtin_bit_cast(float, q.y << 16), __builtin_bit_cast(float, q.y & 0xffff0000u)};
+    return r;
+  }
+  return *reinterpret_cast<const f32x4*>(base + idx);
+}
+template <bool BF>
+__device__ __forceinline__ void stq(float* base, size_t idx, f32x4 v) {
+  if (BF) {
+    uint2 pk;
+    pk.x = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)v[0]) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)v[1]) << 16);
+    pk.y = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)v[2]) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)v[3]) << 16);
+    *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(base) + idx) = pk;
+  } else {
+    *reinterpret_cast<f32x4*>(base + idx) = v;
+  }
+}
+
 // Phase 1, grid (FDSR_CLAM_SLICES, N): per-channel sum and maximum of one pixel slice.
+template <bool BF>
 __global__ void __launch_bounds__(256) clam_pool_kernel(const float* __restrict__ x, int HW, int C, float* __restrict__ pool) {
   __shared__ __attribute__((aligned(16))) float ps[256 * 8];
   const int tid = threadIdx.x, sl = blockIdx.x, n = blockIdx.y;
@@ -494,9 +520,9 @@ __global__ void __launch_bounds__(256) clam_pool_kernel(const float* __restrict_
   const int p0 = (int)((long)sl * HW / FDSR_CLAM_SLICES), p1 = (int)((long)(sl + 1) * HW / FDSR_CLAM_SLICES);
   f32x4 s = {0.f, 0.f, 0.f, 0.f}, m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
   if (r < rows) {
-    const float* base = x + (size_t)n * HW * C + c4 * 4;
+    const size_t base = (size_t)n * HW * C + c4 * 4;
     for (int pix = p0 + r; pix < p1; pix += rows) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(base + (size_t)pix * C);
+      const f32x4 v = ldq<BF>(x, base + (size_t)pix * C);
       s += v;
 #pragma unroll
       for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], v[e]);
@@ -564,11 +590,12 @@ size_t clam_slam_scratch_floats(int N, int HW, int C) {
 }
 
 hipError_t launch_clam_gate(const float* x, int N, int HW, int C, const float* fc1, const float* fc2, int Cr,
-                            float* scratch, hipStream_t s) {
+                            float* scratch, hipStream_t s, int act_bf16) {
   if (C > 1024 || (C & 3)) return hipErrorInvalidValue;
   float* gate = scratch;
   float* pool = scratch + (size_t)N * C;
-  hipLaunchKernelGGL(clam_pool_kernel, dim3(FDSR_CLAM_SLICES, N), dim3(256), 0, s, x, HW, C, pool);
+  if (act_bf16) hipLaunchKernelGGL(clam_pool_kernel<true>, dim3(FDSR_CLAM_SLICES, N), dim3(256), 0, s, x, HW, C, pool);
+  else hipLaunchKernelGGL(clam_pool_kernel<false>, dim3(FDSR_CLAM_SLICES, N), dim3(256), 0, s, x, HW, C, pool);
   const size_t lds = (size_t)(2 * C + 2 * Cr) * sizeof(float);
   hipLaunchKernelGGL(clam_gate_kernel, dim3(N), dim3(256), lds, s, pool, HW, C, fc1, fc2, Cr, gate);
   return hipGetLastError();
@@ -578,10 +605,11 @@ hipError_t launch_clam_gate(const float* x, int N, int HW, int C, const float* f
 // SLAM on y = x*gate: channel mean/max -> 7x7 conv -> sigmoid -> scale   (unet.py:151-173)
 // ---------------------------------------------------------------------------
 // Phase 1, grid (ceil(HW/16), N): one wave per pixel, map[n][0] = mean_c y, map[n][1] = max_c y.
+template <bool BF>
 __global__ void __launch_bounds__(256) slam_map_kernel(const float* __restrict__ x, const float* __restrict__ gate, int HW, int C,
                                                        float* __restrict__ map) {
   const int tid = threadIdx.x, n = blockIdx.y, wave = tid >> 6, lane = tid & 63;
-  const float* xb = x + (size_t)n * HW * C;
+  const size_t xb = (size_t)n * HW * C;
   const float* gb = gate + (size_t)n * C;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -589,7 +617,7 @@ __global__ void __launch_bounds__(256) slam_map_kernel(const float* __restrict__
     if (pix >= HW) break;
     float s = 0.f, m = -INFINITY;
     for (int c = lane * 4; c < C; c += 256) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(xb + (size_t)pix * C + c);
+      const f32x4 v = ldq<BF>(x, xb + (size_t)pix * C + c);
       const f32x4 g = *reinterpret_cast<const f32x4*>(gb + c);
       const f32x4 y = g * v;
       s += (y.x + y.y) + (y.z + y.w);
@@ -603,6 +631,7 @@ __global__ void __launch_bounds__(256) slam_map_kernel(const float* __restrict__
 
 // Phase 2, grid (tiles of 2 x 32 pixels, N): 7x7 conv + sigmoid on the map, out = sig * (gate * x), and the
 // per-tile channel statistics of out (GroupNorm input of the next block, mid.1.block1).
+template <bool BF>
 __global__ void __launch_bounds__(256) slam_apply_kernel(const float* __restrict__ x, const float* __restrict__ gate,
                                                          const float* __restrict__ map, const float* __restrict__ w7, int H, int W,
                                                          int C, float* out, float* part_out) {
@@ -640,9 +669,9 @@ __global__ void __launch_bounds__(256) slam_apply_kernel(const float* __restrict
       const int y = ty * 2 + (px >> 5), xx = tx * 32 + (px & 31);
       if (y >= H || xx >= W) continue;
       const size_t o = ((size_t)n * HW + (size_t)y * W + xx) * C + c4 * 4;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(x + o);
+      const f32x4 v = ldq<BF>(x, o);
       const f32x4 r = sig[px] * (gv * v);
-      *reinterpret_cast<f32x4*>(out + o) = r;
+      stq<BF>(out, o, r);
       s1 += r;
       s2 += r * r;
     }
@@ -667,15 +696,17 @@ __global__ void __launch_bounds__(256) slam_apply_kernel(const float* __restrict
 }
 
 hipError_t launch_slam(const float* x, float* scratch, const float* w7, int N, int H, int W, int C, float* out,
-                       float* part_out, hipStream_t s, int* tiles) {
+                       float* part_out, hipStream_t s, int* tiles, int act_bf16) {
   if (C > 1024 || (C & 3)) return hipErrorInvalidValue;
   const int HW = H * W;
   const float* gate = scratch;
   float* map = scratch + (size_t)N * C + (size_t)N * FDSR_CLAM_SLICES * C * 2;
-  hipLaunchKernelGGL(slam_map_kernel, dim3((HW + 15) / 16, N), dim3(256), 0, s, x, gate, HW, C, map);
+  if (act_bf16) hipLaunchKernelGGL(slam_map_kernel<true>, dim3((HW + 15) / 16, N), dim3(256), 0, s, x, gate, HW, C, map);
+  else hipLaunchKernelGGL(slam_map_kernel<false>, dim3((HW + 15) / 16, N), dim3(256), 0, s, x, gate, HW, C, map);
   const int nt = ((W + 31) / 32) * ((H + 1) / 2);
   if (tiles) *tiles = nt;
-  hipLaunchKernelGGL(slam_apply_kernel, dim3(nt, N), dim3(256), 0, s, x, gate, map, w7, H, W, C, out, part_out);
+  if (act_bf16) hipLaunchKernelGGL(slam_apply_kernel<true>, dim3(nt, N), dim3(256), 0, s, x, gate, map, w7, H, W, C, out, part_out);
+  else hipLaunchKernelGGL(slam_apply_kernel<false>, dim3(nt, N), dim3(256), 0, s, x, gate, map, w7, H, W, C, out, part_out);
   return hipGetLastError();
 }
 

@@ -146,7 +146,8 @@ int fdsr_randn(fdsr_handle h, float* dst_nchw, int batch, int height, int width,
  *   FDSR_PREC_F32    exact fp32 on v_mfma_f32_32x32x2_f32 (default)
  *   FDSR_PREC_F16X3  fp32-grade: operands split hi/lo into two f16, three f16 MFMAs per product,
  *                    fp32 accumulate (stays inside the 1e-3 parity bound)
- *   FDSR_PREC_BF16   one bf16 MFMA per product (BASELINE config 3; judged on PSNR delta) */
+ *   FDSR_PREC_BF16   one bf16 MFMA per product and bf16 activations in HBM (BASELINE config 3; judged on
+ *                    PSNR delta).  FastDiffSR variant with 16-aligned channel counts only. */
 #define FDSR_PREC_F32 0
 #define FDSR_PREC_F16X3 1
 #define FDSR_PREC_BF16 2
@@ -176,6 +177,9 @@ int fdsr_set_debug(fdsr_handle h, int on);
  * of the output of reference module `name` ("downs.4", "mid.0", "ups.7", ...). */
 int fdsr_debug_tensor(fdsr_handle h, const char* name, const float** dev_ptr,
                       int* n, int* hgt, int* wid, int* ch);
+/* Element size of that tensor in the workspace: 4 (fp32), or 2 in bf16 mode, which keeps every
+ * activation but the packed input and eps as bf16 in HBM. */
+int fdsr_debug_tensor_elem_bytes(fdsr_handle h, const char* name, int* bytes);
 /* Timing hooks: record hipEvents on `stream` around every launch of the
  * dominant kernel family (the 3x3 MFMA convolutions) during the next calls,
  * then read back count / total milliseconds / algorithmic FLOPs. */
