@@ -21,7 +21,10 @@
  *  - the caller owns every tensor and the workspace; the library owns its
  *    packed weights and captured graphs.  One handle per device; a handle is
  *    not thread-safe.  All work is stream-ordered on `stream` and asynchronous:
- *    no entry point synchronises the device.
+ *    the execution entry points do not synchronise the device, with one exception: the first
+ *    fdsr_sample after the weights or the schedule changed builds the noise-embedding table for
+ *    all T levels (one small launch + a stream synchronise).  Loading weights, fdsr_set_schedule
+ *    and fdsr_set_seed are host-synchronous copies.
  *  - H and W must be multiples of 2^(n_mults-1) (three stride-2 stages => 8).
  */
 #ifndef FDSR_H_

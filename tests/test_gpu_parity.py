@@ -264,6 +264,13 @@ def test_error_paths(full):
         eng.load_weight('nope.weight', np.zeros((1,), np.float32))                 # unexpected key
     with pytest.raises(_lib.FdsrError):
         eng.workspace_bytes(1, 60, 64)                                             # not a multiple of 8
+    # bf16 mode stores activations as bf16: refused where a kernel on the path would read them as fp32
+    with pytest.raises(_lib.FdsrError, match='multiple of'):
+        Engine(UNetConfig(in_channel=6, out_channel=3, inner_channel=24, norm_groups=8, channel_mults=(1, 2), res_blocks=1))
+    e4 = Engine(UNetConfig(in_channel=6, out_channel=3, inner_channel=32, channel_mults=(1, 2), attn_res=(16,), res_blocks=1,
+                           image_size=32, variant='ddpm'))
+    with pytest.raises(_lib.FdsrError, match='SR3'):
+        e4.set_precision('bf16')
     e2 = Engine(cfg)
     with pytest.raises(_lib.FdsrError):                                            # weights missing
         e2.unet_forward(torch.zeros(1, 6, 32, 32).cuda(), torch.zeros(1).cuda())
