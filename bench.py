@@ -107,6 +107,23 @@ def parity_check(eng, dev, ref):
     return res
 
 
+class _StdoutToStderr:
+    """RCCL prints a version banner on STDOUT when its first communicator comes up; this line-oriented
+    benchmark owes its caller exactly one JSON line there, so fd 1 points at stderr while RCCL initialises."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -127,7 +144,8 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
-    distributed = world > 1
+    # FDSR_BENCH_FORCE_DIST=1: take the RCCL path (init, weight broadcast, barrier, max-reduce) with one rank too
+    distributed = world > 1 or os.environ.get('FDSR_BENCH_FORCE_DIST') == '1'
     if args.gpus != world and distributed:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
 
@@ -140,15 +158,16 @@ def main():
 
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if distributed:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
-
     cfg = UNetConfig(**FASTDIFFSR_UNET)
     # weights: rank 0 builds the random-init UNet, ONE RCCL broadcast replicates it
     sd = synth_state_dict(cfg, 0) if rank == 0 else None
     if distributed:
-        sd = parallel.broadcast_state_dict(sd, cfg, src=0, device=dev)
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        with _StdoutToStderr():
+            dist.init_process_group('nccl', device_id=dev)
+            sd = parallel.broadcast_state_dict(sd, cfg, src=0, device=dev)
+            dist.barrier()
+            torch.cuda.synchronize(dev)
     eng = Engine(cfg)
     eng.load_state_dict(sd)
     bufs, sp = schedule_buffers(FASTDIFFSR_SCHEDULE_VAL)
