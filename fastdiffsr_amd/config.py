@@ -65,3 +65,21 @@ def load_config(path, phase='val', gpu_ids=None, debug=False, enable_wandb=False
     opt['log_infer'] = log_infer
     opt['enable_wandb'] = enable_wandb
     return dict_to_nonedict(opt)
+
+
+def setup_logger(logger_name, root, phase, level=None, screen=False):
+    """core/logger.py:128-141: `<root>/<phase>.log` (mode 'w'), optional stderr echo, the reference's line format."""
+    import logging
+    import os
+    lg = logging.getLogger(logger_name)
+    fmt = logging.Formatter('%(asctime)s.%(msecs)03d - %(levelname)s: %(message)s', datefmt='%y-%m-%d %H:%M:%S')
+    os.makedirs(root, exist_ok=True)
+    fh = logging.FileHandler(os.path.join(root, '{}.log'.format(phase)), mode='w')
+    fh.setFormatter(fmt)
+    lg.setLevel(logging.INFO if level is None else level)
+    lg.addHandler(fh)
+    if screen:
+        sh = logging.StreamHandler()
+        sh.setFormatter(fmt)
+        lg.addHandler(sh)
+    return lg

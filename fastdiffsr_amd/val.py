@@ -67,6 +67,7 @@ def run(opt, batch=1, cond_from_lr=False, precision='f16x3', results=None, max_i
         diffusion.test(continous=False)
         torch.cuda.synchronize()
         t_sample += time.time() - t0
+        logger.info('inference time (s): {:.4f} for {} image(s)'.format(time.time() - t0, len(idxs)))   # sr_mfe.py:279-284
         for j, index in enumerate(idxs):
             idx = index + 1                                                           # sr_mfe.py:274 counts from 1
             hr_img = M.tensor2img(diffusion.data['HR'][j])
@@ -123,8 +124,17 @@ def main(argv=None):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl')
     opt = load_config(a.config, phase=a.phase, gpu_ids=a.gpu_ids, debug=a.debug)
+    log = print
+    if not a.no_save and rank == 0 and (opt.get('path') or {}).get('log'):
+        # sr_mfe.py:50-54: experiments/<name>_<timestamp>/logs/{train,val}.log; the two summary lines go to val.log
+        from .config import setup_logger
+        setup_logger(None, opt['path']['log'], 'train', screen=True)
+        val_logger = setup_logger('val', opt['path']['log'], 'val')
+        log = lambda msg: (print(msg), val_logger.info(msg))     # noqa: E731
+        if a.results is None:
+            a.results = opt['path'].get('results')
     res = run(opt, batch=a.batch, cond_from_lr=a.cond_from_lr, precision=a.precision, results=a.results,
-              max_images=a.max_images, rank=rank, world=world, save_images=not a.no_save, infer=a.infer)
+              max_images=a.max_images, rank=rank, world=world, save_images=not a.no_save, infer=a.infer, log=log)
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()

@@ -46,8 +46,20 @@ def test_val_cli_end_to_end(tmp_path):
     r3 = val.main(['-c', str(cpath), '--max-images', '1', '--no-save'])
     assert r3['images'] == 1
     # infer.py: png outputs, no metrics
-    r4 = val.main(['-c', str(cpath), '--infer', '--batch', '3', '--results', str(tmp_path / 'out4')])
-    assert r4['images'] == 3 and sorted(os.listdir(tmp_path / 'out4')) == ['0_1_sr.png', '0_2_sr.png', '0_3_sr.png']
+    cwd = os.getcwd()
+    os.chdir(tmp_path)                      # like the reference, the CLI writes experiments/<name>_<ts>/ under the cwd
+    try:
+        r4 = val.main(['-c', str(cpath), '--infer', '--batch', '3', '--results', str(tmp_path / 'out4')])
+        assert r4['images'] == 3 and sorted(os.listdir(tmp_path / 'out4')) == ['0_1_sr.png', '0_2_sr.png', '0_3_sr.png']
+        r5 = val.main(['-c', str(cpath), '--batch', '3'])
+        exp = [d for d in os.listdir(tmp_path / 'experiments') if d.startswith('sr_fastdiffsr_test_')]
+        assert exp
+        newest = sorted(exp)[-1]
+        vlog = (tmp_path / 'experiments' / newest / 'logs' / 'val.log').read_text()
+        assert 'sr_psnr' in vlog and 'bic_psnr' in vlog
+        assert len(os.listdir(r5['result_path'])) == 3 and 'experiments' in r5['result_path']
+    finally:
+        os.chdir(cwd)
 
 
 def _config_plain(root):
