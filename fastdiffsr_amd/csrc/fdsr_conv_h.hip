@@ -146,11 +146,12 @@ __global__ void __launch_bounds__(512, 2) conv_mfma_h_kernel(const ConvParams p)
         if (!p.gn_plain) { v.x = silu_h(v.x); v.y = silu_h(v.y); v.z = silu_h(v.z); v.w = silu_h(v.w); }
       }
       const float keep = in_pix[i] >= 0 ? 1.f : 0.f;   // conv zero-pads the ACTIVATED tensor
+      const float lim = in_pix[i] >= 0 ? 65504.f : 0.f;   // f16 range clamp and zero padding in one med3
       unsigned char* dst = buf + (row0 + i * RPP) * ROWB + (q >> 2) * (NP * 32) + (q & 3) * 8;
       if (PREC == PREC_F16X3) {
         // clamp to the f16 range (also maps NaN-free), hi = rn(v), lo = rn(v - hi): 22 mantissa bits
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e] * keep, -65504.f, 65504.f);
+        for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], -lim, lim);   // padding: lim = 0
         h4 hi = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
         h4 lo = {(_Float16)(v.x - (float)hi.x), (_Float16)(v.y - (float)hi.y), (_Float16)(v.z - (float)hi.z),
                  (_Float16)(v.w - (float)hi.w)};

@@ -96,10 +96,11 @@ __global__ void __launch_bounds__(512, 2) conv_up2_h_kernel(const ConvParams p) 
       if (NIN * RPP > NPIX && i == NIN - 1 && row0 + i * RPP >= NPIX) continue;
       f32x4 v = IO::widen(rin[i]);
       const float keep = in_pix[i] >= 0 ? 1.f : 0.f;
+      const float lim = in_pix[i] >= 0 ? 65504.f : 0.f;
       unsigned char* dst = buf + (row0 + i * RPP) * ROWB + q * 8;
       if (PREC == PREC_F16X3) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e] * keep, -65504.f, 65504.f);
+        for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], -lim, lim);   // padding: lim = 0
         h4 hi = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
         h4 lo = {(_Float16)(v.x - (float)hi.x), (_Float16)(v.y - (float)hi.y), (_Float16)(v.z - (float)hi.z),
                  (_Float16)(v.w - (float)hi.w)};
