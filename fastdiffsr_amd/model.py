@@ -29,6 +29,7 @@ class DDPM:
             self.netG.train()
             self.log_dict = OrderedDict()
         self.load_network()                                        # model.py:41
+        self.print_network()                                       # model.py:42
 
     def set_device(self, x):                                       # base_model.py:31-42
         if isinstance(x, dict):
@@ -68,6 +69,17 @@ class DDPM:
             else:
                 out['LR'] = out['INF']
         return out
+
+    def get_network_description(self, network):                    # base_model.py:44-50
+        if isinstance(network, nn.DataParallel):
+            network = network.module
+        return str(network), sum(x.numel() for x in network.parameters())
+
+    def print_network(self):                                       # model.py:112-123
+        s, n = self.get_network_description(self.netG)
+        logger.info('n------Total params: %.3f M' % (n / (1024 * 1024)))
+        logger.info('Network G structure: {}, with parameters: {:,d}'.format(self.netG.__class__.__name__, n))
+        logger.info(s)
 
     def save_network(self, epoch, iter_step):                      # model.py:126-146 (generator part)
         gen_path = os.path.join(self.opt['path']['checkpoint'], 'I{}_E{}_gen.pth'.format(iter_step, epoch))

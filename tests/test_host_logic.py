@@ -167,3 +167,13 @@ def test_config_reader_matches_reference_parser(golden_dir):
         got = json.loads(json.dumps(got))
         got.pop('path', None)
         assert got == want, key
+
+
+def test_parameter_count_matches_reference():
+    """print_network reports 23,802,277 parameters = '22.700 M' (the reference divides by 1024**2, model.py:121;
+    SURVEY section 6): the facade registers exactly the reference's parameters, dead ones included."""
+    from fastdiffsr_amd import diffusion, unet
+    net = unet.UNet(**{**FASTDIFFSR_UNET, 'channel_mults': [1, 2, 4, 4]})
+    G = diffusion.GaussianDiffusion(net, image_size=256, channels=3, loss_type='l1', conditional=True, schedule_opt=None)
+    n = sum(p.numel() for p in G.parameters())
+    assert n == 23802277 and '%.3f' % (n / (1024 * 1024)) == '22.700'
