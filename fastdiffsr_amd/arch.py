@@ -26,7 +26,8 @@ class UNetConfig:
     res_blocks: int = 3
     dropout: float = 0.0
     image_size: int = 256
-    # 'fastdiffsr' (model/fastdiffsr_modules) or 'ddpm' (the SR3 sibling, model/ddpm_modules: integer-time
+    # 'fastdiffsr' (model/fastdiffsr_modules), 'tesr' (model/tesr_modules: the same blocks and noise-level embedding with
+    # SR3's SelfAttention placement) or 'ddpm' (the SR3 sibling, model/ddpm_modules: integer-time
     # embedding, Swish before the per-block Linear, SelfAttention where the resolution is in attn_res)
     variant: str = 'fastdiffsr'
 
@@ -51,7 +52,7 @@ class Layer:
 def build_layers(cfg: UNetConfig) -> List[Layer]:
     """Layer sequence of UNet.__init__/forward (reference unet.py:252-323)."""
     ic = cfg.inner_channel
-    sr3 = cfg.variant == 'ddpm'
+    sr3 = cfg.variant in ('ddpm', 'tesr')      # SelfAttention where the resolution is in attn_res
     now_res = cfg.image_size
     layers: List[Layer] = []
     feat_channels = [ic]
@@ -98,7 +99,7 @@ def param_schema(cfg: UNetConfig) -> "OrderedDict[str, Tuple[int, ...]]":
     (reference unet.py:212) because strict load_state_dict needs them."""
     ic = cfg.inner_channel
     sd: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
-    if cfg.variant == 'ddpm':
+    if cfg.variant in ('ddpm', 'tesr'):
         return _param_schema_sr3(cfg)
     sd['noise_level_mlp.1.weight'] = (ic * 4, ic)
     sd['noise_level_mlp.1.bias'] = (ic * 4,)
@@ -147,11 +148,19 @@ def _param_schema_sr3(cfg: UNetConfig):
     per-block `mlp.1` Linear, SelfAttention (norm, qkv, out) where with_attn; no dead `.conv`."""
     ic = cfg.inner_channel
     sd = OrderedDict()
-    sd['time_mlp.0.inv_freq'] = (ic // 2,)
-    sd['time_mlp.1.weight'] = (ic * 4, ic)
-    sd['time_mlp.1.bias'] = (ic * 4,)
-    sd['time_mlp.3.weight'] = (ic, ic * 4)
-    sd['time_mlp.3.bias'] = (ic,)
+    tesr = cfg.variant == 'tesr'     # model/tesr_modules/unet.py: FastDiffSR's noise-level embedding + this block layout
+    if tesr:
+        sd['noise_level_mlp.1.weight'] = (ic * 4, ic)
+        sd['noise_level_mlp.1.bias'] = (ic * 4,)
+        sd['noise_level_mlp.3.weight'] = (ic, ic * 4)
+        sd['noise_level_mlp.3.bias'] = (ic,)
+    else:
+        sd['time_mlp.0.inv_freq'] = (ic // 2,)
+        sd['time_mlp.1.weight'] = (ic * 4, ic)
+        sd['time_mlp.1.bias'] = (ic * 4,)
+        sd['time_mlp.3.weight'] = (ic, ic * 4)
+        sd['time_mlp.3.bias'] = (ic,)
+    nf = 'noise_func.noise_func.0' if tesr else 'mlp.1'
     for L in build_layers(cfg):
         p = L.name
         if L.kind == 'conv_in':
@@ -162,8 +171,8 @@ def _param_schema_sr3(cfg: UNetConfig):
             sd[f'{p}.conv.bias'] = (L.cout,)
         elif L.kind == 'res':
             r = f'{p}.res_block'
-            sd[f'{r}.mlp.1.weight'] = (L.cout, ic)
-            sd[f'{r}.mlp.1.bias'] = (L.cout,)
+            sd[f'{r}.{nf}.weight'] = (L.cout, ic)
+            sd[f'{r}.{nf}.bias'] = (L.cout,)
             sd[f'{r}.block1.block.0.weight'] = (L.cin,)
             sd[f'{r}.block1.block.0.bias'] = (L.cin,)
             sd[f'{r}.block1.block.3.weight'] = (L.cout, L.cin, 3, 3)
@@ -191,7 +200,7 @@ def _param_schema_sr3(cfg: UNetConfig):
 
 def dead_keys(cfg: UNetConfig):
     out = []
-    if cfg.variant == 'ddpm':
+    if cfg.variant in ('ddpm', 'tesr'):
         return out
     for L in build_layers(cfg):
         if L.kind == 'res':
@@ -215,5 +224,9 @@ FASTDIFFSR_UNET = dict(in_channel=6, out_channel=3, inner_channel=64, norm_group
 SR3_UNET = dict(in_channel=6, out_channel=3, inner_channel=64, norm_groups=32, channel_mults=(1, 1, 2, 2, 4, 4),
                 attn_res=(16,), res_blocks=2, dropout=0.2, image_size=256, variant='ddpm')
 SR3_SCHEDULE_VAL = dict(schedule='linear', n_timestep=1000, linear_start=1e-4, linear_end=2e-2)
+# TESR x4 val config (reference config/sr_tesr_test_64_256.json)
+TESR_UNET = dict(in_channel=6, out_channel=3, inner_channel=64, norm_groups=32, channel_mults=(1, 2, 4, 8, 8),
+                 attn_res=(16,), res_blocks=2, dropout=0.2, image_size=256, variant='tesr')
+TESR_SCHEDULE_VAL = dict(schedule='linear', n_timestep=2000, linear_start=1e-6, linear_end=1e-2)
 FASTDIFFSR_SCHEDULE_VAL = dict(schedule='linear_cosine', n_timestep=20,
                                linear_start=1e-6, linear_end=1e-2)

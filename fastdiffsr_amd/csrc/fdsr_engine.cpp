@@ -102,7 +102,9 @@ struct fdsr_engine {
   std::vector<int> gn_channels;   // per GroupNorm slot
   int w_freq = -1;   // synthetic entry: positional-encoding frequencies (SR3: the checkpoint's inv_freq buffer)
   int w_zero_bias = -1;   // synthetic zeros for bias-free 1x1 convs (attn.qkv)
-  bool sr3 = false;
+  bool sr3 = false;          // SR3 sibling (ddpm_modules): integer-time embedding, noise [T+1]
+  bool attn_blocks = false;  // SR3 and TESR siblings: SelfAttention per attn_res + mid[0], no dead .conv, no CLAM/SLAM
+  bool plain_out = false;    // SR3 and TESR: the sampler returns x_0 itself (no res2img)
   size_t param_floats = 0, noise_w_off = 0, noise_b_off = 0;
   int w_mlp[4] = {-1, -1, -1, -1};
   float* d_params = nullptr;
@@ -211,7 +213,10 @@ int build_plan(fdsr_handle h) {
   if (c.out_channel < 1 || c.out_channel > 32) return fail(h, FDSR_E_INVALID, "out_channel must be in [1,32]");
   h->CP = 8;
 
+  if (c.variant < 0 || c.variant > FDSR_VARIANT_TESR) return fail(h, FDSR_E_INVALID, "unknown variant %d", c.variant);
   h->sr3 = c.variant == FDSR_VARIANT_SR3;
+  h->attn_blocks = c.variant != FDSR_VARIANT_FASTDIFFSR;
+  h->plain_out = c.variant != FDSR_VARIANT_FASTDIFFSR;
   const std::string mlp = h->sr3 ? "time_mlp" : "noise_level_mlp";
   if (h->sr3) h->w_freq = add_weight(h, "time_mlp.0.inv_freq", {ic / 2}, true);   // registered buffer, ddpm_modules/unet.py:27
   add_weight(h, mlp + ".1.weight", {ic * 4, ic}, true);
@@ -220,7 +225,7 @@ int build_plan(fdsr_handle h) {
   add_weight(h, mlp + ".3.bias", {ic}, true);
   int now_res = c.image_size;
   auto attn_here = [&]() {
-    if (!h->sr3) return false;
+    if (!h->attn_blocks) return false;
     for (int i = 0; i < c.n_attn_res && i < FDSR_MAX_MULTS; ++i)
       if (c.attn_res[i] == now_res) return true;
     return false;
@@ -288,7 +293,7 @@ int build_plan(fdsr_handle h) {
     } else if (C1) {
       return fail(h, FDSR_E_INVALID, "%s: identity residual over a concatenated input is not supported", p.c_str());
     }
-    if (!h->sr3) {
+    if (!h->attn_blocks) {
       add_weight(h, p + ".conv.weight", {Cout, Cout, 1, 1}, false);   // dead layer, unet.py:212
       add_weight(h, p + ".conv.bias", {Cout}, false);
     }
@@ -321,8 +326,8 @@ int build_plan(fdsr_handle h) {
     k2.dst = out;
     h->ops.push_back(k2);
     int result = out;
-    if (with_attn && h->sr3) {
-      // SelfAttention (ddpm_modules/unet.py:99-127): GN -> qkv 1x1 (no bias) -> softmax(QK^T/sqrt(C)) V -> out 1x1 + x
+    if (with_attn && h->attn_blocks) {
+      // SelfAttention (ddpm_modules/unet.py:99-127; tesr_modules/unet.py:120-149 is the same module): GN -> qkv 1x1 (no bias) -> softmax(QK^T/sqrt(C)) V -> out 1x1 + x
       if (Cout % 32) return fail(h, FDSR_E_INVALID, "SelfAttention needs channels divisible by 32");
       int gw = add_weight(h, p + ".attn.norm.weight", {Cout}, true);
       int gb = add_weight(h, p + ".attn.norm.bias", {Cout}, true);
@@ -985,7 +990,7 @@ int sample_body(fdsr_handle h, const float* cond, const float* noise, float* out
     pp.N = N; pp.HW = H * W; pp.CP = h->CP;
     pp.c_recip = h->s_recip[t]; pp.c_recipm1 = h->s_recipm1[t];
     pp.coef1 = h->s_c1[t]; pp.coef2 = h->s_c2[t]; pp.sigma = h->s_sigma[t];
-    pp.plain_out = h->sr3 ? 1 : 0;                                        // ddpm_modules: ret_img[-1] is x_0 itself
+    pp.plain_out = h->plain_out ? 1 : 0;                                        // ddpm_modules: ret_img[-1] is x_0 itself
     HIPCHK(h, launch_posterior(pp, st));
   }
   h->prof_step = true;
@@ -1260,7 +1265,7 @@ int fdsr_set_precision(fdsr_handle h, int mode) {
     // bf16 mode stores activations as bf16: every conv but the packed-input one must run on the 16-bit
     // kernels, and the attention kernels of the SR3 variant read fp32
     for (const Op& op : h->ops) {
-      if (op.kind == Op::ATTN) return fail(h, FDSR_E_INVALID, "bf16 mode is not available for the SR3 variant (fp32 attention kernels)");
+      if (op.kind == Op::ATTN) return fail(h, FDSR_E_INVALID, "bf16 mode is not available for the SR3 / TESR variants (fp32 attention kernels)");
       if (op.kind == Op::CONV && !h->weights[op.w].h_ok && op.src0 != h->t_in)
         return fail(h, FDSR_E_INVALID, "bf16 mode needs channel counts that are multiples of 16 (layer %s)", op.name.c_str());
     }

@@ -26,7 +26,7 @@ class Engine:
         for i, m in enumerate(cfg.channel_mults):
             c.channel_mults[i] = int(m)
         c.res_blocks, c.dropout, c.image_size = cfg.res_blocks, float(cfg.dropout), int(cfg.image_size)
-        c.variant = 1 if cfg.variant == 'ddpm' else 0
+        c.variant = {'fastdiffsr': 0, 'ddpm': 1, 'tesr': 2}[cfg.variant]
         c.n_attn_res = min(len(cfg.attn_res), _lib.FDSR_MAX_MULTS)
         for i, r in enumerate(cfg.attn_res[:_lib.FDSR_MAX_MULTS]):
             c.attn_res[i] = int(r)

@@ -5,10 +5,12 @@ def define_G(opt):
     which = model_opt['which_model_G']
     if which == 'ddpm':                     # networks.py:84-85: the SR3 sibling
         from .sr3 import diffusion, unet
+    elif which == 'tesr':                   # networks.py:86-87
+        from .tesr import diffusion, unet
     elif which in ('fastdiffsr', 'fastdiffsr_hip'):
         from . import diffusion, unet
     else:
-        raise NotImplementedError(f"fastdiffsr_amd provides which_model_G in ('fastdiffsr', 'ddpm') (got {which!r})")
+        raise NotImplementedError(f"fastdiffsr_amd provides which_model_G in ('fastdiffsr', 'ddpm', 'tesr') (got {which!r})")
     if ('norm_groups' not in model_opt['unet']) or model_opt['unet']['norm_groups'] is None:
         model_opt['unet']['norm_groups'] = 32
     u = model_opt['unet']

@@ -61,12 +61,13 @@ typedef struct fdsr_config {
   float dropout;         /* 0.2; identity in eval (sampling) mode          */
   int32_t image_size;    /* FastDiffSR: informational.  SR3 variant: attention is placed where the
                             resolution (image_size halved per level) is in attn_res (ddpm_modules/unet.py:183) */
-  int32_t variant;       /* FDSR_VARIANT_FASTDIFFSR (model/fastdiffsr_modules) or FDSR_VARIANT_SR3 (model/ddpm_modules) */
+  int32_t variant;       /* FDSR_VARIANT_FASTDIFFSR (model/fastdiffsr_modules), _SR3 (model/ddpm_modules) or _TESR (model/tesr_modules) */
   int32_t n_attn_res;
   int32_t attn_res[FDSR_MAX_MULTS];
 } fdsr_config;
 #define FDSR_VARIANT_FASTDIFFSR 0
 #define FDSR_VARIANT_SR3 1
+#define FDSR_VARIANT_TESR 2  /* model/tesr_modules: FastDiffSR's blocks and noise-level embedding, SR3's SelfAttention placement, sampler returns x_0 */
 
 /* Per-timestep scalars the reverse process reads (diffusion.py:109-155; only
  * these five buffers + the fp64 sqrt_alphas_cumprod_prev list are used by

@@ -39,6 +39,12 @@ def import_reference():
     sys.modules.setdefault('torchvision', tv)
     sys.modules.setdefault('torchvision.models', tvm)
     sys.modules.setdefault('thop', thop)
+    # tesr_modules/unet.py:9 imports three timm helpers for its (unused) SwinIR classes; timm is not in this image
+    timm, tm, tml = (types.ModuleType(n) for n in ('timm', 'timm.models', 'timm.models.layers'))
+    tml.DropPath = tml.to_2tuple = tml.trunc_normal_ = None
+    timm.models, tm.layers = tm, tml
+    for name, mod in (('timm', timm), ('timm.models', tm), ('timm.models.layers', tml)):
+        sys.modules.setdefault(name, mod)
     sys.path.insert(0, REF)
     from model.fastdiffsr_modules import diffusion, unet
     return diffusion, unet
@@ -337,6 +343,57 @@ def train_goldens():
     print('wrote train_step.npz: l_pix', l_pix.item(), 'tensors with grad', len(names), 'without', int(out['n_params_without_grad']))
 
 
+def tesr_goldens():
+    """(xi) TESR sibling (model/tesr_modules): UNet forwards incl. the SelfAttention levels, the sampler
+    (continous=True frames and the final image) and the Charbonnier training-loss value, from the reference itself."""
+    from unittest import mock
+    import_reference()
+    from model.tesr_modules import diffusion as tdiff, unet as tunet
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    cfg = UNetConfig(in_channel=6, out_channel=3, inner_channel=32, norm_groups=32, channel_mults=(1, 2, 2, 4),
+                     attn_res=(8,), res_blocks=1, dropout=0.2, image_size=32, variant='tesr')
+    net = tunet.UNet(in_channel=6, out_channel=3, norm_groups=32, inner_channel=32, channel_mults=[1, 2, 2, 4],
+                     attn_res=[8], res_blocks=1, dropout=0.2, image_size=32)
+    sd = synth_state_dict(cfg, 9)
+    assert list(net.state_dict().keys()) == list(sd.keys()), 'TESR schema order mismatch'
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    sched = dict(schedule='linear', n_timestep=10, linear_start=1e-4, linear_end=2e-2)
+    G = tdiff.GaussianDiffusion(net, image_size=32, channels=3, loss_type='l1', conditional=True, schedule_opt=sched)
+    G.set_loss('cpu')
+    G.set_new_noise_schedule(sched, 'cpu')
+    G.eval()
+    g = torch.Generator().manual_seed(61)
+    x = torch.randn(2, 6, 32, 32, generator=g)
+    out = {'weights_sha256': np.array(state_dict_sha256(sd)), 'x': x.numpy()}
+    with torch.no_grad():
+        for i, nl in enumerate((0.5, 6.6e-7, 0.99)):
+            out[f'eps/{i}'] = net(x, torch.full((2, 1), nl)).numpy()
+            out[f'nl/{i}'] = np.array(nl, dtype=np.float32)
+    out['sqrt_alphas_cumprod_prev'] = np.asarray(G.sqrt_alphas_cumprod_prev, dtype=np.float64)
+    cond, noise = synth_inputs(1, 32, 32, 10, cond_seed=71, noise_seed=72)
+    draws = iter([noise[k] for k in range(10)])
+    with torch.no_grad(), mock.patch.object(torch, 'randn', lambda *a, **k: next(draws)), \
+            mock.patch.object(torch, 'randn_like', lambda *a, **k: next(draws)):
+        frames = G.super_resolution(cond, continous=True)
+    out['cond'] = cond.numpy()
+    out['noise'] = noise.numpy()
+    out['frames'] = frames.numpy()              # [1 + kept steps, 3, 32, 32]: x_in, then x_t for t % inter == 0
+    hr = torch.rand(2, 3, 32, 32, generator=g) * 2 - 1
+    sr = (hr + 0.2 * torch.randn(2, 3, 32, 32, generator=g)).clamp(-1, 1)
+    nz = torch.randn(2, 3, 32, 32, generator=g)
+    t_fixed = 4
+    lo, hi = G.sqrt_alphas_cumprod_prev[t_fixed - 1], G.sqrt_alphas_cumprod_prev[t_fixed]
+    gam = np.array([lo + 0.25 * (hi - lo), lo + 0.75 * (hi - lo)])
+    with torch.no_grad(), mock.patch.object(np.random, 'randint', lambda a, b: t_fixed), \
+            mock.patch.object(np.random, 'uniform', lambda a, b, size: gam):
+        loss = G({'HR': hr, 'SR': sr}, noise=nz)
+    out.update(hr=hr.numpy(), sr=sr.numpy(), loss_noise=nz.numpy(), gamma=gam.astype(np.float64),
+               loss=np.array(loss.item(), dtype=np.float64))
+    np.savez_compressed(os.path.join(OUT, 'tesr.npz'), **out)
+    print('wrote tesr.npz: frames', frames.shape, 'loss', loss.item())
+
+
 def config_goldens():
     """(ix) the reference's own option parser (core/logger.py:21-94) on its ten fastdiffsr / ddpm configs:
     what `parse` returns, minus the timestamped `path` subtree.  Pins fastdiffsr_amd.config.load_config."""
@@ -380,7 +437,10 @@ if __name__ == '__main__':
         config_goldens()          # only tests/golden/configs.json
     elif len(sys.argv) > 1 and sys.argv[1] == 'train':
         train_goldens()           # only tests/golden/train_step.npz (reads train_loss.npz)
+    elif len(sys.argv) > 1 and sys.argv[1] == 'tesr':
+        tesr_goldens()            # only tests/golden/tesr.npz
     else:
         main()
         config_goldens()
         train_goldens()
+        tesr_goldens()

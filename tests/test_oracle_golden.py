@@ -252,3 +252,38 @@ def test_training_step_matches_reference(full, golden_dir):
     for k in sd:
         if k not in grads:
             assert torch.equal(new_sd[k], sd[k])
+
+
+def test_tesr_oracle_matches_reference(golden_dir):
+    """oracle/tesr_oracle.py vs the reference's own model/tesr_modules (tests/golden/tesr.npz)."""
+    from oracle import tesr_oracle as TO
+    g = _load(golden_dir, 'tesr.npz')
+    cfg = UNetConfig(in_channel=6, out_channel=3, inner_channel=32, norm_groups=32, channel_mults=(1, 2, 2, 4),
+                     attn_res=(8,), res_blocks=1, dropout=0.2, image_size=32, variant='tesr')
+    sd_np = synth_state_dict(cfg, 9)
+    assert state_dict_sha256(sd_np) == str(g['weights_sha256'])
+    assert not any(k.endswith('.conv.weight') and '.res_block' not in k and k.split('.')[0] != 'final_conv' and
+                   'downs' in k and sd_np[k].shape[-1] == 1 for k in sd_np)          # no dead 1x1 convs in this variant
+    sd = O.to_torch_sd(sd_np)
+    x = torch.from_numpy(g['x'])
+    with torch.no_grad():
+        for i in range(3):
+            out = TO.unet_forward(sd, cfg, x, torch.full((2, 1), float(g[f'nl/{i}'])))
+            assert np.abs(out.numpy() - g[f'eps/{i}']).max() <= 2e-5
+    sched = dict(schedule='linear', n_timestep=10, linear_start=1e-4, linear_end=2e-2)
+    tab = O.schedule_tables(sched)
+    np.testing.assert_allclose(tab['sqrt_alphas_cumprod_prev_f64'], g['sqrt_alphas_cumprod_prev'], rtol=0, atol=0)
+    cond, noise = torch.from_numpy(g['cond']), torch.from_numpy(g['noise'])
+    img, traj = TO.p_sample_loop(sd, cfg, tab, cond, noise, return_trajectory=True)
+    frames = g['frames']                                           # x_in, then every x_t (inter = 1 at T = 10)
+    assert frames.shape[0] == 11 and np.array_equal(frames[0], cond[0].numpy())
+    for k in range(10):
+        assert np.abs(traj[k][0].numpy() - frames[k + 1]).max() <= 5e-5, k
+    assert np.abs(img[0].numpy() - frames[-1]).max() <= 5e-5
+    hr, sr, nz = (torch.from_numpy(g[k]) for k in ('hr', 'sr', 'loss_noise'))
+    gamma = torch.FloatTensor(g['gamma']).view(-1, 1)
+    with torch.no_grad():
+        x_noisy = O.q_sample(hr, gamma.view(-1, 1, 1, 1), nz)       # x_start is the image itself (diffusion.py:225)
+        rec = TO.unet_forward(sd, cfg, torch.cat([sr, x_noisy], 1), gamma)
+        loss = TO.charbonnier(nz, rec)
+    assert abs(loss.item() - float(g['loss'])) <= 1e-5 * abs(float(g['loss']))
