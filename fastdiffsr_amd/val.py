@@ -68,11 +68,16 @@ def run(opt, batch=1, cond_from_lr=False, precision='f16x3', results=None, max_i
         torch.cuda.synchronize()
         t_sample += time.time() - t0
         logger.info('inference time (s): {:.4f} for {} image(s)'.format(time.time() - t0, len(idxs)))   # sr_mfe.py:279-284
+        sr_batch = diffusion.SR
+        if sr_batch.dim() == 3:       # the ddpm / tesr siblings return ret_img[-1]: one image (their own convention)
+            if len(idxs) != 1:
+                raise ValueError("which_model_G in ('ddpm', 'tesr') returns one image per call: use --batch 1")
+            sr_batch = sr_batch[None]
         for j, index in enumerate(idxs):
             idx = index + 1                                                           # sr_mfe.py:274 counts from 1
             hr_img = M.tensor2img(diffusion.data['HR'][j])
             fake_img = M.tensor2img(diffusion.data['SR'][j])                          # the bicubic image ('INF')
-            sr_img = M.tensor2img(diffusion.SR[j])
+            sr_img = M.tensor2img(sr_batch[j])
             if save_images:
                 from PIL import Image
                 Image.fromarray(sr_img).save('{}/{}_{}_sr.{}'.format(result_path, current_step, idx, 'png' if infer else 'tif'))
