@@ -84,3 +84,26 @@ def _config_plain(root):
 def _load(cpath):
     from fastdiffsr_amd.config import load_config
     return load_config(str(cpath), phase='val')
+
+
+def test_val_cli_with_tesr_sibling(tmp_path):
+    """The same driver over `which_model_G == 'tesr'` (one image per call: the sibling's own return convention)."""
+    from fastdiffsr_amd import val
+    from test_val_host import make_dataset
+    root = make_dataset(str(tmp_path / 'data'), n=2, l=16, r=64, seed=5)
+    cfg = _config_plain(root)
+    cfg['name'] = 'sr_tesr_test'
+    for ph in ('train', 'val'):
+        cfg['datasets'][ph].update(l_resolution=16, r_resolution=64)
+    sched = dict(schedule='linear', n_timestep=8, linear_start=1e-4, linear_end=2e-2)
+    cfg['model'].update(which_model_G='tesr', beta_schedule={'train': dict(sched), 'val': dict(sched)})
+    cfg['model']['unet'].update(inner_channel=32, channel_multiplier=[1, 2, 2], attn_res=[16], res_blocks=1)
+    cfg['model']['diffusion']['image_size'] = 64
+    cpath = tmp_path / 'tesr.json'
+    cpath.write_text(json.dumps(cfg))
+    lines = []
+    r = val.run(_load(cpath), batch=1, results=str(tmp_path / 'o'), log=lines.append)
+    assert r['images'] == 2 and sorted(os.listdir(tmp_path / 'o')) == ['0_1_sr.tif', '0_2_sr.tif']
+    assert np.isfinite(r['sr_psnr']) and len(lines) == 2
+    with pytest.raises(ValueError, match='--batch 1'):
+        val.run(_load(cpath), batch=2, results=str(tmp_path / 'o2'), log=lines.append)
