@@ -462,8 +462,8 @@ void conv_h_config(ConvKind kind, int Cout, int* TH, int* WN) {
 }
 
 // Rows per workgroup tile, chosen per launch: the largest tile (<= 4 accumulator tiles per wave) that
-// still gives every CU two workgroups' worth of work; small feature maps fall back to smaller tiles so
-// that all 256 CUs are used.
+// still gives every CU a workgroup (measured: a threshold of 256 workgroups beats 512 by 3-4 % at batch
+// 1-4 and is neutral at 16-64; 128 loses); smaller feature maps fall back to the smallest tile and split K.
 static int pick_th(ConvKind kind, int WN, int ksub, const ConvParams& p) {
   if (kind == CONV3_S2) return 4;
   const int WM = 8 / WN;
@@ -475,7 +475,8 @@ static int pick_th(ConvKind kind, int WN, int ksub, const ConvParams& p) {
     if (ksub > 1 && th > 8) continue;          // LDS: 64-channel rows
     const long wgs = (long)p.N * tilesX * ((p.Hout + th - 1) / th) * nco;
     best = th;
-    if (wgs >= 512) break;
+    static const long min_wgs = getenv("FDSR_TH_MIN_WGS") ? atol(getenv("FDSR_TH_MIN_WGS")) : 256;   // one workgroup per CU
+    if (wgs >= min_wgs) break;
   }
   return best;
 }
