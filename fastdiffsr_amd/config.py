@@ -23,6 +23,22 @@ def parse_json_with_comments(text):
     return json.loads(''.join(lines), object_pairs_hook=OrderedDict)
 
 
+# what `-debug` rewrites (core/logger.py:59-68): validate every 2 iterations, checkpoint every 3, batch 2,
+# T = 10 for both schedules, 6 training / 3 validation images
+_DEBUG_OVERRIDES = (
+    (('train', 'val_freq'), 2), (('train', 'print_freq'), 2), (('train', 'save_checkpoint_freq'), 3),
+    (('datasets', 'train', 'batch_size'), 2),
+    (('model', 'beta_schedule', 'train', 'n_timestep'), 10), (('model', 'beta_schedule', 'val', 'n_timestep'), 10),
+    (('datasets', 'train', 'data_len'), 6), (('datasets', 'val', 'data_len'), 3),
+)
+
+
+def _assign(tree, path_, value):
+    for key in path_[:-1]:
+        tree = tree[key]
+    tree[path_[-1]] = value
+
+
 def load_config(path, phase='val', gpu_ids=None, debug=False, enable_wandb=False, log_wandb_ckpt=False,
                 log_eval=False, log_infer=False, timestamp=None):
     """`core.logger.parse(args)` (logger.py:21-94) without its side effects: the experiment directories are
@@ -49,17 +65,11 @@ def load_config(path, phase='val', gpu_ids=None, debug=False, enable_wandb=False
     else:
         gpu_list = ','.join(str(x) for x in opt['gpu_ids'])
     opt['distributed'] = len(gpu_list) > 1
-    if 'debug' in opt['name']:
-        opt['train']['val_freq'] = 2
-        opt['train']['print_freq'] = 2
-        opt['train']['save_checkpoint_freq'] = 3
-        opt['datasets']['train']['batch_size'] = 2
-        opt['model']['beta_schedule']['train']['n_timestep'] = 10
-        opt['model']['beta_schedule']['val']['n_timestep'] = 10
-        opt['datasets']['train']['data_len'] = 6
-        opt['datasets']['val']['data_len'] = 3
-    if phase == 'train':
-        opt['datasets']['val']['data_len'] = 13
+    if 'debug' in opt['name']:                       # logger.py:59-68: the -debug shrink, as a table
+        for path_, value in _DEBUG_OVERRIDES:
+            _assign(opt, path_, value)
+    if phase == 'train':                             # logger.py:71-72
+        _assign(opt, ('datasets', 'val', 'data_len'), 13)
     opt['log_wandb_ckpt'] = log_wandb_ckpt
     opt['log_eval'] = log_eval
     opt['log_infer'] = log_infer
