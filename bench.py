@@ -50,11 +50,22 @@ def host_cores():
     return n
 
 
-def cpu_baseline(cfg, sd, budget_s=20.0):
-    """The oracle (CPU restatement of the reference loop) timed on the host cores, on a BOUNDED
-    sample: the first k reverse steps (t = 19, 18, ...) of ONE 256x256 image, as many as fit in
-    ~budget_s after one warm-up UNet forward; images/s = 1 / (20 * mean step time).  Every step
-    costs the same (one UNet forward + the posterior update).  Reported baseline only."""
+def cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except Exception:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(cfg, sd, budget_s=24.0):
+    """The oracle (CPU restatement of the reference loop) timed on the host cores, on a BOUNDED sample
+    (BASELINE.md section 3): after one warm-up UNet forward, full 20-step loops of 256x256 images at B=1 -- two
+    images, or as many reverse steps as fit in ~budget_s (every step costs the same: one UNet forward + the
+    posterior update) -- then ONE B=4 UNet forward (the reference gains nothing from batching on CPU).
+    images/s = 1 / (20 * mean step time).  Reported baseline only."""
     from oracle import fdsr_oracle as O
     from fastdiffsr_amd.arch import FASTDIFFSR_SCHEDULE_VAL
     from fastdiffsr_amd.synth import synth_inputs
@@ -63,21 +74,38 @@ def cpu_baseline(cfg, sd, budget_s=20.0):
     torch.set_num_threads(threads)
     tsd = O.to_torch_sd(sd)
     tab = O.schedule_tables(FASTDIFFSR_SCHEDULE_VAL)
-    cond, noise = synth_inputs(1, 256, 256, 20)
+    cond, noise = synth_inputs(2, 256, 256, 20)
+    first = None
     with torch.no_grad():
-        O.unet_forward(tsd, cfg, torch.cat([cond, noise[0]], 1), torch.full((1, 1), 0.5))   # warm-up
-        img, k, t0 = noise[0], 0, time.perf_counter()
-        for t in reversed(range(20)):
-            img = O.p_sample(tsd, cfg, tab, img, t, cond, noise[k + 1] if t > 0 else None)
-            k += 1
+        O.unet_forward(tsd, cfg, torch.cat([cond[:1], noise[0, :1]], 1), torch.full((1, 1), 0.5))   # warm-up
+        steps, t0 = 0, time.perf_counter()
+        for i in range(2):
+            c, nz = cond[i:i + 1], noise[:, i:i + 1]
+            img, k = nz[0], 0
+            for t in reversed(range(20)):
+                img = O.p_sample(tsd, cfg, tab, img, t, c, nz[k + 1] if t > 0 else None)
+                k += 1
+                steps += 1
+                if time.perf_counter() - t0 > budget_s:
+                    break
+            if first is None:
+                first = {'cond': c, 'noise': nz, 'k': k, 'x_k': img}
             if time.perf_counter() - t0 > budget_s:
                 break
         dt = time.perf_counter() - t0
-    step = dt / k
-    res = {'value': 1.0 / (20 * step), 'unit': 'images/s', 'cores': threads, 'kind': 'port',
-           'sample': f'{k} of 20 reverse steps of 1 image, 256x256, fp32, PyTorch-CPU restatement (oracle/), '
-                     f'{dt:.1f} s after 1 warm-up forward, {threads} threads (host reports {cores} usable)'}
-    return res, {'cond': cond, 'noise': noise, 'k': k, 'x_k': img}
+        x4 = torch.cat([cond[:1].expand(4, -1, -1, -1), noise[0, :1].expand(4, -1, -1, -1)], 1).contiguous()
+        t1 = time.perf_counter()
+        O.unet_forward(tsd, cfg, x4, torch.full((4, 1), 0.5))
+        dt4 = time.perf_counter() - t1
+    step = dt / steps
+    ips = 1.0 / (20 * step)
+    res = {'value': ips, 'unit': 'images/s', 'cores': threads, 'kind': 'port',
+           'sample': f'{steps} reverse steps ({steps / 20:.2f} images, B=1, full 20-step loops) of 256x256 fp32, PyTorch-CPU '
+                     f'restatement (oracle/), {dt:.1f} s after 1 warm-up forward; then one B=4 UNet forward ({dt4:.2f} s); '
+                     f'{threads} threads (host reports {cores} usable)',
+           'cpu_model': cpu_model(), 'seconds_per_image': 20 * step, 'gflops': FLOPS_PER_IMAGE / 1e9 / (20 * step),
+           'b4_forward_seconds': dt4, 'b4_forward_gflops': 4 * FLOPS_PER_IMAGE / 20 / 1e9 / dt4}
+    return res, first
 
 
 def parity_check(eng, dev, ref):
@@ -124,6 +152,119 @@ class _StdoutToStderr:
         return False
 
 
+def kernel_source_hash():
+    """SHA-256 of the kernel sources: a PMC traffic file under profiles/ is only quoted while it matches."""
+    import hashlib
+    d = os.path.join(ROOT, 'fastdiffsr_amd', 'csrc')
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.endswith(('.hip', '.h')):
+            h.update(f.encode() + b'\0' + open(os.path.join(d, f), 'rb').read() + b'\0')
+    return h.hexdigest()
+
+
+def conv_roofline(prof, precision, B, S, dt_total, round_tag='r02'):
+    """Roofline of the dominant kernel family = every 3x3 convolution launch (implicit-GEMM MFMA kernels incl. the
+    sub-pixel upsample form and the 6-channel input conv): algorithmic FLOPs / HIP-event time around those launches."""
+    ach = prof['conv_flops'] / (prof['conv_ms'] * 1e-3) / 1e12
+    peak = PEAK_F32_MFMA if precision == 'f32' else PEAK_16BIT_MFMA
+    passes = 3 if precision == 'f16x3' else 1     # MFMA products issued per algorithmic product
+    kern = 'conv_mfma_f32_kernel' if precision == 'f32' else 'conv_mfma_h_kernel'
+    # HBM bytes per launch of the SAME launch set (3x3 family), from rocprofv3 --pmc passes of this command kept
+    # under profiles/ (separate FETCH_SIZE / WRITE_SIZE runs, gfx950 x2 read correction: tools/pmc_traffic.py).
+    # Quoted only while the file was measured on these very kernel sources; otherwise null.
+    traffic, traffic_src = None, None
+    tf = os.path.join(ROOT, 'profiles', f'{round_tag}_pmc_hbm_traffic_{precision}_b{B}.json')
+    if S == 256 and os.path.exists(tf):
+        try:
+            t = json.load(open(tf))
+            if t.get('kernel_source_hash') == kernel_source_hash():
+                traffic = t['family_3x3']['hbm_bytes_per_launch']
+                traffic_src = os.path.relpath(tf, ROOT)
+        except Exception:
+            traffic = None
+    n_timed = len(range(0, 20, 4))
+    r = {'bound': 'mfma', 'kernel': f'{kern} (3x3 implicit-GEMM family)',
+         'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
+         'traffic': traffic, 'traffic_unit': 'bytes/launch (PMC)', 'traffic_source': traffic_src,
+         'algorithmic_bytes_per_launch': prof['conv_bytes'] / max(prof['launches'], 1),
+         'launches': prof['launches'],
+         'avg_launch_ms': prof['conv_ms'] / max(prof['launches'], 1),
+         'mfma_passes_per_product': passes, 'executed_tflops': ach * passes,
+         'frac_executed': ach * passes / peak,
+         'algorithmic_gbytes_per_s': prof['conv_bytes'] / (prof['conv_ms'] * 1e-3) / 1e9,
+         # the engine brackets the conv launches of every 4th diffusion step with HIP
+         # events (5 of 20 steps): <1 % overhead in the timed region, measured 2.6 % with all
+         'timed_steps_of_20': n_timed}
+    if dt_total:
+        r['conv_time_share'] = prof['conv_ms'] * 1e-3 * (20 / n_timed) / dt_total
+    return r
+
+
+def whole_path(ips_per_gpu, precision):
+    """the whole path against both roofs, per GPU (ideal-fused traffic 32.85 GB / image fp32, 16.4 bf16)."""
+    gb = 16.4 if precision == 'bf16' else 32.85
+    return {'tflops': ips_per_gpu * FLOPS_PER_IMAGE / 1e12,
+            'frac_mfma_peak': ips_per_gpu * FLOPS_PER_IMAGE / 1e12 / (PEAK_F32_MFMA if precision == 'f32' else PEAK_16BIT_MFMA),
+            'ideal_fused_gbytes_per_s': ips_per_gpu * gb, 'frac_hbm_peak': ips_per_gpu * gb / 8000.0}
+
+
+def run_config(eng, dev, precision, B, S, steps, warmup, graph, noise_mode, rank=0, sync=None, want_profile=True):
+    """Time `steps` passes of the hot path for one configuration.  Returns (seconds, out tensor, profile or None).
+    With graph=True the timed region replays the captured loop; the per-launch roofline then comes from ONE extra
+    eager pass after the timed region (HIP events cannot bracket launches inside a graph replay)."""
+    from fastdiffsr_amd.synth import synth_inputs
+    eng.set_precision(precision)
+    if noise_mode == 'tensor':
+        cond, noise = synth_inputs(B, S, S, 20, cond_seed=1234 + rank, noise_seed=4321 + rank)
+        cond, noise = cond.to(dev), noise.to(dev)
+    else:   # the engine draws x_T and the 19 per-step planes inside the timed loop (seed per rank)
+        cond, _ = synth_inputs(B, S, S, 1, cond_seed=1234 + rank)
+        cond, noise = cond.to(dev), None
+        eng.set_seed(4321 + rank)
+    out = torch.empty(B, 3, S, S, device=dev)
+    if sync is None:
+        def sync():
+            torch.cuda.synchronize(dev)
+    for _ in range(warmup):
+        eng.sample(cond, noise, out=out, graph=graph)
+    sync()
+    profile = want_profile and not graph
+    if profile:
+        eng.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.sample(cond, noise, out=out, graph=graph)
+    sync()
+    dt = time.perf_counter() - t0
+    prof = eng.profile_end() if profile else None
+    prof_dt = dt
+    if want_profile and graph:
+        eng.profile_begin()
+        eng.sample(cond, noise, out=out, graph=False)
+        torch.cuda.synchronize(dev)
+        prof = eng.profile_end()
+        prof_dt = None
+    assert torch.isfinite(out).all()
+    return dt, out, prof, prof_dt
+
+
+def sub_record(eng, dev, name, precision, B, S, steps, warmup, graph, note):
+    try:
+        dt, _, prof, prof_dt = run_config(eng, dev, precision, B, S, steps, warmup, graph, 'engine')
+        ips = B * steps / dt
+        r = {'value': ips, 'unit': 'images/s', 'ms_per_step': 1e3 * dt / steps, 'steps': steps, 'warmup': warmup,
+             'dtype': precision, 'batch': B, 'hipgraph': bool(graph), 'workload': note,
+             'whole_path': whole_path(ips, precision)}
+        if prof and prof['conv_ms'] > 0:
+            r['roofline'] = conv_roofline(prof, precision, B, S, prof_dt)
+            if prof_dt is None:
+                r['roofline']['measured_in'] = 'one eager pass after the timed graph replays'
+        return r
+    except Exception as e:      # a sub-record must never take the headline line down
+        return {'error': f'{type(e).__name__}: {e}'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -132,6 +273,8 @@ def main():
     ap.add_argument('--batch', type=int, default=16, help='images per GPU per step')
     ap.add_argument('--size', type=int, default=256)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-sub-records', action='store_true',
+                    help='skip the exact_f32 / bf16_b64_graph / b1_graph legs that ride in the same JSON line at N=1')
     ap.add_argument('--no-profile', action='store_true', help='skip the per-conv HIP-event timing')
     ap.add_argument('--precision', default='f16x3', choices=['f32', 'f16x3', 'bf16'],
                     help='conv arithmetic: exact fp32 MFMA, fp32-grade split-f16 MFMA, or bf16')
@@ -153,14 +296,15 @@ def main():
     from fastdiffsr_amd.arch import UNetConfig, FASTDIFFSR_UNET, FASTDIFFSR_SCHEDULE_VAL
     from fastdiffsr_amd.engine import Engine
     from fastdiffsr_amd.schedule import schedule_buffers, sampling_scalars
-    from fastdiffsr_amd.synth import synth_state_dict, synth_inputs
-    from fastdiffsr_amd import parallel
+    from fastdiffsr_amd.synth import synth_state_dict, state_dict_sha256
+    from fastdiffsr_amd import parallel, _lib
 
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     cfg = UNetConfig(**FASTDIFFSR_UNET)
     # weights: rank 0 builds the random-init UNet, ONE RCCL broadcast replicates it
     sd = synth_state_dict(cfg, 0) if rank == 0 else None
+    weights_sha_rank0 = state_dict_sha256(sd) if rank == 0 else None
     if distributed:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         with _StdoutToStderr():
@@ -172,18 +316,8 @@ def main():
     eng.load_state_dict(sd)
     bufs, sp = schedule_buffers(FASTDIFFSR_SCHEDULE_VAL)
     eng.set_schedule(sampling_scalars(bufs, sp))
-    eng.set_precision(args.precision)
 
     B, S = args.batch, args.size
-    # independent per-GPU batch (weak scaling): rank r samples its own B images
-    if args.noise == 'tensor':
-        cond, noise = synth_inputs(B, S, S, 20, cond_seed=1234 + rank, noise_seed=4321 + rank)
-        cond, noise = cond.to(dev), noise.to(dev)
-    else:   # the engine draws x_T and the 19 per-step planes inside the timed loop (seed per rank)
-        cond, _ = synth_inputs(B, S, S, 1, cond_seed=1234 + rank)
-        cond, noise = cond.to(dev), None
-        eng.set_seed(4321 + rank)
-    out = torch.empty(B, 3, S, S, device=dev)
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -191,26 +325,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        eng.sample(cond, noise, out=out, graph=args.graph)
-    sync()
-    profile = (not args.no_profile) and not args.graph
-    if profile:
-        eng.profile_begin()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        eng.sample(cond, noise, out=out, graph=args.graph)
-    sync()
-    dt = time.perf_counter() - t0
-    prof = eng.profile_end() if profile else None
+    # independent per-GPU batch (weak scaling): rank r samples its own B images
+    dt, out, prof, _ = run_config(eng, dev, args.precision, B, S, args.steps, args.warmup, args.graph, args.noise,
+                                  rank=rank, sync=sync, want_profile=not args.no_profile)
     if distributed:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    assert torch.isfinite(out).all()
 
     if rank == 0:
         ips = world * B * args.steps / dt
+        version = _lib.load().fdsr_version().decode()
         res = {
             'metric': '256x256 SR images/sec at T=20', 'value': ips, 'unit': 'images/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
@@ -221,41 +346,28 @@ def main():
                                                   else 'pre-drawn tensor in HBM'), 'hipgraph': bool(args.graph),
                        'parallelism': f'dp{world} (independent batches, weights broadcast once)'},
             'whole_path_tflops': ips / world * FLOPS_PER_IMAGE / 1e12,
-            # the whole path against both roofs, per GPU (ideal-fused fp32 traffic 32.85 GB / image)
-            'whole_path': {'frac_mfma_peak': ips / world * FLOPS_PER_IMAGE / 1e12 / (PEAK_F32_MFMA if args.precision == 'f32' else PEAK_16BIT_MFMA),
-                           'ideal_fused_gbytes_per_s': ips / world * 32.85,
-                           'frac_hbm_peak': ips / world * 32.85 / 8000.0},
+            'whole_path': whole_path(ips / world, args.precision),
+            'library': {'version': version.split(' FDSR_SRC_SHA256=')[0], 'source_sha256': version.rsplit('=', 1)[-1]},
         }
+        if distributed:   # every rank loaded what rank 0 broadcast: its hash is checked against rank 0's own arrays
+            res['weights'] = {'sha256_rank0_source': weights_sha_rank0, 'sha256_after_broadcast': state_dict_sha256(sd),
+                              'broadcast_bytes': int(sum(np.asarray(v).nbytes for v in sd.values()))}
         if prof and prof['conv_ms'] > 0:
-            ach = prof['conv_flops'] / (prof['conv_ms'] * 1e-3) / 1e12
-            peak = PEAK_F32_MFMA if args.precision == 'f32' else PEAK_16BIT_MFMA
-            passes = 3 if args.precision == 'f16x3' else 1     # MFMA products issued per algorithmic product
-            kern = 'conv_mfma_f32_kernel' if args.precision == 'f32' else 'conv_mfma_h_kernel'
-            # HBM bytes per launch from the committed rocprofv3 --pmc passes of THIS command (separate
-            # FETCH_SIZE / WRITE_SIZE runs, gfx950 x2 read correction: tools/pmc_traffic.py); includes the
-            # 1x1 launches of the same kernel family.  null for configurations that were not profiled.
-            traffic = None
-            tf = os.path.join(ROOT, 'profiles', f'r01_pmc_hbm_traffic_{args.precision}_b{B}.json')
-            if S == 256 and os.path.exists(tf):
-                try:
-                    traffic = json.load(open(tf))[kern]['hbm_bytes_per_launch']
-                except Exception:
-                    traffic = None
-            res['roofline'] = {'bound': 'mfma', 'kernel': f'{kern} (3x3 implicit-GEMM family)',
-                               'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
-                               'traffic': traffic, 'traffic_unit': 'bytes/launch (PMC, profiles/)',
-                               'algorithmic_bytes_per_launch': prof['conv_bytes'] / max(prof['launches'], 1),
-                               'launches': prof['launches'],
-                               'avg_launch_ms': prof['conv_ms'] / max(prof['launches'], 1),
-                               'mfma_passes_per_product': passes, 'executed_tflops': ach * passes,
-                               'frac_executed': ach * passes / peak,
-                               'algorithmic_gbytes_per_s': prof['conv_bytes'] / (prof['conv_ms'] * 1e-3) / 1e9,
-                               # the engine brackets the conv launches of every 4th diffusion step with HIP
-                               # events (5 of 20 steps): <1 % overhead in the timed region, measured 2.6 % with all
-                               'timed_steps_of_20': len(range(0, 20, 4)),
-                               'conv_time_share': prof['conv_ms'] * 1e-3 * (20 / len(range(0, 20, 4))) / dt}
+            res['roofline'] = conv_roofline(prof, args.precision, B, S, dt)
+        if world == 1 and not distributed and not args.no_sub_records:
+            # the other arithmetic modes and batch regimes of BASELINE.json, driver-visible in the same line
+            res['sub_records'] = {
+                'exact_f32': sub_record(eng, dev, 'exact_f32', 'f32', 16, S, 2, 1, False,
+                                        'configs[1] in exact fp32 MFMA arithmetic (v_mfma_f32_32x32x2_f32), B=16'),
+                'bf16_b64_graph': sub_record(eng, dev, 'bf16_b64_graph', 'bf16', 64, S, 2, 1, True,
+                                             'configs[2]: B=64, bf16 activations + bf16 MFMA, 20-step loop replayed as a hipGraph'),
+                'b1_graph': sub_record(eng, dev, 'b1_graph', 'f16x3', 1, S, 10, 2, True,
+                                       'configs[0] regime (the reference val loop is B=1, sr_mfe.py:279-284): latency per image, hipGraph'),
+            }
+            eng.set_precision(args.precision)
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'], ref = cpu_baseline(cfg, sd)
+            eng.set_precision(args.precision)
             res['parity_check'] = parity_check(eng, dev, ref)
         print(json.dumps(res), flush=True)
     if distributed:

@@ -21,31 +21,86 @@ def _hipcc():
     return 'hipcc'
 
 
+STAMP_MARK = b'FDSR_SRC_SHA256='
+
+
+def source_hash():
+    """SHA-256 over every file the library is built from (csrc/*.hip|cpp|h, include/fdsr.h) and the compile
+    flags.  build() compiles it into the library (fdsr_version() ends with it), so a binary can be matched to
+    the tree it came from -- the gitignored .so travels with the snapshot to the GPU box."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(f for f in os.listdir(CSRC) if f.endswith(('.hip', '.cpp', '.h')))
+    paths = [os.path.join(CSRC, f) for f in files] + [os.path.normpath(os.path.join(CSRC, '..', '..', 'include', 'fdsr.h'))]
+    for pth in paths:
+        h.update(os.path.basename(pth).encode() + b'\0')
+        h.update(open(pth, 'rb').read())
+        h.update(b'\0')
+    h.update(repr((SOURCES, COMMON)).encode())
+    return h.hexdigest()
+
+
+def library_stamp(lib=None):
+    """The source hash compiled into an existing library, read from the file (no dlopen); None if absent."""
+    lib = lib or LIB
+    if not os.path.exists(lib):
+        return None
+    blob = open(lib, 'rb').read()
+    i = blob.find(STAMP_MARK)
+    if i < 0:
+        return None
+    stamp = blob[i + len(STAMP_MARK):i + len(STAMP_MARK) + 64]
+    try:
+        return stamp.decode('ascii')
+    except UnicodeDecodeError:
+        return None
+
+
 def needs_build():
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.hip', '.cpp', '.h'))]
-    deps.append(os.path.join(os.path.dirname(CSRC), '..', 'include', 'fdsr.h'))
-    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+    return library_stamp() != source_hash()
+
+
+def _object_key(src, flags):
+    """What one object file depends on: its source, every internal header, its flags."""
+    import hashlib
+    h = hashlib.sha256()
+    deps = [src] + sorted(f for f in os.listdir(CSRC) if f.endswith('.h'))
+    for f in deps:
+        h.update(f.encode() + b'\0' + open(os.path.join(CSRC, f), 'rb').read() + b'\0')
+    h.update(open(os.path.normpath(os.path.join(CSRC, '..', '..', 'include', 'fdsr.h')), 'rb').read())
+    h.update(repr((flags, COMMON)).encode())
+    return h.hexdigest()
 
 
 def build(force=False, verbose=True):
     if not force and not needs_build():
         return LIB
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = _hipcc()
-    objs = []
-    for src, flags in SOURCES:
+    stamp = source_hash()
+
+    def compile_one(item):
+        src, flags = item
         obj = os.path.join(CSRC, src.rsplit('.', 1)[0] + '.o')
-        cmd = [hipcc] + COMMON + flags + ['-c', os.path.join(CSRC, src), '-o', obj]
+        extra = ['-DFDSR_SRC_SHA256="%s"' % stamp] if src == 'fdsr_engine.cpp' else []
+        key = _object_key(src, flags + extra)
+        keyfile = obj + '.key'       # objects whose inputs did not change are reused (kernel files take ~30 s each)
+        if not force and os.path.exists(obj) and os.path.exists(keyfile) and open(keyfile).read() == key:
+            return obj
+        cmd = [hipcc] + COMMON + flags + extra + ['-c', os.path.join(CSRC, src), '-o', obj]
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.check_call(cmd)
-        objs.append(obj)
+        open(keyfile, 'w').write(key)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(4, len(SOURCES))) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
     cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', LIB]
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.check_call(cmd)
+    assert library_stamp() == stamp, 'built library does not carry its source hash'
     return LIB
 
 

@@ -1004,7 +1004,13 @@ int sample_body(fdsr_handle h, const float* cond, const float* noise, float* out
 // ---------------------------------------------------------------------------
 extern "C" {
 
-const char* fdsr_version(void) { return "fdsr-hip 0.3 (gfx950; NHWC implicit-GEMM MFMA convolutions: f16x3 / f32 / bf16)"; }
+#ifndef FDSR_SRC_SHA256
+#define FDSR_SRC_SHA256 "unstamped"
+#endif
+// ends with the SHA-256 of the sources this binary was built from (fastdiffsr_amd/build.py: source_hash)
+const char* fdsr_version(void) {
+  return "fdsr-hip 0.4 (gfx950; NHWC implicit-GEMM MFMA convolutions: f16x3 / f32 / bf16) FDSR_SRC_SHA256=" FDSR_SRC_SHA256;
+}
 
 const char* fdsr_last_error(fdsr_handle h) { return h ? h->err.c_str() : g_global_error.c_str(); }
 
@@ -1145,7 +1151,9 @@ int fdsr_sample(fdsr_handle h, const float* cond_nchw, const float* noise, float
   char* ws = reinterpret_cast<char*>(workspace);
   if ((rc = ensure_temb_table(h, st))) return rc;
   if (!noise && (rc = ensure_rng(h))) return rc;
-  const bool use_graph = (flags & FDSR_SAMPLE_GRAPH) && !h->profiling && st != nullptr;
+  if ((flags & FDSR_SAMPLE_GRAPH) && st == nullptr)
+    return fail(h, FDSR_E_INVALID, "FDSR_SAMPLE_GRAPH needs a non-default stream (stream capture cannot run on the NULL stream)");
+  const bool use_graph = (flags & FDSR_SAMPLE_GRAPH) && !h->profiling;
   if (!use_graph) return sample_body(h, cond_nchw, noise, out_nchw, traj_nchw, batch, height, width, ws, st);
 
   for (auto& g : h->graphs)

@@ -37,6 +37,7 @@ class Engine:
         self.h = h
         self._ws = None
         self._keep = None
+        self._gstream = None
         self.T = 0
 
     def __del__(self):
@@ -140,10 +141,19 @@ class Engine:
             out = torch.empty(B, 3, H, W, device=cond.device, dtype=torch.float32)
         if want_traj and traj is None:
             traj = torch.empty(self.T, B, 3, H, W, device=cond.device, dtype=torch.float32)
-        st = torch.cuda.current_stream(cond.device).cuda_stream
+        cur = torch.cuda.current_stream(cond.device)
         flags = _lib.FDSR_SAMPLE_GRAPH if graph else 0
-        _lib.check(self.h, self.lib.fdsr_sample(self.h, _ptr(cond), _ptr(noise), _ptr(out), _ptr(traj if want_traj else None),
-                                                B, H, W, _ptr(ws), ws.numel(), C.c_void_p(st), flags))
+        args = (self.h, _ptr(cond), _ptr(noise), _ptr(out), _ptr(traj if want_traj else None), B, H, W, _ptr(ws), ws.numel())
+        if graph and cur.cuda_stream == 0:
+            # stream capture cannot run on the NULL stream: replay on a stream of our own, ordered after and
+            # before the caller's current stream
+            if self._gstream is None or self._gstream.device != cond.device:
+                self._gstream = torch.cuda.Stream(cond.device)
+            self._gstream.wait_stream(cur)
+            _lib.check(self.h, self.lib.fdsr_sample(*args, C.c_void_p(self._gstream.cuda_stream), flags))
+            cur.wait_stream(self._gstream)
+        else:
+            _lib.check(self.h, self.lib.fdsr_sample(*args, C.c_void_p(cur.cuda_stream), flags))
         self._keep = (cond, noise, out, traj)
         return (out, traj) if want_traj else out
 

@@ -94,6 +94,12 @@ class UNet(nn.Module):
             self._uploaded_version = ver
 
     def forward(self, x, time):
+        if self.training and self.cfg.dropout > 0:
+            # reference: nn.Dropout(p) in block2 is live whenever .training (unet.py:89-101); running the eval
+            # network here would silently compute a different loss, so refuse instead
+            raise NotImplementedError(
+                f'train-mode forward with dropout={self.cfg.dropout} is not implemented in the HIP engine '
+                '(no dropout mask kernel yet): call .eval() first, or build the UNet with dropout=0')
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
             raise NotImplementedError(
                 'training (autograd through the HIP UNet) is not implemented yet; call under torch.no_grad() / eval()')

@@ -131,7 +131,8 @@ int fdsr_unet_forward(fdsr_handle h, const float* x_nchw, const float* noise_lev
  *   out_nchw  [B,3,H,W]        res2img(x_0, cond) (:214, :275-281) == ret_img[-1]
  *   traj_nchw [T,B,3,H,W] or NULL: x_t after every step (t = T-1..0), for
  *                              continous=True frames and parity tests.
- * flags: FDSR_SAMPLE_GRAPH replays the 20-step loop as one captured hipGraph. */
+ * flags: FDSR_SAMPLE_GRAPH replays the 20-step loop as one captured hipGraph; hip_stream must then be a
+ *        created stream (capture cannot run on the NULL stream: FDSR_E_INVALID). */
 #define FDSR_SAMPLE_GRAPH 1
 int fdsr_sample(fdsr_handle h, const float* cond_nchw, const float* noise,
                 float* out_nchw, float* traj_nchw, int batch, int height, int width,

@@ -24,6 +24,9 @@ def test_header_symbols_exported_and_bound():
         assert hasattr(lib, n), f'{n} declared in fdsr.h but not exported'
     assert set(names) == set(_lib.SYMBOLS), 'ctypes binding table and header disagree'
     assert b'gfx950' in lib.fdsr_version()
+    # provenance: the library carries the hash of the tree it was built from, and that is THIS tree
+    stamp = lib.fdsr_version().decode().rsplit('FDSR_SRC_SHA256=', 1)[1]
+    assert stamp == build.source_hash() == build.library_stamp()
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

@@ -28,7 +28,7 @@ def _engine(cfg, sd):
     return eng
 
 
-@pytest.mark.parametrize('precision,graph,with_noise', [(1, 0, True), (0, 1, True), (1, 1, False)])
+@pytest.mark.parametrize('precision,graph,with_noise', [(1, 0, True), (0, 1, True), (1, 1, False), (2, 1, True)])
 def test_c_host_matches_python_facade(tmp_path, precision, graph, with_noise):
     from export_bundle import write_bundle
     from fastdiffsr_amd import build as b

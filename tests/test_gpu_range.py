@@ -1,0 +1,91 @@
+"""Dynamic range and conditioning of the fp32-grade paths (exact f32 and split-f16 "f16x3").
+
+The synthetic weights keep every activation O(1); a trained checkpoint need not.  These cases push the
+arithmetic where f16x3 could differ from fp32: a large DC offset riding the residual stream (GroupNorm
+statistics are E[x^2] - E[x]^2 over per-tile partial sums), an activation plane near the f16 limit
+(+-6.2e4: the staging clamps to +-65504 before the hi/lo split), and a plane at 1e-6 scale (the lo part
+goes subnormal below 2^-14).  Every reference module output is compared layer by layer with the oracle:
+|delta| <= 1e-4 * max(1, max|ref|), both modes."""
+import numpy as np
+import pytest
+import torch
+
+from fastdiffsr_amd.arch import UNetConfig, build_layers
+from fastdiffsr_amd.synth import synth_state_dict
+
+pytestmark = pytest.mark.gpu
+
+CFG = dict(in_channel=6, out_channel=3, inner_channel=64, norm_groups=32, channel_mults=(1, 2, 4, 4), attn_res=(16,),
+           res_blocks=2, dropout=0.2, image_size=64)
+TOL = 1e-4
+
+
+def _layerwise(sd, cfg, x, nl, prec):
+    from fastdiffsr_amd.engine import Engine
+    from oracle import fdsr_oracle as O
+    cap = {}
+    with torch.no_grad():
+        ref = O.unet_forward(O.to_torch_sd(sd), cfg, x, nl, capture=cap)
+    eng = Engine(cfg)
+    eng.load_state_dict(sd)
+    eng.set_precision(prec)
+    eng.set_debug(True)
+    out = eng.unet_forward(x.cuda(), nl.cuda()).cpu()
+    worst = (0.0, '')
+    for L in build_layers(cfg):
+        got = eng.debug_tensor(L.name).cpu()
+        assert torch.isfinite(got).all(), L.name
+        d = (got - cap[L.name]).abs().max().item()
+        scale = max(1.0, cap[L.name].abs().max().item())
+        worst = max(worst, (d / scale, L.name))
+        assert d <= TOL * scale, f'{L.name}: max|d| {d:.3e} at max|ref| {scale:.3e} [{prec}]'
+    d = (out - ref).abs().max().item()
+    assert d <= TOL * max(1.0, ref.abs().max().item())
+    return d, worst
+
+
+@pytest.mark.parametrize('prec', ['f32', 'f16x3'])
+@pytest.mark.parametrize('offset', [0.0, 20.0, 100.0, 400.0])
+def test_dc_offset_on_residual_stream(offset, prec):
+    """A constant added by the first conv's bias (and a quarter of it by every block2 bias) rides the identity
+    residuals through the whole network: GroupNorm sees mean >> std on every block input."""
+    cfg = UNetConfig(**CFG)
+    sd = synth_state_dict(cfg, 0)
+    sd['downs.0.bias'] = sd['downs.0.bias'] + np.float32(offset)
+    for k in list(sd):
+        if k.endswith('block2.block.3.bias'):
+            sd[k] = sd[k] + np.float32(offset * 0.25)
+    x = torch.randn(2, 6, 64, 64, generator=torch.Generator().manual_seed(1))
+    nl = torch.tensor([[0.3], [0.8]])
+    d, worst = _layerwise(sd, cfg, x, nl, prec)
+    print(f'DC offset {offset:6.1f} [{prec}]: final max|d| {d:.3e}; worst layer {worst[1]} at {worst[0]:.3e} x max(1,|ref|)')
+
+
+@pytest.mark.parametrize('prec', ['f32', 'f16x3'])
+@pytest.mark.parametrize('scale', [1.1e4, 1.0e-6])
+def test_activation_plane_scale(scale, prec):
+    """downs.0 scaled so that the first activation plane (and with it the first skip tensor, which is read RAW by
+    the 1x1 res_conv of ups.14 and re-normalised by every GroupNorm it enters) sits near the f16 limit
+    (|x| up to 6.2e4 < 65504 anywhere on the residual stream) or at 1e-6."""
+    cfg = UNetConfig(**CFG)
+    sd = synth_state_dict(cfg, 0)
+    sd['downs.0.weight'] = sd['downs.0.weight'] * np.float32(scale)
+    sd['downs.0.bias'] = sd['downs.0.bias'] * np.float32(scale)
+    x = torch.randn(2, 6, 64, 64, generator=torch.Generator().manual_seed(2)).clamp(-3, 3)
+    nl = torch.tensor([[0.05], [0.6]])
+    from oracle import fdsr_oracle as O
+    cap = {}
+    with torch.no_grad():
+        O.unet_forward(O.to_torch_sd(sd), cfg, x, nl, capture=cap)
+    top = cap['downs.0'].abs().max().item()
+    if scale > 1:
+        # the case is what it says: the whole residual stream near, not beyond, the f16 range.  Beyond it the
+        # f16x3 staging saturates RAW conv inputs (res_conv, down/upsample convs) at +-65504 -- a documented
+        # limit of that mode; GroupNorm'ed inputs are re-scaled before the split.
+        peak = max(v.abs().max().item() for k, v in cap.items() if k != 'final_conv')
+        assert 3.0e4 < top and peak < 65504.0, (top, peak)
+    else:
+        assert top < 1e-5
+    d, worst = _layerwise(sd, cfg, x, nl, prec)
+    print(f'plane scale {scale:.0e} (max|downs.0| {top:.3e}) [{prec}]: final max|d| {d:.3e}; worst layer {worst[1]} '
+          f'at {worst[0]:.3e} x max(1,|ref|)')

@@ -177,3 +177,16 @@ def test_parameter_count_matches_reference():
     G = diffusion.GaussianDiffusion(net, image_size=256, channels=3, loss_type='l1', conditional=True, schedule_opt=None)
     n = sum(p.numel() for p in G.parameters())
     assert n == 23802277 and '%.3f' % (n / (1024 * 1024)) == '22.700'
+
+
+def test_train_mode_dropout_is_refused_not_skipped():
+    """unet.py:89-101: Dropout(p) in block2 is live whenever .training.  Until the engine has the mask kernel the
+    facade must refuse a train-mode forward (also under no_grad, which p_losses uses) instead of running eval."""
+    import pytest
+    import torch
+    from fastdiffsr_amd.unet import UNet
+    net = UNet(in_channel=6, out_channel=3, inner_channel=32, channel_mults=(1, 2), attn_res=(16,), res_blocks=1,
+               dropout=0.2, image_size=16)
+    assert net.training
+    with torch.no_grad(), pytest.raises(NotImplementedError, match='dropout'):
+        net(torch.zeros(1, 6, 16, 16), torch.zeros(1, 1))
