@@ -139,14 +139,26 @@ class _StdoutToStderr:
     """RCCL prints a version banner on STDOUT when its first communicator comes up; this line-oriented
     benchmark owes its caller exactly one JSON line there, so fd 1 points at stderr while RCCL initialises."""
 
+    @staticmethod
+    def _flush_c_stdio():
+        # RCCL writes through C stdio: with stdout a pipe that buffer is flushed only at exit, i.e. AFTER fd 1
+        # has been restored -- flush it while fd 1 still points at stderr
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+
     def __enter__(self):
         sys.stdout.flush()
+        self._flush_c_stdio()
         self._saved = os.dup(1)
         os.dup2(2, 1)
         return self
 
     def __exit__(self, *exc):
         sys.stdout.flush()
+        self._flush_c_stdio()
         os.dup2(self._saved, 1)
         os.close(self._saved)
         return False

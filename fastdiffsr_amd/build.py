@@ -10,7 +10,7 @@ LIB = os.path.join(CSRC, 'libfdsr_hip.so')
 # gfx950 (MI355X_MICROARCH.md, cycle constants); +0.8 % end to end in a same-box A/B
 SOURCES = [('fdsr_kernels.hip', ['-O3', '-munsafe-fp-atomics']), ('fdsr_conv_h.hip', ['-O3', '-fno-slp-vectorize']),
            ('fdsr_conv_up2.hip', ['-O3', '-fno-slp-vectorize']),
-           ('fdsr_engine.cpp', ['-O2'])]
+           ('fdsr_train.hip', ['-O3']), ('fdsr_engine.cpp', ['-O2']), ('fdsr_train.cpp', ['-O2'])]
 COMMON = ['--offload-arch=gfx950', '-std=c++17', '-fPIC', '-Wno-unused-result']
 
 
@@ -81,7 +81,7 @@ def build(force=False, verbose=True):
 
     def compile_one(item):
         src, flags = item
-        obj = os.path.join(CSRC, src.rsplit('.', 1)[0] + '.o')
+        obj = os.path.join(CSRC, src.replace('.', '_') + '.o')   # fdsr_train.hip and fdsr_train.cpp both exist
         extra = ['-DFDSR_SRC_SHA256="%s"' % stamp] if src == 'fdsr_engine.cpp' else []
         key = _object_key(src, flags + extra)
         keyfile = obj + '.key'       # objects whose inputs did not change are reused (kernel files take ~30 s each)
@@ -94,7 +94,7 @@ def build(force=False, verbose=True):
         open(keyfile, 'w').write(key)
         return obj
 
-    with ThreadPoolExecutor(max_workers=min(4, len(SOURCES))) as ex:
+    with ThreadPoolExecutor(max_workers=min(6, len(SOURCES))) as ex:
         objs = list(ex.map(compile_one, SOURCES))
     cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', LIB]
     if verbose:

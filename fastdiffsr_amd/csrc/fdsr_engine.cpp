@@ -15,127 +15,13 @@
 #include <string>
 #include <vector>
 
-#include "../../include/fdsr.h"
-#include "fdsr_kernels.h"
+#include "fdsr_engine_int.h"
 
 using namespace fdsr;
+using namespace fdsr_int;
 
-namespace {
-
+namespace fdsr_int {
 thread_local std::string g_global_error;
-
-struct WeightEntry {
-  std::string key;
-  std::vector<int64_t> shape;
-  bool live = true;
-  bool loaded = false;
-  // sink: how the tensor is stored on the device
-  enum Sink { RAW, CONV_PACK, NOISE_W, NOISE_B } sink = RAW;
-  size_t dev_off = 0;      // float offset into the parameter arena
-  int ks = 1, cin_pad = 0, cout_pad = 0;   // CONV_PACK
-  int row_off = 0;                          // NOISE_W / NOISE_B: first row inside the concatenated table
-  // 16-bit MFMA forms (CONV_PACK entries that the h-kernels can run)
-  bool h_ok = false;
-  ConvKind ck = CONV3_S1;
-  int h_WN = 0, h_cin_pad = 0, h_cout_pad = 0;
-  size_t hq_off[3] = {0, 0, 0};             // byte offsets into the 16-bit weight arena, per Precision
-  float h_inv_scale[3] = {1.f, 1.f, 1.f};
-  size_t up2_off[3] = {0, 0, 0};            // CONV3_UP only: sub-pixel (4 x 2x2) form
-  float up2_inv_scale[3] = {1.f, 1.f, 1.f};
-};
-
-struct TensorDesc {
-  int C = 0;
-  int level = 0;        // spatial = (H >> level, W >> level)
-  bool persistent = false;
-  bool need_part = false;  // feeds a GroupNorm: its producer also writes per-tile channel sums
-  int first_def = -1, last_use = -1;
-  size_t off = 0;       // byte offset inside the workspace (per plan)
-  std::string name;     // reference module whose output this is ("" for temporaries)
-};
-
-struct Op {
-  enum Kind { GN_FINALIZE, CONV, CLAM, SLAM, ATTN } kind;
-  std::string name;
-  int src0 = -1, src1 = -1, dst = -1, res = -1;
-  ConvKind ck = CONV3_S1;
-  int C0 = 0, C1 = 0, Cout = 0;
-  int lvl_in = 0, lvl_out = 0;
-  int gn_slot = -1;
-  int w = -1, b = -1, gamma = -1, beta = -1;   // weight-entry indices
-  int temb_off = -1;
-  int fc1 = -1, fc2 = -1;
-  bool no_part = false;   // dst is overwritten later by another producer (res_conv pre-fill)
-  int aux = -1;           // ATTN: scratch tensor for the scores
-};
-
-struct ShapePlan {
-  int N = 0, H = 0, W = 0;
-  bool debug = false;
-  size_t bytes = 0;
-  size_t off_temb = 0, off_gate = 0, off_splitk = 0;
-  std::vector<int> op_ksplit;      // per op: K-loop split factor of a 16-bit conv at this shape (1 = none)
-  std::vector<size_t> tensor_off;
-  std::vector<size_t> part_off;    // per tensor: per-tile channel sums [N][max_tiles][C][2] (0 = none)
-  std::vector<size_t> gn_off;      // per GroupNorm slot: scale [N][C] then shift [N][C]
-  std::vector<int> tensor_nt;      // tiles per image its producer actually used (set at launch)
-};
-
-struct GraphEntry {
-  const void *cond, *noise, *out, *traj, *ws;
-  int N, H, W;
-  hipGraphExec_t exec;
-};
-
-}  // namespace
-
-struct fdsr_engine {
-  fdsr_config cfg{};
-  std::string err;
-  std::vector<WeightEntry> weights;
-  std::map<std::string, int> key2w;
-  std::vector<TensorDesc> tensors;
-  std::vector<Op> ops;
-  int t_in = -1, t_eps = -1, CP = 8;
-  int n_gn_slots = 0, TE = 0, Cmid = 0, max_qkv = 0;
-  int n_schema = 0;   // checkpoint tensors (the entries after them are synthetic)
-  std::vector<int> gn_channels;   // per GroupNorm slot
-  int w_freq = -1;   // synthetic entry: positional-encoding frequencies (SR3: the checkpoint's inv_freq buffer)
-  int w_zero_bias = -1;   // synthetic zeros for bias-free 1x1 convs (attn.qkv)
-  bool sr3 = false;          // SR3 sibling (ddpm_modules): integer-time embedding, noise [T+1]
-  bool attn_blocks = false;  // SR3 and TESR siblings: SelfAttention per attn_res + mid[0], no dead .conv, no CLAM/SLAM
-  bool plain_out = false;    // SR3 and TESR: the sampler returns x_0 itself (no res2img)
-  size_t param_floats = 0, noise_w_off = 0, noise_b_off = 0;
-  int w_mlp[4] = {-1, -1, -1, -1};
-  float* d_params = nullptr;
-  unsigned char* d_wq = nullptr;
-  // Sampling feeds every image of a batch the same noise level, and only T distinct ones ever
-  // occur (diffusion.py:169-170), so the whole embedding table [T][TE] is evaluated once per
-  // (weights, schedule) and the conv epilogues index it with batch stride 0.
-  unsigned long long* d_rng = nullptr;   // {seed, call counter}: noise drawn by the engine (fdsr_sample, noise == NULL)
-  unsigned long long rng_seed = 0;
-  float* d_temb_table = nullptr;
-  float* d_nl = nullptr;
-  bool temb_table_valid = false;
-  size_t wq_bytes = 0;
-  int prec = PREC_F32;
-  bool kernels_ready = false;
-  // schedule
-  int T = 0;
-  std::vector<float> s_nl, s_recip, s_recipm1, s_c1, s_c2, s_sigma;
-  // plan cache
-  ShapePlan plan;
-  bool debug = false;
-  // profiling
-  bool profiling = false;
-  bool prof_step = true;     // in sampling only every 4th step is bracketed by events: <1 % overhead in the timed region
-  std::vector<hipEvent_t> ev_pool;
-  size_t ev_used = 0;
-  double prof_flops = 0, prof_bytes = 0;
-  std::vector<GraphEntry> graphs;
-};
-
-namespace {
 
 int fail(fdsr_handle h, int code, const char* fmt, ...) {
   char buf[512];
@@ -146,16 +32,10 @@ int fail(fdsr_handle h, int code, const char* fmt, ...) {
   if (h) h->err = buf; else g_global_error = buf;
   return code;
 }
+}  // namespace fdsr_int
 
-#define HIPCHK(h, expr)                                                                     \
-  do {                                                                                      \
-    hipError_t e__ = (expr);                                                                \
-    if (e__ != hipSuccess)                                                                  \
-      return fail(h, FDSR_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
-  } while (0)
+namespace fdsr_int {
 
-size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-int round_up(int v, int a) { return (v + a - 1) / a * a; }
 
 int add_weight(fdsr_handle h, const std::string& key, std::vector<int64_t> shape, bool live) {
   WeightEntry w;
@@ -165,12 +45,6 @@ int add_weight(fdsr_handle h, const std::string& key, std::vector<int64_t> shape
   h->weights.push_back(w);
   h->key2w[key] = (int)h->weights.size() - 1;
   return (int)h->weights.size() - 1;
-}
-
-size_t numel(const std::vector<int64_t>& s) {
-  size_t n = 1;
-  for (auto d : s) n *= (size_t)d;
-  return n;
 }
 
 int new_tensor(fdsr_handle h, int C, int level, const std::string& name = "") {
@@ -465,6 +339,16 @@ int build_plan(fdsr_handle h) {
     }
   }
   h->n_schema = (int)h->weights.size();
+  {   // master copy (checkpoint layout) of every live tensor: what the optimiser updates, what fdsr_get_weight returns
+    size_t mo = 0;
+    h->master_off.assign(h->weights.size(), SIZE_MAX);
+    for (int i = 0; i < h->n_schema; ++i) {
+      if (!h->weights[i].live) continue;
+      h->master_off[i] = mo;
+      mo += align_up(numel(h->weights[i].shape), 4);
+    }
+    h->master_floats = mo;
+  }
   if (h->max_qkv) {   // zeros standing in for the missing bias of attn.qkv (Conv2d(bias=False))
     WeightEntry z;
     z.key = "__zero_bias";
@@ -538,6 +422,8 @@ int ensure_device(fdsr_handle h) {
     }
     HIPCHK(h, hipMemcpy(h->d_params + h->weights[h->w_freq].dev_off, fr.data(), half * sizeof(float), hipMemcpyHostToDevice));
   }
+  HIPCHK(h, hipMalloc((void**)&h->d_master, std::max<size_t>(h->master_floats, 4) * sizeof(float)));
+  HIPCHK(h, hipMemset(h->d_master, 0, std::max<size_t>(h->master_floats, 4) * sizeof(float)));
   if (h->wq_bytes) {
     HIPCHK(h, hipMalloc((void**)&h->d_wq, h->wq_bytes));
     HIPCHK(h, hipMemset(h->d_wq, 0, h->wq_bytes));
@@ -565,6 +451,11 @@ int make_shape_plan(fdsr_handle h, int N, int H, int W, ShapePlan* sp) {
       sp->gn_off[op.gn_slot] = off;
       off += align_up((size_t)2 * N * (op.C0 + op.C1) * sizeof(float), 256);
     }
+  sp->gn_stats_off.assign(h->n_gn_slots, 0);
+  for (int g = 0; g < h->n_gn_slots; ++g) {
+    sp->gn_stats_off[g] = off;
+    off += align_up((size_t)N * h->cfg.norm_groups * 2 * sizeof(float), 256);
+  }
   sp->off_temb = off;  off += align_up((size_t)N * h->TE * sizeof(float), 256);
   {
     size_t gate_floats = 1;
@@ -673,7 +564,7 @@ double conv_flops(const Op& op, int N, int H, int W) {
 int fill_temb(fdsr_handle h, float* temb, int N, const float* nl_dev, float nl_scalar, hipStream_t st);
 
 int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, float nl_scalar, hipStream_t st,
-             const float* temb_row = nullptr) {
+             const float* temb_row) {
   ShapePlan& sp = h->plan;
   const int G = h->cfg.norm_groups;
   const float* temb = temb_row ? temb_row : reinterpret_cast<const float*>(ws + sp.off_temb);
@@ -699,6 +590,7 @@ int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, 
         g.gamma = P(op.gamma); g.beta = P(op.beta);
         g.scale = reinterpret_cast<float*>(ws + sp.gn_off[op.gn_slot]);
         g.shift = g.scale + (size_t)N * (op.C0 + op.C1);
+        g.stats = h->keep_stats ? reinterpret_cast<float*>(ws + sp.gn_stats_off[op.gn_slot]) : nullptr;
         g.N = N; g.G = G; g.HW = Hi * Wi; g.eps = 1e-5f;
         HIPCHK(h, launch_gn_finalize(g, st));
         break;
@@ -997,7 +889,7 @@ int sample_body(fdsr_handle h, const float* cond, const float* noise, float* out
   return FDSR_OK;
 }
 
-}  // namespace
+}  // namespace fdsr_int
 
 // ---------------------------------------------------------------------------
 // C ABI
@@ -1037,6 +929,8 @@ void fdsr_destroy(fdsr_handle h) {
   if (h->d_temb_table) (void)hipFree(h->d_temb_table);
   if (h->d_nl) (void)hipFree(h->d_nl);
   if (h->d_rng) (void)hipFree(h->d_rng);
+  for (float* q : {h->d_master, h->d_grad, h->d_adam_m, h->d_adam_v, h->d_wt, h->d_zero})
+    if (q) (void)hipFree(q);
   delete h;
 }
 
@@ -1070,6 +964,7 @@ int fdsr_load_weight(fdsr_handle h, const char* key, const float* host, const in
   int rc = ensure_device(h);
   if (rc) return rc;
   float* dst = h->d_params + w.dev_off;
+  HIPCHK(h, hipMemcpy(h->d_master + h->master_off[it->second], host, numel(w.shape) * sizeof(float), hipMemcpyHostToDevice));
   if (w.sink == WeightEntry::CONV_PACK) {
     const int Cout = (int)w.shape[0], Cin = (int)w.shape[1], ks = w.ks;
     std::vector<float> pk((size_t)ks * ks * w.cout_pad * w.cin_pad, 0.f);
@@ -1086,6 +981,7 @@ int fdsr_load_weight(fdsr_handle h, const char* key, const float* host, const in
     HIPCHK(h, hipMemcpy(dst, host, numel(w.shape) * sizeof(float), hipMemcpyHostToDevice));
   }
   w.loaded = true;
+  h->wt_valid = false;
   h->temb_table_valid = false;
   for (auto& g : h->graphs) (void)hipGraphExecDestroy(g.exec);   // weights are baked by address only, but be safe
   h->graphs.clear();
@@ -1277,6 +1173,10 @@ int fdsr_set_precision(fdsr_handle h, int mode) {
       if (op.kind == Op::CONV && !h->weights[op.w].h_ok && op.src0 != h->t_in)
         return fail(h, FDSR_E_INVALID, "bf16 mode needs channel counts that are multiples of 16 (layer %s)", op.name.c_str());
     }
+  }
+  if (mode != PREC_F32 && h->h_forms_stale) {   // optimiser steps moved the master copy: refresh the 16-bit forms
+    int rc = fdsr_sync_weight_forms(h);
+    if (rc) return rc;
   }
   if (h->prec != mode) {
     for (auto& g : h->graphs) (void)hipGraphExecDestroy(g.exec);

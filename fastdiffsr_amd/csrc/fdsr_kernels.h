@@ -75,6 +75,7 @@ struct GnFinalizeParams {
   const float* part1; int nt1, C1;
   const float* gamma; const float* beta;   // [C0+C1]
   float* scale; float* shift;              // [N][C0+C1]
+  float* stats;                            // optional [N][G][2]: (mean, rstd) kept for the backward pass
   int N, G, HW;
   float eps;
 };

@@ -405,6 +405,10 @@ __global__ void __launch_bounds__(256) gn_finalize_kernel(const GnFinalizeParams
       var = var < 0.0 ? 0.0 : var;
       gs[0] = mean;
       gs[1] = 1.0 / sqrt(var + (double)p.eps);
+      if (p.stats) {
+        p.stats[((size_t)n * p.G + g) * 2] = (float)gs[0];
+        p.stats[((size_t)n * p.G + g) * 2 + 1] = (float)gs[1];
+      }
     }
   }
   __syncthreads();

@@ -1,0 +1,437 @@
+// Training step of the FastDiffSR UNet on the device: forward in "keep" mode, loss, backward
+// pass, Adam, re-packing of the updated weights.  Reference: DDPM.optimize_parameters (model/model.py:47-57),
+// GaussianDiffusion.p_losses (model/fastdiffsr_modules/diffusion.py:242-270), UNet.forward (unet.py:299-323).
+//
+// The backward walks the forward plan in reverse.  For a convolution op  y = conv(a) + b + shift (+ res),
+// a = swish(gn(x)) or a = x, x = cat(x0, x1):
+//   * d res  += dy                                  (identity residual; a 1x1 res_conv shares the buffer)
+//   * S[n][c] = sum_p dy                            -> bias gradient, and the noise-embedding gradient of the block
+//   * dW      = wgrad(dy, a)                        (fdsr_train.hip, exact fp32 MFMA)
+//   * dA      = conv(dy; W transposed, taps flipped) on the FORWARD kernel (stride 2: zero-inserted dy;
+//               upsample: 2x2 sum-pool afterwards)
+//   * dx0/dx1 += GroupNorm+Swish backward(dA)       or += dA where the conv reads its input raw
+// Gradient tensors are zeroed up front and every contribution is a += in stream order: deterministic.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+#include "fdsr_engine_int.h"
+#include "fdsr_train.h"
+
+using namespace fdsr;
+using namespace fdsr_int;
+
+namespace {
+
+struct TrainPlan {
+  size_t base = 0;                      // first byte after the forward plan
+  std::vector<size_t> grad_off;         // per tensor: its gradient [N][HW][C] (eps: 8 channels)
+  size_t grad_bytes = 0;                // all gradient tensors (one memset)
+  size_t off_tmpA = 0, off_tmpZ = 0, off_S = 0, off_dtemb = 0, off_dwn = 0, off_dbn = 0, off_dbl = 0, off_wg = 0, off_csb = 0,
+         off_tb = 0, off_loss = 0, off_deps = 0;
+  size_t bytes = 0;                     // total workspace (forward plan + extras)
+};
+
+int tensor_channels(fdsr_handle h, int t) { return t == h->t_eps ? 8 : h->tensors[t].C; }
+
+int make_train_plan(fdsr_handle h, int N, int H, int W, TrainPlan* tp) {
+  const ShapePlan& sp = h->plan;
+  size_t off = align_up(sp.bytes, 256);
+  tp->base = off;
+  tp->grad_off.assign(h->tensors.size(), 0);
+  const size_t g0 = off;
+  for (size_t t = 0; t < h->tensors.size(); ++t) {
+    const TensorDesc& td = h->tensors[t];
+    if (td.C < 0 || (int)t == h->t_in) continue;       // attention scratch; the network input needs no gradient
+    const size_t hw = (size_t)(H >> td.level) * (W >> td.level);
+    tp->grad_off[t] = off;
+    off += align_up((size_t)N * hw * tensor_channels(h, (int)t) * sizeof(float), 256);
+  }
+  tp->grad_bytes = off - g0;
+  size_t tmpA = 256, tmpZ = 256, wg = 256, csb = 256, dbl = 256;
+  int maxC = 8;
+  for (const Op& op : h->ops) {
+    if (op.kind == Op::SLAM) {
+      const int hw = (H >> op.lvl_in) * (W >> op.lvl_in);
+      csb = std::max(csb, clam_slam_bwd_scratch_floats(N, hw, op.C0, op.C0 / 16) * sizeof(float));
+    }
+    if (op.kind != Op::CONV) continue;
+    const int Ho = H >> op.lvl_out, Wo = W >> op.lvl_out, Hi = H >> op.lvl_in, Wi = W >> op.lvl_in;
+    const int Cin = op.C0 + op.C1;
+    maxC = std::max(maxC, std::max(Cin, op.Cout));
+    // dA at the grid the taps walk on (fine grid for stride 2 and for the upsample conv)
+    const size_t fine = (size_t)(op.ck == CONV3_UP ? Ho * Wo : Hi * Wi);
+    tmpA = std::max(tmpA, (size_t)N * fine * Cin * sizeof(float));
+    if (op.ck == CONV3_S2) tmpZ = std::max(tmpZ, (size_t)N * Hi * Wi * op.Cout * sizeof(float));
+    wg = std::max(wg, wgrad_scratch_floats(op.ck, N, Ho, Wo, Cin, op.Cout) * sizeof(float));
+    dbl = std::max(dbl, colsum_scratch_doubles(N, Ho * Wo, std::max(op.Cout, 8)) * sizeof(double));
+    if (op.gn_slot >= 0) dbl = std::max(dbl, gn_bwd_scratch_doubles(N, Hi * Wi, Cin) * sizeof(double));
+  }
+  dbl = std::max(dbl, loss_partial_count((size_t)N * H * W) * sizeof(double));
+  auto take = [&](size_t b) { const size_t r = off; off += align_up(b, 256); return r; };
+  tp->off_tmpA = take(tmpA);
+  tp->off_tmpZ = take(tmpZ);
+  tp->off_S = take((size_t)N * maxC * sizeof(float));
+  tp->off_dtemb = take((size_t)N * h->TE * sizeof(float));
+  tp->off_dwn = take((size_t)h->TE * h->cfg.inner_channel * sizeof(float));
+  tp->off_dbn = take((size_t)h->TE * sizeof(float));
+  tp->off_dbl = take(dbl);
+  tp->off_wg = take(wg);
+  tp->off_csb = take(csb);
+  tp->off_tb = take((size_t)N * 10 * h->cfg.inner_channel * sizeof(float));
+  tp->off_loss = take(256);
+  tp->bytes = off;
+  return FDSR_OK;
+}
+
+// transposed weights: per conv weight, per concat source (fdsr_train.hip: pack_conv_f32_t)
+struct WtDims { int rows_pad, cols_pad; };
+WtDims wt_dims(ConvKind ck, int K, int Csub) {
+  int KC, BN;
+  const ConvKind k = ck == CONV1 ? CONV1 : CONV3_S1;     // the transposed conv always runs at stride 1
+  conv_tile_config(k, K, 0, Csub, &KC, &BN);
+  return WtDims{round_up(Csub, BN), round_up(K, KC)};
+}
+
+int conv_K(fdsr_handle h, const Op& op) { return op.dst == h->t_eps ? 8 : op.Cout; }   // channels of dy as stored
+
+int train_prepare(fdsr_handle h) {
+  if (h->train_ready) return FDSR_OK;
+  if (h->cfg.variant != FDSR_VARIANT_FASTDIFFSR)
+    return fail(h, FDSR_E_INVALID, "the training step is implemented for the FastDiffSR variant only");
+  for (const Op& op : h->ops)
+    if (op.kind == Op::CONV && op.src0 != h->t_in && (conv_K(h, op) % 8 || (op.C0 % 16) || (op.C1 % 16)))
+      return fail(h, FDSR_E_INVALID, "training needs channel counts that are multiples of 16 (layer %s)", op.name.c_str());
+  const size_t nb = std::max<size_t>(h->master_floats, 4) * sizeof(float);
+  HIPCHK(h, hipMalloc((void**)&h->d_grad, nb));
+  HIPCHK(h, hipMalloc((void**)&h->d_adam_m, nb));
+  HIPCHK(h, hipMalloc((void**)&h->d_adam_v, nb));
+  HIPCHK(h, hipMemset(h->d_grad, 0, nb));
+  HIPCHK(h, hipMemset(h->d_adam_m, 0, nb));
+  HIPCHK(h, hipMemset(h->d_adam_v, 0, nb));
+  h->adam_t = 0;
+  // transposed-weight arena
+  h->wt_off0.assign(h->weights.size(), SIZE_MAX);
+  h->wt_off1.assign(h->weights.size(), SIZE_MAX);
+  size_t off = 0;
+  int maxC = 8;
+  for (const Op& op : h->ops) {
+    if (op.kind != Op::CONV || op.src0 == h->t_in) continue;
+    const int T = op.ck == CONV1 ? 1 : 9, K = conv_K(h, op);
+    maxC = std::max(maxC, op.C0 + op.C1);
+    const bool whole = op.gn_slot >= 0;                   // GroupNorm'ed input: one transposed conv over all input channels
+    if (whole || op.C1 == 0) {
+      const WtDims d = wt_dims(op.ck, K, op.C0 + op.C1);
+      h->wt_off0[op.w] = off;
+      off += align_up((size_t)T * d.rows_pad * d.cols_pad, 64);
+    } else {                                              // raw concat input: one transposed conv per source
+      const WtDims d0 = wt_dims(op.ck, K, op.C0), d1 = wt_dims(op.ck, K, op.C1);
+      h->wt_off0[op.w] = off;  off += align_up((size_t)T * d0.rows_pad * d0.cols_pad, 64);
+      h->wt_off1[op.w] = off;  off += align_up((size_t)T * d1.rows_pad * d1.cols_pad, 64);
+    }
+  }
+  h->wt_floats = off;
+  HIPCHK(h, hipMalloc((void**)&h->d_wt, std::max<size_t>(off, 4) * sizeof(float)));
+  HIPCHK(h, hipMalloc((void**)&h->d_zero, (size_t)round_up(maxC, 64) * sizeof(float)));
+  HIPCHK(h, hipMemset(h->d_zero, 0, (size_t)round_up(maxC, 64) * sizeof(float)));
+  HIPCHK(h, train_kernels_init());
+  h->train_ready = true;
+  return FDSR_OK;
+}
+
+// (re-)build every device form the fp32 kernels read from the master copy: after load and after each Adam step
+int repack_from_master(fdsr_handle h, hipStream_t st, bool forward_forms) {
+  for (int i = 0; i < h->n_schema; ++i) {
+    WeightEntry& w = h->weights[i];
+    if (!w.live) continue;
+    const float* src = h->d_master + h->master_off[i];
+    if (forward_forms) {
+      if (w.sink == WeightEntry::CONV_PACK) {
+        HIPCHK(h, launch_pack_conv_f32(src, h->d_params + w.dev_off, (int)w.shape[0], (int)w.shape[1], w.ks, w.cout_pad, w.cin_pad, st));
+      } else {
+        HIPCHK(h, hipMemcpyAsync(h->d_params + w.dev_off, src, numel(w.shape) * sizeof(float), hipMemcpyDeviceToDevice, st));
+      }
+    }
+  }
+  for (const Op& op : h->ops) {
+    if (op.kind != Op::CONV || op.src0 == h->t_in) continue;
+    const WeightEntry& w = h->weights[op.w];
+    const float* src = h->d_master + h->master_off[op.w];
+    const int K = conv_K(h, op), Cout = (int)w.shape[0], Cin = (int)w.shape[1];
+    if (h->wt_off1[op.w] == SIZE_MAX) {
+      const WtDims d = wt_dims(op.ck, K, op.C0 + op.C1);
+      HIPCHK(h, launch_pack_conv_f32_t(src, h->d_wt + h->wt_off0[op.w], Cout, Cin, w.ks, 0, op.C0 + op.C1, d.rows_pad, d.cols_pad, st));
+    } else {
+      const WtDims d0 = wt_dims(op.ck, K, op.C0), d1 = wt_dims(op.ck, K, op.C1);
+      HIPCHK(h, launch_pack_conv_f32_t(src, h->d_wt + h->wt_off0[op.w], Cout, Cin, w.ks, 0, op.C0, d0.rows_pad, d0.cols_pad, st));
+      HIPCHK(h, launch_pack_conv_f32_t(src, h->d_wt + h->wt_off1[op.w], Cout, Cin, w.ks, op.C0, op.C1, d1.rows_pad, d1.cols_pad, st));
+    }
+  }
+  h->temb_table_valid = false;
+  return FDSR_OK;
+}
+
+// one transposed convolution on the forward fp32 kernel: out (+)= conv(dy; wt)
+int launch_dgrad(fdsr_handle h, ConvKind ck, const float* dy, int K, int Hs, int Ws, const float* wt, int Csub, float* out,
+                 bool accumulate, int N, hipStream_t st) {
+  const ConvKind k = ck == CONV1 ? CONV1 : CONV3_S1;
+  const WtDims d = wt_dims(ck, K, Csub);
+  ConvParams p{};
+  p.x0 = dy; p.w = wt; p.bias = h->d_zero; p.out = out; p.res = accumulate ? out : nullptr;
+  p.N = N; p.Hin = Hs; p.Win = Ws; p.Hout = Hs; p.Wout = Ws;
+  p.C0 = K; p.C1 = 0; p.Cout = Csub; p.Cin_pad = d.cols_pad; p.Cout_pad = d.rows_pad;
+  HIPCHK(h, launch_conv(k, p, st, nullptr));
+  return FDSR_OK;
+}
+
+}  // namespace
+
+namespace fdsr_int {
+int train_workspace_extra(fdsr_handle h, int N, int H, int W, size_t* bytes) {
+  TrainPlan tp;
+  int rc = make_train_plan(h, N, H, W, &tp);
+  if (rc) return rc;
+  *bytes = tp.bytes;
+  return FDSR_OK;
+}
+}  // namespace fdsr_int
+
+extern "C" {
+
+int fdsr_train_workspace_bytes(fdsr_handle h, int batch, int height, int width, size_t* bytes) {
+  if (!h || !bytes) return fail(h, FDSR_E_INVALID, "null argument");
+  const bool dbg = h->debug;
+  h->debug = true;                                        // keep mode: every activation has its own buffer
+  int rc = get_plan(h, batch, height, width);
+  h->debug = dbg;
+  if (rc) return rc;
+  return train_workspace_extra(h, batch, height, width, bytes);
+}
+
+int fdsr_train_grads(fdsr_handle h, const float* x_nchw, const float* noise_level, const float* target_nchw, int loss_l2,
+                     float loss_scale, float* loss_host, int batch, int height, int width, void* workspace, size_t workspace_bytes,
+                     void* hip_stream) {
+  if (!h || !x_nchw || !noise_level || !target_nchw) return fail(h, FDSR_E_INVALID, "null argument");
+  if (h->prec != PREC_F32) return fail(h, FDSR_E_INVALID, "the training step runs the exact-fp32 kernels: fdsr_set_precision(FDSR_PREC_F32) first");
+  if (h->cfg.in_channel != 6 || h->cfg.out_channel != 3) return fail(h, FDSR_E_INVALID, "training needs in_channel=6, out_channel=3");
+  int rc = check_ready(h, false);
+  if (rc) return rc;
+  if ((rc = train_prepare(h))) return rc;
+  hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+  const int N = batch, H = height, W = width, G = h->cfg.norm_groups;
+  h->debug = true;
+  rc = get_plan(h, N, H, W);
+  if (rc) { h->debug = false; return rc; }
+  TrainPlan tp;
+  if ((rc = make_train_plan(h, N, H, W, &tp))) { h->debug = false; return rc; }
+  if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 255) || workspace_bytes < tp.bytes) {
+    h->debug = false;
+    return fail(h, FDSR_E_WORKSPACE, "training workspace too small or misaligned: %zu < %zu bytes", workspace_bytes, tp.bytes);
+  }
+  char* ws = reinterpret_cast<char*>(workspace);
+  ShapePlan& sp = h->plan;
+  // the transposed forms follow the master copy
+  if (!h->wt_valid) {
+    if ((rc = repack_from_master(h, st, false))) { h->debug = false; return rc; }
+    h->wt_valid = true;
+  }
+
+  // ---- forward, keeping every activation and the GroupNorm statistics ----
+  float* xin = reinterpret_cast<float*>(ws + sp.tensor_off[h->t_in]);
+  HIPCHK(h, launch_nchw_to_nhwc(x_nchw, xin, N, h->cfg.in_channel, H, W, h->CP, 0, 1, st));
+  h->keep_stats = true;
+  rc = run_unet(h, N, H, W, ws, noise_level, 0.f, st);
+  h->keep_stats = false;
+  h->debug = false;
+  if (rc) return rc;
+
+  auto P = [&](int widx) -> const float* { return widx >= 0 ? h->d_params + h->weights[widx].dev_off : nullptr; };
+  auto TP = [&](int t) -> float* { return t >= 0 ? reinterpret_cast<float*>(ws + sp.tensor_off[t]) : nullptr; };
+  auto GT = [&](int t) -> float* { return t >= 0 ? reinterpret_cast<float*>(ws + tp.grad_off[t]) : nullptr; };
+  auto DG = [&](int widx) -> float* { return h->d_grad + h->master_off[widx]; };
+  float* tmpA = reinterpret_cast<float*>(ws + tp.off_tmpA);
+  float* tmpZ = reinterpret_cast<float*>(ws + tp.off_tmpZ);
+  float* S = reinterpret_cast<float*>(ws + tp.off_S);
+  float* dtemb = reinterpret_cast<float*>(ws + tp.off_dtemb);
+  double* dbl = reinterpret_cast<double*>(ws + tp.off_dbl);
+  float* wg = reinterpret_cast<float*>(ws + tp.off_wg);
+  float* loss_dev = reinterpret_cast<float*>(ws + tp.off_loss);
+
+  // ---- loss and its gradient ----
+  {
+    size_t g0 = SIZE_MAX;
+    for (size_t t = 0; t < h->tensors.size(); ++t)
+      if (tp.grad_off[t]) g0 = std::min(g0, tp.grad_off[t]);
+    HIPCHK(h, hipMemsetAsync(ws + g0, 0, tp.grad_bytes, st));
+  }
+  HIPCHK(h, hipMemsetAsync(dtemb, 0, (size_t)N * h->TE * sizeof(float), st));
+  const float* eps = TP(h->t_eps);
+  HIPCHK(h, launch_loss_grad(eps, target_nchw, GT(h->t_eps), dbl, loss_dev, N, H * W, loss_l2, loss_scale, st));
+
+  // ---- backward over the plan ----
+  for (int oi = (int)h->ops.size() - 1; oi >= 0; --oi) {
+    const Op& op = h->ops[oi];
+    const int Hi = H >> op.lvl_in, Wi = W >> op.lvl_in;
+    if (op.kind == Op::ATTN) return fail(h, FDSR_E_INVALID, "internal: attention in the training plan");
+    if (op.kind == Op::SLAM) {
+      // the CLAM op right before shares src0: gate and map are recomputed from x
+      const Op* ca = nullptr;
+      for (int k = oi - 1; k >= 0; --k)
+        if (h->ops[k].kind == Op::CLAM) { ca = &h->ops[k]; break; }
+      if (!ca) return fail(h, FDSR_E_STATE, "internal: SLAM without CLAM");
+      ClamSlamBwdParams c{};
+      c.x = TP(op.src0); c.dout = GT(op.dst); c.dx = GT(op.src0);
+      c.fc1 = P(ca->fc1); c.fc2 = P(ca->fc2); c.w7 = P(op.w);
+      c.dfc1 = DG(ca->fc1); c.dfc2 = DG(ca->fc2); c.dw7 = DG(op.w);
+      c.scratch = reinterpret_cast<float*>(ws + tp.off_csb);
+      c.N = N; c.H = Hi; c.W = Wi; c.C = op.C0; c.Cr = op.C0 / 16;
+      HIPCHK(h, launch_clam_slam_bwd(c, st));
+      continue;
+    }
+    if (op.kind != Op::CONV) continue;
+    const WeightEntry& w = h->weights[op.w];
+    const int Ho = H >> op.lvl_out, Wo = W >> op.lvl_out, Cin = op.C0 + op.C1, K = conv_K(h, op);
+    const float* dy = GT(op.dst);
+    // residual (identity): the same gradient flows to the block input
+    if (op.res >= 0 && op.res != op.dst)
+      HIPCHK(h, launch_add_slice(dy, GT(op.res), (size_t)N * Ho * Wo, op.Cout, 0, op.Cout, st));
+    // bias and noise-embedding gradients
+    HIPCHK(h, launch_colsum(dy, S, dbl, N, Ho * Wo, K, st));
+    if (op.b >= 0) HIPCHK(h, launch_sum_rows(S, N, K, op.Cout, DG(op.b), st));   // db[c] = sum_n S[n][c]
+    if (op.temb_off >= 0)
+      for (int n = 0; n < N; ++n)
+        HIPCHK(h, hipMemcpyAsync(dtemb + (size_t)n * h->TE + op.temb_off, S + (size_t)n * K, (size_t)op.Cout * sizeof(float),
+                                 hipMemcpyDeviceToDevice, st));
+    // weight gradient
+    {
+      WgradParams q{};
+      q.dy = dy; q.x0 = TP(op.src0); q.x1 = TP(op.src1);
+      if (op.gn_slot >= 0) {
+        q.gn_scale = reinterpret_cast<const float*>(ws + sp.gn_off[op.gn_slot]);
+        q.gn_shift = q.gn_scale + (size_t)N * Cin;
+        q.gn_plain = op.b == -2 ? 1 : 0;
+      }
+      q.dw = DG(op.w); q.scratch = wg;
+      q.N = N; q.Hin = Hi; q.Win = Wi; q.Hout = Ho; q.Wout = Wo;
+      q.C0 = op.C0; q.C1 = op.C1; q.Cin_real = (int)w.shape[1]; q.Cout = op.Cout; q.Cout_s = K;
+      HIPCHK(h, launch_wgrad(op.ck, q, st));
+    }
+    if (op.src0 == h->t_in) continue;                     // no gradient w.r.t. the network input
+    // input gradient
+    if (op.gn_slot >= 0) {
+      if ((rc = launch_dgrad(h, op.ck, dy, K, Ho, Wo, h->d_wt + h->wt_off0[op.w], Cin, tmpA, false, N, st))) return rc;
+      GnBwdParams g{};
+      g.dA = tmpA; g.x0 = TP(op.src0); g.x1 = TP(op.src1); g.C0 = op.C0; g.C1 = op.C1;
+      g.scale = reinterpret_cast<const float*>(ws + sp.gn_off[op.gn_slot]);
+      g.shift = g.scale + (size_t)N * Cin;
+      g.stats = reinterpret_cast<const float*>(ws + sp.gn_stats_off[op.gn_slot]);
+      g.gamma = P(op.gamma);
+      g.dx0 = GT(op.src0); g.dx1 = GT(op.src1);
+      g.dgamma = DG(op.gamma); g.dbeta = DG(op.beta);
+      g.scratch = dbl;
+      g.N = N; g.HW = Hi * Wi; g.G = G; g.plain = op.b == -2 ? 1 : 0;
+      HIPCHK(h, launch_gn_bwd(g, st));
+    } else if (op.ck == CONV3_S2) {
+      HIPCHK(h, launch_zero_insert(dy, tmpZ, N, Ho, Wo, K, st));
+      if ((rc = launch_dgrad(h, op.ck, tmpZ, K, Hi, Wi, h->d_wt + h->wt_off0[op.w], op.C0, GT(op.src0), true, N, st))) return rc;
+    } else if (op.ck == CONV3_UP) {
+      if ((rc = launch_dgrad(h, op.ck, dy, K, Ho, Wo, h->d_wt + h->wt_off0[op.w], op.C0, tmpA, false, N, st))) return rc;
+      HIPCHK(h, launch_pool2_add(tmpA, GT(op.src0), N, Hi, Wi, op.C0, st));
+    } else {
+      if ((rc = launch_dgrad(h, op.ck, dy, K, Ho, Wo, h->d_wt + h->wt_off0[op.w], op.C0, GT(op.src0), true, N, st))) return rc;
+      if (op.C1 > 0 &&
+          (rc = launch_dgrad(h, op.ck, dy, K, Ho, Wo, h->d_wt + h->wt_off1[op.w], op.C1, GT(op.src1), true, N, st)))
+        return rc;
+    }
+  }
+
+  // ---- noise-level embedding ----
+  {
+    TembBwdParams t{};
+    t.freq = P(h->w_freq); t.w1 = P(h->w_mlp[0]); t.b1 = P(h->w_mlp[1]); t.w2 = P(h->w_mlp[2]); t.b2 = P(h->w_mlp[3]);
+    t.wn = h->d_params + h->noise_w_off;
+    t.nl = noise_level; t.dtemb = dtemb;
+    t.dw1 = DG(h->w_mlp[0]); t.db1 = DG(h->w_mlp[1]); t.dw2 = DG(h->w_mlp[2]); t.db2 = DG(h->w_mlp[3]);
+    t.dwn = reinterpret_cast<float*>(ws + tp.off_dwn); t.dbn = reinterpret_cast<float*>(ws + tp.off_dbn);
+    t.scratch = reinterpret_cast<float*>(ws + tp.off_tb);
+    t.inner = h->cfg.inner_channel; t.TE = h->TE; t.N = N;
+    HIPCHK(h, launch_temb_bwd(t, st));
+    for (int i = 0; i < h->n_schema; ++i) {               // scatter the concatenated tables back to the per-block tensors
+      const WeightEntry& w = h->weights[i];
+      if (!w.live) continue;
+      if (w.sink == WeightEntry::NOISE_W)
+        HIPCHK(h, hipMemcpyAsync(DG(i), t.dwn + (size_t)w.row_off * t.inner, numel(w.shape) * sizeof(float), hipMemcpyDeviceToDevice, st));
+      else if (w.sink == WeightEntry::NOISE_B)
+        HIPCHK(h, hipMemcpyAsync(DG(i), t.dbn + w.row_off, numel(w.shape) * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
+  }
+  if (loss_host) {
+    HIPCHK(h, hipMemcpyAsync(loss_host, loss_dev, sizeof(float), hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+  }
+  return FDSR_OK;
+}
+
+int fdsr_adam_step(fdsr_handle h, float lr, float beta1, float beta2, float eps, void* hip_stream) {
+  if (!h) return FDSR_E_INVALID;
+  if (!h->train_ready) return fail(h, FDSR_E_STATE, "fdsr_train_grads has not run yet");
+  hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+  h->adam_t += 1;
+  HIPCHK(h, launch_adam(h->d_master, h->d_grad, h->d_adam_m, h->d_adam_v, h->master_floats, lr, beta1, beta2, eps, h->adam_t, st));
+  int rc = repack_from_master(h, st, true);
+  if (rc) return rc;
+  h->wt_valid = true;
+  h->h_forms_stale = true;
+  for (auto& g : h->graphs) (void)hipGraphExecDestroy(g.exec);
+  h->graphs.clear();
+  return FDSR_OK;
+}
+
+static int find_weight(fdsr_handle h, const char* key) {
+  auto it = h->key2w.find(key);
+  if (it == h->key2w.end() || it->second >= h->n_schema) return -1;
+  return it->second;
+}
+
+int fdsr_get_weight(fdsr_handle h, const char* key, float* host) {
+  if (!h || !key || !host) return fail(h, FDSR_E_INVALID, "null argument");
+  const int i = find_weight(h, key);
+  if (i < 0) return fail(h, FDSR_E_KEY, "unexpected key '%s'", key);
+  if (!h->weights[i].live) return fail(h, FDSR_E_KEY, "'%s' is never executed (unet.py:212): the engine keeps no copy", key);
+  if (!h->d_master) return fail(h, FDSR_E_STATE, "no weights loaded");
+  HIPCHK(h, hipMemcpy(host, h->d_master + h->master_off[i], numel(h->weights[i].shape) * sizeof(float), hipMemcpyDeviceToHost));
+  return FDSR_OK;
+}
+
+int fdsr_get_grad(fdsr_handle h, const char* key, float* host) {
+  if (!h || !key || !host) return fail(h, FDSR_E_INVALID, "null argument");
+  const int i = find_weight(h, key);
+  if (i < 0) return fail(h, FDSR_E_KEY, "unexpected key '%s'", key);
+  if (!h->weights[i].live) return fail(h, FDSR_E_KEY, "'%s' is never executed (unet.py:212): it has no gradient", key);
+  if (!h->d_grad) return fail(h, FDSR_E_STATE, "fdsr_train_grads has not run yet");
+  HIPCHK(h, hipMemcpy(host, h->d_grad + h->master_off[i], numel(h->weights[i].shape) * sizeof(float), hipMemcpyDeviceToHost));
+  return FDSR_OK;
+}
+
+// Bring the 16-bit weight forms (f16x3 / bf16 sampling) in line with the master copy after optimiser steps.
+int fdsr_sync_weight_forms(fdsr_handle h) {
+  if (!h) return FDSR_E_INVALID;
+  if (!h->h_forms_stale) return FDSR_OK;
+  HIPCHK(h, hipDeviceSynchronize());
+  std::vector<float> host;
+  for (int i = 0; i < h->n_schema; ++i) {
+    WeightEntry& w = h->weights[i];
+    if (!w.live || w.sink != WeightEntry::CONV_PACK || !w.h_ok) continue;
+    host.resize(numel(w.shape));
+    HIPCHK(h, hipMemcpy(host.data(), h->d_master + h->master_off[i], host.size() * sizeof(float), hipMemcpyDeviceToHost));
+    int rc = pack_weights_h(h, w, host.data());
+    if (rc) return rc;
+  }
+  h->h_forms_stale = false;
+  return FDSR_OK;
+}
+
+}  // extern "C"

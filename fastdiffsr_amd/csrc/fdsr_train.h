@@ -1,0 +1,114 @@
+// Launch interfaces of the training-step kernels (fdsr_train.hip): the backward pass of the FastDiffSR UNet,
+// the loss, Adam and the device-side re-packing of updated weights.  Internal header (not the C ABI).
+//
+// Reference: DDPM.optimize_parameters (model/model.py:47-57) = zero_grad, l_pix = netG(data) (p_losses,
+// model/fastdiffsr_modules/diffusion.py:242-270), l_pix.sum() / (b*c*h*w), backward, Adam.step.
+// All arithmetic here is fp32 (accumulations that cross many pixels in fp64), reductions in a fixed order:
+// a training step is bitwise reproducible like the sampling path.
+#pragma once
+#include "fdsr_kernels.h"
+
+namespace fdsr {
+
+// ---- loss -------------------------------------------------------------------------------------------------
+// eps [N,H,W,3] NHWC (the UNet output), target [N,3,H,W] NCHW (the noise q_sample mixed in):
+//   loss = sum |target - eps| (l1, nn.L1Loss(reduction='sum')) or sum (target - eps)^2 (l2), one fp32 scalar
+//   deps [N,H,W,8] (channels 3..7 zero): d(loss * scale) / d eps
+// partial: scratch of >= loss_partial_floats(N*HW) doubles-as-floats pairs.
+size_t loss_partial_count(size_t npix);
+hipError_t launch_loss_grad(const float* eps, const float* target, float* deps8, double* partial, float* loss_out, int N, int HW,
+                            int l2, float scale, hipStream_t s);
+
+// ---- small helpers -----------------------------------------------------------------------------------------
+// S[n][c] = sum over the pixels of image n of dy[n][p][c]   (bias / noise-shift gradients); fixed order
+hipError_t launch_colsum(const float* dy, float* S, double* scratch, int N, int HW, int C, hipStream_t s);
+size_t colsum_scratch_doubles(int N, int HW, int C);
+// out[c] = sum_n S[n*stride + c], c < C, in image order
+hipError_t launch_sum_rows(const float* S, int N, int stride, int C, float* out, hipStream_t s);
+// z [N,2H,2W,C] = dy [N,H,W,C] at the even positions, zero elsewhere (the stride-2 conv's transpose)
+hipError_t launch_zero_insert(const float* dy, float* z, int N, int H, int W, int C, hipStream_t s);
+// dx [N,H,W,C] += sum of the 2x2 block of du [N,2H,2W,C]   (nearest x2 upsampling, transposed)
+hipError_t launch_pool2_add(const float* du, float* dx, int N, int H, int W, int C, hipStream_t s);
+// dst[n][p][0..C) += src[n][p][off .. off+C) of a tensor with Cs channels (routes a concat half)
+hipError_t launch_add_slice(const float* src, float* dst, size_t npix, int Cs, int off, int C, hipStream_t s);
+
+// ---- GroupNorm + Swish backward ------------------------------------------------------------------------------
+// a = swish(u), u = x * scale + shift  (scale = rstd*gamma, shift = beta - mean*scale; x = virtual concat x0|x1)
+// Given dA [N,HW,C]: g = dA * swish'(u);  dgamma[c] = sum g*xhat, dbeta[c] = sum g,
+// dx = rstd * (gamma*g - mean_grp(gamma*g) - xhat * mean_grp(gamma*g*xhat)), accumulated into dx0 / dx1.
+struct GnBwdParams {
+  const float* dA;                // [N][HW][C0+C1]
+  const float* x0; const float* x1;
+  int C0, C1;
+  const float* scale; const float* shift;   // [N][C]
+  const float* stats;             // [N][G][2] (mean, rstd)
+  const float* gamma;             // [C]
+  float* dx0; float* dx1;         // accumulated (+=); dx1 may be null when C1 == 0
+  float* dgamma; float* dbeta;    // [C], written (=)
+  double* scratch;                // gn_bwd_scratch_doubles()
+  int N, HW, G;
+  int plain;                      // 1: GroupNorm only (no Swish)
+};
+size_t gn_bwd_scratch_doubles(int N, int HW, int C);
+hipError_t launch_gn_bwd(const GnBwdParams& p, hipStream_t s);
+
+// ---- convolution weight gradient -----------------------------------------------------------------------------
+// dW[co][ci][tap] = sum_{n,p} dy[n][p][co] * a[n][p (+) tap][ci], a = the conv's (virtually concatenated,
+// optionally GroupNorm+Swish-activated, optionally nearest-x2 upsampled) input exactly as the forward staged it.
+// Exact fp32 on v_mfma_f32_32x32x2_f32; the pixel range is split over workgroups, slices are summed in order.
+struct WgradParams {
+  const float* dy;                 // [N][Hout][Wout][Cout_s]  (Cout_s = channel stride of dy, >= Cout)
+  const float* x0; const float* x1;
+  const float* gn_scale; const float* gn_shift;   // [N][C0+C1] or null
+  int gn_plain;
+  float* dw;                       // [Cout][Cin][ks][ks] (checkpoint layout), written (=)
+  float* scratch;                  // wgrad_scratch_floats()
+  int N, Hin, Win, Hout, Wout;     // Hin/Win: source dims (before upsampling)
+  int C0, C1, Cin_real;            // Cin_real: channels of the weight tensor (the packed input conv: 6 of 8)
+  int Cout, Cout_s;
+};
+size_t wgrad_scratch_floats(ConvKind kind, int N, int Hout, int Wout, int Cin, int Cout);
+hipError_t launch_wgrad(ConvKind kind, const WgradParams& p, hipStream_t s);
+hipError_t train_kernels_init();
+
+// ---- CLAM / SLAM backward (unet.py:123-173) -----------------------------------------------------------------
+// forward: gate = sigmoid(fc2 relu(fc1 avg) + fc2 relu(fc1 max)), y = x*gate, m = [mean_c y, max_c y],
+//          out = y * sigmoid(conv7x7(m))
+struct ClamSlamBwdParams {
+  const float* x;          // [N][HW][C] input of the pair (the ResnetBlock output)
+  const float* dout;       // [N][HW][C]
+  float* dx;               // [N][HW][C] accumulated (+=)
+  const float* fc1; const float* fc2; const float* w7;   // [Cr][C], [C][Cr], [2][7][7]
+  float* dfc1; float* dfc2; float* dw7;                  // written (=)
+  float* scratch;          // clam_slam_bwd_scratch_floats()
+  int N, H, W, C, Cr;
+};
+size_t clam_slam_bwd_scratch_floats(int N, int HW, int C, int Cr);
+hipError_t launch_clam_slam_bwd(const ClamSlamBwdParams& p, hipStream_t s);
+
+// ---- noise-level embedding backward (unet.py:22-54, :242-248) ---------------------------------------------------
+// forward: enc = [sin, cos](nl * freq); hid = swish(W1 enc + b1); t = W2 hid + b2; temb = Wn t + bn
+// dtemb [N][TE] = per-(image, channel) sums of the block1 output gradients.
+struct TembBwdParams {
+  const float* freq; const float* w1; const float* b1; const float* w2; const float* b2; const float* wn;
+  const float* nl;         // [N]
+  const float* dtemb;      // [N][TE]
+  float* dw1; float* db1; float* dw2; float* db2; float* dwn; float* dbn;   // written (=)
+  float* scratch;          // N * (6*inner) floats
+  int inner, TE, N;
+};
+hipError_t launch_temb_bwd(const TembBwdParams& p, hipStream_t s);
+
+// ---- optimiser -----------------------------------------------------------------------------------------------
+// torch.optim.Adam (defaults of model.py:37-38: betas (0.9, 0.999), eps 1e-8, no weight decay, no amsgrad):
+//   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; w -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+hipError_t launch_adam(float* w, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, int step,
+                       hipStream_t s);
+// checkpoint layout [Cout][Cin][ks][ks] -> the fp32 kernel's [tap][Cout_pad][Cin_pad] (zero padded)
+hipError_t launch_pack_conv_f32(const float* w, float* packed, int Cout, int Cin, int ks, int cout_pad, int cin_pad, hipStream_t s);
+// ... and the transposed, tap-flipped form the input-gradient convolution runs on:
+// packed_t[tap][ci][co] = w[co][c_off + ci][flip(tap)], ci < Csub: [tap][round_up(Csub,BN)][round_up(Cout,KC)]
+hipError_t launch_pack_conv_f32_t(const float* w, float* packed_t, int Cout, int Cin, int ks, int c_off, int Csub, int rows_pad,
+                                  int cols_pad, hipStream_t s);
+
+}  // namespace fdsr

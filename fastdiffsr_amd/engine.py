@@ -174,6 +174,54 @@ class Engine:
         _lib.check(self.h, self.lib.fdsr_set_precision(self.h, code))
         self.precision = mode
 
+    # -- training step ------------------------------------------------------------
+    def train_workspace_bytes(self, B, H, W):
+        n = C.c_size_t()
+        _lib.check(self.h, self.lib.fdsr_train_workspace_bytes(self.h, B, H, W, C.byref(n)))
+        return int(n.value)
+
+    def train_grads(self, x, noise_level, target, loss_type='l1', loss_scale=1.0):
+        """Forward + loss + backward on the device (include/fdsr.h: fdsr_train_grads).  Returns the unscaled
+        summed loss (python float); the gradients stay on the device (get_grad / adam_step)."""
+        x = self._check_input(x, 'x')
+        target = self._check_input(target, 'target')
+        B, _, H, W = x.shape
+        nl = self._check_input(noise_level.to(x.device), 'noise_level').reshape(-1)
+        if nl.numel() != B or tuple(target.shape) != (B, 3, H, W):
+            raise ValueError('noise_level must be [B] and target [B,3,H,W]')
+        need = self.train_workspace_bytes(B, H, W)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != x.device:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+        ws = self._ws
+        loss = C.c_float()
+        st = torch.cuda.current_stream(x.device).cuda_stream
+        _lib.check(self.h, self.lib.fdsr_train_grads(self.h, _ptr(x), _ptr(nl), _ptr(target), {'l1': 0, 'l2': 1}[loss_type],
+                                                     C.c_float(float(loss_scale)), C.byref(loss), B, H, W, _ptr(ws), ws.numel(),
+                                                     C.c_void_p(st)))
+        self._keep = (x, nl, target)
+        return float(loss.value)
+
+    def adam_step(self, lr, betas=(0.9, 0.999), eps=1e-8):
+        st = torch.cuda.current_stream().cuda_stream
+        _lib.check(self.h, self.lib.fdsr_adam_step(self.h, C.c_float(lr), C.c_float(betas[0]), C.c_float(betas[1]), C.c_float(eps),
+                                                   C.c_void_p(st)))
+
+    def _fetch(self, fn, key):
+        shape = {k: s for k, s, _ in self.schema()}[key]
+        a = np.empty(shape, dtype=np.float32)
+        _lib.check(self.h, fn(self.h, key.encode(), a.ctypes.data_as(C.c_void_p)))
+        return a
+
+    def get_weight(self, key):
+        """Master copy of one executed tensor (checkpoint layout), after any optimiser steps."""
+        torch.cuda.synchronize()
+        return self._fetch(self.lib.fdsr_get_weight, key)
+
+    def get_grad(self, key):
+        torch.cuda.synchronize()
+        return self._fetch(self.lib.fdsr_get_grad, key)
+
     # -- introspection ----------------------------------------------------------
     def set_debug(self, on=True):
         _lib.check(self.h, self.lib.fdsr_set_debug(self.h, int(on)))

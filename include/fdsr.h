@@ -192,6 +192,43 @@ int fdsr_profile_begin(fdsr_handle h);
 int fdsr_profile_end(fdsr_handle h, int* launches, double* conv_ms, double* conv_flops,
                      double* conv_bytes);
 
+/* ---- training step (FastDiffSR variant) -------------------------------------------------
+ * DDPM.optimize_parameters (model/model.py:47-57): zero_grad, l_pix = netG(data) = p_losses
+ * (fastdiffsr_modules/diffusion.py:242-270), l_pix.sum() / (b*c*h*w), backward, Adam.step.  The engine keeps
+ * an fp32 master copy of every executed checkpoint tensor, its gradient and the two Adam moments on the
+ * device; the convolutions of the step run in exact fp32 (fdsr_set_precision(FDSR_PREC_F32)), every
+ * reduction in a fixed order: a step is bitwise reproducible.  The 44 never-executed tensors of the schema
+ * (unet.py:212) get no gradient and are not touched, as in torch. */
+
+/* Workspace for fdsr_train_grads at this shape (the forward keeps every activation). */
+int fdsr_train_workspace_bytes(fdsr_handle h, int batch, int height, int width, size_t* bytes);
+
+/* Forward + loss + backward: gradients of  loss_scale * loss(target, UNet(x, noise_level))  w.r.t. every
+ * executed parameter, left on the device (fdsr_get_grad).
+ *   x_nchw       [B,6,H,W]  cat([SR, x_noisy]) (diffusion.py:265-266), x_noisy = q_sample(img2res(HR,SR), gamma, noise)
+ *   noise_level  [B]        gamma, the continuous sqrt(alpha_bar) drawn per sample (:246-255)
+ *   target_nchw  [B,3,H,W]  the noise that q_sample mixed in (:259)
+ *   loss_l2      0: nn.L1Loss(reduction='sum') (loss_type 'l1', :101-103); 1: nn.MSELoss(reduction='sum')
+ *   loss_scale   the reference divides the summed loss by b*c*h*w before backward (model.py:50-52)
+ *   loss_host    optional: receives the UNSCALED summed loss (what netG(data) returns); synchronises the stream
+ * All pointers but loss_host are device pointers. */
+int fdsr_train_grads(fdsr_handle h, const float* x_nchw, const float* noise_level, const float* target_nchw,
+                     int loss_l2, float loss_scale, float* loss_host, int batch, int height, int width,
+                     void* workspace, size_t workspace_bytes, void* hip_stream);
+
+/* torch.optim.Adam.step on every executed tensor (model.py:37-38, :56: lr from the config, betas (0.9, 0.999),
+ * eps 1e-8), then the device-side re-packing of the fp32 kernel forms. */
+int fdsr_adam_step(fdsr_handle h, float lr, float beta1, float beta2, float eps, void* hip_stream);
+
+/* Copy one tensor of the master copy / of the last gradients to the host, in checkpoint layout
+ * (state_dict() after training; tests).  Never-executed tensors: FDSR_E_KEY. */
+int fdsr_get_weight(fdsr_handle h, const char* key, float* host);
+int fdsr_get_grad(fdsr_handle h, const char* key, float* host);
+
+/* After optimiser steps: rebuild the 16-bit weight forms (f16x3 / bf16 sampling) from the master copy.
+ * fdsr_set_precision does this by itself when needed. */
+int fdsr_sync_weight_forms(fdsr_handle h);
+
 #ifdef __cplusplus
 }
 #endif

@@ -46,7 +46,8 @@ def _synthetic_hr(cond):
 def _psnr_delta(out, ref, cond):
     from oracle import fdsr_oracle as O
     hr = O.tensor2img_u8(_synthetic_hr(cond)[0])
-    return O.psnr_u8(O.tensor2img_u8(out[0]), hr) - O.psnr_u8(O.tensor2img_u8(ref[0]), hr)
+    # tensor2img clamps its argument in place (like the reference's): work on copies
+    return O.psnr_u8(O.tensor2img_u8(out[0].clone()), hr) - O.psnr_u8(O.tensor2img_u8(ref[0].clone()), hr)
 
 
 def _oracle_image(sd, cfg, cond1, noise1):
@@ -86,10 +87,13 @@ def test_config2_bf16_b64_hipgraph_256(full):
         i = 41
         ref = _oracle_image(sd, cfg, cond[i:i + 1], noise[:, i:i + 1])
         dps = _psnr_delta(out[i:i + 1].cpu(), ref, cond[i:i + 1])
-        d = (out[i:i + 1].cpu() - ref).abs().max().item()
-        print(f'configs[2] bf16 B=64 graph: image {i} vs oracle PSNR delta {dps:+.5f} dB, max|d| {d:.3e}')
+        diff = out[i:i + 1].cpu() - ref
+        d, rmse = diff.abs().max().item(), diff.pow(2).mean().sqrt().item()
+        print(f'configs[2] bf16 B=64 graph: image {i} vs oracle PSNR delta {dps:+.5f} dB, max|d| {d:.3e}, rmse {rmse:.3e}')
         assert abs(dps) <= 0.01
-        assert d <= 0.25            # sanity only: bf16 is outside the 1e-3 bound by design
+        # sanity only: bf16 is outside the 1e-3 bound by design (CPU bf16 autocast differs by rmse 1.9e-3,
+        # max 4.9e-2; isolated pixels can flip the x_0 clamp)
+        assert rmse <= 0.02
     finally:
         eng.set_precision('f32')
 

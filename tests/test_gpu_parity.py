@@ -175,7 +175,7 @@ def _oracle_256(sd, cfg, idx, cond, noise):
     if idx not in _ORACLE_256:
         tab = O.schedule_tables(FASTDIFFSR_SCHEDULE_VAL)
         _ORACLE_256[idx] = O.p_sample_loop(O.to_torch_sd(sd), cfg, tab, cond, noise)
-    return _ORACLE_256[idx]
+    return _ORACLE_256[idx].clone()          # tensor2img clamps its argument in place, like the reference's
 
 
 @pytest.mark.parametrize('prec', ['f32', 'f16x3'])

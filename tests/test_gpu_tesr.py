@@ -91,6 +91,7 @@ def test_tesr_facade_reference_config_and_loss(golden_dir):
     assert abs(loss.item() - float(g['loss'])) <= 1e-5 * abs(float(g['loss']))
     # the reference's TESR x4 config at 64x64 (attention where image_size / 2^level == 16 and in mid[0])
     big = networks.define_G(opt_for(TESR_UNET, TESR_SCHEDULE_VAL, 256)).to(dev)
+    big.eval()                                       # train mode has live dropout (refused until the mask kernel exists)
     cfg = UNetConfig(**TESR_UNET)
     sdb = synth_state_dict(cfg, 4)
     big.denoise_fn.load_state_dict({k: torch.from_numpy(v) for k, v in sdb.items()}, strict=True)

@@ -1,0 +1,134 @@
+"""One optimisation step on the device against one step of the reference itself
+(tests/golden/train_step.npz, made by oracle/make_goldens.py from model/model.py:47-57 with dropout off) and,
+tensor by tensor, against autograd over the oracle: loss, all 273 gradients, the Adam update."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from fastdiffsr_amd.arch import UNetConfig, FASTDIFFSR_UNET
+from fastdiffsr_amd.synth import synth_state_dict
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(golden_dir):
+    tl = np.load(os.path.join(golden_dir, 'train_loss.npz'))
+    hr, sr, nz = (torch.from_numpy(tl[k]) for k in ('hr', 'sr', 'noise'))
+    gamma = torch.FloatTensor(tl['gamma'])
+    return hr, sr, nz, gamma
+
+
+def _x_noisy(hr, sr, nz, gamma):
+    """img2res + q_sample in torch, as the facade forms them (diffusion.py:233-241, :283-289)."""
+    x_start = ((hr - sr) * 2.0).clamp(-1, 1)
+    g = gamma.view(-1, 1, 1, 1)
+    return g * x_start + (1 - g ** 2).sqrt() * nz
+
+
+@pytest.fixture(scope='module')
+def stepped(golden_dir):
+    from fastdiffsr_amd.engine import Engine
+    from oracle import fdsr_oracle as O
+    cfg = UNetConfig(**FASTDIFFSR_UNET)
+    sd = synth_state_dict(cfg, 0)
+    eng = Engine(cfg)
+    eng.load_state_dict(sd)
+    eng.set_precision('f32')
+    hr, sr, nz, gamma = _inputs(golden_dir)
+    b, c, h, w = hr.shape
+    x = torch.cat([sr, _x_noisy(hr, sr, nz, gamma)], 1)
+    loss = eng.train_grads(x.cuda(), gamma.cuda(), nz.cuda(), 'l1', 1.0 / (b * c * h * w))
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    l_ref, grads_ref, new_ref = O.train_step(O.to_torch_sd(sd), cfg, hr, sr, gamma, nz, lr=1e-4)
+    return cfg, sd, eng, loss, (b * c * h * w), l_ref, grads_ref, new_ref
+
+
+def test_loss_matches_reference_step(stepped, golden_dir):
+    cfg, sd, eng, loss, numel, l_ref, grads_ref, new_ref = stepped
+    g = np.load(os.path.join(golden_dir, 'train_step.npz'))
+    l_pix = loss / numel
+    assert abs(l_pix - float(g['l_pix'])) <= 1e-5 * abs(float(g['l_pix'])), (l_pix, float(g['l_pix']))
+    assert abs(l_pix - l_ref.item()) <= 1e-5 * abs(l_ref.item())
+
+
+def test_all_gradients(stepped, golden_dir):
+    """Every executed tensor: max |g_hip - g_autograd| <= 1e-4 * max|g|; and the per-tensor (sum, sum of squares)
+    the reference's own backward produced.  The 44 never-executed tensors have no gradient."""
+    from fastdiffsr_amd import _lib
+    cfg, sd, eng, loss, numel, l_ref, grads_ref, new_ref = stepped
+    g = np.load(os.path.join(golden_dir, 'train_step.npz'))
+    keys = [str(k) for k in g['grad_keys']]
+    assert len(keys) == 273 and sorted(keys) == sorted(grads_ref.keys())
+    worst = (0.0, '')
+    for k, (s1, s2) in zip(keys, g['grad_stats']):
+        got = eng.get_grad(k)
+        ref = grads_ref[k].numpy()
+        assert got.shape == ref.shape, k
+        scale = max(float(np.abs(ref).max()), 1e-12)
+        d = float(np.abs(got - ref).max())
+        worst = max(worst, (d / scale, k))
+        assert d <= 1e-4 * scale, f'{k}: max|d| {d:.3e} vs max|g| {scale:.3e}'
+        g64 = got.astype(np.float64)
+        assert abs(g64.sum() - s1) <= 3e-4 * max(np.sqrt(s2), 1e-12) + 1e-9, k
+        assert abs((g64 * g64).sum() - s2) <= 3e-4 * s2 + 1e-18, k
+    print(f'worst gradient: {worst[1]} at {worst[0]:.3e} x max|g|')
+    for k in ('downs.0.weight', 'mid.0.sa.conv1.weight', 'final_conv.block.3.bias'):     # the reference's own tensors
+        ref = g['grad/' + k]
+        assert np.abs(eng.get_grad(k) - ref).max() <= 2e-4 * np.abs(ref).max() + 1e-9, k
+    dead = [k for k in sd if k not in grads_ref]
+    assert len(dead) == 44 == int(g['n_params_without_grad'])
+    with pytest.raises(_lib.FdsrError):
+        eng.get_grad(dead[0])
+
+
+def test_adam_update_and_weights_in_use(stepped, golden_dir):
+    cfg, sd, eng, loss, numel, l_ref, grads_ref, new_ref = stepped
+    g = np.load(os.path.join(golden_dir, 'train_step.npz'))
+    lr = float(g['lr'])
+    eng.adam_step(lr)
+    for k in ('downs.0.weight', 'mid.0.sa.conv1.weight', 'final_conv.block.3.bias'):
+        ref_g, aft, ref_aft = g['grad/' + k], eng.get_weight(k), g['after/' + k]
+        mask = np.abs(ref_g) > 1e-3 * np.abs(ref_g).max()          # Adam's first step is ~lr*sign(g): compare where |g| is not tiny
+        assert np.abs(aft - ref_aft)[mask].max() <= 2e-7, k
+        assert np.abs(aft - ref_aft).max() <= 2.1 * lr, k
+    # every executed tensor against the oracle's update, where its gradient is not tiny
+    for k, ref in new_ref.items():
+        if k not in grads_ref:
+            continue
+        gk = grads_ref[k].numpy()
+        mask = np.abs(gk) > 1e-3 * np.abs(gk).max()
+        if mask.any():
+            assert np.abs(eng.get_weight(k) - ref.numpy())[mask].max() <= 3e-7, k
+    # the forward now runs on the updated weights (device-side re-pack): same as a fresh engine loaded with them
+    from fastdiffsr_amd.engine import Engine
+    new_sd = {k: (eng.get_weight(k) if k in grads_ref else v) for k, v in sd.items()}
+    e2 = Engine(cfg)
+    e2.load_state_dict(new_sd)
+    x = torch.randn(1, 6, 32, 32, generator=torch.Generator().manual_seed(3)).cuda()
+    nl = torch.tensor([[0.4]]).cuda()
+    for prec in ('f32', 'f16x3'):
+        eng.set_precision(prec)
+        e2.set_precision(prec)
+        assert torch.equal(eng.unet_forward(x, nl), e2.unet_forward(x, nl)), prec
+    eng.set_precision('f32')
+
+
+def test_step_is_bitwise_reproducible(golden_dir):
+    from fastdiffsr_amd.engine import Engine
+    cfg = UNetConfig(**FASTDIFFSR_UNET)
+    sd = synth_state_dict(cfg, 0)
+    hr, sr, nz, gamma = _inputs(golden_dir)
+    x = torch.cat([sr, _x_noisy(hr, sr, nz, gamma)], 1).cuda()
+    outs = []
+    for _ in range(2):
+        eng = Engine(cfg)
+        eng.load_state_dict(sd)
+        eng.set_precision('f32')
+        loss = eng.train_grads(x, gamma.cuda(), nz.cuda(), 'l1', 1.0 / x.numel() * 2)
+        outs.append((loss, eng.get_grad('downs.4.res_block.block1.block.3.weight'), eng.get_grad('noise_level_mlp.1.weight'),
+                     eng.get_grad('ups.14.res_block.block2.block.0.weight')))
+    assert outs[0][0] == outs[1][0]
+    for a, b in zip(outs[0][1:], outs[1][1:]):
+        assert np.array_equal(a, b)
