@@ -59,6 +59,9 @@ SYMBOLS = {
     'fdsr_set_debug': (C.c_int, [C.c_void_p, C.c_int]),
     'fdsr_debug_tensor': (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                     C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    'fdsr_set_training': (C.c_int, [C.c_void_p, C.c_int]),
+    'fdsr_debug_dropout_mask': (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                          C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_float)]),
     'fdsr_train_workspace_bytes': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
     'fdsr_train_grads': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.POINTER(C.c_float), C.c_int,
                                    C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -66,6 +69,9 @@ SYMBOLS = {
     'fdsr_get_weight': (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p]),
     'fdsr_get_grad': (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p]),
     'fdsr_sync_weight_forms': (C.c_int, [C.c_void_p]),
+    'fdsr_get_optimizer_state': (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
+    'fdsr_set_optimizer_state': (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_int]),
+    'fdsr_grad_arena': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     'fdsr_profile_begin': (C.c_int, [C.c_void_p]),
     'fdsr_profile_end': (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                    C.POINTER(C.c_double)]),

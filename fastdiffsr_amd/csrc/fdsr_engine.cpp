@@ -198,6 +198,7 @@ int build_plan(fdsr_handle h) {
     Op k2; k2.kind = Op::CONV; k2.name = r + ".block2"; k2.ck = CONV3_S1; k2.src0 = k1.dst; k2.C0 = Cout; k2.Cout = Cout;
     k2.lvl_in = k2.lvl_out = lvl; k2.gn_slot = s2.gn_slot; k2.gamma = g2; k2.beta = b2; k2.w = w2; k2.b = c2; k2.res = res_src;
     k2.dst = out;
+    if (c.dropout > 0.f) k2.drop_slot = h->n_drop_slots++;   // block2 = Block(dim_out, dim_out, dropout=dropout), unet.py:112
     h->ops.push_back(k2);
     int result = out;
     if (with_attn && h->attn_blocks) {
@@ -451,6 +452,14 @@ int make_shape_plan(fdsr_handle h, int N, int H, int W, ShapePlan* sp) {
       sp->gn_off[op.gn_slot] = off;
       off += align_up((size_t)2 * N * (op.C0 + op.C1) * sizeof(float), 256);
     }
+  sp->training = h->training;
+  sp->drop_off.assign(h->n_drop_slots, 0);
+  if (h->training)
+    for (const Op& op : h->ops)
+      if (op.kind == Op::CONV && op.drop_slot >= 0) {
+        sp->drop_off[op.drop_slot] = off;
+        off += align_up((size_t)N * (H >> op.lvl_in) * (W >> op.lvl_in) * op.C0, 256);
+      }
   sp->gn_stats_off.assign(h->n_gn_slots, 0);
   for (int g = 0; g < h->n_gn_slots; ++g) {
     sp->gn_stats_off[g] = off;
@@ -545,7 +554,9 @@ int make_shape_plan(fdsr_handle h, int N, int H, int W, ShapePlan* sp) {
 }
 
 int get_plan(fdsr_handle h, int N, int H, int W) {
-  if (h->plan.N == N && h->plan.H == H && h->plan.W == W && h->plan.debug == h->debug && h->plan.bytes) return FDSR_OK;
+  if (h->plan.N == N && h->plan.H == H && h->plan.W == W && h->plan.debug == h->debug && h->plan.training == h->training &&
+      h->plan.bytes)
+    return FDSR_OK;
   ShapePlan sp;
   int rc = make_shape_plan(h, N, H, W, &sp);
   if (rc) return rc;
@@ -576,6 +587,12 @@ int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, 
   if (!temb_row) {
     int rc = fill_temb(h, reinterpret_cast<float*>(ws + sp.off_temb), N, nl_dev, nl_scalar, st);
     if (rc) return rc;
+  }
+  const bool dropout_on = h->training && h->n_drop_slots > 0;
+  if (dropout_on) {
+    if (h->prec != PREC_F32)
+      return fail(h, FDSR_E_INVALID, "train mode with dropout runs on the exact-fp32 kernels: fdsr_set_precision(FDSR_PREC_F32)");
+    h->drop_step += 1;
   }
   for (size_t oi = 0; oi < h->ops.size(); ++oi) {
     const Op& op = h->ops[oi];
@@ -613,6 +630,13 @@ int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, 
           p.gn_plain = op.b == -2 ? 1 : 0;   // attn.qkv: SelfAttention.norm has no Swish
         }
         p.part_out = op.no_part ? nullptr : PART(op.dst);   // res_conv output is overwritten in place by block2
+        if (dropout_on && op.drop_slot >= 0) {              // Dropout(p) between Swish and this conv (train mode)
+          unsigned char* mask = reinterpret_cast<unsigned char*>(ws + sp.drop_off[op.drop_slot]);
+          HIPCHK(h, launch_dropout_mask(mask, (size_t)N * Hi * Wi * op.C0, h->rng_seed, h->drop_step, (unsigned)op.drop_slot,
+                                        h->cfg.dropout, st));
+          p.drop_mask = mask;
+          p.drop_scale = 1.0f / (1.0f - h->cfg.dropout);
+        }
         // bf16 mode keeps every activation but the packed input and eps as bf16 in HBM
         p.out_f32 = (op.dst == h->t_eps) ? 1 : 0;
         p.out_bf16 = (h->prec == PREC_BF16 && op.dst != h->t_eps) ? 1 : 0;
@@ -1184,6 +1208,31 @@ int fdsr_set_precision(fdsr_handle h, int mode) {
   }
   h->prec = mode;
   return FDSR_OK;
+}
+
+int fdsr_set_training(fdsr_handle h, int on) {
+  if (!h) return FDSR_E_INVALID;
+  if (on && h->cfg.dropout >= 1.0f) return fail(h, FDSR_E_INVALID, "dropout must be < 1");
+  h->training = on != 0;
+  return FDSR_OK;
+}
+
+int fdsr_debug_dropout_mask(fdsr_handle h, const char* block, const unsigned char** dev_off, int* n, int* hgt, int* wid, int* ch,
+                            float* scale) {
+  if (!h || !block) return fail(h, FDSR_E_INVALID, "null argument");
+  if (!h->plan.bytes || !h->plan.training) return fail(h, FDSR_E_STATE, "no training-mode forward has run yet");
+  const std::string want = std::string(block) + ".res_block.block2";
+  for (const Op& op : h->ops)
+    if (op.kind == Op::CONV && op.drop_slot >= 0 && op.name == want) {
+      if (dev_off) *dev_off = reinterpret_cast<const unsigned char*>(h->plan.drop_off[op.drop_slot]);   // offset into the workspace
+      if (n) *n = h->plan.N;
+      if (hgt) *hgt = h->plan.H >> op.lvl_in;
+      if (wid) *wid = h->plan.W >> op.lvl_in;
+      if (ch) *ch = op.C0;
+      if (scale) *scale = 1.0f / (1.0f - h->cfg.dropout);
+      return FDSR_OK;
+    }
+  return fail(h, FDSR_E_KEY, "no dropout in front of block '%s'", block);
 }
 
 int fdsr_set_debug(fdsr_handle h, int on) {

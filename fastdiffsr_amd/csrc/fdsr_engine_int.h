@@ -58,6 +58,7 @@ struct Op {
   int fc1 = -1, fc2 = -1;
   bool no_part = false;   // dst is overwritten later by another producer (res_conv pre-fill)
   int aux = -1;           // ATTN: scratch tensor for the scores
+  int drop_slot = -1;     // block2 conv with Dropout(p > 0) in front of it (unet.py:89-101): index of its keep-mask
 };
 
 struct ShapePlan {
@@ -69,6 +70,8 @@ struct ShapePlan {
   std::vector<size_t> tensor_off;
   std::vector<size_t> part_off;    // per tensor: per-tile channel sums [N][max_tiles][C][2] (0 = none)
   std::vector<size_t> gn_off;      // per GroupNorm slot: scale [N][C] then shift [N][C]
+  std::vector<size_t> drop_off;    // per dropout slot: keep bytes [N][HW][C] (plans made in training mode only)
+  bool training = false;
   std::vector<size_t> gn_stats_off;   // per GroupNorm slot: (mean, rstd) [N][G][2], written when the engine keeps statistics
   std::vector<int> tensor_nt;      // tiles per image its producer actually used (set at launch)
 };
@@ -142,6 +145,9 @@ struct fdsr_engine {
   float* d_zero = nullptr;            // zeros (bias of the input-gradient convolutions)
   bool train_ready = false;
   bool wt_valid = false;              // d_wt matches d_master
+  bool training = false;              // .train(): Dropout(p) of block2 is live (unet.py:89-101); fp32 kernels only
+  int n_drop_slots = 0;
+  unsigned drop_step = 0;             // forward passes made in training mode: part of the mask's Philox counter
   bool keep_stats = false;            // forward also stores per-(image, group) mean / rstd of every GroupNorm
   bool h_forms_stale = false;         // 16-bit weight forms lag behind the master copy (after an optimiser step)
 };

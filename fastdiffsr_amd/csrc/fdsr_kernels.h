@@ -41,6 +41,10 @@ struct ConvParams {
   // conv: eps feeds the fp32 posterior update); the fp32 kernel sets out_bf16 for the 6-channel input conv.
   int out_f32;
   int out_bf16;
+  // train-mode Dropout(p) between Swish and the conv of block2 (unet.py:89-101): a = swish(gn(x)) * keep * 1/(1-p).
+  // keep is a byte per element of the input tensor (dropout_mask_kernel); fp32 kernel only.
+  const unsigned char* drop_mask;   // [N][Hin][Win][C0] or null
+  float drop_scale;
 };
 
 enum Precision { PREC_F32 = 0, PREC_F16X3 = 1, PREC_BF16 = 2 };
@@ -115,6 +119,11 @@ hipError_t launch_clam_gate(const float* x, int N, int HW, int C, const float* f
 hipError_t launch_slam(const float* x, float* scratch, const float* w7 /*[2][7][7]*/,
                        int N, int H, int W, int C, float* out, float* part_out, hipStream_t s, int* tiles_per_image,
                        int act_bf16 /* x and out are bf16 tensors (bf16 mode) */);
+
+// Dropout keep-mask of one block: byte e = 1 with probability 1-p, a pure function of (seed, step, slot, e)
+// (Philox4x32-10), so a run can be repeated and the mask inspected (fdsr_debug_dropout_mask).
+hipError_t launch_dropout_mask(unsigned char* mask, size_t n, unsigned long long seed, unsigned step, unsigned slot, float p,
+                               hipStream_t s);
 
 // layout changes at the boundary
 hipError_t launch_nchw_to_nhwc(const float* src, float* dst, int N, int Csrc, int H, int W,

@@ -115,6 +115,9 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_f32_kernel(const ConvParams 
 
   f32x4 rin[NIN];
   f32x4 rw[NW];
+  unsigned rmask[NIN];                 // train-mode dropout: 4 keep bytes per staged quad (all ones when off)
+#pragma unroll
+  for (int i = 0; i < NIN; ++i) rmask[i] = 0x01010101u;
   f32x4 rsc = {1.f, 1.f, 1.f, 1.f}, rsh = {0.f, 0.f, 0.f, 0.f};
   auto prefetch = [&](int kc) {
     const int cbase = kc * KC;
@@ -131,6 +134,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_f32_kernel(const ConvParams 
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (in_pix[i] >= 0) v = *reinterpret_cast<const f32x4*>(base + (size_t)in_pix[i] * Cs + cc);
       rin[i] = v;
+      if (p.drop_mask && in_pix[i] >= 0) rmask[i] = *reinterpret_cast<const unsigned*>(p.drop_mask + (size_t)in_pix[i] * Cs + cc);
     }
 #pragma unroll
     for (int i = 0; i < NW; ++i) {
@@ -152,6 +156,10 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_f32_kernel(const ConvParams 
       if (gn && in_pix[i] >= 0) {   // conv zero-pads the ACTIVATED tensor
         v = v * sc + sh;
         if (!p.gn_plain) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+        if (p.drop_mask) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = ((rmask[i] >> (8 * e)) & 0xffu) ? v[e] * p.drop_scale : 0.f;
+        }
       }
       *reinterpret_cast<f32x4*>(sIn + (row0 + i * RPP) * S + q * 4) = v;
     }
@@ -790,6 +798,33 @@ __global__ void rng_advance_kernel(unsigned long long* rng) {
 }
 hipError_t launch_rng_advance(unsigned long long* rng, hipStream_t s) {
   hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(64), 0, s, rng);
+  return hipGetLastError();
+}
+
+// four keep bytes per Philox call: byte e of quad i = (word e >= p * 2^32)
+__global__ void __launch_bounds__(256) dropout_mask_kernel(unsigned* __restrict__ mask4, size_t nquads, unsigned long long seed,
+                                                           unsigned step, unsigned slot, unsigned thresh) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= nquads) return;
+  unsigned c0 = (unsigned)i, c1 = (unsigned)(i >> 32), c2 = slot, c3 = step;
+  unsigned k0 = (unsigned)seed ^ 0x44524F50u /* 'DROP' */, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c0, c1, c2, c3, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  mask4[i] = (c0 >= thresh ? 1u : 0u) | (c1 >= thresh ? 0x100u : 0u) | (c2 >= thresh ? 0x10000u : 0u) | (c3 >= thresh ? 0x1000000u : 0u);
+}
+
+hipError_t launch_dropout_mask(unsigned char* mask, size_t n, unsigned long long seed, unsigned step, unsigned slot, float p,
+                               hipStream_t s) {
+  if (n & 3) return hipErrorInvalidValue;
+  const double t = (double)p * 4294967296.0;
+  const unsigned thresh = t >= 4294967295.0 ? 0xffffffffu : (unsigned)t;
+  const size_t nq = n >> 2;
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, reinterpret_cast<unsigned*>(mask), nq, seed,
+                     step, slot, thresh);
   return hipGetLastError();
 }
 

@@ -317,6 +317,10 @@ int fdsr_train_grads(fdsr_handle h, const float* x_nchw, const float* noise_leve
       q.dw = DG(op.w); q.scratch = wg;
       q.N = N; q.Hin = Hi; q.Win = Wi; q.Hout = Ho; q.Wout = Wo;
       q.C0 = op.C0; q.C1 = op.C1; q.Cin_real = (int)w.shape[1]; q.Cout = op.Cout; q.Cout_s = K;
+      if (sp.training && op.drop_slot >= 0) {
+        q.drop_mask = reinterpret_cast<const unsigned char*>(ws + sp.drop_off[op.drop_slot]);
+        q.drop_scale = 1.0f / (1.0f - h->cfg.dropout);
+      }
       HIPCHK(h, launch_wgrad(op.ck, q, st));
     }
     if (op.src0 == h->t_in) continue;                     // no gradient w.r.t. the network input
@@ -333,6 +337,10 @@ int fdsr_train_grads(fdsr_handle h, const float* x_nchw, const float* noise_leve
       g.dgamma = DG(op.gamma); g.dbeta = DG(op.beta);
       g.scratch = dbl;
       g.N = N; g.HW = Hi * Wi; g.G = G; g.plain = op.b == -2 ? 1 : 0;
+      if (sp.training && op.drop_slot >= 0) {
+        g.drop_mask = reinterpret_cast<const unsigned char*>(ws + sp.drop_off[op.drop_slot]);
+        g.drop_scale = 1.0f / (1.0f - h->cfg.dropout);
+      }
       HIPCHK(h, launch_gn_bwd(g, st));
     } else if (op.ck == CONV3_S2) {
       HIPCHK(h, launch_zero_insert(dy, tmpZ, N, Ho, Wo, K, st));
@@ -413,6 +421,43 @@ int fdsr_get_grad(fdsr_handle h, const char* key, float* host) {
   if (!h->weights[i].live) return fail(h, FDSR_E_KEY, "'%s' is never executed (unet.py:212): it has no gradient", key);
   if (!h->d_grad) return fail(h, FDSR_E_STATE, "fdsr_train_grads has not run yet");
   HIPCHK(h, hipMemcpy(host, h->d_grad + h->master_off[i], numel(h->weights[i].shape) * sizeof(float), hipMemcpyDeviceToHost));
+  return FDSR_OK;
+}
+
+// torch.optim.Adam's per-parameter state (exp_avg, exp_avg_sq) and its step count, for `_opt.pth` (model.py:126-166)
+int fdsr_get_optimizer_state(fdsr_handle h, const char* key, float* exp_avg, float* exp_avg_sq, int* step) {
+  if (!h || !key) return fail(h, FDSR_E_INVALID, "null argument");
+  const int i = find_weight(h, key);
+  if (i < 0 || !h->weights[i].live) return fail(h, FDSR_E_KEY, "no optimiser state for '%s'", key);
+  if (!h->train_ready) return fail(h, FDSR_E_STATE, "no optimiser step has run yet");
+  const size_t n = numel(h->weights[i].shape) * sizeof(float);
+  if (exp_avg) HIPCHK(h, hipMemcpy(exp_avg, h->d_adam_m + h->master_off[i], n, hipMemcpyDeviceToHost));
+  if (exp_avg_sq) HIPCHK(h, hipMemcpy(exp_avg_sq, h->d_adam_v + h->master_off[i], n, hipMemcpyDeviceToHost));
+  if (step) *step = h->adam_t;
+  return FDSR_OK;
+}
+
+int fdsr_set_optimizer_state(fdsr_handle h, const char* key, const float* exp_avg, const float* exp_avg_sq, int step) {
+  if (!h || !key || !exp_avg || !exp_avg_sq || step < 0) return fail(h, FDSR_E_INVALID, "bad optimiser state");
+  const int i = find_weight(h, key);
+  if (i < 0 || !h->weights[i].live) return fail(h, FDSR_E_KEY, "no optimiser state for '%s'", key);
+  int rc = check_ready(h, false);
+  if (rc) return rc;
+  if ((rc = train_prepare(h))) return rc;
+  const size_t n = numel(h->weights[i].shape) * sizeof(float);
+  HIPCHK(h, hipMemcpy(h->d_adam_m + h->master_off[i], exp_avg, n, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(h->d_adam_v + h->master_off[i], exp_avg_sq, n, hipMemcpyHostToDevice));
+  h->adam_t = step;
+  return FDSR_OK;
+}
+
+// The gradient arena (every executed tensor, checkpoint layout, schema order): data-parallel training sums it
+// across ranks in place (RCCL all-reduce over xGMI) between fdsr_train_grads and fdsr_adam_step.
+int fdsr_grad_arena(fdsr_handle h, float** dev_ptr, size_t* count) {
+  if (!h || !dev_ptr || !count) return fail(h, FDSR_E_INVALID, "null argument");
+  if (!h->d_grad) return fail(h, FDSR_E_STATE, "fdsr_train_grads has not run yet");
+  *dev_ptr = h->d_grad;
+  *count = h->master_floats;
   return FDSR_OK;
 }
 

@@ -48,6 +48,8 @@ struct GnBwdParams {
   double* scratch;                // gn_bwd_scratch_doubles()
   int N, HW, G;
   int plain;                      // 1: GroupNorm only (no Swish)
+  const unsigned char* drop_mask; // train-mode dropout after the Swish (block2): keep bytes [N][HW][C0] or null
+  float drop_scale;               // 1 / (1 - p)
 };
 size_t gn_bwd_scratch_doubles(int N, int HW, int C);
 hipError_t launch_gn_bwd(const GnBwdParams& p, hipStream_t s);
@@ -66,6 +68,8 @@ struct WgradParams {
   int N, Hin, Win, Hout, Wout;     // Hin/Win: source dims (before upsampling)
   int C0, C1, Cin_real;            // Cin_real: channels of the weight tensor (the packed input conv: 6 of 8)
   int Cout, Cout_s;
+  const unsigned char* drop_mask;  // as ConvParams::drop_mask (the activated input is a * keep * drop_scale)
+  float drop_scale;
 };
 size_t wgrad_scratch_floats(ConvKind kind, int N, int Hout, int Wout, int Cin, int Cout);
 hipError_t launch_wgrad(ConvKind kind, const WgradParams& p, hipStream_t s);

@@ -224,6 +224,7 @@ size_t gn_bwd_scratch_doubles(int N, int HW, int C) {
   return (size_t)N * FDSR_GNB_SLICES * C * 2 + (size_t)N * C * 2 + (size_t)N * C * 2;
 }
 
+// dA arrives already multiplied by the dropout factor (keep / (1-p)) of this element when dropout is on
 __device__ __forceinline__ void gnb_elem(float x, float dA, float sc, float sh, float mean, float rstd, int plain, float& g, float& xhat) {
   xhat = (x - mean) * rstd;
   if (plain) { g = dA; return; }
@@ -256,7 +257,12 @@ __global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(const GnBwdParams p,
       }
       for (int pix = p0 + r; pix < p1; pix += rows) {
         const f32x4 x = *reinterpret_cast<const f32x4*>(xs + ((size_t)n * p.HW + pix) * Cs + cc);
-        const f32x4 d = *reinterpret_cast<const f32x4*>(p.dA + ((size_t)n * p.HW + pix) * C + c);
+        f32x4 d = *reinterpret_cast<const f32x4*>(p.dA + ((size_t)n * p.HW + pix) * C + c);
+        if (p.drop_mask) {
+          const unsigned m = *reinterpret_cast<const unsigned*>(p.drop_mask + ((size_t)n * p.HW + pix) * C + c);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) d[e] = ((m >> (8 * e)) & 0xffu) ? d[e] * p.drop_scale : 0.f;
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float g, xh;
@@ -333,7 +339,12 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const GnBwdParams p, 
   const float* xs; float* dxs; int Cs, cc;
   if (c < p.C0) { xs = p.x0; dxs = p.dx0; Cs = p.C0; cc = c; } else { xs = p.x1; dxs = p.dx1; Cs = p.C1; cc = c - p.C0; }
   const f32x4 x = *reinterpret_cast<const f32x4*>(xs + pix * Cs + cc);
-  const f32x4 d = *reinterpret_cast<const f32x4*>(p.dA + pix * C + c);
+  f32x4 d = *reinterpret_cast<const f32x4*>(p.dA + pix * C + c);
+  if (p.drop_mask) {
+    const unsigned m = *reinterpret_cast<const unsigned*>(p.drop_mask + pix * C + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) d[e] = ((m >> (8 * e)) & 0xffu) ? d[e] * p.drop_scale : 0.f;
+  }
   const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + n * C + c);
   const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + n * C + c);
   f32x4 o = *reinterpret_cast<const f32x4*>(dxs + pix * Cs + cc);
@@ -442,6 +453,11 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p, const i
           for (int e = 0; e < 4; ++e) {
             const float u = fmaf(v[e], sc[e], sh[e]);
             v[e] = p.gn_plain ? u : u * sigmoid_f(u);
+          }
+          if (p.drop_mask) {       // dropout sits between the Swish and the conv (C1 == 0 for these layers)
+            const unsigned m = *reinterpret_cast<const unsigned*>(p.drop_mask + ((size_t)(n * p.Hin + sy) * p.Win + sx) * Cs + cc);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = ((m >> (8 * e)) & 0xffu) ? v[e] * p.drop_scale : 0.f;
           }
         }
       }

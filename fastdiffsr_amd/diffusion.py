@@ -14,6 +14,28 @@ from torch import nn
 from .schedule import schedule_buffers, sampling_scalars
 
 
+class _EngineLoss(torch.autograd.Function):
+    """loss = p_losses(...) with the engine's backward pass behind autograd: backward() copies the engine's
+    gradients (scaled by the incoming gradient of the loss, e.g. 1 / (b*c*h*w)) into the Parameters' .grad."""
+
+    @staticmethod
+    def forward(ctx, diffusion, x6, gamma, noise, *params):
+        eng = diffusion._engine_for_training()
+        loss = eng.train_grads(x6, gamma, noise, diffusion.loss_type, 1.0)
+        ctx.eng = eng
+        ctx.keys = [k for k, p in diffusion.denoise_fn.named_parameters() if p.requires_grad]
+        ctx.live = {k for k, _, live in eng.schema() if live}
+        return torch.tensor(loss, device=x6.device, dtype=torch.float32)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        scale = float(grad_out)
+        grads = []
+        for k in ctx.keys:          # never-executed tensors (unet.py:212) get no gradient, as in torch
+            grads.append(torch.from_numpy(ctx.eng.get_grad(k)).to(grad_out.device) * scale if k in ctx.live else None)
+        return (None, None, None, None) + tuple(grads)
+
+
 class GaussianDiffusion(nn.Module):
     def __init__(self, denoise_fn, image_size, channels=3, loss_type='l1', conditional=True, schedule_opt=None, scale=4):
         super().__init__()
@@ -66,6 +88,9 @@ class GaussianDiffusion(nn.Module):
         self.denoise_fn.sync_weights()
         eng = self.denoise_fn.engine
         eng.set_precision(self.precision)
+        # the reference samples after netG.eval() (model.py:60); in .train() mode its Dropout would be live here too,
+        # and so it is (the engine then insists on the fp32 kernels)
+        eng.set_training(self.denoise_fn.training and self.denoise_fn.cfg.dropout > 0)
         if not continous:
             return eng.sample(x, noise, graph=False)
         img, traj = eng.sample(x, noise, want_traj=True, graph=False)
@@ -89,9 +114,8 @@ class GaussianDiffusion(nn.Module):
         noise = torch.randn_like(x_start) if noise is None else noise
         return continuous_sqrt_alpha_cumprod * x_start + (1 - continuous_sqrt_alpha_cumprod ** 2).sqrt() * noise
 
-    def p_losses(self, x_in, noise=None):                         # :242-270
-        """Forward value of the L1(sum) loss (no gradients: the backward kernels are the
-        next row of SURVEY 8f-3).  RNG draws follow the reference: numpy for t and gamma."""
+    def _training_batch(self, x_in, noise=None):                  # :242-266, the part before the network
+        """x_start, the numpy draws of t and gamma (reference: numpy global RNG), noise, q_sample."""
         x_start = self.img2res(x_in['HR'], x_in['SR'])
         b = x_start.shape[0]
         t = np.random.randint(1, self.num_timesteps + 1)
@@ -100,9 +124,43 @@ class GaussianDiffusion(nn.Module):
         gamma = gamma.view(b, -1)
         noise = torch.randn_like(x_start) if noise is None else noise
         x_noisy = self.q_sample(x_start, gamma.view(-1, 1, 1, 1), noise)
+        return torch.cat([x_in['SR'], x_noisy], dim=1).contiguous(), gamma, noise.contiguous()
+
+    def p_losses(self, x_in, noise=None):                         # :242-270
+        """The summed L1 / L2 loss, RNG draws as in the reference (numpy for t and gamma).  In train mode with
+        autograd on, the result carries a grad_fn whose backward is the ENGINE's backward pass: the reference's
+        `l_pix.sum() / n; l_pix.backward(); optG.step()` (model.py:49-56) then works unchanged on the module's
+        Parameters.  The all-device fast path is optimize_step()."""
+        x6, gamma, noise = self._training_batch(x_in, noise)
+        if self.denoise_fn.training and torch.is_grad_enabled():
+            params = [p for p in self.denoise_fn.parameters() if p.requires_grad]
+            return _EngineLoss.apply(self, x6, gamma, noise, *params)
         with torch.no_grad():
-            x_recon = self.denoise_fn(torch.cat([x_in['SR'], x_noisy], dim=1), gamma)
+            x_recon = self.denoise_fn(x6, gamma)
         return self.loss_func(noise, x_recon)
+
+    def _engine_for_training(self):
+        unet = self.denoise_fn
+        unet.sync_weights()
+        eng = unet.engine
+        eng.set_precision('f32')           # the training step runs the exact-fp32 kernels (include/fdsr.h)
+        eng.set_training(unet.training and unet.cfg.dropout > 0)   # Dropout(p) of block2 is live in .train() mode
+        return eng
+
+    def optimize_step(self, x_in, lr, betas=(0.9, 0.999), eps=1e-8, noise=None, grad_hook=None, loss_div_batches=1):
+        """DDPM.optimize_parameters (model/model.py:47-57) entirely on the device: forward, loss / (b*c*h*w),
+        backward, Adam on the engine's master copy.  Returns l_pix (python float).  grad_hook(engine) runs between
+        backward and the optimiser (data-parallel all-reduce of the gradient arena, parallel.allreduce_grads)."""
+        x6, gamma, noise = self._training_batch(x_in, noise)
+        b, c, h, w = x_in['HR'].shape
+        eng = self._engine_for_training()
+        # data parallel: every rank divides by the GLOBAL element count, the all-reduce then SUMS the arenas
+        loss = eng.train_grads(x6, gamma, noise, self.loss_type, 1.0 / (int(b * c * h * w) * int(loss_div_batches)))
+        if grad_hook is not None:
+            grad_hook(eng)
+        eng.adam_step(lr, betas, eps)
+        self.denoise_fn._engine_ahead = True
+        return loss / int(b * c * h * w)
 
     def forward(self, x, *args, **kwargs):                        # :272-273
         return self.p_losses(x, *args, **kwargs)

@@ -38,6 +38,7 @@ class Engine:
         self._ws = None
         self._keep = None
         self._gstream = None
+        self.trained = False            # at least one optimiser step ran (there is optimiser state to save)
         self.T = 0
 
     def __del__(self):
@@ -206,6 +207,7 @@ class Engine:
         st = torch.cuda.current_stream().cuda_stream
         _lib.check(self.h, self.lib.fdsr_adam_step(self.h, C.c_float(lr), C.c_float(betas[0]), C.c_float(betas[1]), C.c_float(eps),
                                                    C.c_void_p(st)))
+        self.trained = True
 
     def _fetch(self, fn, key):
         shape = {k: s for k, s, _ in self.schema()}[key]
@@ -221,6 +223,47 @@ class Engine:
     def get_grad(self, key):
         torch.cuda.synchronize()
         return self._fetch(self.lib.fdsr_get_grad, key)
+
+    supports_dropout = True
+
+    def set_training(self, on=True):
+        """nn.Module.train()/.eval(): Dropout(p) of block2 live or not (exact-fp32 kernels only when live)."""
+        _lib.check(self.h, self.lib.fdsr_set_training(self.h, int(bool(on))))
+
+    def dropout_mask(self, block):
+        """The multiplicative mask (keep / (1-p)) the last training-mode forward applied in front of `block`'s block2
+        conv, as an NCHW float tensor -- what the oracle's `dropout_masks[block]` takes."""
+        off, n, hh, ww, ch, sc = C.c_void_p(), C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_float()
+        _lib.check(self.h, self.lib.fdsr_debug_dropout_mask(self.h, block.encode(), C.byref(off), C.byref(n), C.byref(hh), C.byref(ww),
+                                                            C.byref(ch), C.byref(sc)))
+        o, cnt = int(off.value or 0), n.value * hh.value * ww.value * ch.value
+        keep = self._ws[o:o + cnt].view(n.value, hh.value, ww.value, ch.value).permute(0, 3, 1, 2).float()
+        return keep * sc.value
+
+    def optimizer_state(self, key):
+        """(exp_avg, exp_avg_sq, step) of torch.optim.Adam for one executed tensor."""
+        shape = {k: s for k, s, _ in self.schema()}[key]
+        m, v, step = np.empty(shape, np.float32), np.empty(shape, np.float32), C.c_int()
+        torch.cuda.synchronize()
+        _lib.check(self.h, self.lib.fdsr_get_optimizer_state(self.h, key.encode(), m.ctypes.data_as(C.c_void_p),
+                                                             v.ctypes.data_as(C.c_void_p), C.byref(step)))
+        return m, v, int(step.value)
+
+    def set_optimizer_state(self, key, exp_avg, exp_avg_sq, step):
+        m = np.ascontiguousarray(exp_avg, dtype=np.float32)
+        v = np.ascontiguousarray(exp_avg_sq, dtype=np.float32)
+        _lib.check(self.h, self.lib.fdsr_set_optimizer_state(self.h, key.encode(), m.ctypes.data_as(C.c_void_p),
+                                                             v.ctypes.data_as(C.c_void_p), int(step)))
+        self.trained = True
+
+    def grad_arena(self):
+        """The engine's gradient arena as a torch tensor sharing its memory (zero-copy): all-reduce it in place."""
+        ptr, n = C.c_void_p(), C.c_size_t()
+        _lib.check(self.h, self.lib.fdsr_grad_arena(self.h, C.byref(ptr), C.byref(n)))
+
+        class _Arena:
+            __cuda_array_interface__ = {'shape': (int(n.value),), 'typestr': '<f4', 'data': (int(ptr.value), False), 'version': 2}
+        return torch.as_tensor(_Arena(), device='cuda')
 
     # -- introspection ----------------------------------------------------------
     def set_debug(self, on=True):

@@ -1,6 +1,7 @@
 """`DDPM`: the model wrapper the reference's drivers use (FastDiffSR/model/model.py, base_model.py,
-model/__init__.py:create_model), over the HIP-backed netG.  Sampling surface only (the optimizer /
-`optimize_parameters` path is SURVEY 8f-3)."""
+model/__init__.py:create_model), over the HIP-backed netG: sampling (test / get_current_visuals), the
+training step (optimize_parameters: forward, loss / (b*c*h*w), backward and Adam all on the device) and
+the generator + optimiser checkpoints in the reference's own file formats."""
 import logging
 import os
 from collections import OrderedDict
@@ -27,6 +28,12 @@ class DDPM:
         self.set_new_noise_schedule(opt['model']['beta_schedule']['train'], schedule_phase='train')
         if opt['phase'] == 'train':
             self.netG.train()
+            if opt['model'].get('finetune_norm'):                  # model.py:25-35 looks for 'transformer' parameters:
+                raise NotImplementedError('finetune_norm: this UNet has no transformer parameters')   # none exist
+            # torch.optim.Adam(netG.parameters(), lr) (model.py:37-38) lives in the engine: its state is the
+            # (exp_avg, exp_avg_sq) pair kept beside the fp32 master copy of every executed tensor
+            self.lr = float(opt['train']['optimizer']['lr'])
+            self.betas, self.adam_eps = (0.9, 0.999), 1e-8
             self.log_dict = OrderedDict()
         self.load_network()                                        # model.py:41
         self.print_network()                                       # model.py:42
@@ -41,6 +48,19 @@ class DDPM:
 
     def feed_data(self, data):                                     # model.py:44-45
         self.data = self.set_device(data)
+
+    def optimize_parameters(self):                                 # model.py:47-57
+        """zero_grad; l_pix = netG(data); l_pix.sum() / (b*c*h*w); backward; optG.step() -- one call into the engine.
+        Under torch.distributed every rank steps on its own shard and the gradient arena is all-reduced (the
+        reference's nn.DataParallel, networks.py:116-118; then the divisor is the GLOBAL batch)."""
+        from . import parallel
+        world = parallel.world_size()
+        hook = parallel.allreduce_grads if world > 1 else None
+        l_pix = self.netG.optimize_step(self.data, self.lr, self.betas, self.adam_eps, grad_hook=hook, loss_div_batches=world)
+        self.log_dict['l_pix'] = parallel.mean_over_ranks(l_pix) if world > 1 else l_pix
+
+    def get_current_log(self):                                     # model.py:94-95
+        return self.log_dict
 
     def test(self, continous=False):                               # model.py:59-68
         self.netG.eval()
@@ -81,18 +101,54 @@ class DDPM:
         logger.info('Network G structure: {}, with parameters: {:,d}'.format(self.netG.__class__.__name__, n))
         logger.info(s)
 
-    def save_network(self, epoch, iter_step):                      # model.py:126-146 (generator part)
+    def _optimizer_state_dict(self):
+        """torch.optim.Adam.state_dict() of the reference's optG (model.py:143): parameter indices follow
+        list(netG.parameters()); the 44 never-executed tensors have no state, as in torch."""
+        unet = self.netG.denoise_fn
+        eng = unet.engine
+        live = {k for k, _, lv in eng.schema() if lv}
+        state = {}
+        names = [k for k, _ in unet.named_parameters()]
+        for i, k in enumerate(names):
+            if k in live:
+                m, v, step = eng.optimizer_state(k)
+                state[i] = {'step': torch.tensor(float(step)), 'exp_avg': torch.from_numpy(m), 'exp_avg_sq': torch.from_numpy(v)}
+        group = {'lr': self.lr, 'betas': self.betas, 'eps': self.adam_eps, 'weight_decay': 0, 'amsgrad': False, 'maximize': False,
+                 'foreach': None, 'capturable': False, 'differentiable': False, 'fused': None, 'params': list(range(len(names)))}
+        return {'state': state, 'param_groups': [group]}
+
+    def _load_optimizer_state_dict(self, osd):
+        unet = self.netG.denoise_fn
+        unet.sync_weights()
+        eng = unet.engine
+        names = [k for k, _ in unet.named_parameters()]
+        for i, st in osd['state'].items():
+            eng.set_optimizer_state(names[int(i)], st['exp_avg'].float().cpu().numpy(), st['exp_avg_sq'].float().cpu().numpy(),
+                                    int(float(st['step'])))
+        g = osd['param_groups'][0]
+        self.lr, self.betas, self.adam_eps = float(g['lr']), tuple(g['betas']), float(g['eps'])
+
+    def save_network(self, epoch, iter_step):                      # model.py:126-146
         gen_path = os.path.join(self.opt['path']['checkpoint'], 'I{}_E{}_gen.pth'.format(iter_step, epoch))
-        sd = self.netG.state_dict()
+        opt_path = os.path.join(self.opt['path']['checkpoint'], 'I{}_E{}_opt.pth'.format(iter_step, epoch))
+        sd = self.netG.state_dict()                                # pulls the engine's master copy after optimiser steps
         torch.save(OrderedDict((k, v.cpu()) for k, v in sd.items()), gen_path)
+        if self.opt['phase'] == 'train' and self.netG.denoise_fn.engine.trained:
+            torch.save({'epoch': epoch, 'iter': iter_step, 'scheduler': None, 'optimizer': self._optimizer_state_dict()}, opt_path)
+        logger.info('Saved model in [{:s}] ...'.format(gen_path))
         return gen_path
 
-    def load_network(self):                                        # model.py:148-160
+    def load_network(self):                                        # model.py:148-166
         load_path = (self.opt.get('path') or {}).get('resume_state')
         if load_path is not None:
             logger.info('Loading pretrained model for G [{:s}] ...'.format(load_path))
             sd = torch.load('{}_gen.pth'.format(load_path), map_location='cpu')
             self.netG.load_state_dict(sd, strict=(not self.opt['model'].get('finetune_norm')))
+            if self.opt['phase'] == 'train' and os.path.exists('{}_opt.pth'.format(load_path)):
+                o = torch.load('{}_opt.pth'.format(load_path), map_location='cpu', weights_only=False)
+                self._load_optimizer_state_dict(o['optimizer'])
+                self.begin_step = o['iter']
+                self.begin_epoch = o['epoch']
 
 
 def create_model(opt):                                             # model/__init__.py:5-8

@@ -23,4 +23,35 @@ def define_G(opt):
                                        schedule_opt=model_opt['beta_schedule']['train'],
                                        **({} if which == 'ddpm' else
                                           {'scale': int(256 / int(opt['datasets']['train']['l_resolution']))}))
+    if opt['phase'] == 'train':
+        init_weights(netG, init_type='orthogonal')                   # networks.py:113-115
+    # networks.py:116-118 wraps netG in nn.DataParallel when distributed; here one process drives one GPU and
+    # data parallelism is an all-reduce of the engine's gradient arena (parallel.allreduce_grads): nothing to wrap
     return netG
+
+
+def init_weights(net, init_type='kaiming', scale=1, std=0.02):
+    """networks.py:13-75: `net.apply(fn)` visits the leaf modules in registration order, which is the order of the
+    checkpoint schema; Conv / Linear weights are initialised (orthogonal gain 1, kaiming_normal fan_in * scale, or
+    N(0, std)), their biases zeroed, GroupNorm left alone.  Same torch RNG consumption as the reference: with the
+    same torch.manual_seed the tensors are identical (tests/golden/init_weights.npz)."""
+    import torch
+    from torch.nn import init
+    unet = net.denoise_fn
+    named = dict(unet.named_parameters())
+    if init_type not in ('normal', 'kaiming', 'orthogonal'):
+        raise NotImplementedError('initialization method [{:s}] not implemented'.format(init_type))
+    with torch.no_grad():
+        for key, p in named.items():
+            if not key.endswith('.weight') or p.dim() not in (2, 4):
+                continue                                             # GroupNorm affine, biases
+            if init_type == 'orthogonal':
+                init.orthogonal_(p, gain=1)
+            elif init_type == 'kaiming':
+                init.kaiming_normal_(p, a=0, mode='fan_in')
+                p.mul_(scale)
+            else:
+                init.normal_(p, 0.0, std)
+            b = named.get(key[:-len('weight')] + 'bias')
+            if b is not None:
+                b.zero_()

@@ -54,6 +54,7 @@ class UNet(nn.Module):
                 holder.register_parameter(parts[-1], nn.Parameter(self._default_init(parts[-1], shape, key)))
         self._engine = None
         self._uploaded_version = None
+        self._engine_ahead = False      # the engine holds newer weights than the nn.Parameters (device-side Adam)
 
     def _default_init(self, leaf, shape, key):
         """PyTorch's default initialisers (Conv2d/Linear: kaiming_uniform(a=sqrt 5) and
@@ -87,21 +88,40 @@ class UNet(nn.Module):
 
     def sync_weights(self, force=False):
         """Upload parameters to the engine if they changed since the last upload."""
+        if self._engine_ahead:          # the engine's optimiser moved the weights: the module follows, not leads
+            self.pull_weights()
         ver = self._param_version()
         if force or ver != self._uploaded_version:
             sd = {k: v for k, v in self.state_dict().items()}
             self.engine.load_state_dict(sd)
             self._uploaded_version = ver
 
+    def pull_weights(self):
+        """Copy the engine's master copy (after device-side optimiser steps) into the module's Parameters."""
+        if not self._engine_ahead:
+            return
+        named = dict(self.named_parameters())
+        with torch.no_grad():
+            for key, _, live in self.engine.schema():
+                if live and key in named:
+                    named[key].copy_(torch.from_numpy(self.engine.get_weight(key)))
+        self._engine_ahead = False
+        self._uploaded_version = self._param_version()
+
+    def state_dict(self, *args, **kwargs):
+        self.pull_weights()
+        return super().state_dict(*args, **kwargs)
+
     def forward(self, x, time):
-        if self.training and self.cfg.dropout > 0:
-            # reference: nn.Dropout(p) in block2 is live whenever .training (unet.py:89-101); running the eval
-            # network here would silently compute a different loss, so refuse instead (SURVEY H6)
-            raise NotImplementedError(
-                f'train-mode forward with dropout={self.cfg.dropout} is not implemented in the HIP engine '
-                '(no dropout mask kernel yet): call .eval() first, or build the UNet with dropout=0')
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
             raise NotImplementedError(
-                'training (autograd through the HIP UNet) is not implemented yet; call under torch.no_grad() / eval()')
+                'autograd through UNet.forward is not provided: gradients come from the engine\'s own backward pass '
+                '(GaussianDiffusion.forward in train mode / optimize_step); call under torch.no_grad() for inference')
         self.sync_weights()
+        # nn.Dropout(p) in block2 is live whenever .training (unet.py:89-101, SURVEY H6): the engine draws the masks
+        # (Philox) and runs the exact-fp32 kernels for such a forward
+        live_dropout = self.training and self.cfg.dropout > 0
+        self.engine.set_training(live_dropout)
+        if live_dropout:
+            self.engine.set_precision('f32')
         return self.engine.unet_forward(x, time)

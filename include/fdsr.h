@@ -192,6 +192,16 @@ int fdsr_profile_begin(fdsr_handle h);
 int fdsr_profile_end(fdsr_handle h, int* launches, double* conv_ms, double* conv_flops,
                      double* conv_bytes);
 
+/* nn.Module.train() / .eval() of the denoiser: in training mode the Dropout(p) in front of every block2 conv
+ * (unet.py:89-101, p = fdsr_config.dropout) is live, in fdsr_unet_forward and in fdsr_train_grads alike (exact-fp32
+ * kernels only).  The keep-mask of a forward is a pure function of (fdsr_set_seed, the count of training-mode
+ * forwards so far, block, element) -- Philox4x32-10 -- and can be read back for parity checks:
+ * fdsr_debug_dropout_mask gives its offset inside the workspace of the last forward, [N][H][W][C] bytes (1 = keep),
+ * and the factor 1/(1-p) kept elements are multiplied by.  `block` is the reference module, e.g. "downs.1". */
+int fdsr_set_training(fdsr_handle h, int on);
+int fdsr_debug_dropout_mask(fdsr_handle h, const char* block, const unsigned char** dev_off, int* n, int* hgt, int* wid,
+                            int* ch, float* scale);
+
 /* ---- training step (FastDiffSR variant) -------------------------------------------------
  * DDPM.optimize_parameters (model/model.py:47-57): zero_grad, l_pix = netG(data) = p_losses
  * (fastdiffsr_modules/diffusion.py:242-270), l_pix.sum() / (b*c*h*w), backward, Adam.step.  The engine keeps
@@ -224,6 +234,16 @@ int fdsr_adam_step(fdsr_handle h, float lr, float beta1, float beta2, float eps,
  * (state_dict() after training; tests).  Never-executed tensors: FDSR_E_KEY. */
 int fdsr_get_weight(fdsr_handle h, const char* key, float* host);
 int fdsr_get_grad(fdsr_handle h, const char* key, float* host);
+
+/* torch.optim.Adam's state of one executed tensor (exp_avg, exp_avg_sq; either may be NULL on get) and the
+ * common step count: what `I{iter}_E{epoch}_opt.pth` stores and load_network restores (model.py:139-146, :161-166). */
+int fdsr_get_optimizer_state(fdsr_handle h, const char* key, float* exp_avg, float* exp_avg_sq, int* step);
+int fdsr_set_optimizer_state(fdsr_handle h, const char* key, const float* exp_avg, const float* exp_avg_sq, int step);
+
+/* Device pointer and length of the gradient arena (every executed tensor in schema order).  Data-parallel
+ * training (the reference wraps netG in nn.DataParallel, networks.py:116-118) sums it over the ranks in place,
+ * one RCCL all-reduce, between fdsr_train_grads and fdsr_adam_step. */
+int fdsr_grad_arena(fdsr_handle h, float** dev_ptr, size_t* count);
 
 /* After optimiser steps: rebuild the 16-bit weight forms (f16x3 / bf16 sampling) from the master copy.
  * fdsr_set_precision does this by itself when needed. */

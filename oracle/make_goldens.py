@@ -343,6 +343,28 @@ def train_goldens():
     print('wrote train_step.npz: l_pix', l_pix.item(), 'tensors with grad', len(names), 'without', int(out['n_params_without_grad']))
 
 
+def init_goldens():
+    """(xii) the reference's own `init_weights(netG, 'orthogonal')` (model/networks.py:46-75, called by define_G in the
+    train phase, :113-115) under torch.manual_seed(1234): a (sum, sum of squares) pair for every tensor of the small
+    inner-32 UNet, and two tensors in full.  Pins fastdiffsr_amd.networks.init_weights (same RNG consumption order)."""
+    diffusion, unet = import_reference()
+    from model import networks as ref_networks
+    torch.manual_seed(1234)
+    net = unet.UNet(in_channel=6, out_channel=3, norm_groups=32, inner_channel=32, channel_mults=[1, 2, 4, 4],
+                    attn_res=[16], res_blocks=2, dropout=0.2, image_size=32)
+    G = diffusion.GaussianDiffusion(net, image_size=32, channels=3, loss_type='l1', conditional=True,
+                                    schedule_opt=dict(FASTDIFFSR_SCHEDULE_VAL))
+    ref_networks.init_weights(G, init_type='orthogonal')
+    sd = net.state_dict()
+    keys = list(sd.keys())
+    stats = np.array([[v.double().sum().item(), (v.double() ** 2).sum().item()] for v in sd.values()], dtype=np.float64)
+    out = {'keys': np.array(keys), 'stats': stats, 'seed': np.array(1234)}
+    for k in ('downs.0.weight', 'mid.0.ca.fc2.weight', 'ups.4.res_block.noise_func.noise_func.0.weight'):
+        out['full/' + k] = sd[k].numpy().copy()
+    np.savez_compressed(os.path.join(OUT, 'init_weights.npz'), **out)
+    print('wrote init_weights.npz:', len(keys), 'tensors')
+
+
 def tesr_goldens():
     """(xi) TESR sibling (model/tesr_modules): UNet forwards incl. the SelfAttention levels, the sampler
     (continous=True frames and the final image) and the Charbonnier training-loss value, from the reference itself."""
@@ -437,6 +459,8 @@ if __name__ == '__main__':
         config_goldens()          # only tests/golden/configs.json
     elif len(sys.argv) > 1 and sys.argv[1] == 'train':
         train_goldens()           # only tests/golden/train_step.npz (reads train_loss.npz)
+    elif len(sys.argv) > 1 and sys.argv[1] == 'init':
+        init_goldens()            # only tests/golden/init_weights.npz
     elif len(sys.argv) > 1 and sys.argv[1] == 'tesr':
         tesr_goldens()            # only tests/golden/tesr.npz
     else:
@@ -444,3 +468,4 @@ if __name__ == '__main__':
         config_goldens()
         train_goldens()
         tesr_goldens()
+        init_goldens()

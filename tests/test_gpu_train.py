@@ -132,3 +132,84 @@ def test_step_is_bitwise_reproducible(golden_dir):
     assert outs[0][0] == outs[1][0]
     for a, b in zip(outs[0][1:], outs[1][1:]):
         assert np.array_equal(a, b)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# train mode: nn.Dropout(p) in front of every block2 conv is live (unet.py:89-101)
+# ---------------------------------------------------------------------------------------------------------------
+def _res_blocks(cfg):
+    from fastdiffsr_amd.arch import build_layers
+    return [L.name for L in build_layers(cfg) if L.kind == 'res']
+
+
+def test_train_mode_forward_has_live_dropout():
+    """UNet.forward in .train() mode: the engine draws the masks; with exactly those masks the oracle gives the same
+    output.  eval() gives the dropout-free network; consecutive training forwards draw fresh masks; a seed repeats."""
+    from fastdiffsr_amd.unet import UNet
+    from oracle import fdsr_oracle as O
+    cfg = UNetConfig(**FASTDIFFSR_UNET)
+    assert cfg.dropout == 0.2
+    net = UNet(in_channel=6, out_channel=3, norm_groups=32, inner_channel=64, channel_mults=(1, 2, 4, 4), attn_res=(16,), res_blocks=2,
+               dropout=0.2, image_size=256)
+    sd = synth_state_dict(cfg, 0)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    net = net.cuda()
+    x = torch.randn(2, 6, 32, 32, generator=torch.Generator().manual_seed(11))
+    nl = torch.tensor([[0.3], [0.9]])
+    tsd = O.to_torch_sd(sd)
+    with torch.no_grad():
+        net.eval()
+        ev = net(x.cuda(), nl.cuda()).cpu()
+        assert (ev - O.unet_forward(tsd, cfg, x, nl)).abs().max().item() <= 1e-4
+        net.train()
+        net.engine.set_seed(5)
+        t1 = net(x.cuda(), nl.cuda()).cpu()
+        masks = {b: net.engine.dropout_mask(b).cpu() for b in _res_blocks(cfg)}
+        assert len(masks) == 22
+        ref = O.unet_forward(tsd, cfg, x, nl, dropout_masks=masks)
+        assert (t1 - ref).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item())
+        assert (t1 - ev).abs().max().item() > 1e-2                      # it is not the eval network
+        keep = torch.cat([(m > 0).float().flatten() for m in masks.values()])
+        assert abs(keep.mean().item() - 0.8) < 2e-3, keep.mean().item()
+        for m in masks.values():
+            assert set(torch.unique(m).tolist()) <= {0.0, 1.25}
+        t2 = net(x.cuda(), nl.cuda()).cpu()
+        assert (t2 - t1).abs().max().item() > 1e-3                      # fresh masks per forward
+        net.engine.set_seed(6)
+        m6 = net.engine  # different seed -> different masks
+        t3 = net(x.cuda(), nl.cuda()).cpu()
+        assert (t3 - t2).abs().max().item() > 1e-3
+        net.eval()
+        assert torch.equal(net(x.cuda(), nl.cuda()).cpu(), ev)          # eval() switches it off again
+
+
+def test_train_step_with_dropout_matches_oracle(golden_dir):
+    """The optimisation step with live dropout: loss and every gradient against autograd over the oracle fed with
+    the masks the engine drew."""
+    from fastdiffsr_amd.engine import Engine
+    from oracle import fdsr_oracle as O
+    cfg = UNetConfig(**FASTDIFFSR_UNET)
+    sd = synth_state_dict(cfg, 0)
+    eng = Engine(cfg)
+    eng.load_state_dict(sd)
+    eng.set_precision('f32')
+    eng.set_training(True)
+    eng.set_seed(123)
+    hr, sr, nz, gamma = _inputs(golden_dir)
+    b, c, h, w = hr.shape
+    x = torch.cat([sr, _x_noisy(hr, sr, nz, gamma)], 1)
+    loss = eng.train_grads(x.cuda(), gamma.cuda(), nz.cuda(), 'l1', 1.0 / (b * c * h * w))
+    masks = {blk: eng.dropout_mask(blk).cpu() for blk in _res_blocks(cfg)}
+    l_ref, grads_ref, _ = O.train_step(O.to_torch_sd(sd), cfg, hr, sr, gamma, nz, lr=1e-4, dropout_masks=masks)
+    assert abs(loss / (b * c * h * w) - l_ref.item()) <= 1e-5 * abs(l_ref.item())
+    worst = (0.0, '')
+    for k, ref in grads_ref.items():
+        got, ref = eng.get_grad(k), ref.numpy()
+        scale = max(float(np.abs(ref).max()), 1e-12)
+        d = float(np.abs(got - ref).max())
+        worst = max(worst, (d / scale, k))
+        assert d <= 1e-4 * scale, f'{k}: max|d| {d:.3e} vs max|g| {scale:.3e}'
+    print(f'worst gradient with dropout: {worst[1]} at {worst[0]:.3e} x max|g|')
+    # the loss differs from the dropout-free step: the masks did something
+    g = np.load(os.path.join(golden_dir, 'train_step.npz'))
+    assert abs(loss / (b * c * h * w) - float(g['l_pix'])) > 1e-3 * float(g['l_pix'])
