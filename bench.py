@@ -261,6 +261,60 @@ def run_config(eng, dev, precision, B, S, steps, warmup, graph, noise_mode, rank
     return dt, out, prof, prof_dt
 
 
+def run_train(eng, dev, B, S, steps, warmup, rank=0, sync=None, allreduce=None):
+    """Time `steps` optimisation steps (BASELINE configs[4], "training step"): q_sample in torch (pointwise), then
+    forward + L1 loss / (b*c*h*w) + backward + Adam on the device, exact fp32, Dropout(0.2) live as in .train() mode.
+    Returns seconds.  A "step" = one optimizer step over one batch of B synthetic 256x256 HR/SR pairs per GPU."""
+    g = torch.Generator().manual_seed(777 + rank)
+    hr = (torch.rand(B, 3, S, S, generator=g) * 2 - 1).to(dev)
+    sr = (hr + 0.1 * torch.randn(B, 3, S, S, generator=g).to(dev)).clamp(-1, 1)
+    eng.set_precision('f32')
+    eng.set_training(True)
+    eng.set_seed(99 + rank)
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if sync is None:
+        def sync():
+            torch.cuda.synchronize(dev)
+
+    def one():
+        gamma = torch.rand(B, device=dev) * 0.5 + 0.4                      # continuous sqrt(alpha_bar) per sample
+        noise = torch.randn(B, 3, S, S, device=dev)
+        x_start = ((hr - sr) * 2.0).clamp(-1, 1)                            # img2res (diffusion.py:283-289)
+        gg = gamma.view(-1, 1, 1, 1)
+        x_noisy = gg * x_start + (1 - gg ** 2).sqrt() * noise               # q_sample (:233-241)
+        loss = eng.train_grads(torch.cat([sr, x_noisy], 1), gamma, noise, 'l1', 1.0 / (B * 3 * S * S * world))
+        if allreduce is not None:
+            allreduce(eng)
+        eng.adam_step(1e-4)
+        return loss
+    for _ in range(warmup):
+        one()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = one()
+    sync()
+    dt = time.perf_counter() - t0
+    eng.set_training(False)
+    assert loss == loss
+    return dt
+
+
+def train_record(eng, dev, B, S, steps, warmup):
+    try:
+        dt = run_train(eng, dev, B, S, steps, warmup)
+        ips = B * steps / dt
+        # forward + backward = 3 x the forward's 268.31 GFLOP per image (SURVEY 8d), exact fp32 MFMA
+        tf = ips * 3 * FLOPS_PER_IMAGE / 20 / 1e12
+        return {'value': ips, 'unit': 'images/s (one optimisation step per batch)', 'ms_per_step': 1e3 * dt / steps, 'steps': steps,
+                'warmup': warmup, 'dtype': 'f32', 'batch': B,
+                'workload': 'configs[4] per-GPU slice: batch 32, 256x256, q_sample + L1(sum)/(b*c*h*w) (define_G fixes loss_type l1) + '
+                            'backward + Adam, Dropout(0.2) live, exact fp32',
+                'algorithmic_tflops': tf, 'frac_f32_mfma_peak': tf / PEAK_F32_MFMA}
+    except Exception as e:
+        return {'error': f'{type(e).__name__}: {e}'}
+
+
 def sub_record(eng, dev, name, precision, B, S, steps, warmup, graph, note):
     try:
         dt, _, prof, prof_dt = run_config(eng, dev, precision, B, S, steps, warmup, graph, 'engine')
@@ -291,6 +345,9 @@ def main():
     ap.add_argument('--precision', default='f16x3', choices=['f32', 'f16x3', 'bf16'],
                     help='conv arithmetic: exact fp32 MFMA, fp32-grade split-f16 MFMA, or bf16')
     ap.add_argument('--graph', action='store_true', help='replay the 20-step loop as a hipGraph')
+    ap.add_argument('--train', action='store_true',
+                    help='time optimisation steps (forward + loss + backward + Adam, BASELINE configs[4]) instead of sampling; '
+                         'the metric is then images/s through one training step')
     ap.add_argument('--noise', default='engine', choices=['engine', 'tensor'],
                     help="engine: N(0,1) drawn inside the timed loop by the engine (Philox), as the reference draws "
                          "randn_like per step; tensor: a pre-drawn [T,B,3,H,W] tensor resident in HBM (the parity-run form)")
@@ -337,6 +394,29 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    if args.train:
+        Bt = args.batch if args.batch != 16 else 32
+        hook = parallel.allreduce_grads if distributed else None
+        dt = run_train(eng, dev, Bt, S, args.steps, args.warmup, rank=rank, sync=sync, allreduce=hook)
+        if distributed:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        if rank == 0:
+            ips = world * Bt * args.steps / dt
+            tf = ips / world * 3 * FLOPS_PER_IMAGE / 20 / 1e12
+            print(json.dumps({
+                'metric': '256x256 images/sec through one optimisation step (forward + loss + backward + Adam)', 'value': ips,
+                'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
+                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+                'config': {'workload': f'BASELINE configs[4] training step: x8 32->256 shapes, batch={Bt}/GPU, 256x256, q_sample + L1(sum)/(b*c*h*w), '
+                                       'Dropout(0.2) live, exact fp32; data parallel = one all-reduce of the 91.6 MB gradient arena per step',
+                           'batch_per_gpu': Bt, 'global_batch': Bt * world, 'parallelism': f'dp{world}'},
+                'algorithmic_tflops_per_gpu': tf, 'frac_f32_mfma_peak': tf / PEAK_F32_MFMA}), flush=True)
+        if distributed:
+            dist.destroy_process_group()
+        return
+
     # independent per-GPU batch (weak scaling): rank r samples its own B images
     dt, out, prof, _ = run_config(eng, dev, args.precision, B, S, args.steps, args.warmup, args.graph, args.noise,
                                   rank=rank, sync=sync, want_profile=not args.no_profile)
@@ -376,6 +456,7 @@ def main():
                 'b1_graph': sub_record(eng, dev, 'b1_graph', 'f16x3', 1, S, 10, 2, True,
                                        'configs[0] regime (the reference val loop is B=1, sr_mfe.py:279-284): latency per image, hipGraph'),
             }
+            res['sub_records']['train_step_b32'] = train_record(eng, dev, 32, S, 2, 1)
             eng.set_precision(args.precision)
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'], ref = cpu_baseline(cfg, sd)

@@ -81,7 +81,7 @@ int make_train_plan(fdsr_handle h, int N, int H, int W, TrainPlan* tp) {
   tp->off_dbl = take(dbl);
   tp->off_wg = take(wg);
   tp->off_csb = take(csb);
-  tp->off_tb = take((size_t)N * 10 * h->cfg.inner_channel * sizeof(float));
+  tp->off_tb = take((size_t)N * 11 * h->cfg.inner_channel * sizeof(float));
   tp->off_loss = take(256);
   tp->bytes = off;
   return FDSR_OK;
@@ -301,10 +301,9 @@ int fdsr_train_grads(fdsr_handle h, const float* x_nchw, const float* noise_leve
     // bias and noise-embedding gradients
     HIPCHK(h, launch_colsum(dy, S, dbl, N, Ho * Wo, K, st));
     if (op.b >= 0) HIPCHK(h, launch_sum_rows(S, N, K, op.Cout, DG(op.b), st));   // db[c] = sum_n S[n][c]
-    if (op.temb_off >= 0)
-      for (int n = 0; n < N; ++n)
-        HIPCHK(h, hipMemcpyAsync(dtemb + (size_t)n * h->TE + op.temb_off, S + (size_t)n * K, (size_t)op.Cout * sizeof(float),
-                                 hipMemcpyDeviceToDevice, st));
+    if (op.temb_off >= 0)   // rows of S (stride K) -> this block's columns of the [N][TE] table
+      HIPCHK(h, hipMemcpy2DAsync(dtemb + op.temb_off, (size_t)h->TE * sizeof(float), S, (size_t)K * sizeof(float),
+                                 (size_t)op.Cout * sizeof(float), N, hipMemcpyDeviceToDevice, st));
     // weight gradient
     {
       WgradParams q{};

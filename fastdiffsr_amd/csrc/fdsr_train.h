@@ -98,7 +98,7 @@ struct TembBwdParams {
   const float* nl;         // [N]
   const float* dtemb;      // [N][TE]
   float* dw1; float* db1; float* dw2; float* db2; float* dwn; float* dbn;   // written (=)
-  float* scratch;          // N * (6*inner) floats
+  float* scratch;          // N * 11 * inner floats
   int inner, TE, N;
 };
 hipError_t launch_temb_bwd(const TembBwdParams& p, hipStream_t s);

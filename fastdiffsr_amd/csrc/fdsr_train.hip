@@ -378,14 +378,16 @@ hipError_t launch_gn_bwd(const GnBwdParams& p, hipStream_t s) {
 // convolution weight gradient: exact fp32 on v_mfma_f32_32x32x2_f32
 // ---------------------------------------------------------------------------
 // Workgroup = 4 waves = one (64 output channels x 64 input channels) block of dW, all taps, over a slice of
-// 8x16-pixel output tiles.  Per tile the dy tile [128 px][64 co] and the activated input halo
-// [(8-1)*S+KS x (16-1)*S+KS px][64 ci] are staged in LDS (GroupNorm-apply + Swish fused, as the forward does);
+// 4x16-pixel output tiles.  Per tile the dy tile [64 px][64 co] and the activated input halo
+// [(4-1)*S+KS x (16-1)*S+KS px][64 ci] are staged in LDS (GroupNorm-apply + Swish fused, as the forward does);
 // wave (wc, wi) then accumulates, for every tap, dW[32 co][32 ci] += dy^T (32 x 2 px) * a (2 px x 32) over the
-// 64 pixel pairs: 9 accumulator tiles (144 VGPRs) per wave.  Slices write their blocks to scratch; a second
+// 32 pixel pairs: 9 accumulator tiles (144 VGPRs) per wave.  Slices write their blocks to scratch; a second
 // kernel sums the slices in order and scatters into the checkpoint layout [Cout][Cin][ks][ks].
 template <int KS, int STRIDE, bool UP>
 struct WgCfg {
-  static constexpr int TH = STRIDE == 2 ? 4 : 8, TW = 16, T = KS * KS;   // stride 2: the halo of an 8-row tile would not fit the LDS
+  // 4x16-pixel tiles (2x16 at stride 2): 47 KB of LDS per workgroup, so two workgroups share a CU and one's
+  // staging runs beside the other's MFMAs (an 8x16 tile needs 84 KB: one workgroup per CU, nothing overlaps)
+  static constexpr int TH = STRIDE == 2 ? 2 : 4, TW = 16, T = KS * KS;
   static constexpr int HH = (TH - 1) * STRIDE + KS, HWD = (TW - 1) * STRIDE + KS, NPIX = HH * HWD;
   static constexpr int ROW = 64 + 4;                       // floats per staged pixel (pad: conflict-free 32-lane rows)
   static constexpr int LDS_FLOATS = (TH * TW + NPIX) * ROW;
@@ -516,7 +518,7 @@ static int wgrad_slices(int ntiles, int ncb, int nib) {
 }
 
 size_t wgrad_scratch_floats(ConvKind kind, int N, int Hout, int Wout, int Cin, int Cout) {
-  const int T = kind == CONV1 ? 1 : 9, TH = kind == CONV3_S2 ? 4 : 8;
+  const int T = kind == CONV1 ? 1 : 9, TH = kind == CONV3_S2 ? 2 : 4;
   const int ncb = (Cout + 63) / 64, nib = (Cin + 63) / 64;
   const int ntiles = N * ((Wout + 15) / 16) * ((Hout + TH - 1) / TH);
   return (size_t)wgrad_slices(ntiles, ncb, nib) * ncb * nib * T * 4096;
@@ -836,7 +838,7 @@ hipError_t launch_clam_slam_bwd(const ClamSlamBwdParams& p, hipStream_t s) {
 // noise-level embedding backward
 // ---------------------------------------------------------------------------
 // (1) per image: recompute enc / pre-activation / hid / t, then dt, dhid, dpre.  scratch per image:
-//     enc[inner] | hid[4 inner] | dt[inner] | dpre[4 inner]   (t itself is not needed downstream)
+//     enc[inner] | hid[4 inner] | dt[inner] | dpre[4 inner] | t[inner]
 __global__ void __launch_bounds__(256) temb_bwd_image_kernel(const TembBwdParams p) {
   extern __shared__ __attribute__((aligned(16))) float st[];   // enc[inner] | pre[hid] | hidv[hid] | dt[inner]
   const int inner = p.inner, hid = 4 * inner, tid = threadIdx.x, n = blockIdx.x, half = inner / 2;
@@ -864,8 +866,14 @@ __global__ void __launch_bounds__(256) temb_bwd_image_kernel(const TembBwdParams
     dt[k] = a;
   }
   __syncthreads();
-  float* out = p.scratch + (size_t)n * 10 * inner;
-  for (int k = tid; k < inner; k += 256) { out[k] = enc[k]; out[5 * inner + k] = dt[k]; }
+  float* out = p.scratch + (size_t)n * 11 * inner;
+  for (int k = tid; k < inner; k += 256) {
+    out[k] = enc[k];
+    out[5 * inner + k] = dt[k];
+    float t = p.b2[k];                                       // t[k] = b2[k] + sum_q w2[k][q] hid[q]: the input of the per-block Linear
+    for (int q = 0; q < hid; ++q) t = fmaf(p.w2[(size_t)k * hid + q], hv[q], t);
+    out[10 * inner + k] = t;
+  }
   for (int j = tid; j < hid; j += 256) {
     float a = 0.f;                                           // dhid[j] = sum_k dt[k] * w2[k][j]
     for (int k = 0; k < inner; ++k) a = fmaf(dt[k], p.w2[(size_t)k * hid + j], a);
@@ -882,18 +890,11 @@ __global__ void __launch_bounds__(256) temb_bwd_param_kernel(const TembBwdParams
   const int inner = p.inner, hid = 4 * inner, TE = p.TE, N = p.N;
   const size_t n_wn = (size_t)TE * inner, n_w2 = (size_t)inner * hid, n_w1 = (size_t)hid * inner;
   size_t j = i;
-  auto S = [&](int n, int off) { return p.scratch + (size_t)n * 10 * inner + off; };
-  // t[n][k] = b2[k] + sum_j w2[k][j] hid[n][j] is needed for dwn: recompute it here (inner x hid MACs per element are too many),
-  // so dwn uses a per-image t kept implicitly: t = W2 hid + b2 evaluated per (n, k) on demand below.
+  auto S = [&](int n, int off) { return p.scratch + (size_t)n * 11 * inner + off; };
   if (j < n_wn) {                       // dwn[o][k] = sum_n dtemb[n][o] * t[n][k]
     const int o = (int)(j / inner), k = (int)(j % inner);
     float a = 0.f;
-    for (int n = 0; n < N; ++n) {
-      float t = p.b2[k];
-      const float* hvv = S(n, inner);
-      for (int q = 0; q < hid; ++q) t = fmaf(p.w2[(size_t)k * hid + q], hvv[q], t);
-      a += p.dtemb[(size_t)n * TE + o] * t;
-    }
+    for (int n = 0; n < N; ++n) a += p.dtemb[(size_t)n * TE + o] * S(n, 10 * inner)[k];
     p.dwn[j] = a;
     return;
   }

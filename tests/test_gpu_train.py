@@ -213,3 +213,122 @@ def test_train_step_with_dropout_matches_oracle(golden_dir):
     # the loss differs from the dropout-free step: the masks did something
     g = np.load(os.path.join(golden_dir, 'train_step.npz'))
     assert abs(loss / (b * c * h * w) - float(g['l_pix'])) > 1e-3 * float(g['l_pix'])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the DDPM wrapper: optimize_parameters, checkpoints (model/model.py:47-57, :126-166)
+# ---------------------------------------------------------------------------------------------------------------
+def _train_opt(tmp_path, resume=None, dropout=0.0):
+    return {'phase': 'train', 'gpu_ids': [0], 'distributed': False,
+            'path': {'checkpoint': str(tmp_path), 'resume_state': resume},
+            'datasets': {'train': {'l_resolution': 64}},
+            'train': {'optimizer': {'type': 'adam', 'lr': 1e-4}},
+            'model': {'which_model_G': 'fastdiffsr', 'finetune_norm': False,
+                      'unet': {'in_channel': 6, 'out_channel': 3, 'inner_channel': 32, 'norm_groups': 32,
+                               'channel_multiplier': [1, 2, 4, 4], 'attn_res': [16], 'res_blocks': 1, 'dropout': dropout},
+                      'beta_schedule': {'train': dict(schedule='linear_cosine', n_timestep=20, linear_start=1e-6, linear_end=1e-2),
+                                        'val': dict(schedule='linear_cosine', n_timestep=20, linear_start=1e-6, linear_end=1e-2)},
+                      'diffusion': {'image_size': 32, 'channels': 3, 'conditional': True}}}
+
+
+def test_ddpm_optimize_parameters_and_checkpoints(tmp_path):
+    """Three optimize_parameters() calls through the DDPM wrapper == three oracle train steps with the same draws;
+    save_network / load_network round-trip the generator AND the optimiser state (resumed step == uninterrupted step)."""
+    from unittest import mock
+    from fastdiffsr_amd import model as M
+    from fastdiffsr_amd.arch import UNetConfig as UC
+    from oracle import fdsr_oracle as O
+    torch.manual_seed(7)
+    ddpm = M.create_model(_train_opt(tmp_path))
+    unet = ddpm.netG.denoise_fn
+    cfg = unet.cfg
+    sd0 = {k: v.detach().cpu().numpy().copy() for k, v in unet.state_dict().items()}
+    gen = torch.Generator().manual_seed(3)
+    hr = torch.rand(2, 3, 32, 32, generator=gen) * 2 - 1
+    sr = (hr + 0.2 * torch.randn(2, 3, 32, 32, generator=gen)).clamp(-1, 1)
+    draws = [(5, np.array([0.61, 0.58])), (12, np.array([0.31, 0.27])), (2, np.array([0.93, 0.91]))]
+    noises = [torch.randn(2, 3, 32, 32, generator=gen) for _ in draws]
+
+    def step(model, i):
+        t, gam = draws[i]
+        model.feed_data({'HR': hr.clone(), 'SR': sr.clone()})
+        with mock.patch.object(np.random, 'randint', lambda a, b: t), mock.patch.object(np.random, 'uniform', lambda a, b, size: gam), \
+                mock.patch.object(torch, 'randn_like', lambda x: noises[i].to(x.device)):
+            model.optimize_parameters()
+        return model.get_current_log()['l_pix']
+
+    # oracle: three Adam steps with torch.optim.Adam over autograd (the reference's own optimiser)
+    leaves = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in sd0.items()}
+    opt = torch.optim.Adam(list(leaves.values()), lr=1e-4)
+    ref_losses = []
+    for i, (t, gam) in enumerate(draws):
+        opt.zero_grad()
+        loss = O.p_losses(leaves, cfg, hr, sr, torch.FloatTensor(gam), noises[i], 'l1') / hr.numel()
+        loss.backward()
+        opt.step()
+        ref_losses.append(loss.item())
+    l0 = step(ddpm, 0)
+    l1 = step(ddpm, 1)
+    gen_path = ddpm.save_network(epoch=1, iter_step=2)
+    assert os.path.exists(gen_path) and os.path.exists(gen_path.replace('_gen.pth', '_opt.pth'))
+    l2 = step(ddpm, 2)
+    for got, ref in zip((l0, l1, l2), ref_losses):
+        assert abs(got - ref) <= 2e-5 * abs(ref), (got, ref)
+    final = unet.state_dict()
+    for k in ('downs.0.weight', 'mid.0.ca.fc1.weight', 'ups.1.res_block.block2.block.3.weight', 'noise_level_mlp.3.bias'):
+        d = (final[k].cpu() - leaves[k].detach()).abs().max().item()
+        assert d <= 3e-5, (k, d)      # three steps of lr 1e-4 move weights by ~3e-4; where |g| is tiny Adam's m/sqrt(v) amplifies fp32 noise
+    # resume from the checkpoint written after step 2 and repeat step 3: same loss, same weights
+    ck = torch.load(gen_path, map_location='cpu')
+    assert list(ck.keys()) == list(ddpm.netG.state_dict().keys())
+    o = torch.load(gen_path.replace('_gen.pth', '_opt.pth'), map_location='cpu', weights_only=False)
+    assert o['iter'] == 2 and o['epoch'] == 1 and o['scheduler'] is None
+    assert set(o['optimizer'].keys()) == {'state', 'param_groups'} and len(o['optimizer']['state']) == len(
+        [1 for k, _, live in unet.engine.schema() if live])
+    resumed = M.create_model(_train_opt(tmp_path, resume=gen_path[:-len('_gen.pth')]))
+    assert resumed.begin_step == 2 and resumed.begin_epoch == 1
+    l2r = step(resumed, 2)
+    assert l2r == l2
+    fr = resumed.netG.denoise_fn.state_dict()
+    for k in final:
+        assert torch.equal(fr[k].cpu(), final[k].cpu()), k
+
+
+def test_autograd_compatible_loss_fills_param_grads():
+    """The reference's own sequence (model.py:48-56) on the module: l_pix = netG(data); l_pix.sum() / n; backward();
+    torch.optim.Adam.step() -- gradients arrive in Parameter.grad, the next forward uses the stepped weights."""
+    from unittest import mock
+    from fastdiffsr_amd import networks
+    torch.manual_seed(9)
+    opt = _train_opt('/tmp', dropout=0.2)
+    netG = networks.define_G(opt).cuda()
+    netG.set_loss('cuda')
+    netG.set_new_noise_schedule(opt['model']['beta_schedule']['train'], 'cuda')
+    netG.train()
+    optG = torch.optim.Adam(list(netG.parameters()), lr=1e-4)
+    gen = torch.Generator().manual_seed(4)
+    hr = (torch.rand(2, 3, 32, 32, generator=gen) * 2 - 1).cuda()
+    sr = (hr + 0.1 * torch.randn(2, 3, 32, 32, generator=gen).cuda()).clamp(-1, 1)
+    optG.zero_grad()
+    l_pix = netG({'HR': hr, 'SR': sr})
+    b, c, h, w = hr.shape
+    l_pix = l_pix.sum() / int(b * c * h * w)
+    l_pix.backward()
+    unet = netG.denoise_fn
+    named = dict(unet.named_parameters())
+    live = {k for k, _, lv in unet.engine.schema() if lv}
+    for k, p in named.items():
+        if k in live:
+            assert p.grad is not None and torch.isfinite(p.grad).all(), k
+            assert np.allclose(p.grad.cpu().numpy(), unet.engine.get_grad(k) / (b * c * h * w), rtol=1e-6, atol=1e-12), k
+        else:
+            assert p.grad is None, k                                   # never executed (unet.py:212)
+    before = named['downs.0.weight'].detach().clone()
+    optG.step()
+    assert (named['downs.0.weight'] - before).abs().max().item() > 1e-5
+    netG.eval()
+    with torch.no_grad():
+        x = torch.randn(1, 6, 32, 32, generator=gen).cuda()
+        y = unet(x, torch.tensor([[0.5]]).cuda())                      # re-uploads the stepped Parameters
+    assert np.array_equal(unet.engine.get_weight('downs.0.weight'), named['downs.0.weight'].detach().cpu().numpy())
+    assert torch.isfinite(y).all()
