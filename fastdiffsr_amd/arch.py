@@ -101,6 +101,9 @@ def param_schema(cfg: UNetConfig) -> "OrderedDict[str, Tuple[int, ...]]":
     sd: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
     if cfg.variant in ('ddpm', 'tesr'):
         return _param_schema_sr3(cfg)
+    if cfg.variant == 'gdp':
+        from .gdp.arch import gdp_param_schema
+        return gdp_param_schema(cfg)
     sd['noise_level_mlp.1.weight'] = (ic * 4, ic)
     sd['noise_level_mlp.1.bias'] = (ic * 4,)
     sd['noise_level_mlp.3.weight'] = (ic, ic * 4)
@@ -200,7 +203,7 @@ def _param_schema_sr3(cfg: UNetConfig):
 
 def dead_keys(cfg: UNetConfig):
     out = []
-    if cfg.variant in ('ddpm', 'tesr'):
+    if cfg.variant in ('ddpm', 'tesr', 'gdp'):
         return out
     for L in build_layers(cfg):
         if L.kind == 'res':
@@ -228,5 +231,10 @@ SR3_SCHEDULE_VAL = dict(schedule='linear', n_timestep=1000, linear_start=1e-4, l
 TESR_UNET = dict(in_channel=6, out_channel=3, inner_channel=64, norm_groups=32, channel_mults=(1, 2, 4, 8, 8),
                  attn_res=(16,), res_blocks=2, dropout=0.2, image_size=256, variant='tesr')
 TESR_SCHEDULE_VAL = dict(schedule='linear', n_timestep=2000, linear_start=1e-6, linear_end=1e-2)
+# GDP x4 val config (reference config/sr_gdp_test_64_256.json): the reference's UNet keeps model_channels = 128 and
+# attention_resolutions = (32, 16, 8) whatever the config's inner_channel / attn_res say (gdp_modules/unet.py:561-590)
+GDP_UNET = dict(in_channel=6, out_channel=3, inner_channel=128, norm_groups=32, channel_mults=(1, 2, 4, 8), attn_res=(32, 16, 8),
+                res_blocks=2, dropout=0.2, image_size=256, variant='gdp')
+GDP_SCHEDULE_VAL = dict(schedule='linear', n_timestep=1000, linear_start=1e-4, linear_end=2e-2)
 FASTDIFFSR_SCHEDULE_VAL = dict(schedule='linear_cosine', n_timestep=20,
                                linear_start=1e-6, linear_end=1e-2)

@@ -77,6 +77,94 @@ void mark_conv_pack(fdsr_handle h, int widx, ConvKind ck, int cin_store, int C0,
   }
 }
 
+// Shared tail of the plan builders: device layout of the parameters (the per-block embedding Linears concatenated
+// into one [TE][row_len] table), master-copy offsets, synthetic entries, 16-bit weight arena, tensor liveness.
+int finish_plan(fdsr_handle h, const std::string mlp_keys[4], int row_len) {
+  const int ic = row_len;
+  // parameter arena layout
+  size_t off = 0;
+  auto take = [&](size_t n) { size_t o = off; off += align_up(n, 64); return o; };
+  const size_t noise_w_off = h->noise_w_off = take((size_t)h->TE * ic);
+  const size_t noise_b_off = h->noise_b_off = take((size_t)h->TE);
+  for (int i = 0; i < 4; ++i) h->w_mlp[i] = h->key2w[mlp_keys[i]];
+  for (auto& w : h->weights) {
+    if (!w.live) continue;
+    switch (w.sink) {
+      case WeightEntry::RAW: w.dev_off = take(numel(w.shape)); break;
+      case WeightEntry::CONV_PACK: w.dev_off = take((size_t)w.ks * w.ks * w.cout_pad * w.cin_pad); break;
+      case WeightEntry::NOISE_W: w.dev_off = noise_w_off + (size_t)w.row_off * ic; break;
+      case WeightEntry::NOISE_B: w.dev_off = noise_b_off + (size_t)w.row_off; break;
+    }
+  }
+  h->n_schema = (int)h->weights.size();
+  {   // master copy (checkpoint layout) of every live tensor: what the optimiser updates, what fdsr_get_weight returns
+    size_t mo = 0;
+    h->master_off.assign(h->weights.size(), SIZE_MAX);
+    for (int i = 0; i < h->n_schema; ++i) {
+      if (!h->weights[i].live) continue;
+      h->master_off[i] = mo;
+      mo += align_up(numel(h->weights[i].shape), 4);
+    }
+    h->master_floats = mo;
+  }
+  if (h->max_qkv) {   // zeros standing in for the missing bias of attn.qkv (Conv2d(bias=False))
+    WeightEntry z;
+    z.key = "__zero_bias";
+    z.shape = {h->max_qkv};
+    z.live = false;
+    z.loaded = true;
+    z.dev_off = take(h->max_qkv);
+    h->weights.push_back(z);
+    h->w_zero_bias = (int)h->weights.size() - 1;
+  }
+  // positional-encoding frequency table (not a checkpoint tensor): filled at device init
+  if (!h->sr3) {
+    WeightEntry f;
+    f.key = "__posenc_freq";
+    f.shape = {h->freq_count};
+    f.live = false;
+    f.loaded = true;
+    f.dev_off = take(h->freq_count);
+    h->weights.push_back(f);
+    h->w_freq = (int)h->weights.size() - 1;
+  }
+  h->param_floats = off;
+  // 16-bit weight arena: [cot][kc][wn][tap][plane][lane] x 16 B per conv, for f16x3 (2 planes) and bf16 (1)
+  {
+    size_t qoff = 0;
+    for (auto& w : h->weights) {
+      if (!w.live || w.sink != WeightEntry::CONV_PACK || !w.h_ok) continue;
+      const size_t frag = (size_t)(w.h_cout_pad / 32) * (w.h_cin_pad / 16) * w.ks * w.ks * 64 * 16;
+      w.hq_off[PREC_F16X3] = qoff; qoff += align_up(frag * 2, 256);
+      w.hq_off[PREC_BF16] = qoff;  qoff += align_up(frag, 256);
+      if (w.ck == CONV3_UP) {   // 16 (parity, tap) slots instead of 9 taps
+        const size_t f2 = (size_t)(w.h_cout_pad / 32) * (w.h_cin_pad / 16) * 16 * 64 * 16;
+        w.up2_off[PREC_F16X3] = qoff; qoff += align_up(f2 * 2, 256);
+        w.up2_off[PREC_BF16] = qoff;  qoff += align_up(f2, 256);
+      }
+    }
+    h->wq_bytes = qoff;
+  }
+
+  // liveness
+  for (size_t i = 0; i < h->ops.size(); ++i) {
+    const Op& op = h->ops[i];
+    auto use = [&](int t) { if (t >= 0) h->tensors[t].last_use = (int)i; };
+    use(op.src0); use(op.src1); use(op.res);
+    if (op.aux >= 0) {
+      if (h->tensors[op.aux].first_def < 0) h->tensors[op.aux].first_def = (int)i;
+      h->tensors[op.aux].last_use = (int)i;
+    }
+    if (op.dst >= 0) {
+      if (h->tensors[op.dst].first_def < 0) h->tensors[op.dst].first_def = (int)i;
+      h->tensors[op.dst].last_use = std::max(h->tensors[op.dst].last_use, (int)i);
+    }
+  }
+  return FDSR_OK;
+}
+
+int build_plan_gdp(fdsr_handle h);
+
 // Build the static plan (ops, tensors, weight schema).  unet.py:224-323.
 int build_plan(fdsr_handle h) {
   const fdsr_config& c = h->cfg;
@@ -87,7 +175,8 @@ int build_plan(fdsr_handle h) {
   if (c.out_channel < 1 || c.out_channel > 32) return fail(h, FDSR_E_INVALID, "out_channel must be in [1,32]");
   h->CP = 8;
 
-  if (c.variant < 0 || c.variant > FDSR_VARIANT_TESR) return fail(h, FDSR_E_INVALID, "unknown variant %d", c.variant);
+  if (c.variant < 0 || c.variant > FDSR_VARIANT_GDP) return fail(h, FDSR_E_INVALID, "unknown variant %d", c.variant);
+  if (c.variant == FDSR_VARIANT_GDP) return build_plan_gdp(h);
   h->sr3 = c.variant == FDSR_VARIANT_SR3;
   h->attn_blocks = c.variant != FDSR_VARIANT_FASTDIFFSR;
   h->plain_out = c.variant != FDSR_VARIANT_FASTDIFFSR;
@@ -217,7 +306,7 @@ int build_plan(fdsr_handle h) {
       h->tensors[out].need_part = true;
       h->ops.push_back(sg);
       Op kq; kq.kind = Op::CONV; kq.name = p + ".attn.qkv"; kq.ck = CONV1; kq.src0 = out; kq.C0 = Cout; kq.Cout = 3 * Cout;
-      kq.lvl_in = kq.lvl_out = lvl; kq.gn_slot = sg.gn_slot; kq.w = wq; kq.b = -2;   // -2: the shared zero bias
+      kq.lvl_in = kq.lvl_out = lvl; kq.gn_slot = sg.gn_slot; kq.w = wq; kq.b = -2; kq.gn_plain = true;   // -2: the shared zero bias
       kq.dst = new_tensor(h, 3 * Cout, lvl, p + ".attn.qkv");
       h->ops.push_back(kq);
       Op at; at.kind = Op::ATTN; at.name = p + ".attn.core"; at.src0 = kq.dst; at.C0 = Cout; at.lvl_in = lvl;
@@ -323,87 +412,251 @@ int build_plan(fdsr_handle h) {
   // The reference registers res_block (noise_func, block1, block2, res_conv), then conv,
   // then ca, sa -- add_weight() above was called in that order for every block.
 
-  // parameter arena layout
-  size_t off = 0;
-  auto take = [&](size_t n) { size_t o = off; off += align_up(n, 64); return o; };
-  const size_t noise_w_off = h->noise_w_off = take((size_t)h->TE * ic);
-  const size_t noise_b_off = h->noise_b_off = take((size_t)h->TE);
-  h->w_mlp[0] = h->key2w[mlp + ".1.weight"]; h->w_mlp[1] = h->key2w[mlp + ".1.bias"];
-  h->w_mlp[2] = h->key2w[mlp + ".3.weight"]; h->w_mlp[3] = h->key2w[mlp + ".3.bias"];
-  for (auto& w : h->weights) {
-    if (!w.live) continue;
-    switch (w.sink) {
-      case WeightEntry::RAW: w.dev_off = take(numel(w.shape)); break;
-      case WeightEntry::CONV_PACK: w.dev_off = take((size_t)w.ks * w.ks * w.cout_pad * w.cin_pad); break;
-      case WeightEntry::NOISE_W: w.dev_off = noise_w_off + (size_t)w.row_off * ic; break;
-      case WeightEntry::NOISE_B: w.dev_off = noise_b_off + (size_t)w.row_off; break;
-    }
-  }
-  h->n_schema = (int)h->weights.size();
-  {   // master copy (checkpoint layout) of every live tensor: what the optimiser updates, what fdsr_get_weight returns
-    size_t mo = 0;
-    h->master_off.assign(h->weights.size(), SIZE_MAX);
-    for (int i = 0; i < h->n_schema; ++i) {
-      if (!h->weights[i].live) continue;
-      h->master_off[i] = mo;
-      mo += align_up(numel(h->weights[i].shape), 4);
-    }
-    h->master_floats = mo;
-  }
-  if (h->max_qkv) {   // zeros standing in for the missing bias of attn.qkv (Conv2d(bias=False))
-    WeightEntry z;
-    z.key = "__zero_bias";
-    z.shape = {h->max_qkv};
-    z.live = false;
-    z.loaded = true;
-    z.dev_off = take(h->max_qkv);
-    h->weights.push_back(z);
-    h->w_zero_bias = (int)h->weights.size() - 1;
-  }
-  // positional-encoding frequency table (not a checkpoint tensor): filled at device init
-  if (!h->sr3) {
-    WeightEntry f;
-    f.key = "__posenc_freq";
-    f.shape = {ic / 2};
-    f.live = false;
-    f.loaded = true;
-    f.dev_off = take(ic / 2);
-    h->weights.push_back(f);
-    h->w_freq = (int)h->weights.size() - 1;
-  }
-  h->param_floats = off;
-  // 16-bit weight arena: [cot][kc][wn][tap][plane][lane] x 16 B per conv, for f16x3 (2 planes) and bf16 (1)
-  {
-    size_t qoff = 0;
-    for (auto& w : h->weights) {
-      if (!w.live || w.sink != WeightEntry::CONV_PACK || !w.h_ok) continue;
-      const size_t frag = (size_t)(w.h_cout_pad / 32) * (w.h_cin_pad / 16) * w.ks * w.ks * 64 * 16;
-      w.hq_off[PREC_F16X3] = qoff; qoff += align_up(frag * 2, 256);
-      w.hq_off[PREC_BF16] = qoff;  qoff += align_up(frag, 256);
-      if (w.ck == CONV3_UP) {   // 16 (parity, tap) slots instead of 9 taps
-        const size_t f2 = (size_t)(w.h_cout_pad / 32) * (w.h_cin_pad / 16) * 16 * 64 * 16;
-        w.up2_off[PREC_F16X3] = qoff; qoff += align_up(f2 * 2, 256);
-        w.up2_off[PREC_BF16] = qoff;  qoff += align_up(f2, 256);
-      }
-    }
-    h->wq_bytes = qoff;
-  }
+  const std::string mlp_keys[4] = {mlp + ".1.weight", mlp + ".1.bias", mlp + ".3.weight", mlp + ".3.bias"};
+  h->temb_in = ic;
+  h->freq_count = ic / 2;
+  return finish_plan(h, mlp_keys, ic);
+}
 
-  // liveness
-  for (size_t i = 0; i < h->ops.size(); ++i) {
-    const Op& op = h->ops[i];
-    auto use = [&](int t) { if (t >= 0) h->tensors[t].last_use = (int)i; };
-    use(op.src0); use(op.src1); use(op.res);
-    if (op.aux >= 0) {
-      if (h->tensors[op.aux].first_def < 0) h->tensors[op.aux].first_def = (int)i;
-      h->tensors[op.aux].last_use = (int)i;
+// Plan of the GDP sibling: model/gdp_modules/unet.py:530-800 (the guided-diffusion UNet as define_G instantiates it:
+// use_scale_shift_norm, resblock_updown, num_head_channels = 64, conv_resample).  cfg.inner_channel carries
+// model_channels (the reference's constructor ignores `inner_channel` and keeps its default 128), cfg.attn_res the
+// attention_resolutions (downsample rates at which AttentionBlocks sit; reference default (32, 16, 8)).
+int build_plan_gdp(fdsr_handle h) {
+  const fdsr_config& c = h->cfg;
+  const int mc = c.inner_channel, G = c.norm_groups, ted = 4 * mc;
+  if (c.n_mults < 1 || c.n_mults > FDSR_MAX_MULTS) return fail(h, FDSR_E_INVALID, "n_mults out of range");
+  if (mc % G != 0 || mc % 16 != 0) return fail(h, FDSR_E_INVALID, "model_channels must be a multiple of norm_groups and of 16");
+  if (c.in_channel < 1 || c.in_channel > 8) return fail(h, FDSR_E_INVALID, "in_channel must be in [1,8]");
+  if (c.out_channel < 1 || c.out_channel > 32) return fail(h, FDSR_E_INVALID, "out_channel must be in [1,32]");
+  h->CP = 8;
+  h->gdp = true;
+  h->attn_blocks = true;
+  h->plain_out = true;
+  add_weight(h, "time_embed.0.weight", {ted, mc}, true);
+  add_weight(h, "time_embed.0.bias", {ted}, true);
+  add_weight(h, "time_embed.2.weight", {ted, ted}, true);
+  add_weight(h, "time_embed.2.bias", {ted}, true);
+  h->t_in = new_tensor(h, h->CP, 0, "input");
+  h->tensors[h->t_in].persistent = true;
+  int te = 0, lvl = 0;
+
+  auto attn_at = [&](int ds) {
+    for (int i = 0; i < c.n_attn_res && i < FDSR_MAX_MULTS; ++i)
+      if (c.attn_res[i] == ds) return true;
+    return false;
+  };
+  auto gn_op = [&](const std::string& name, int x0, int C0, int x1, int C1, int gamma, int beta, int film_off) -> int {
+    Op s; s.kind = Op::GN_FINALIZE; s.name = name; s.src0 = x0; s.src1 = x1; s.C0 = C0; s.C1 = C1; s.lvl_in = lvl;
+    s.gn_slot = h->n_gn_slots++; s.gamma = gamma; s.beta = beta; s.film_off = film_off;
+    h->tensors[x0].need_part = true;
+    if (x1 >= 0) h->tensors[x1].need_part = true;
+    h->ops.push_back(s);
+    return s.gn_slot;
+  };
+  enum Mode { PLAIN, DOWN, UP };
+  // ResBlock (gdp_modules/unet.py:276-390): out = skip(x') + conv(dropout(silu(norm(h) * (1 + s) + t))),
+  // h = conv(resample(silu(norm(x)))), (s, t) = Linear(silu(emb)); x' = resample(x)
+  auto res_block = [&](const std::string& p, int x0, int C0, int x1, int C1, int Cout, Mode mode) -> int {
+    const int Cin = C0 + C1;
+    if (Cin % G || Cout % G) return fail(h, FDSR_E_INVALID, "%s: channels not divisible by norm_groups", p.c_str());
+    if (Cin % 16 || (C1 && C0 % 16)) return fail(h, FDSR_E_INVALID, "%s: channel counts must be multiples of 16", p.c_str());
+    if (mode != PLAIN && (C1 || Cin != Cout)) return fail(h, FDSR_E_INVALID, "%s: up/down ResBlocks keep the channel count", p.c_str());
+    int g1 = add_weight(h, p + ".in_layers.0.weight", {Cin}, true);
+    int b1 = add_weight(h, p + ".in_layers.0.bias", {Cin}, true);
+    int w1 = add_weight(h, p + ".in_layers.2.weight", {Cout, Cin, 3, 3}, true);
+    int c1 = add_weight(h, p + ".in_layers.2.bias", {Cout}, true);
+    int wn = add_weight(h, p + ".emb_layers.1.weight", {2 * Cout, ted}, true);
+    int bn = add_weight(h, p + ".emb_layers.1.bias", {2 * Cout}, true);
+    h->weights[wn].sink = WeightEntry::NOISE_W; h->weights[wn].row_off = te;
+    h->weights[bn].sink = WeightEntry::NOISE_B; h->weights[bn].row_off = te;
+    const int my_te = te;
+    te += 2 * Cout;
+    int g2 = add_weight(h, p + ".out_layers.0.weight", {Cout}, true);
+    int b2 = add_weight(h, p + ".out_layers.0.bias", {Cout}, true);
+    int w2 = add_weight(h, p + ".out_layers.3.weight", {Cout, Cout, 3, 3}, true);
+    int c2 = add_weight(h, p + ".out_layers.3.bias", {Cout}, true);
+    int wr = -1, br = -1;
+    if (Cin != Cout) {
+      wr = add_weight(h, p + ".skip_connection.weight", {Cout, Cin, 1, 1}, true);
+      br = add_weight(h, p + ".skip_connection.bias", {Cout}, true);
+      mark_conv_pack(h, wr, CONV1, Cin, C0, C1, Cout);
+    } else if (C1) {
+      return fail(h, FDSR_E_INVALID, "%s: identity skip over a concatenated input is not supported", p.c_str());
     }
-    if (op.dst >= 0) {
-      if (h->tensors[op.dst].first_def < 0) h->tensors[op.dst].first_def = (int)i;
-      h->tensors[op.dst].last_use = std::max(h->tensors[op.dst].last_use, (int)i);
+    mark_conv_pack(h, w2, CONV3_S1, Cout, Cout, 0, Cout);
+    const int slot1 = gn_op(p + ".in_layers.gn", x0, C0, x1, C1, g1, b1, -1);
+    const int lvl_out = mode == DOWN ? lvl + 1 : (mode == UP ? lvl - 1 : lvl);
+    int hsrc = x0, xres = x0;
+    Op k1; k1.kind = Op::CONV; k1.name = p + ".in_layers"; k1.Cout = Cout; k1.w = w1; k1.b = c1; k1.lvl_out = lvl_out;
+    if (mode == DOWN) {   // avg_pool(silu(norm(x))) and avg_pool(x), materialised one level down
+      Op pa; pa.kind = Op::POOL2; pa.name = p + ".h_upd"; pa.src0 = x0; pa.C0 = Cin; pa.lvl_in = lvl; pa.lvl_out = lvl + 1; pa.gn_slot = slot1;
+      pa.dst = new_tensor(h, Cin, lvl + 1, "");
+      h->ops.push_back(pa);
+      Op px; px.kind = Op::POOL2; px.name = p + ".x_upd"; px.src0 = x0; px.C0 = Cin; px.lvl_in = lvl; px.lvl_out = lvl + 1;
+      px.dst = new_tensor(h, Cin, lvl + 1, "");
+      h->ops.push_back(px);
+      mark_conv_pack(h, w1, CONV3_S1, Cin, Cin, 0, Cout);
+      k1.ck = CONV3_S1; k1.src0 = pa.dst; k1.C0 = Cin; k1.lvl_in = lvl + 1;   // no GroupNorm prologue: the pooled tensor is activated
+      hsrc = pa.dst; xres = px.dst;
+    } else if (mode == UP) {   // conv over nearest-x2(silu(norm(x))): the upsample conv with the GroupNorm prologue; x' = nearest-x2(x)
+      Op ux; ux.kind = Op::UP2X; ux.name = p + ".x_upd"; ux.src0 = x0; ux.C0 = Cin; ux.lvl_in = lvl; ux.lvl_out = lvl - 1;
+      ux.dst = new_tensor(h, Cin, lvl - 1, "");
+      h->ops.push_back(ux);
+      mark_conv_pack(h, w1, CONV3_UP, Cin, Cin, 0, Cout);
+      k1.ck = CONV3_UP; k1.src0 = x0; k1.C0 = Cin; k1.lvl_in = lvl; k1.gn_slot = slot1; k1.gamma = g1; k1.beta = b1; k1.force_generic = true;
+      xres = ux.dst;
+    } else {
+      mark_conv_pack(h, w1, CONV3_S1, Cin, C0, C1, Cout);
+      k1.ck = CONV3_S1; k1.src0 = x0; k1.src1 = x1; k1.C0 = C0; k1.C1 = C1; k1.lvl_in = lvl; k1.gn_slot = slot1; k1.gamma = g1; k1.beta = b1;
+    }
+    (void)hsrc;
+    k1.dst = new_tensor(h, Cout, lvl_out, p + ".in_layers");
+    h->ops.push_back(k1);
+    const int lvl_save = lvl;
+    lvl = lvl_out;
+    const int slot2 = gn_op(p + ".out_layers.gn", k1.dst, Cout, -1, 0, g2, b2, my_te);
+    const int out = new_tensor(h, Cout, lvl_out, p);
+    int res_src = xres;
+    if (wr >= 0) {
+      Op kr; kr.kind = Op::CONV; kr.name = p + ".skip_connection"; kr.ck = CONV1; kr.src0 = x0; kr.src1 = x1; kr.C0 = C0; kr.C1 = C1;
+      kr.Cout = Cout; kr.lvl_in = kr.lvl_out = lvl_out; kr.w = wr; kr.b = br; kr.dst = out; kr.no_part = true;
+      h->ops.push_back(kr);
+      res_src = out;
+    }
+    Op k2; k2.kind = Op::CONV; k2.name = p + ".out_layers"; k2.ck = CONV3_S1; k2.src0 = k1.dst; k2.C0 = Cout; k2.Cout = Cout;
+    k2.lvl_in = k2.lvl_out = lvl_out; k2.gn_slot = slot2; k2.gamma = g2; k2.beta = b2; k2.w = w2; k2.b = c2; k2.res = res_src; k2.dst = out;
+    if (c.dropout > 0.f) k2.drop_slot = h->n_drop_slots++;
+    h->ops.push_back(k2);
+    (void)lvl_save;
+    return out;
+  };
+  // AttentionBlock (gdp_modules/unet.py:392-439): x + proj_out(attention(qkv(norm(x)))), heads of 64 channels
+  auto attn_block = [&](const std::string& p, int x, int C) -> int {
+    if (C % 64) return fail(h, FDSR_E_INVALID, "%s: AttentionBlock needs channels divisible by num_head_channels = 64", p.c_str());
+    int gw = add_weight(h, p + ".norm.weight", {C}, true);
+    int gb = add_weight(h, p + ".norm.bias", {C}, true);
+    int wq = add_weight(h, p + ".qkv.weight", {3 * C, C, 1}, true);       // Conv1d
+    int bq = add_weight(h, p + ".qkv.bias", {3 * C}, true);
+    int wo = add_weight(h, p + ".proj_out.weight", {C, C, 1}, true);
+    int bo = add_weight(h, p + ".proj_out.bias", {C}, true);
+    mark_conv_pack(h, wq, CONV1, C, C, 0, 3 * C);
+    mark_conv_pack(h, wo, CONV1, C, C, 0, C);
+    const int slot = gn_op(p + ".norm", x, C, -1, 0, gw, gb, -1);
+    Op kq; kq.kind = Op::CONV; kq.name = p + ".qkv"; kq.ck = CONV1; kq.src0 = x; kq.C0 = C; kq.Cout = 3 * C;
+    kq.lvl_in = kq.lvl_out = lvl; kq.gn_slot = slot; kq.gamma = gw; kq.beta = gb; kq.w = wq; kq.b = bq; kq.gn_plain = true;
+    kq.dst = new_tensor(h, 3 * C, lvl, p + ".qkv");
+    h->ops.push_back(kq);
+    Op at; at.kind = Op::ATTN; at.name = p + ".attention"; at.src0 = kq.dst; at.C0 = C; at.lvl_in = lvl; at.heads = C / 64;
+    at.aux = new_tensor(h, -(C / 64), lvl, p + ".scores");   // C < 0: score scratch of |C| heads, sized in the shape plan
+    at.dst = new_tensor(h, C, lvl, p + ".attention");
+    h->ops.push_back(at);
+    Op ko; ko.kind = Op::CONV; ko.name = p + ".proj_out"; ko.ck = CONV1; ko.src0 = at.dst; ko.C0 = C; ko.Cout = C;
+    ko.lvl_in = ko.lvl_out = lvl; ko.w = wo; ko.b = bo; ko.res = x;
+    ko.dst = new_tensor(h, C, lvl, p);
+    h->ops.push_back(ko);
+    return ko.dst;
+  };
+
+  struct Feat { int t, C; };
+  std::vector<Feat> hs;
+  int ch = mc * c.channel_mults[0], ds = 1, idx = 0;
+  const int input_ch = ch;
+  int cur;
+  {   // input_blocks.0 = conv(in_channel -> ch)
+    int wi = add_weight(h, "input_blocks.0.0.weight", {ch, c.in_channel, 3, 3}, true);
+    int bi = add_weight(h, "input_blocks.0.0.bias", {ch}, true);
+    mark_conv_pack(h, wi, CONV3_S1, h->CP, h->CP, 0, ch);
+    Op op; op.kind = Op::CONV; op.name = "input_blocks.0"; op.ck = CONV3_S1; op.src0 = h->t_in; op.C0 = h->CP; op.Cout = ch;
+    op.lvl_in = op.lvl_out = 0; op.w = wi; op.b = bi; op.dst = new_tensor(h, ch, 0, "input_blocks.0");
+    h->ops.push_back(op);
+    cur = op.dst;
+  }
+  hs.push_back({cur, ch});
+  idx = 1;
+  for (int level = 0; level < c.n_mults; ++level) {
+    const int cm = mc * c.channel_mults[level];
+    for (int rb = 0; rb < c.res_blocks; ++rb) {
+      const std::string p = "input_blocks." + std::to_string(idx);
+      int o = res_block(p + ".0", cur, ch, -1, 0, cm, PLAIN);
+      if (o < 0) return o;
+      cur = o; ch = cm;
+      if (attn_at(ds)) {
+        o = attn_block(p + ".1", cur, ch);
+        if (o < 0) return o;
+        cur = o;
+      }
+      h->tensors[cur].name = p;
+      hs.push_back({cur, ch});
+      ++idx;
+    }
+    if (level != c.n_mults - 1) {
+      const std::string p = "input_blocks." + std::to_string(idx);
+      int o = res_block(p + ".0", cur, ch, -1, 0, ch, DOWN);
+      if (o < 0) return o;
+      cur = o;
+      h->tensors[cur].name = p;
+      hs.push_back({cur, ch});
+      ds *= 2; ++idx;
     }
   }
-  return FDSR_OK;
+  {
+    int o = res_block("middle_block.0", cur, ch, -1, 0, ch, PLAIN);
+    if (o < 0) return o;
+    o = attn_block("middle_block.1", o, ch);
+    if (o < 0) return o;
+    o = res_block("middle_block.2", o, ch, -1, 0, ch, PLAIN);
+    if (o < 0) return o;
+    cur = o;
+    h->tensors[cur].name = "middle_block";
+  }
+  idx = 0;
+  for (int level = c.n_mults - 1; level >= 0; --level) {
+    const int cm = mc * c.channel_mults[level];
+    for (int i = 0; i < c.res_blocks + 1; ++i) {
+      const Feat f = hs.back();
+      hs.pop_back();
+      const std::string p = "output_blocks." + std::to_string(idx);
+      int sub = 0;
+      int o = res_block(p + "." + std::to_string(sub++), cur, ch, f.t, f.C, cm, PLAIN);   // th.cat([h, hs.pop()], dim=1)
+      if (o < 0) return o;
+      cur = o; ch = cm;
+      if (attn_at(ds)) {
+        o = attn_block(p + "." + std::to_string(sub++), cur, ch);
+        if (o < 0) return o;
+        cur = o;
+      }
+      if (level && i == c.res_blocks) {
+        o = res_block(p + "." + std::to_string(sub++), cur, ch, -1, 0, ch, UP);
+        if (o < 0) return o;
+        cur = o;
+        ds /= 2;
+      }
+      h->tensors[cur].name = p;
+      ++idx;
+    }
+  }
+  {   // out = GroupNorm -> SiLU -> conv(input_ch -> out_channel)
+    if (ch != input_ch) return fail(h, FDSR_E_INVALID, "internal: GDP output width");
+    int g = add_weight(h, "out.0.weight", {ch}, true);
+    int b = add_weight(h, "out.0.bias", {ch}, true);
+    int w = add_weight(h, "out.2.weight", {c.out_channel, ch, 3, 3}, true);
+    int cb = add_weight(h, "out.2.bias", {c.out_channel}, true);
+    mark_conv_pack(h, w, CONV3_S1, ch, ch, 0, c.out_channel);
+    const int slot = gn_op("out.gn", cur, ch, -1, 0, g, b, -1);
+    Op k; k.kind = Op::CONV; k.name = "out"; k.ck = CONV3_S1; k.src0 = cur; k.C0 = ch; k.Cout = c.out_channel;
+    k.lvl_in = k.lvl_out = lvl; k.gn_slot = slot; k.gamma = g; k.beta = b; k.w = w; k.b = cb;
+    k.dst = new_tensor(h, c.out_channel, lvl, "out");
+    h->ops.push_back(k);
+    h->t_eps = k.dst;
+    h->tensors[h->t_eps].persistent = true;
+  }
+  if (lvl != 0) return fail(h, FDSR_E_INVALID, "internal: level bookkeeping");
+  h->TE = te;
+  h->temb_in = ted;
+  h->freq_count = mc / 2;
+  const std::string mlp_keys[4] = {"time_embed.0.weight", "time_embed.0.bias", "time_embed.2.weight", "time_embed.2.bias"};
+  return finish_plan(h, mlp_keys, ted);
 }
 
 int ensure_device(fdsr_handle h) {
@@ -415,11 +668,13 @@ int ensure_device(fdsr_handle h) {
   HIPCHK(h, hipMemset(h->d_params, 0, h->param_floats * sizeof(float)));
   if (!h->sr3) {
   // unet.py:27-31: step = arange(count)/count ; exp(-ln(1e4) * step), in fp32
-    const int half = h->cfg.inner_channel / 2;
+    const int half = h->freq_count;
     std::vector<float> fr(half);
     for (int k = 0; k < half; ++k) {
       const float step = (float)k / (float)half;
       fr[k] = expf((float)(-std::log(1e4)) * step);
+      // gdp_modules/unet.py:130-132: exp(-log(max_period) * arange(half) / half): multiply first, then divide (fp32)
+      if (h->gdp) fr[k] = expf(((float)(-std::log(1e4)) * (float)k) / (float)half);
     }
     HIPCHK(h, hipMemcpy(h->d_params + h->weights[h->w_freq].dev_off, fr.data(), half * sizeof(float), hipMemcpyHostToDevice));
   }
@@ -492,7 +747,7 @@ int make_shape_plan(fdsr_handle h, int N, int H, int W, ShapePlan* sp) {
   sp->tensor_nt.assign(h->tensors.size(), 0);
   auto act_bytes = [&](const TensorDesc& t) {
     const size_t hw = (size_t)(H >> t.level) * (W >> t.level);
-    if (t.C < 0) return align_up(attn_scratch_floats(N, (int)hw) * sizeof(float), 256);   // attention scores
+    if (t.C < 0) return align_up(attn_scratch_floats(N, (int)hw, -t.C) * sizeof(float), 256);   // attention scores of |C| heads
     return align_up((size_t)N * hw * t.C * sizeof(float), 256);
   };
   auto part_bytes = [&](const TensorDesc& t) -> size_t {
@@ -608,6 +863,7 @@ int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, 
         g.scale = reinterpret_cast<float*>(ws + sp.gn_off[op.gn_slot]);
         g.shift = g.scale + (size_t)N * (op.C0 + op.C1);
         g.stats = h->keep_stats ? reinterpret_cast<float*>(ws + sp.gn_stats_off[op.gn_slot]) : nullptr;
+        if (op.film_off >= 0) { g.film = temb; g.film_stride = temb_row ? 0 : h->TE; g.film_off = op.film_off; }
         g.N = N; g.G = G; g.HW = Hi * Wi; g.eps = 1e-5f;
         HIPCHK(h, launch_gn_finalize(g, st));
         break;
@@ -627,7 +883,7 @@ int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, 
         if (op.gn_slot >= 0) {
           p.gn_scale = reinterpret_cast<const float*>(ws + sp.gn_off[op.gn_slot]);
           p.gn_shift = p.gn_scale + (size_t)N * (op.C0 + op.C1);
-          p.gn_plain = op.b == -2 ? 1 : 0;   // attn.qkv: SelfAttention.norm has no Swish
+          p.gn_plain = op.gn_plain ? 1 : 0;   // attn.qkv: SelfAttention.norm has no Swish
         }
         p.part_out = op.no_part ? nullptr : PART(op.dst);   // res_conv output is overwritten in place by block2
         if (dropout_on && op.drop_slot >= 0) {              // Dropout(p) between Swish and this conv (train mode)
@@ -658,7 +914,7 @@ int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, 
           p.Cin_pad = w.h_cin_pad;
           p.Cout_pad = w.h_cout_pad;
           static const bool no_up2 = getenv("FDSR_NO_UP2") != nullptr;
-          if (op.ck == CONV3_UP && !no_up2) {
+          if (op.ck == CONV3_UP && !no_up2 && !op.force_generic) {
             p.wq = h->d_wq + w.up2_off[h->prec];
             p.w_inv_scale = w.up2_inv_scale[h->prec];
             HIPCHK(h, launch_conv_up2_h(h->prec, p, st, &nt));
@@ -682,9 +938,17 @@ int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, 
         break;
       }
       case Op::ATTN: {
-        HIPCHK(h, launch_self_attention(TP(op.src0), TP(op.aux), TP(op.dst), N, Hi * Wi, op.C0, st));
+        HIPCHK(h, launch_self_attention(TP(op.src0), TP(op.aux), TP(op.dst), N, Hi * Wi, op.C0, op.heads, st));
         break;
       }
+      case Op::POOL2: {
+        const float* sc = op.gn_slot >= 0 ? reinterpret_cast<const float*>(ws + sp.gn_off[op.gn_slot]) : nullptr;
+        HIPCHK(h, launch_pool2(TP(op.src0), sc, sc ? sc + (size_t)N * op.C0 : nullptr, TP(op.dst), N, Hi, Wi, op.C0, st));
+        break;
+      }
+      case Op::UP2X:
+        HIPCHK(h, launch_upsample2(TP(op.src0), TP(op.dst), N, Hi, Wi, op.C0, st));
+        break;
       case Op::CLAM:
         HIPCHK(h, launch_clam_gate(TP(op.src0), N, Hi * Wi, op.C0, P(op.fc1), P(op.fc2), op.C0 / 16, gate, st,
                                    h->prec == PREC_BF16));
@@ -832,7 +1096,9 @@ int fill_temb(fdsr_handle h, float* temb, int N, const float* nl_dev, float nl_s
   tp.inner = h->cfg.inner_channel;
   tp.TE = h->TE;
   tp.N = N;
-  tp.swish_block = h->sr3 ? 1 : 0;
+  tp.swish_block = (h->sr3 || h->gdp) ? 1 : 0;
+  tp.enc_dim = tp.hid_dim = tp.t_dim = tp.cos_first = 0;
+  if (h->gdp) { tp.enc_dim = h->cfg.inner_channel; tp.hid_dim = tp.t_dim = 4 * h->cfg.inner_channel; tp.cos_first = 1; }
   HIPCHK(h, launch_temb(tp, st));
   return FDSR_OK;
 }
@@ -846,7 +1112,7 @@ int ensure_temb_table(fdsr_handle h, hipStream_t st) {
   HIPCHK(h, hipMalloc(&h->d_temb_table, (size_t)h->T * h->TE * sizeof(float)));
   HIPCHK(h, hipMalloc(&h->d_nl, (size_t)h->T * sizeof(float)));
   std::vector<float> nl(h->T);
-  for (int t = 0; t < h->T; ++t) nl[t] = h->sr3 ? (float)t : h->s_nl[t];
+  for (int t = 0; t < h->T; ++t) nl[t] = (h->sr3 || h->gdp) ? (float)t : h->s_nl[t];
   HIPCHK(h, hipMemcpy(h->d_nl, nl.data(), nl.size() * sizeof(float), hipMemcpyHostToDevice));
   int rc = fill_temb(h, h->d_temb_table, h->T, h->d_nl, 0.f, st);
   if (rc) return rc;
@@ -882,12 +1148,14 @@ int sample_body(fdsr_handle h, const float* cond, const float* noise, float* out
   float* eps = reinterpret_cast<float*>(ws + h->plan.tensor_off[h->t_eps]);
   const size_t img = (size_t)N * 3 * H * W;
   // x_in = cond, img = randn(shape)                                       diffusion.py:204-208
-  HIPCHK(h, launch_nchw_to_nhwc(cond, xin, N, 3, H, W, h->CP, 0, 1, st));
+  // packed input: cat([cond, x_t]) (diffusion.py:173); GDP: cat([x_t, cond]) (gdp_modules/diffusion.py:191)
+  const int x_off = h->gdp ? 0 : 3, c_off = h->gdp ? 3 : 0;
+  HIPCHK(h, launch_nchw_to_nhwc(cond, xin, N, 3, H, W, h->CP, c_off, 1, st));
   if (noise) {
-    HIPCHK(h, launch_nchw_to_nhwc(noise, xin, N, 3, H, W, h->CP, 3, 0, st));
+    HIPCHK(h, launch_nchw_to_nhwc(noise, xin, N, 3, H, W, h->CP, x_off, 0, st));
   } else {   // the engine draws: a new call counter per sample (also under graph replay), plane 0 = x_T
     HIPCHK(h, launch_rng_advance(h->d_rng, st));
-    HIPCHK(h, launch_randn_xin(h->d_rng, xin, N, H * W, h->CP, st));
+    HIPCHK(h, launch_randn_xin(h->d_rng, xin, N, H * W, h->CP, st, x_off));
   }
   for (int k = 0; k < h->T; ++k) {                                        // for i in reversed(range(T))  :209
     const int t = h->T - 1 - k;
@@ -906,6 +1174,7 @@ int sample_body(fdsr_handle h, const float* cond, const float* noise, float* out
     pp.N = N; pp.HW = H * W; pp.CP = h->CP;
     pp.c_recip = h->s_recip[t]; pp.c_recipm1 = h->s_recipm1[t];
     pp.coef1 = h->s_c1[t]; pp.coef2 = h->s_c2[t]; pp.sigma = h->s_sigma[t];
+    pp.x_off = x_off; pp.x0_pred = h->gdp ? 1 : 0;
     pp.plain_out = h->plain_out ? 1 : 0;                                        // ddpm_modules: ret_img[-1] is x_0 itself
     HIPCHK(h, launch_posterior(pp, st));
   }

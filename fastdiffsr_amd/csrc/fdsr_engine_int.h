@@ -46,7 +46,7 @@ struct TensorDesc {
 };
 
 struct Op {
-  enum Kind { GN_FINALIZE, CONV, CLAM, SLAM, ATTN } kind;
+  enum Kind { GN_FINALIZE, CONV, CLAM, SLAM, ATTN, POOL2, UP2X } kind;
   std::string name;
   int src0 = -1, src1 = -1, dst = -1, res = -1;
   ConvKind ck = CONV3_S1;
@@ -58,6 +58,10 @@ struct Op {
   int fc1 = -1, fc2 = -1;
   bool no_part = false;   // dst is overwritten later by another producer (res_conv pre-fill)
   int aux = -1;           // ATTN: scratch tensor for the scores
+  bool gn_plain = false;  // the GroupNorm in front of this conv has no Swish (SelfAttention.norm / AttentionBlock.norm)
+  int film_off = -1;      // GN_FINALIZE: FiLM (1 + scale, shift) of the GDP ResBlock from the embedding table at this column
+  int heads = 1;          // ATTN
+  bool force_generic = false;   // CONV3_UP with a GroupNorm prologue: not the sub-pixel kernel
   int drop_slot = -1;     // block2 conv with Dropout(p > 0) in front of it (unet.py:89-101): index of its keep-mask
 };
 
@@ -101,6 +105,9 @@ struct fdsr_engine {
   int w_freq = -1;   // synthetic entry: positional-encoding frequencies (SR3: the checkpoint's inv_freq buffer)
   int w_zero_bias = -1;   // synthetic zeros for bias-free 1x1 convs (attn.qkv)
   bool sr3 = false;          // SR3 sibling (ddpm_modules): integer-time embedding, noise [T+1]
+  bool gdp = false;          // GDP sibling (gdp_modules): guided-diffusion UNet, predicts x_0, input cat[x, cond], integer time
+  int temb_in = 0;           // row length of the per-block embedding table (inner_channel; GDP: 4 * model_channels)
+  int freq_count = 0;        // sinusoid frequencies of the time / noise-level encoding
   bool attn_blocks = false;  // SR3 and TESR siblings: SelfAttention per attn_res + mid[0], no dead .conv, no CLAM/SLAM
   bool plain_out = false;    // SR3 and TESR: the sampler returns x_0 itself (no res2img)
   size_t param_floats = 0, noise_w_off = 0, noise_b_off = 0;

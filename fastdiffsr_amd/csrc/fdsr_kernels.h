@@ -80,6 +80,10 @@ struct GnFinalizeParams {
   const float* gamma; const float* beta;   // [C0+C1]
   float* scale; float* shift;              // [N][C0+C1]
   float* stats;                            // optional [N][G][2]: (mean, rstd) kept for the backward pass
+  // optional FiLM of the guided-diffusion ResBlock (gdp_modules/unet.py:377-381, use_scale_shift_norm):
+  // norm(h) * (1 + s) + t with s = film[n*film_stride + film_off + c], t = film[... + C + c], folded into scale / shift
+  const float* film;
+  int film_stride, film_off;
   int N, G, HW;
   float eps;
 };
@@ -103,7 +107,10 @@ struct TembParams {
   float nl_scalar;
   float* temb;        // [N][TE]
   int inner, TE, N;
-  int swish_block;    // SR3 variant: per-block Linear applied to Swish(t)
+  int swish_block;    // SR3 / GDP variants: per-block Linear applied to Swish(t)
+  // dimensions (0: the FastDiffSR defaults enc = t = inner, hid = 4*inner); GDP: enc = model_channels, hid = t = 4*model_channels
+  int enc_dim, hid_dim, t_dim;
+  int cos_first;      // GDP timestep_embedding: cat([cos, sin]) (gdp_modules/unet.py:120-138) instead of [sin, cos]
 };
 hipError_t launch_temb(const TembParams& p, hipStream_t s);
 
@@ -133,8 +140,15 @@ hipError_t launch_nhwc_to_nchw(const float* src, float* dst, int N, int C, int H
 
 // SelfAttention (n_head = 1) of the SR3 sibling on the NHWC qkv tensor [N][HW][3C]:
 // S (scratch [N][HW][HW]) = softmax(Q K^T / sqrt(C)), O [N][HW][C] = S V.
-hipError_t launch_self_attention(const float* qkv, float* S, float* O, int N, int HW, int C, hipStream_t s);
-size_t attn_scratch_floats(int N, int HW);
+// heads > 1 (GDP AttentionBlock, QKVAttentionLegacy, gdp_modules/unet.py:461-488): qkv channels are laid out
+// [head][q | k | v][C/heads]; every head attends on its own, scores / sqrt(C/heads).  heads == 1: [q | k | v][C].
+hipError_t launch_self_attention(const float* qkv, float* S, float* O, int N, int HW, int C, int heads, hipStream_t s);
+size_t attn_scratch_floats(int N, int HW, int heads);
+// 2x2 average pool of x (optionally of swish(x*scale + shift), the activated GroupNorm output) and nearest x2
+// upsampling, materialised: the up/down ResBlocks of GDP resample h AND the skip input (gdp_modules/unet.py:369-376)
+hipError_t launch_pool2(const float* x, const float* gn_scale, const float* gn_shift, float* out, int N, int H, int W, int C,
+                        hipStream_t s);   // x [N,H,W,C] -> out [N,H/2,W/2,C]
+hipError_t launch_upsample2(const float* x, float* out, int N, int H, int W, int C, hipStream_t s);   // -> [N,2H,2W,C]
 
 // tensor2img of the val loop (core/metrics.py:16-42): NCHW fp32 -> HWC uint8
 hipError_t launch_tensor2img_u8(const float* src, unsigned char* dst, int N, int C, int H, int W, float lo, float hi,
@@ -158,6 +172,8 @@ struct PosteriorParams {
   int N, HW, CP;
   float c_recip, c_recipm1, coef1, coef2, sigma;
   int plain_out;       // SR3 variant: out = x_0 itself (no res2img)
+  int x_off;           // first channel of x_t inside xin (3: cat[cond, x]; GDP: 0, cat[x, cond], gdp_modules/diffusion.py:191)
+  int x0_pred;         // GDP: the network predicts x_0 itself (clamped), not the noise (:190-195)
 };
 hipError_t launch_posterior(const PosteriorParams& p, hipStream_t s);
 
@@ -167,6 +183,6 @@ hipError_t launch_rng_advance(unsigned long long* rng, hipStream_t s);          
 // plane `plane` of the noise the engine would use, as [N,3,H,W] fp32 (tests) ...
 hipError_t launch_randn_plane(const unsigned long long* rng, float* dst_nchw, int N, int HW, int plane, hipStream_t s);
 // ... and x_T = plane 0 written straight into channels 3..5 of the packed UNet input
-hipError_t launch_randn_xin(const unsigned long long* rng, float* xin, int N, int HW, int CP, hipStream_t s);
+hipError_t launch_randn_xin(const unsigned long long* rng, float* xin, int N, int HW, int CP, hipStream_t s, int c_off = 3);
 
 }  // namespace fdsr

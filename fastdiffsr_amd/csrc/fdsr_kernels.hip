@@ -422,9 +422,16 @@ __global__ void __launch_bounds__(256) gn_finalize_kernel(const GnFinalizeParams
   __syncthreads();
   if (tid < cpg) {
     const int cc = g * cpg + tid;
-    const float sc = (float)gs[1] * p.gamma[cc];
+    float sc = (float)gs[1] * p.gamma[cc];
+    float sh = p.beta[cc] - (float)gs[0] * sc;
+    if (p.film) {   // (x_hat*gamma + beta) * (1 + s) + t
+      const float* f = p.film + (size_t)n * p.film_stride + p.film_off;
+      const float one_s = 1.0f + f[cc];
+      sc *= one_s;
+      sh = sh * one_s + f[C + cc];
+    }
     p.scale[(size_t)n * C + cc] = sc;
-    p.shift[(size_t)n * C + cc] = p.beta[cc] - (float)gs[0] * sc;
+    p.shift[(size_t)n * C + cc] = sh;
   }
 }
 
@@ -445,44 +452,46 @@ int conv_max_tiles(int H, int W) {
 // noise-level embedding + all per-block shifts
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) temb_kernel(const TembParams p) {
-  extern __shared__ __attribute__((aligned(16))) float st[];   // enc[inner] | hid[4*inner] | t[inner]
-  const int inner = p.inner, hid = 4 * inner, tid = threadIdx.x, n = blockIdx.x;
+  extern __shared__ __attribute__((aligned(16))) float st[];   // enc[E] | hid[Hd] | t[Td]
+  const int E = p.enc_dim ? p.enc_dim : p.inner, hid = p.hid_dim ? p.hid_dim : 4 * p.inner, Td = p.t_dim ? p.t_dim : p.inner;
+  const int tid = threadIdx.x, n = blockIdx.x;
   float* enc = st;
-  float* hbuf = st + inner;
+  float* hbuf = st + E;
   float* tv = hbuf + hid;
-  const float nl = p.nl_dev ? p.nl_dev[n] : p.nl_scalar;   // noise level, or the integer time (SR3 variant)
-  const int half = inner / 2;
-  for (int k = tid; k < half; k += 256) {   // unet.py:27-35 / ddpm_modules TimeEmbedding: cat([sin, cos], -1)
+  const float nl = p.nl_dev ? p.nl_dev[n] : p.nl_scalar;   // noise level, or the integer time (SR3 / GDP variants)
+  const int half = E / 2;
+  for (int k = tid; k < half; k += 256) {   // unet.py:27-35 / ddpm_modules TimeEmbedding: cat([sin, cos], -1); GDP: cat([cos, sin])
     const float e = nl * p.freq[k];
-    enc[k] = sinf(e);
-    enc[half + k] = cosf(e);
+    enc[p.cos_first ? half + k : k] = sinf(e);
+    enc[p.cos_first ? k : half + k] = cosf(e);
   }
   __syncthreads();
   for (int j = tid; j < hid; j += 256) {
     float a = p.b1[j];
-    const float* w = p.w1 + (size_t)j * inner;
-    for (int k = 0; k < inner; ++k) a = fmaf(w[k], enc[k], a);
+    const float* w = p.w1 + (size_t)j * E;
+    for (int k = 0; k < E; ++k) a = fmaf(w[k], enc[k], a);
     hbuf[j] = a / (1.0f + expf(-a));
   }
   __syncthreads();
-  for (int j = tid; j < inner; j += 256) {
+  for (int j = tid; j < Td; j += 256) {
     float a = p.b2[j];
     const float* w = p.w2 + (size_t)j * hid;
     for (int k = 0; k < hid; ++k) a = fmaf(w[k], hbuf[k], a);
-    // SR3 variant (ddpm_modules/unet.py:81-84): the per-block Linear is applied to Swish(t)
+    // SR3 (ddpm_modules/unet.py:81-84) and GDP (gdp_modules/unet.py:336-342): the per-block Linear is applied to Swish(t)
     tv[j] = p.swish_block ? a / (1.0f + expf(-a)) : a;
   }
   __syncthreads();
   for (int o = tid; o < p.TE; o += 256) {
     float a = p.bn[o];
-    const float* w = p.wn + (size_t)o * inner;
-    for (int k = 0; k < inner; ++k) a = fmaf(w[k], tv[k], a);
+    const float* w = p.wn + (size_t)o * Td;
+    for (int k = 0; k < Td; ++k) a = fmaf(w[k], tv[k], a);
     p.temb[(size_t)n * p.TE + o] = a;
   }
 }
 
 hipError_t launch_temb(const TembParams& p, hipStream_t s) {
-  hipLaunchKernelGGL(temb_kernel, dim3(p.N), dim3(256), (size_t)6 * p.inner * sizeof(float), s, p);
+  const int E = p.enc_dim ? p.enc_dim : p.inner, hid = p.hid_dim ? p.hid_dim : 4 * p.inner, Td = p.t_dim ? p.t_dim : p.inner;
+  hipLaunchKernelGGL(temb_kernel, dim3(p.N), dim3(256), (size_t)(E + hid + Td) * sizeof(float), s, p);
   return hipGetLastError();
 }
 
@@ -848,9 +857,9 @@ hipError_t launch_randn_plane(const unsigned long long* rng, float* dst, int N, 
   hipLaunchKernelGGL(randn_plane_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, rng, dst, HW, 0, 0, plane, total);
   return hipGetLastError();
 }
-hipError_t launch_randn_xin(const unsigned long long* rng, float* xin, int N, int HW, int CP, hipStream_t s) {
+hipError_t launch_randn_xin(const unsigned long long* rng, float* xin, int N, int HW, int CP, hipStream_t s, int c_off) {
   const size_t total = (size_t)N * HW;
-  hipLaunchKernelGGL(randn_plane_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, rng, xin, HW, CP, 3, 0, total);
+  hipLaunchKernelGGL(randn_plane_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, rng, xin, HW, CP, c_off, 0, total);
   return hipGetLastError();
 }
 
@@ -867,21 +876,21 @@ __global__ void __launch_bounds__(256) posterior_kernel(const PosteriorParams p)
   if (p.rng) randn3(p.rng, p.rng_plane, i, z);
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    const float x = xs[3 + c];
+    const float x = xs[p.x_off + c];
     const float e = p.eps[i * 3 + c];
     // two separately rounded products, then subtract: no fma contraction
     const float a = __fmul_rn(p.c_recip, x);
     const float b = __fmul_rn(p.c_recipm1, e);
-    float x0 = __fsub_rn(a, b);
+    float x0 = p.x0_pred ? e : __fsub_rn(a, b);                               // GDP: the network output IS x_0
     x0 = fminf(fmaxf(x0, -1.f), 1.f);                                        // clamp_(-1, 1)  :178-179
     const float mean = __fadd_rn(__fmul_rn(p.coef1, x0), __fmul_rn(p.coef2, x));   // :161-165
     float xn = mean;
     const size_t o = (n * 3 + c) * p.HW + pix;
     if (p.noise) xn = __fadd_rn(mean, __fmul_rn(p.noise[o], p.sigma));       // :189-190
     else if (p.rng) xn = __fadd_rn(mean, __fmul_rn(z[c], p.sigma));
-    xs[3 + c] = xn;
+    xs[p.x_off + c] = xn;
     if (p.traj) p.traj[o] = xn;
-    if (p.out) p.out[o] = p.plain_out ? xn : fminf(fmaxf(xn, -1.f), 1.f) / 2.0f + xs[c];   // res2img :275-281 (SR3: the image itself)
+    if (p.out) p.out[o] = p.plain_out ? xn : fminf(fmaxf(xn, -1.f), 1.f) / 2.0f + xs[(p.x_off ? 0 : 3) + c];   // res2img :275-281 (SR3: the image itself)
   }
 }
 
@@ -994,17 +1003,27 @@ hipError_t launch_resize_bicubic_u8(const unsigned char* src, unsigned char* tmp
 // instruction: S = Q K^T / sqrt(C) -> row softmax -> O = P V.  q/k/v are channel slices of the
 // NHWC qkv tensor [N][HW][3C]; one wave per 32x32 output tile (the whole op is <1 % of a forward).
 // ---------------------------------------------------------------------------
+// qkv [N][HW][3C]; head hd of image b: q / k / v start at channel qo / ko / vo (attn_offsets), `ch` channels each
+__device__ __forceinline__ void attn_offsets(int C, int heads, int hd, int& qo, int& ko, int& vo) {
+  const int ch = C / heads;
+  if (heads > 1) { qo = hd * 3 * ch; ko = qo + ch; vo = qo + 2 * ch; }   // QKVAttentionLegacy: [head][q|k|v][ch]
+  else { qo = 0; ko = C; vo = 2 * C; }
+}
+
 __global__ void __launch_bounds__(64) attn_scores_kernel(const float* __restrict__ qkv, float* __restrict__ S, int HW, int HWp,
-                                                         int C, float inv_div) {
+                                                         int C, int heads, float inv_div) {
   const int lane = threadIdx.x, r31 = lane & 31, h = lane >> 5;
-  const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32, b = blockIdx.z;
+  const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32, bh = blockIdx.z, b = bh / heads, hd = bh % heads;
+  const int ch = C / heads;
+  int qo, ko, vo;
+  attn_offsets(C, heads, hd, qo, ko, vo);
   const float* base = qkv + (size_t)b * HW * 3 * C;
-  const float* qrow = base + (size_t)min(m0 + r31, HW - 1) * 3 * C + 4 * h;          // A[i = query][k = channel]
-  const float* krow = base + (size_t)min(n0 + r31, HW - 1) * 3 * C + C + 4 * h;      // B[k][j = key] = K[j][k]
+  const float* qrow = base + (size_t)min(m0 + r31, HW - 1) * 3 * C + qo + 4 * h;      // A[i = query][k = channel]
+  const float* krow = base + (size_t)min(n0 + r31, HW - 1) * 3 * C + ko + 4 * h;      // B[k][j = key] = K[j][k]
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-  for (int k = 0; k < C; k += 8) {
+  for (int k = 0; k < ch; k += 8) {
     const f32x4 a = *reinterpret_cast<const f32x4*>(qrow + k);
     const f32x4 bb = *reinterpret_cast<const f32x4*>(krow + k);
 #pragma unroll
@@ -1014,7 +1033,7 @@ __global__ void __launch_bounds__(64) attn_scores_kernel(const float* __restrict
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int row = m0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-    if (row < HW && col < HW) S[((size_t)b * HW + row) * HWp + col] = acc[i] * inv_div;
+    if (row < HW && col < HW) S[((size_t)bh * HW + row) * HWp + col] = acc[i] * inv_div;
   }
 }
 
@@ -1034,11 +1053,14 @@ __global__ void __launch_bounds__(256) softmax_rows_kernel(float* __restrict__ S
 }
 
 __global__ void __launch_bounds__(64) attn_pv_kernel(const float* __restrict__ P, const float* __restrict__ qkv,
-                                                     float* __restrict__ O, int HW, int HWp, int C) {
+                                                     float* __restrict__ O, int HW, int HWp, int C, int heads) {
   const int lane = threadIdx.x, r31 = lane & 31, h = lane >> 5;
-  const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32, b = blockIdx.z;   // n: channel, m: query
-  const float* prow = P + ((size_t)b * HW + min(m0 + r31, HW - 1)) * HWp + 4 * h;   // A[i = query][k = key]
-  const float* vcol = qkv + (size_t)b * HW * 3 * C + 2 * C + n0 + r31;               // B[k = key][j = channel]
+  const int ch = C / heads, nblk = ch / 32;
+  const int hd = blockIdx.x / nblk, n0 = (blockIdx.x % nblk) * 32, m0 = blockIdx.y * 32, b = blockIdx.z;   // n: channel of the head, m: query
+  int qo, ko, vo;
+  attn_offsets(C, heads, hd, qo, ko, vo);
+  const float* prow = P + ((size_t)(b * heads + hd) * HW + min(m0 + r31, HW - 1)) * HWp + 4 * h;   // A[i = query][k = key]
+  const float* vcol = qkv + (size_t)b * HW * 3 * C + vo + n0 + r31;                               // B[k = key][j = channel]
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -1053,21 +1075,85 @@ __global__ void __launch_bounds__(64) attn_pv_kernel(const float* __restrict__ P
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int row = m0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-    if (row < HW) O[((size_t)b * HW + row) * C + n0 + r31] = acc[i];
+    if (row < HW) O[((size_t)b * HW + row) * C + hd * ch + n0 + r31] = acc[i];   // a.reshape(bs, heads*ch, T): head-major channels
   }
 }
 
-// S: scratch of attn_scratch_floats(N, HW) floats
-size_t attn_scratch_floats(int N, int HW) { return (size_t)N * HW * ((HW + 7) / 8 * 8); }
+// S: scratch of attn_scratch_floats(N, HW, heads) floats
+size_t attn_scratch_floats(int N, int HW, int heads) { return (size_t)N * heads * HW * ((HW + 7) / 8 * 8); }
 
-hipError_t launch_self_attention(const float* qkv, float* S, float* O, int N, int HW, int C, hipStream_t s) {
-  if (C % 32) return hipErrorInvalidValue;
-  const int HWp = (HW + 7) / 8 * 8;
-  const float inv_div = 1.0f / sqrtf((float)C);
-  hipLaunchKernelGGL(attn_scores_kernel, dim3((HW + 31) / 32, (HW + 31) / 32, N), dim3(64), 0, s, qkv, S, HW, HWp, C, inv_div);
-  const size_t rows = (size_t)N * HW;
+hipError_t launch_self_attention(const float* qkv, float* S, float* O, int N, int HW, int C, int heads, hipStream_t s) {
+  if (heads < 1 || C % heads || (C / heads) % 32) return hipErrorInvalidValue;
+  const int HWp = (HW + 7) / 8 * 8, ch = C / heads;
+  // QKVAttentionLegacy scales q and k by ch^-1/4 each (gdp_modules/unet.py:480-483); SelfAttention divides by sqrt(C)
+  const float inv_div = 1.0f / sqrtf((float)ch);
+  hipLaunchKernelGGL(attn_scores_kernel, dim3((HW + 31) / 32, (HW + 31) / 32, N * heads), dim3(64), 0, s, qkv, S, HW, HWp, C, heads, inv_div);
+  const size_t rows = (size_t)N * heads * HW;
   hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, S, HW, HWp, rows);
-  hipLaunchKernelGGL(attn_pv_kernel, dim3(C / 32, (HW + 31) / 32, N), dim3(64), 0, s, S, qkv, O, HW, HWp, C);
+  hipLaunchKernelGGL(attn_pv_kernel, dim3(C / 32, (HW + 31) / 32, N), dim3(64), 0, s, S, qkv, O, HW, HWp, C, heads);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// materialised resampling of the GDP up/down ResBlocks
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) pool2_kernel(const float* __restrict__ x, const float* __restrict__ sc, const float* __restrict__ sh,
+                                                    float* __restrict__ out, int H, int W, int cq, size_t total) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;   // over [N][H/2][W/2][cq]
+  if (i >= total) return;
+  const int c4 = (int)(i % cq);
+  size_t r = i / cq;
+  const int Wo = W >> 1, Ho = H >> 1;
+  const int ox = (int)(r % Wo);
+  r /= Wo;
+  const int oy = (int)(r % Ho);
+  const size_t n = r / Ho;
+  f32x4 a = {1.f, 1.f, 1.f, 1.f}, b = {0.f, 0.f, 0.f, 0.f};
+  if (sc) {
+    a = *reinterpret_cast<const f32x4*>(sc + (n * cq + c4) * 4);
+    b = *reinterpret_cast<const f32x4*>(sh + (n * cq + c4) * 4);
+  }
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(x + (((n * H + 2 * oy + dy) * W + 2 * ox + dx) * cq + c4) * 4);
+      if (sc) {
+        v = v * a + b;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+      }
+      acc += v;
+    }
+  *reinterpret_cast<f32x4*>(out + i * 4) = acc * 0.25f;
+}
+
+hipError_t launch_pool2(const float* x, const float* gn_scale, const float* gn_shift, float* out, int N, int H, int W, int C,
+                        hipStream_t s) {
+  if ((C & 3) || (H & 1) || (W & 1)) return hipErrorInvalidValue;
+  const size_t total = (size_t)N * (H >> 1) * (W >> 1) * (C >> 2);
+  hipLaunchKernelGGL(pool2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, gn_scale, gn_shift, out, H, W, C >> 2, total);
+  return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256) upsample2_kernel(const float* __restrict__ x, float* __restrict__ out, int H, int W, int cq,
+                                                        size_t total) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;   // over [N][2H][2W][cq]
+  if (i >= total) return;
+  const int c4 = (int)(i % cq);
+  size_t r = i / cq;
+  const int ox = (int)(r % (2 * W));
+  r /= (2 * W);
+  const int oy = (int)(r % (2 * H));
+  const size_t n = r / (2 * H);
+  *reinterpret_cast<f32x4*>(out + i * 4) = *reinterpret_cast<const f32x4*>(x + (((n * H + (oy >> 1)) * W + (ox >> 1)) * cq + c4) * 4);
+}
+
+hipError_t launch_upsample2(const float* x, float* out, int N, int H, int W, int C, hipStream_t s) {
+  if (C & 3) return hipErrorInvalidValue;
+  const size_t total = (size_t)N * 2 * H * 2 * W * (C >> 2);
+  hipLaunchKernelGGL(upsample2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, out, H, W, C >> 2, total);
   return hipGetLastError();
 }
 

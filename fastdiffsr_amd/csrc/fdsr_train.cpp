@@ -311,7 +311,7 @@ int fdsr_train_grads(fdsr_handle h, const float* x_nchw, const float* noise_leve
       if (op.gn_slot >= 0) {
         q.gn_scale = reinterpret_cast<const float*>(ws + sp.gn_off[op.gn_slot]);
         q.gn_shift = q.gn_scale + (size_t)N * Cin;
-        q.gn_plain = op.b == -2 ? 1 : 0;
+        q.gn_plain = op.gn_plain ? 1 : 0;
       }
       q.dw = DG(op.w); q.scratch = wg;
       q.N = N; q.Hin = Hi; q.Win = Wi; q.Hout = Ho; q.Wout = Wo;
@@ -335,7 +335,7 @@ int fdsr_train_grads(fdsr_handle h, const float* x_nchw, const float* noise_leve
       g.dx0 = GT(op.src0); g.dx1 = GT(op.src1);
       g.dgamma = DG(op.gamma); g.dbeta = DG(op.beta);
       g.scratch = dbl;
-      g.N = N; g.HW = Hi * Wi; g.G = G; g.plain = op.b == -2 ? 1 : 0;
+      g.N = N; g.HW = Hi * Wi; g.G = G; g.plain = op.gn_plain ? 1 : 0;
       if (sp.training && op.drop_slot >= 0) {
         g.drop_mask = reinterpret_cast<const unsigned char*>(ws + sp.drop_off[op.drop_slot]);
         g.drop_scale = 1.0f / (1.0f - h->cfg.dropout);

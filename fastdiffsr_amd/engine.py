@@ -26,7 +26,7 @@ class Engine:
         for i, m in enumerate(cfg.channel_mults):
             c.channel_mults[i] = int(m)
         c.res_blocks, c.dropout, c.image_size = cfg.res_blocks, float(cfg.dropout), int(cfg.image_size)
-        c.variant = {'fastdiffsr': 0, 'ddpm': 1, 'tesr': 2}[cfg.variant]
+        c.variant = {'fastdiffsr': 0, 'ddpm': 1, 'tesr': 2, 'gdp': 3}[cfg.variant]
         c.n_attn_res = min(len(cfg.attn_res), _lib.FDSR_MAX_MULTS)
         for i, r in enumerate(cfg.attn_res[:_lib.FDSR_MAX_MULTS]):
             c.attn_res[i] = int(r)
@@ -134,7 +134,7 @@ class Engine:
         B, _, H, W = cond.shape
         if noise is not None:
             noise = self._check_input(noise, 'noise')
-            nT = self.T + (1 if self.cfg.variant == 'ddpm' else 0)     # SR3 draws noise at t = 0 too
+            nT = self.T + (1 if self.cfg.variant in ('ddpm', 'gdp') else 0)     # SR3 / GDP draw noise at t = 0 too (masked)
             if tuple(noise.shape) != (nT, B, 3, H, W):
                 raise ValueError(f'noise must be [{nT},{B},3,{H},{W}], got {tuple(noise.shape)}')
         ws = self._workspace(B, H, W, cond.device)

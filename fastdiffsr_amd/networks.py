@@ -7,10 +7,12 @@ def define_G(opt):
         from .sr3 import diffusion, unet
     elif which == 'tesr':                   # networks.py:86-87
         from .tesr import diffusion, unet
+    elif which == 'gdp':                    # networks.py:88-89
+        from .gdp import diffusion, unet
     elif which in ('fastdiffsr', 'fastdiffsr_hip'):
         from . import diffusion, unet
     else:
-        raise NotImplementedError(f"fastdiffsr_amd provides which_model_G in ('fastdiffsr', 'ddpm', 'tesr') (got {which!r})")
+        raise NotImplementedError(f"fastdiffsr_amd provides which_model_G in ('fastdiffsr', 'ddpm', 'tesr', 'gdp') (got {which!r})")
     if ('norm_groups' not in model_opt['unet']) or model_opt['unet']['norm_groups'] is None:
         model_opt['unet']['norm_groups'] = 32
     u = model_opt['unet']
@@ -43,7 +45,7 @@ def init_weights(net, init_type='kaiming', scale=1, std=0.02):
         raise NotImplementedError('initialization method [{:s}] not implemented'.format(init_type))
     with torch.no_grad():
         for key, p in named.items():
-            if not key.endswith('.weight') or p.dim() not in (2, 4):
+            if not key.endswith(".weight") or p.dim() not in (2, 3, 4):      # Linear, Conv1d (GDP attention), Conv2d
                 continue                                             # GroupNorm affine, biases
             if init_type == 'orthogonal':
                 init.orthogonal_(p, gain=1)

@@ -60,7 +60,8 @@ class UNet(nn.Module):
         """PyTorch's default initialisers (Conv2d/Linear: kaiming_uniform(a=sqrt 5) and
         bias ~ U(+-1/sqrt(fan_in)); GroupNorm: weight 1, bias 0)."""
         t = torch.empty(shape)
-        if '.block.0.' in key or '.attn.norm.' in key:          # GroupNorm
+        sibling = self._schema.get(key[:-len(leaf)] + 'weight')
+        if len(shape) == 1 and sibling is not None and len(sibling) == 1:   # GroupNorm: the only 1-D `.weight` tensors
             return t.fill_(1.0 if leaf == 'weight' else 0.0)
         if leaf == 'weight':
             nn.init.kaiming_uniform_(t, a=math.sqrt(5))

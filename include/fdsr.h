@@ -67,6 +67,7 @@ typedef struct fdsr_config {
 } fdsr_config;
 #define FDSR_VARIANT_FASTDIFFSR 0
 #define FDSR_VARIANT_SR3 1
+#define FDSR_VARIANT_GDP 3   /* model/gdp_modules: the guided-diffusion UNet (scale-shift-norm ResBlocks, up/down ResBlocks, multi-head attention); inner_channel = model_channels, attn_res = attention_resolutions (downsample rates); predicts x_0; input cat[x, cond] */
 #define FDSR_VARIANT_TESR 2  /* model/tesr_modules: FastDiffSR's blocks and noise-level embedding, SR3's SelfAttention placement, sampler returns x_0 */
 
 /* Per-timestep scalars the reverse process reads (diffusion.py:109-155; only

@@ -365,6 +365,62 @@ def init_goldens():
     print('wrote init_weights.npz:', len(keys), 'tensors')
 
 
+def gdp_goldens():
+    """(xiii) GDP sibling (model/gdp_modules): the guided-diffusion UNet as define_G builds it (scale-shift-norm ResBlocks,
+    up/down ResBlocks, multi-head attention), small: model_channels 64, mults (1, 2, 2), one ResBlock per level, attention
+    at downsample rates 2 and 4.  UNet forwards at three timesteps, the sampler (continous=True) at T=8, the MSE loss."""
+    from unittest import mock
+    import_reference()
+    # gdp_modules/diffusion.py:9 imports torchvision.transforms.functional (unused on this path): stub it like torchvision itself
+    tvt, tvf = types.ModuleType('torchvision.transforms'), types.ModuleType('torchvision.transforms.functional')
+    tvt.functional = tvf
+    sys.modules.setdefault('torchvision.transforms', tvt)
+    sys.modules.setdefault('torchvision.transforms.functional', tvf)
+    sys.modules['torchvision'].transforms = sys.modules['torchvision.transforms']
+    from model.gdp_modules import diffusion as gdiff, unet as gunet
+    from fastdiffsr_amd.arch import param_schema
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    cfg = UNetConfig(in_channel=6, out_channel=3, inner_channel=64, norm_groups=32, channel_mults=(1, 2, 2), attn_res=(2, 4),
+                     res_blocks=1, dropout=0.1, image_size=32, variant='gdp')
+    net = gunet.UNet(image_size=32, in_channel=6, model_channels=64, out_channel=3, res_blocks=1, attention_resolutions=(2, 4),
+                     dropout=0.1, channel_mults=(1, 2, 2), inner_channel=64, norm_groups=32, attn_res=(16,))
+    sd = synth_state_dict(cfg, 13)
+    ref_keys = list(net.state_dict().keys())
+    assert ref_keys == list(sd.keys()), 'GDP schema order mismatch'
+    assert [tuple(v.shape) for v in net.state_dict().values()] == [tuple(v.shape) for v in sd.values()]
+    assert list(param_schema(cfg).keys()) == ref_keys
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    sched = dict(schedule='linear', n_timestep=8, linear_start=1e-4, linear_end=2e-2)
+    G = gdiff.GaussianDiffusion(net, image_size=32, channels=3, loss_type='l1', conditional=True, schedule_opt=sched)
+    G.set_loss('cpu')
+    G.set_new_noise_schedule(sched, 'cpu')
+    G.eval()
+    g = torch.Generator().manual_seed(83)
+    x = torch.randn(2, 6, 32, 32, generator=g)
+    out = {'weights_sha256': np.array(state_dict_sha256(sd)), 'x': x.numpy(), 'keys': np.array(ref_keys)}
+    with torch.no_grad():
+        for i, t in enumerate(((0, 7), (3, 3), (999, 500))):
+            out[f'rec/{i}'] = net(x, torch.tensor(t, dtype=torch.long)).numpy()
+            out[f't/{i}'] = np.array(t, dtype=np.int64)
+    cond, noise = synth_inputs(1, 32, 32, 9, cond_seed=91, noise_seed=92)       # x_T + one draw per step (t = 0 masked)
+    draws = iter([noise[k] for k in range(9)])
+    with torch.no_grad(), mock.patch.object(torch, 'randn', lambda *a, **k: next(draws)):
+        frames = G.super_resolution(cond, continous=True)
+    out['cond'] = cond.numpy()
+    out['noise'] = noise.numpy()
+    out['frames'] = frames.numpy()              # [1 + 8, 3, 32, 32]: x_in, then x_t after every step (sample_inter = 1)
+    hr = torch.rand(2, 3, 32, 32, generator=g) * 2 - 1
+    sr = (hr + 0.2 * torch.randn(2, 3, 32, 32, generator=g)).clamp(-1, 1)
+    nz = torch.randn(2, 3, 32, 32, generator=g)
+    tt = torch.tensor([5, 2], dtype=torch.long)
+    with torch.no_grad(), mock.patch.object(torch, 'randint', lambda *a, **k: tt):
+        loss = G({'HR': hr, 'SR': sr, 'LR': sr}, noise=nz)
+    out.update({'hr': hr.numpy(), 'sr': sr.numpy(), 'loss_noise': nz.numpy(), 'loss_t': tt.numpy(), 'loss': np.array(loss.item())})
+    np.savez_compressed(os.path.join(OUT, 'gdp.npz'), **out)
+    print('wrote gdp.npz: loss', loss.item(), 'frames', frames.shape)
+
+
 def tesr_goldens():
     """(xi) TESR sibling (model/tesr_modules): UNet forwards incl. the SelfAttention levels, the sampler
     (continous=True frames and the final image) and the Charbonnier training-loss value, from the reference itself."""
@@ -459,6 +515,8 @@ if __name__ == '__main__':
         config_goldens()          # only tests/golden/configs.json
     elif len(sys.argv) > 1 and sys.argv[1] == 'train':
         train_goldens()           # only tests/golden/train_step.npz (reads train_loss.npz)
+    elif len(sys.argv) > 1 and sys.argv[1] == 'gdp':
+        gdp_goldens()             # only tests/golden/gdp.npz
     elif len(sys.argv) > 1 and sys.argv[1] == 'init':
         init_goldens()            # only tests/golden/init_weights.npz
     elif len(sys.argv) > 1 and sys.argv[1] == 'tesr':
@@ -469,3 +527,4 @@ if __name__ == '__main__':
         train_goldens()
         tesr_goldens()
         init_goldens()
+        gdp_goldens()

@@ -287,3 +287,34 @@ def test_tesr_oracle_matches_reference(golden_dir):
         rec = TO.unet_forward(sd, cfg, torch.cat([sr, x_noisy], 1), gamma)
         loss = TO.charbonnier(nz, rec)
     assert abs(loss.item() - float(g['loss'])) <= 1e-5 * abs(float(g['loss']))
+
+
+def test_gdp_oracle_matches_reference(golden_dir):
+    """oracle/gdp_oracle.py vs the reference's own model/gdp_modules (tests/golden/gdp.npz): the guided-diffusion UNet
+    (scale-shift-norm and up/down ResBlocks, multi-head attention), the x_0-predicting sampler, the MSE loss."""
+    from oracle import gdp_oracle as GO
+    from fastdiffsr_amd.arch import param_schema
+    g = _load(golden_dir, 'gdp.npz')
+    cfg = UNetConfig(in_channel=6, out_channel=3, inner_channel=64, norm_groups=32, channel_mults=(1, 2, 2), attn_res=(2, 4),
+                     res_blocks=1, dropout=0.1, image_size=32, variant='gdp')
+    sd_np = synth_state_dict(cfg, 13)
+    assert state_dict_sha256(sd_np) == str(g['weights_sha256'])
+    assert list(param_schema(cfg).keys()) == [str(k) for k in g['keys']]          # the reference's state_dict() order
+    sd = O.to_torch_sd(sd_np)
+    x = torch.from_numpy(g['x'])
+    with torch.no_grad():
+        for i in range(3):
+            out = GO.unet_forward(sd, cfg, x, torch.from_numpy(g[f't/{i}']))
+            assert np.abs(out.numpy() - g[f'rec/{i}']).max() <= 2e-5 * max(1.0, np.abs(g[f'rec/{i}']).max())
+    sched = dict(schedule='linear', n_timestep=8, linear_start=1e-4, linear_end=2e-2)
+    tab = O.schedule_tables(sched)
+    cond, noise = torch.from_numpy(g['cond']), torch.from_numpy(g['noise'])
+    img, traj = GO.p_sample_loop(sd, cfg, tab, cond, noise, return_trajectory=True)
+    frames = g['frames']
+    assert np.abs(frames[0:1] - cond.numpy()).max() == 0.0
+    for k in range(8):
+        assert np.abs(traj[k].numpy() - frames[k + 1:k + 2]).max() <= 5e-5, k
+    with torch.no_grad():
+        loss = GO.p_losses(sd, cfg, tab, torch.from_numpy(g['hr']), torch.from_numpy(g['sr']), torch.from_numpy(g['loss_t']),
+                           torch.from_numpy(g['loss_noise']))
+    assert abs(loss.item() - float(g['loss'])) <= 1e-5 * abs(float(g['loss']))
