@@ -261,14 +261,14 @@ def run_config(eng, dev, precision, B, S, steps, warmup, graph, noise_mode, rank
     return dt, out, prof, prof_dt
 
 
-def run_train(eng, dev, B, S, steps, warmup, rank=0, sync=None, allreduce=None):
+def run_train(eng, dev, B, S, steps, warmup, rank=0, sync=None, allreduce=None, precision='f16x3'):
     """Time `steps` optimisation steps (BASELINE configs[4], "training step"): q_sample in torch (pointwise), then
     forward + L1 loss / (b*c*h*w) + backward + Adam on the device, exact fp32, Dropout(0.2) live as in .train() mode.
     Returns seconds.  A "step" = one optimizer step over one batch of B synthetic 256x256 HR/SR pairs per GPU."""
     g = torch.Generator().manual_seed(777 + rank)
     hr = (torch.rand(B, 3, S, S, generator=g) * 2 - 1).to(dev)
     sr = (hr + 0.1 * torch.randn(B, 3, S, S, generator=g).to(dev)).clamp(-1, 1)
-    eng.set_precision('f32')
+    eng.set_precision('f32' if precision == 'bf16' else precision)
     eng.set_training(True)
     eng.set_seed(99 + rank)
     world = int(os.environ.get('WORLD_SIZE', 1))
@@ -300,17 +300,18 @@ def run_train(eng, dev, B, S, steps, warmup, rank=0, sync=None, allreduce=None):
     return dt
 
 
-def train_record(eng, dev, B, S, steps, warmup):
+def train_record(eng, dev, B, S, steps, warmup, precision='f16x3'):
     try:
-        dt = run_train(eng, dev, B, S, steps, warmup)
+        dt = run_train(eng, dev, B, S, steps, warmup, precision=precision)
         ips = B * steps / dt
         # forward + backward = 3 x the forward's 268.31 GFLOP per image, exact fp32 MFMA
         tf = ips * 3 * FLOPS_PER_IMAGE / 20 / 1e12
         return {'value': ips, 'unit': 'images/s (one optimisation step per batch)', 'ms_per_step': 1e3 * dt / steps, 'steps': steps,
-                'warmup': warmup, 'dtype': 'f32', 'batch': B,
+                'warmup': warmup, 'dtype': precision, 'batch': B,
                 'workload': 'configs[4] per-GPU slice: batch 32, 256x256, q_sample + L1(sum)/(b*c*h*w) (define_G fixes loss_type l1) + '
-                            'backward + Adam, Dropout(0.2) live, exact fp32',
-                'algorithmic_tflops': tf, 'frac_f32_mfma_peak': tf / PEAK_F32_MFMA}
+                            'backward + Adam, Dropout(0.2) live; ' + ('everything exact fp32' if precision == 'f32' else
+                                                                 'forward + input gradients f16x3 (fp32-grade), weight gradients exact fp32'),
+                'algorithmic_tflops': tf, 'frac_f32_mfma_peak': tf / PEAK_F32_MFMA}   # priced against the f32 roof in both modes
     except Exception as e:
         return {'error': f'{type(e).__name__}: {e}'}
 
@@ -397,7 +398,7 @@ def main():
     if args.train:
         Bt = args.batch if args.batch != 16 else 32
         hook = parallel.allreduce_grads if distributed else None
-        dt = run_train(eng, dev, Bt, S, args.steps, args.warmup, rank=rank, sync=sync, allreduce=hook)
+        dt = run_train(eng, dev, Bt, S, args.steps, args.warmup, rank=rank, sync=sync, allreduce=hook, precision=args.precision)
         if distributed:
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -408,9 +409,9 @@ def main():
             print(json.dumps({
                 'metric': '256x256 images/sec through one optimisation step (forward + loss + backward + Adam)', 'value': ips,
                 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
-                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.precision, 'data': 'synthetic',
                 'config': {'workload': f'BASELINE configs[4] training step: x8 32->256 shapes, batch={Bt}/GPU, 256x256, q_sample + L1(sum)/(b*c*h*w), '
-                                       'Dropout(0.2) live, exact fp32; data parallel = one all-reduce of the 91.6 MB gradient arena per step',
+                                       'Dropout(0.2) live, ' + ('exact fp32' if args.precision == 'f32' else 'f16x3 forward / input gradients + fp32 weight gradients') + '; data parallel = one all-reduce of the 91.6 MB gradient arena per step',
                            'batch_per_gpu': Bt, 'global_batch': Bt * world, 'parallelism': f'dp{world}'},
                 'algorithmic_tflops_per_gpu': tf, 'frac_f32_mfma_peak': tf / PEAK_F32_MFMA}), flush=True)
         if distributed:
@@ -456,7 +457,8 @@ def main():
                 'b1_graph': sub_record(eng, dev, 'b1_graph', 'f16x3', 1, S, 10, 2, True,
                                        'configs[0] regime (the reference val loop is B=1, sr_mfe.py:279-284): latency per image, hipGraph'),
             }
-            res['sub_records']['train_step_b32'] = train_record(eng, dev, 32, S, 2, 1)
+            res['sub_records']['train_step_b32'] = train_record(eng, dev, 32, S, 2, 1, 'f16x3')
+            res['sub_records']['train_step_b32_f32'] = train_record(eng, dev, 32, S, 2, 1, 'f32')
             eng.set_precision(args.precision)
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'], ref = cpu_baseline(cfg, sd)

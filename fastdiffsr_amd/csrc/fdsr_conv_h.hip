@@ -256,6 +256,7 @@ __global__ void __launch_bounds__(512, 2) conv_mfma_h_kernel(const ConvParams p)
     if (p.temb) add += p.temb[(size_t)n * p.temb_stride + p.temb_off + co];
   }
   float s1 = 0.f, s2 = 0.f;
+  const float winv = p.w_inv_scale_dev ? *p.w_inv_scale_dev : p.w_inv_scale;   // uniform: a scalar load
   const bool interior = (oy0 + TH <= p.Hout) && (ox0 + TW <= p.Wout) && (co0 + BN <= p.Cout);
   if (SK > 1) {   // raw partial accumulators; bias, shift, residual and statistics happen in the reduce
     float* sb = p.kscratch + (size_t)ksi * p.N * p.Hout * p.Wout * p.Cout;
@@ -303,7 +304,7 @@ __global__ void __launch_bounds__(512, 2) conv_mfma_h_kernel(const ConvParams p)
       for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          const float v = acc[mb][i] * p.w_inv_scale + add + rv[mb][i];
+          const float v = acc[mb][i] * winv + add + rv[mb][i];
           put(obase + mb * rstride + (size_t)((i & 3) + 8 * (i >> 2)) * p.Cout, v);
           s1 += v;
           s2 += v * v;
@@ -326,7 +327,7 @@ __global__ void __launch_bounds__(512, 2) conv_mfma_h_kernel(const ConvParams p)
         for (int i = 0; i < 16; ++i) {
           const int oy = oy0 + wm + mb * WM, ox = ox0 + (i & 3) + 8 * (i >> 2) + 4 * h;
           if (cok && oy < p.Hout && ox < p.Wout) {
-            float v = acc[mb][i] * p.w_inv_scale + add;
+            float v = acc[mb][i] * winv + add;
             if (p.res) v += rv[mb][i];
             put(((size_t)(n * p.Hout + oy) * p.Wout + ox) * p.Cout + co, v);
             s1 += v;
@@ -380,7 +381,7 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const ConvParams p, 
       f32x4 a = *reinterpret_cast<const f32x4*>(p.kscratch + o);
 #pragma unroll 4
       for (int s = 1; s < p.ksplit; ++s) a += *reinterpret_cast<const f32x4*>(p.kscratch + s * slice + o);
-      a = a * p.w_inv_scale + add;
+      a = a * (p.w_inv_scale_dev ? *p.w_inv_scale_dev : p.w_inv_scale) + add;
       if (p.out_bf16) {   // bf16 mode: residual and output are bf16 tensors
         if (p.res) a += ActIO<PREC_BF16>::widen(ActIO<PREC_BF16>::load4(p.res, o));
         uint2 pk;

@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "fdsr_engine_int.h"
+#include "fdsr_train.h"
 
 using namespace fdsr;
 using namespace fdsr_int;
@@ -680,6 +681,11 @@ int ensure_device(fdsr_handle h) {
   }
   HIPCHK(h, hipMalloc((void**)&h->d_master, std::max<size_t>(h->master_floats, 4) * sizeof(float)));
   HIPCHK(h, hipMemset(h->d_master, 0, std::max<size_t>(h->master_floats, 4) * sizeof(float)));
+  HIPCHK(h, hipMalloc((void**)&h->d_hscale, h->weights.size() * 2 * sizeof(float)));
+  {
+    std::vector<float> ones(h->weights.size() * 2, 1.0f);
+    HIPCHK(h, hipMemcpy(h->d_hscale, ones.data(), ones.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
   if (h->wq_bytes) {
     HIPCHK(h, hipMalloc((void**)&h->d_wq, h->wq_bytes));
     HIPCHK(h, hipMemset(h->d_wq, 0, h->wq_bytes));
@@ -715,6 +721,13 @@ int make_shape_plan(fdsr_handle h, int N, int H, int W, ShapePlan* sp) {
         sp->drop_off[op.drop_slot] = off;
         off += align_up((size_t)N * (H >> op.lvl_in) * (W >> op.lvl_in) * op.C0, 256);
       }
+  if (h->training && h->n_drop_slots > 0) {
+    size_t mx = 0;
+    for (const Op& op : h->ops)
+      if (op.kind == Op::CONV && op.drop_slot >= 0) mx = std::max(mx, (size_t)N * (H >> op.lvl_in) * (W >> op.lvl_in) * op.C0 * sizeof(float));
+    sp->off_dropA = off;
+    off += align_up(mx, 256);
+  }
   sp->gn_stats_off.assign(h->n_gn_slots, 0);
   for (int g = 0; g < h->n_gn_slots; ++g) {
     sp->gn_stats_off[g] = off;
@@ -845,8 +858,8 @@ int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, 
   }
   const bool dropout_on = h->training && h->n_drop_slots > 0;
   if (dropout_on) {
-    if (h->prec != PREC_F32)
-      return fail(h, FDSR_E_INVALID, "train mode with dropout runs on the exact-fp32 kernels: fdsr_set_precision(FDSR_PREC_F32)");
+    if (h->prec == PREC_BF16)
+      return fail(h, FDSR_E_INVALID, "train mode with dropout runs on the fp32-grade kernels: fdsr_set_precision(FDSR_PREC_F32 or _F16X3)");
     h->drop_step += 1;
   }
   for (size_t oi = 0; oi < h->ops.size(); ++oi) {
@@ -890,8 +903,16 @@ int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, 
           unsigned char* mask = reinterpret_cast<unsigned char*>(ws + sp.drop_off[op.drop_slot]);
           HIPCHK(h, launch_dropout_mask(mask, (size_t)N * Hi * Wi * op.C0, h->rng_seed, h->drop_step, (unsigned)op.drop_slot,
                                         h->cfg.dropout, st));
-          p.drop_mask = mask;
-          p.drop_scale = 1.0f / (1.0f - h->cfg.dropout);
+          const float dscale = 1.0f / (1.0f - h->cfg.dropout);
+          if (h->prec == PREC_F32) {           // the fp32 kernel applies the mask in its staging
+            p.drop_mask = mask;
+            p.drop_scale = dscale;
+          } else {                             // f16x3: the dropped activation is materialised and read raw
+            float* a = reinterpret_cast<float*>(ws + sp.off_dropA);
+            HIPCHK(h, launch_gn_silu_drop(p.x0, p.gn_scale, p.gn_shift, mask, dscale, a, N, Hi * Wi, op.C0, st));
+            p.x0 = a;
+            p.gn_scale = p.gn_shift = nullptr;
+          }
         }
         // bf16 mode keeps every activation but the packed input and eps as bf16 in HBM
         p.out_f32 = (op.dst == h->t_eps) ? 1 : 0;
@@ -913,8 +934,11 @@ int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, 
           p.w_inv_scale = w.h_inv_scale[h->prec];
           p.Cin_pad = w.h_cin_pad;
           p.Cout_pad = w.h_cout_pad;
+          if (h->prec == PREC_F16X3) p.w_inv_scale_dev = h->d_hscale + 2 * (size_t)op.w + 1;
           static const bool no_up2 = getenv("FDSR_NO_UP2") != nullptr;
-          if (op.ck == CONV3_UP && !no_up2 && !op.force_generic) {
+          // (after optimiser steps the sub-pixel forms lag until fdsr_sync_weight_forms: training forwards use the generic kernel)
+          if (op.ck == CONV3_UP && !no_up2 && !op.force_generic && !h->h_forms_stale && !h->keep_stats) {
+            p.w_inv_scale_dev = nullptr;
             p.wq = h->d_wq + w.up2_off[h->prec];
             p.w_inv_scale = w.up2_inv_scale[h->prec];
             HIPCHK(h, launch_conv_up2_h(h->prec, p, st, &nt));
@@ -1019,6 +1043,11 @@ int pack_weights_h(fdsr_handle h, WeightEntry& w, const float* host) {
               qb[fb * 8 + j] = f32_to_bf16_rn(v);
             }
           }
+  {
+    const float sc2[2] = {scale, w.h_inv_scale[PREC_F16X3]};
+    const size_t widx = (size_t)(&w - h->weights.data());
+    HIPCHK(h, hipMemcpy(h->d_hscale + 2 * widx, sc2, sizeof sc2, hipMemcpyHostToDevice));
+  }
   HIPCHK(h, hipMemcpy(h->d_wq + w.hq_off[PREC_F16X3], q3.data(), q3.size() * 2, hipMemcpyHostToDevice));
   HIPCHK(h, hipMemcpy(h->d_wq + w.hq_off[PREC_BF16], qb.data(), qb.size() * 2, hipMemcpyHostToDevice));
   if (w.ck != CONV3_UP) return FDSR_OK;
@@ -1222,7 +1251,8 @@ void fdsr_destroy(fdsr_handle h) {
   if (h->d_temb_table) (void)hipFree(h->d_temb_table);
   if (h->d_nl) (void)hipFree(h->d_nl);
   if (h->d_rng) (void)hipFree(h->d_rng);
-  for (float* q : {h->d_master, h->d_grad, h->d_adam_m, h->d_adam_v, h->d_wt, h->d_zero})
+  if (h->d_wtq) (void)hipFree(h->d_wtq);
+  for (float* q : {h->d_master, h->d_grad, h->d_adam_m, h->d_adam_v, h->d_wt, h->d_zero, h->d_hscale})
     if (q) (void)hipFree(q);
   delete h;
 }

@@ -75,6 +75,7 @@ struct ShapePlan {
   std::vector<size_t> part_off;    // per tensor: per-tile channel sums [N][max_tiles][C][2] (0 = none)
   std::vector<size_t> gn_off;      // per GroupNorm slot: scale [N][C] then shift [N][C]
   std::vector<size_t> drop_off;    // per dropout slot: keep bytes [N][HW][C] (plans made in training mode only)
+  size_t off_dropA = 0;            // f16x3 training forward: the dropped activation of the current block2, materialised
   bool training = false;
   std::vector<size_t> gn_stats_off;   // per GroupNorm slot: (mean, rstd) [N][G][2], written when the engine keeps statistics
   std::vector<int> tensor_nt;      // tiles per image its producer actually used (set at launch)
@@ -149,6 +150,10 @@ struct fdsr_engine {
   float* d_wt = nullptr;              // transposed, tap-flipped fp32 conv weights (input-gradient convolutions)
   size_t wt_floats = 0;
   std::vector<size_t> wt_off0, wt_off1;   // per weight entry: offsets into d_wt for concat source 0 / 1 (SIZE_MAX: none)
+  float* d_hscale = nullptr;          // per weight entry: {2^e, 2^-e} of its f16x3 forms (read by the kernels after device re-packs)
+  unsigned char* d_wtq = nullptr;     // transposed, tap-flipped f16x3 fragment forms (input-gradient convolutions in f16x3)
+  size_t wtq_bytes = 0;
+  std::vector<size_t> wtq_off0, wtq_off1;   // per weight entry (SIZE_MAX: this conv's input gradient stays on the fp32 kernel)
   float* d_zero = nullptr;            // zeros (bias of the input-gradient convolutions)
   bool train_ready = false;
   bool wt_valid = false;              // d_wt matches d_master

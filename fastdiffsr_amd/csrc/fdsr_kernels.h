@@ -32,6 +32,7 @@ struct ConvParams {
   // 16-bit MFMA path (fdsr_conv_h.hip): weights in MFMA-fragment order, see pack_weights_h()
   const void* wq;
   float w_inv_scale;     // accumulator un-scaling (weights are stored multiplied by a power of two)
+  const float* w_inv_scale_dev;   // if set, the un-scaling factor is read from here (weights re-packed on the device after optimiser steps)
   // split-K (small grids only, see conv_h_ksplit): slice s of the K loop writes its raw accumulators
   // to kscratch[s][N,Hout,Wout,Cout]; splitk_reduce_kernel sums the slices in order and applies the epilogue
   int ksplit;            // <= 1: off

@@ -134,6 +134,29 @@ int train_prepare(fdsr_handle h) {
     }
   }
   h->wt_floats = off;
+  // the same forms as f16x3 MFMA fragments, for the convs whose transposed shape the 16-bit kernels take
+  // (16-channel K chunks: K % 16 == 0 and the produced channel count % 16 == 0)
+  h->wtq_off0.assign(h->weights.size(), SIZE_MAX);
+  h->wtq_off1.assign(h->weights.size(), SIZE_MAX);
+  size_t qoff = 0;
+  for (const Op& op : h->ops) {
+    if (op.kind != Op::CONV || op.src0 == h->t_in) continue;
+    const int T = op.ck == CONV1 ? 1 : 9, K = conv_K(h, op);
+    if (K % 16 || op.C0 % 16 || op.C1 % 16) continue;
+    auto frag_bytes = [&](int rows) {
+      int TH, WN;
+      conv_h_config(op.ck == CONV1 ? CONV1 : CONV3_S1, rows, &TH, &WN);
+      return align_up((size_t)(round_up(rows, 32 * WN) / 32) * (round_up(K, 16) / 16) * T * 64 * 16 * 2, 256);
+    };
+    if (op.gn_slot >= 0 || op.C1 == 0) {
+      h->wtq_off0[op.w] = qoff;  qoff += frag_bytes(op.C0 + op.C1);
+    } else {
+      h->wtq_off0[op.w] = qoff;  qoff += frag_bytes(op.C0);
+      h->wtq_off1[op.w] = qoff;  qoff += frag_bytes(op.C1);
+    }
+  }
+  h->wtq_bytes = qoff;
+  HIPCHK(h, hipMalloc((void**)&h->d_wtq, std::max<size_t>(qoff, 256)));
   HIPCHK(h, hipMalloc((void**)&h->d_wt, std::max<size_t>(off, 4) * sizeof(float)));
   HIPCHK(h, hipMalloc((void**)&h->d_zero, (size_t)round_up(maxC, 64) * sizeof(float)));
   HIPCHK(h, hipMemset(h->d_zero, 0, (size_t)round_up(maxC, 64) * sizeof(float)));
@@ -170,6 +193,35 @@ int repack_from_master(fdsr_handle h, hipStream_t st, bool forward_forms) {
       HIPCHK(h, launch_pack_conv_f32_t(src, h->d_wt + h->wt_off1[op.w], Cout, Cin, w.ks, op.C0, op.C1, d1.rows_pad, d1.cols_pad, st));
     }
   }
+  // f16x3 forms (forward + transposed), packed on the device with a per-tensor power-of-two scale
+  for (int i = 0; i < h->n_schema; ++i) {
+    WeightEntry& w = h->weights[i];
+    if (!w.live || w.sink != WeightEntry::CONV_PACK || !w.h_ok) continue;
+    const float* src = h->d_master + h->master_off[i];
+    float* sc2 = h->d_hscale + 2 * (size_t)i;
+    HIPCHK(h, launch_hscale(src, numel(w.shape), sc2, st));
+    if (forward_forms)
+      HIPCHK(h, launch_pack_conv_h(src, h->d_wq + w.hq_off[PREC_F16X3], sc2, (int)w.shape[0], (int)w.shape[1], w.ks, w.h_WN,
+                                   w.h_cout_pad, w.h_cin_pad, 0, 0, 0, st));
+  }
+  for (const Op& op : h->ops) {
+    if (op.kind != Op::CONV || op.src0 == h->t_in || h->wtq_off0[op.w] == SIZE_MAX) continue;
+    const WeightEntry& w = h->weights[op.w];
+    const float* src = h->d_master + h->master_off[op.w];
+    const float* sc2 = h->d_hscale + 2 * (size_t)op.w;
+    const int K = conv_K(h, op), Cout = (int)w.shape[0], Cin = (int)w.shape[1];
+    auto pack_t = [&](size_t qo, int c_off, int rows) -> hipError_t {
+      int TH, WN;
+      conv_h_config(op.ck == CONV1 ? CONV1 : CONV3_S1, rows, &TH, &WN);
+      return launch_pack_conv_h(src, h->d_wtq + qo, sc2, Cout, Cin, w.ks, WN, round_up(rows, 32 * WN), round_up(K, 16), 1, c_off, rows, st);
+    };
+    if (h->wtq_off1[op.w] == SIZE_MAX) {
+      HIPCHK(h, pack_t(h->wtq_off0[op.w], 0, op.C0 + op.C1));
+    } else {
+      HIPCHK(h, pack_t(h->wtq_off0[op.w], 0, op.C0));
+      HIPCHK(h, pack_t(h->wtq_off1[op.w], op.C0, op.C1));
+    }
+  }
   h->temb_table_valid = false;
   return FDSR_OK;
 }
@@ -184,6 +236,25 @@ int launch_dgrad(fdsr_handle h, ConvKind ck, const float* dy, int K, int Hs, int
   p.N = N; p.Hin = Hs; p.Win = Ws; p.Hout = Hs; p.Wout = Ws;
   p.C0 = K; p.C1 = 0; p.Cout = Csub; p.Cin_pad = d.cols_pad; p.Cout_pad = d.rows_pad;
   HIPCHK(h, launch_conv(k, p, st, nullptr));
+  return FDSR_OK;
+}
+
+// the same on the f16x3 kernels (fp32-grade: three f16 MFMAs per product), fragments from d_wtq
+int launch_dgrad_h(fdsr_handle h, const Op& op, const float* dy, int K, int Hs, int Ws, size_t qoff, int Csub, float* out,
+                   bool accumulate, int N, hipStream_t st) {
+  const ConvKind k = op.ck == CONV1 ? CONV1 : CONV3_S1;
+  int TH, WN;
+  conv_h_config(k, Csub, &TH, &WN);
+  ConvParams p{};
+  p.x0 = dy; p.bias = h->d_zero; p.out = out; p.res = accumulate ? out : nullptr;
+  p.N = N; p.Hin = Hs; p.Win = Ws; p.Hout = Hs; p.Wout = Ws;
+  p.C0 = K; p.C1 = 0; p.Cout = Csub; p.Cin_pad = round_up(K, 16); p.Cout_pad = round_up(Csub, 32 * WN);
+  p.wq = h->d_wtq + qoff;
+  p.w_inv_scale = 1.0f;
+  p.w_inv_scale_dev = h->d_hscale + 2 * (size_t)op.w + 1;
+  p.ksplit = 1;
+  p.out_f32 = 1;
+  HIPCHK(h, launch_conv_h(k, PREC_F16X3, p, st, nullptr));
   return FDSR_OK;
 }
 
@@ -215,7 +286,8 @@ int fdsr_train_grads(fdsr_handle h, const float* x_nchw, const float* noise_leve
                      float loss_scale, float* loss_host, int batch, int height, int width, void* workspace, size_t workspace_bytes,
                      void* hip_stream) {
   if (!h || !x_nchw || !noise_level || !target_nchw) return fail(h, FDSR_E_INVALID, "null argument");
-  if (h->prec != PREC_F32) return fail(h, FDSR_E_INVALID, "the training step runs the exact-fp32 kernels: fdsr_set_precision(FDSR_PREC_F32) first");
+  if (h->prec == PREC_BF16)
+    return fail(h, FDSR_E_INVALID, "the training step runs the fp32-grade kernels: fdsr_set_precision(FDSR_PREC_F32 or FDSR_PREC_F16X3) first");
   if (h->cfg.in_channel != 6 || h->cfg.out_channel != 3) return fail(h, FDSR_E_INVALID, "training needs in_channel=6, out_channel=3");
   int rc = check_ready(h, false);
   if (rc) return rc;
@@ -269,7 +341,12 @@ int fdsr_train_grads(fdsr_handle h, const float* x_nchw, const float* noise_leve
   }
   HIPCHK(h, hipMemsetAsync(dtemb, 0, (size_t)N * h->TE * sizeof(float), st));
   const float* eps = TP(h->t_eps);
-  HIPCHK(h, launch_loss_grad(eps, target_nchw, GT(h->t_eps), dbl, loss_dev, N, H * W, loss_l2, loss_scale, st));
+  // f16x3: the gradients that flow through the split-f16 convolutions are kept near 1 by a power-of-two factor
+  // (the loss gradient is +-loss_scale, typically 1e-7; f16's hi/lo split keeps 22 bits only above ~6e-5) and the
+  // arena is un-scaled at the end.  Powers of two: exact in fp32, so the fp32 parts of the backward do not see it.
+  float gscale = 1.0f;
+  if (h->prec == PREC_F16X3 && loss_scale > 0.f) gscale = std::ldexp(1.0f, -(int)std::floor(std::log2((double)loss_scale)));
+  HIPCHK(h, launch_loss_grad(eps, target_nchw, GT(h->t_eps), dbl, loss_dev, N, H * W, loss_l2, loss_scale * gscale, st));
 
   // ---- backward over the plan ----
   for (int oi = (int)h->ops.size() - 1; oi >= 0; --oi) {
@@ -323,9 +400,14 @@ int fdsr_train_grads(fdsr_handle h, const float* x_nchw, const float* noise_leve
       HIPCHK(h, launch_wgrad(op.ck, q, st));
     }
     if (op.src0 == h->t_in) continue;                     // no gradient w.r.t. the network input
-    // input gradient
+    // input gradient: on the f16x3 kernels in that mode (where the transposed shape fits them), else exact fp32
+    auto dgrad = [&](const float* dyp, int Hs, int Ws, int src, int Csub, float* outp, bool acc) -> int {
+      const size_t qo = src == 0 ? h->wtq_off0[op.w] : h->wtq_off1[op.w];
+      if (h->prec == PREC_F16X3 && qo != SIZE_MAX) return launch_dgrad_h(h, op, dyp, K, Hs, Ws, qo, Csub, outp, acc, N, st);
+      return launch_dgrad(h, op.ck, dyp, K, Hs, Ws, h->d_wt + (src == 0 ? h->wt_off0[op.w] : h->wt_off1[op.w]), Csub, outp, acc, N, st);
+    };
     if (op.gn_slot >= 0) {
-      if ((rc = launch_dgrad(h, op.ck, dy, K, Ho, Wo, h->d_wt + h->wt_off0[op.w], Cin, tmpA, false, N, st))) return rc;
+      if ((rc = dgrad(dy, Ho, Wo, 0, Cin, tmpA, false))) return rc;
       GnBwdParams g{};
       g.dA = tmpA; g.x0 = TP(op.src0); g.x1 = TP(op.src1); g.C0 = op.C0; g.C1 = op.C1;
       g.scale = reinterpret_cast<const float*>(ws + sp.gn_off[op.gn_slot]);
@@ -343,15 +425,13 @@ int fdsr_train_grads(fdsr_handle h, const float* x_nchw, const float* noise_leve
       HIPCHK(h, launch_gn_bwd(g, st));
     } else if (op.ck == CONV3_S2) {
       HIPCHK(h, launch_zero_insert(dy, tmpZ, N, Ho, Wo, K, st));
-      if ((rc = launch_dgrad(h, op.ck, tmpZ, K, Hi, Wi, h->d_wt + h->wt_off0[op.w], op.C0, GT(op.src0), true, N, st))) return rc;
+      if ((rc = dgrad(tmpZ, Hi, Wi, 0, op.C0, GT(op.src0), true))) return rc;
     } else if (op.ck == CONV3_UP) {
-      if ((rc = launch_dgrad(h, op.ck, dy, K, Ho, Wo, h->d_wt + h->wt_off0[op.w], op.C0, tmpA, false, N, st))) return rc;
+      if ((rc = dgrad(dy, Ho, Wo, 0, op.C0, tmpA, false))) return rc;
       HIPCHK(h, launch_pool2_add(tmpA, GT(op.src0), N, Hi, Wi, op.C0, st));
     } else {
-      if ((rc = launch_dgrad(h, op.ck, dy, K, Ho, Wo, h->d_wt + h->wt_off0[op.w], op.C0, GT(op.src0), true, N, st))) return rc;
-      if (op.C1 > 0 &&
-          (rc = launch_dgrad(h, op.ck, dy, K, Ho, Wo, h->d_wt + h->wt_off1[op.w], op.C1, GT(op.src1), true, N, st)))
-        return rc;
+      if ((rc = dgrad(dy, Ho, Wo, 0, op.C0, GT(op.src0), true))) return rc;
+      if (op.C1 > 0 && (rc = dgrad(dy, Ho, Wo, 1, op.C1, GT(op.src1), true))) return rc;
     }
   }
 
@@ -375,6 +455,7 @@ int fdsr_train_grads(fdsr_handle h, const float* x_nchw, const float* noise_leve
         HIPCHK(h, hipMemcpyAsync(DG(i), t.dbn + w.row_off, numel(w.shape) * sizeof(float), hipMemcpyDeviceToDevice, st));
     }
   }
+  if (gscale != 1.0f) HIPCHK(h, launch_scale_inplace(h->d_grad, h->master_floats, 1.0f / gscale, st));
   if (loss_host) {
     HIPCHK(h, hipMemcpyAsync(loss_host, loss_dev, sizeof(float), hipMemcpyDeviceToHost, st));
     HIPCHK(h, hipStreamSynchronize(st));

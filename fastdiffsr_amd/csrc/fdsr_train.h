@@ -23,6 +23,8 @@ hipError_t launch_loss_grad(const float* eps, const float* target, float* deps8,
 // S[n][c] = sum over the pixels of image n of dy[n][p][c]   (bias / noise-shift gradients); fixed order
 hipError_t launch_colsum(const float* dy, float* S, double* scratch, int N, int HW, int C, hipStream_t s);
 size_t colsum_scratch_doubles(int N, int HW, int C);
+// x[i] *= f
+hipError_t launch_scale_inplace(float* x, size_t n, float f, hipStream_t s);
 // out[c] = sum_n S[n*stride + c], c < C, in image order
 hipError_t launch_sum_rows(const float* S, int N, int stride, int C, float* out, hipStream_t s);
 // z [N,2H,2W,C] = dy [N,H,W,C] at the even positions, zero elsewhere (the stride-2 conv's transpose)
@@ -114,5 +116,18 @@ hipError_t launch_pack_conv_f32(const float* w, float* packed, int Cout, int Cin
 // packed_t[tap][ci][co] = w[co][c_off + ci][flip(tap)], ci < Csub: [tap][round_up(Csub,BN)][round_up(Cout,KC)]
 hipError_t launch_pack_conv_f32_t(const float* w, float* packed_t, int Cout, int Cin, int ks, int c_off, int Csub, int rows_pad,
                                   int cols_pad, hipStream_t s);
+
+// ---- f16x3 forms on the device (fp32-grade split-f16 MFMA convolutions, fdsr_conv_h.hip) ------------------------
+// scale2[0] = 2^e with e = min(12, floor(log2(32768 / max|w|))) (what pack_weights_h chooses on the host), scale2[1] = 2^-e
+hipError_t launch_hscale(const float* w, size_t n, float* scale2, hipStream_t s);
+// checkpoint layout [Cout][Cin][ks][ks] -> MFMA B-fragment order [cot][kc][wn][tap][hi|lo][lane] x 16 B (see
+// pack_weights_h in fdsr_engine.cpp), values multiplied by scale2[0].  transposed != 0: the input-gradient form, the
+// conv weight  W'[co' = ci - c_off][ci' = co][tap'] = W[co][ci][T-1-tap'],  co' < rows (the Cin slice of one concat source)
+hipError_t launch_pack_conv_h(const float* w, void* frags, const float* scale2, int Cout, int Cin, int ks, int WN, int cout_pad,
+                              int cin_pad, int transposed, int c_off, int rows, hipStream_t s);
+// a[n][p][c] = swish(x*scale + shift) * keep * drop_scale: the dropped activation of block2 materialised, for the f16x3
+// forward (the 16-bit conv kernel then reads it raw; its staging has no spare registers for the mask)
+hipError_t launch_gn_silu_drop(const float* x, const float* gn_scale, const float* gn_shift, const unsigned char* mask, float drop_scale,
+                               float* out, int N, int HW, int C, hipStream_t s);
 
 }  // namespace fdsr

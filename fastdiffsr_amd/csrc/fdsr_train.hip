@@ -132,6 +132,16 @@ hipError_t launch_colsum(const float* dy, float* S, double* scratch, int N, int 
   return hipGetLastError();
 }
 
+__global__ void __launch_bounds__(256) scale_inplace_kernel(float* __restrict__ x, size_t n, float f) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) x[i] *= f;
+}
+
+hipError_t launch_scale_inplace(float* x, size_t n, float f, hipStream_t s) {
+  hipLaunchKernelGGL(scale_inplace_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, n, f);
+  return hipGetLastError();
+}
+
 __global__ void __launch_bounds__(256) sum_rows_kernel(const float* __restrict__ S, int N, int stride, int C, float* __restrict__ out) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
@@ -1004,6 +1014,110 @@ hipError_t launch_pack_conv_f32_t(const float* w, float* packed_t, int Cout, int
   const size_t total = (size_t)T * rows_pad * cols_pad;
   hipLaunchKernelGGL(pack_conv_f32_t_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, packed_t, Cout, Cin, T, c_off, Csub,
                      rows_pad, cols_pad, total);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// f16x3 weight forms, packed on the device
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) hscale_kernel(const float* __restrict__ w, size_t n, float* __restrict__ scale2) {
+  __shared__ float sm[16];
+  float m = 0.f;
+  for (size_t i = threadIdx.x; i < n; i += 1024) m = fmaxf(m, fabsf(w[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float amax = 0.f;
+    for (int i = 0; i < 16; ++i) amax = fmaxf(amax, sm[i]);
+    int e = 12;
+    if (amax > 0.f) {
+      const int f = (int)floor(log2(32768.0 / (double)amax));
+      e = f < 12 ? f : 12;
+    }
+    scale2[0] = ldexpf(1.0f, e);
+    scale2[1] = ldexpf(1.0f, -e);
+  }
+}
+
+hipError_t launch_hscale(const float* w, size_t n, float* scale2, hipStream_t s) {
+  hipLaunchKernelGGL(hscale_kernel, dim3(1), dim3(1024), 0, s, w, n, scale2);
+  return hipGetLastError();
+}
+
+// thread = (fragment, lane): 8 hi and 8 lo halves
+__global__ void __launch_bounds__(256) pack_conv_h_kernel(const float* __restrict__ w, uint4* __restrict__ frags,
+                                                          const float* __restrict__ scale2, int Cout, int Cin, int T, int WN, int nk,
+                                                          int transposed, int c_off, int rows, size_t total) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;   // over [cot][kc][wn][t][lane]
+  if (i >= total) return;
+  const int l = (int)(i & 63);
+  size_t f = i >> 6;
+  const int t = (int)(f % T);  f /= T;
+  const int wn = (int)(f % WN);  f /= WN;
+  const int kc = (int)(f % nk);
+  const int cot = (int)(f / nk);
+  const int BN = 32 * WN;
+  const int co = cot * BN + wn * 32 + (l & 31);
+  const float scale = scale2[0];
+  unsigned short hi[8], lo[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = kc * 16 + 8 * (l >> 5) + j;
+    float v = 0.f;
+    if (!transposed) {
+      if (co < Cout && k < Cin) v = w[((size_t)co * Cin + k) * T + t];
+    } else {   // rows = the slice of input channels that become output channels; k runs over the forward Cout
+      if (co < rows && k < Cout) v = w[((size_t)k * Cin + c_off + co) * T + (T - 1 - t)];
+    }
+    const float vs = v * scale;
+    const _Float16 h = (_Float16)vs;
+    const _Float16 lw = (_Float16)(vs - (float)h);
+    hi[j] = __builtin_bit_cast(unsigned short, h);
+    lo[j] = __builtin_bit_cast(unsigned short, lw);
+  }
+  const size_t fidx = (i >> 6);                   // fragment index (cot, kc, wn, t)
+  uint4 a, b;
+  a.x = hi[0] | ((unsigned)hi[1] << 16); a.y = hi[2] | ((unsigned)hi[3] << 16); a.z = hi[4] | ((unsigned)hi[5] << 16); a.w = hi[6] | ((unsigned)hi[7] << 16);
+  b.x = lo[0] | ((unsigned)lo[1] << 16); b.y = lo[2] | ((unsigned)lo[3] << 16); b.z = lo[4] | ((unsigned)lo[5] << 16); b.w = lo[6] | ((unsigned)lo[7] << 16);
+  frags[(fidx * 2) * 64 + l] = a;                 // plane 0 = hi
+  frags[(fidx * 2 + 1) * 64 + l] = b;             // plane 1 = lo
+}
+
+hipError_t launch_pack_conv_h(const float* w, void* frags, const float* scale2, int Cout, int Cin, int ks, int WN, int cout_pad,
+                              int cin_pad, int transposed, int c_off, int rows, hipStream_t s) {
+  const int T = ks * ks, BN = 32 * WN, ncot = cout_pad / BN, nk = cin_pad / 16;
+  const size_t total = (size_t)ncot * nk * WN * T * 64;
+  hipLaunchKernelGGL(pack_conv_h_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, reinterpret_cast<uint4*>(frags), scale2,
+                     Cout, Cin, T, WN, nk, transposed, c_off, rows, total);
+  return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256) gn_silu_drop_kernel(const float* __restrict__ x, const float* __restrict__ sc, const float* __restrict__ sh,
+                                                           const unsigned char* __restrict__ mask, float drop_scale, float* __restrict__ out,
+                                                           int HW, int cq, size_t total) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;   // over [N][HW][cq]
+  if (i >= total) return;
+  const int c4 = (int)(i % cq);
+  const size_t n = i / ((size_t)HW * cq);
+  f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
+  const f32x4 a = *reinterpret_cast<const f32x4*>(sc + (n * cq + c4) * 4), b = *reinterpret_cast<const f32x4*>(sh + (n * cq + c4) * 4);
+  const unsigned m = *reinterpret_cast<const unsigned*>(mask + i * 4);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float u = fmaf(v[e], a[e], b[e]);
+    v[e] = ((m >> (8 * e)) & 0xffu) ? u * sigmoid_f(u) * drop_scale : 0.f;
+  }
+  *reinterpret_cast<f32x4*>(out + i * 4) = v;
+}
+
+hipError_t launch_gn_silu_drop(const float* x, const float* gn_scale, const float* gn_shift, const unsigned char* mask, float drop_scale,
+                               float* out, int N, int HW, int C, hipStream_t s) {
+  if (C & 3) return hipErrorInvalidValue;
+  const size_t total = (size_t)N * HW * (C >> 2);
+  hipLaunchKernelGGL(gn_silu_drop_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, gn_scale, gn_shift, mask, drop_scale,
+                     out, HW, C >> 2, total);
   return hipGetLastError();
 }
 

@@ -143,7 +143,8 @@ class GaussianDiffusion(nn.Module):
         unet = self.denoise_fn
         unet.sync_weights()
         eng = unet.engine
-        eng.set_precision('f32')           # the training step runs the exact-fp32 kernels (include/fdsr.h)
+        # 'f32' (exact) or 'f16x3' (fp32-grade forward and input gradients; weight gradients stay exact fp32)
+        eng.set_precision('f32' if self.precision == 'bf16' else self.precision)
         eng.set_training(unet.training and unet.cfg.dropout > 0)   # Dropout(p) of block2 is live in .train() mode
         return eng
 

@@ -123,6 +123,6 @@ class UNet(nn.Module):
         # (Philox) and runs the exact-fp32 kernels for such a forward
         live_dropout = self.training and self.cfg.dropout > 0
         self.engine.set_training(live_dropout)
-        if live_dropout:
-            self.engine.set_precision('f32')
+        if live_dropout and getattr(self.engine, 'precision', 'f32') == 'bf16':
+            self.engine.set_precision('f16x3')       # live dropout needs one of the fp32-grade modes
         return self.engine.unet_forward(x, time)

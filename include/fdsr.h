@@ -194,8 +194,8 @@ int fdsr_profile_end(fdsr_handle h, int* launches, double* conv_ms, double* conv
                      double* conv_bytes);
 
 /* nn.Module.train() / .eval() of the denoiser: in training mode the Dropout(p) in front of every block2 conv
- * (unet.py:89-101, p = fdsr_config.dropout) is live, in fdsr_unet_forward and in fdsr_train_grads alike (exact-fp32
- * kernels only).  The keep-mask of a forward is a pure function of (fdsr_set_seed, the count of training-mode
+ * (unet.py:89-101, p = fdsr_config.dropout) is live, in fdsr_unet_forward and in fdsr_train_grads alike (the two
+ * fp32-grade precisions only).  The keep-mask of a forward is a pure function of (fdsr_set_seed, the count of training-mode
  * forwards so far, block, element) -- Philox4x32-10 -- and can be read back for parity checks:
  * fdsr_debug_dropout_mask gives its offset inside the workspace of the last forward, [N][H][W][C] bytes (1 = keep),
  * and the factor 1/(1-p) kept elements are multiplied by.  `block` is the reference module, e.g. "downs.1". */
@@ -207,8 +207,9 @@ int fdsr_debug_dropout_mask(fdsr_handle h, const char* block, const unsigned cha
  * DDPM.optimize_parameters (model/model.py:47-57): zero_grad, l_pix = netG(data) = p_losses
  * (fastdiffsr_modules/diffusion.py:242-270), l_pix.sum() / (b*c*h*w), backward, Adam.step.  The engine keeps
  * an fp32 master copy of every executed checkpoint tensor, its gradient and the two Adam moments on the
- * device; the convolutions of the step run in exact fp32 (fdsr_set_precision(FDSR_PREC_F32)), every
- * reduction in a fixed order: a step is bitwise reproducible.  The 44 never-executed tensors of the schema
+ * device; the step runs in FDSR_PREC_F32 (everything exact fp32) or FDSR_PREC_F16X3 (forward and input-gradient
+ * convolutions fp32-grade on the split-f16 MFMA kernels, weight gradients exact fp32), every reduction in a fixed
+ * order: a step is bitwise reproducible.  The 44 never-executed tensors of the schema
  * (unet.py:212) get no gradient and are not touched, as in torch. */
 
 /* Workspace for fdsr_train_grads at this shape (the forward keeps every activation). */

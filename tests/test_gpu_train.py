@@ -27,15 +27,15 @@ def _x_noisy(hr, sr, nz, gamma):
     return g * x_start + (1 - g ** 2).sqrt() * nz
 
 
-@pytest.fixture(scope='module')
-def stepped(golden_dir):
+@pytest.fixture(scope='module', params=['f32', 'f16x3'])
+def stepped(golden_dir, request):
     from fastdiffsr_amd.engine import Engine
     from oracle import fdsr_oracle as O
     cfg = UNetConfig(**FASTDIFFSR_UNET)
     sd = synth_state_dict(cfg, 0)
     eng = Engine(cfg)
     eng.load_state_dict(sd)
-    eng.set_precision('f32')
+    eng.set_precision(request.param)
     hr, sr, nz, gamma = _inputs(golden_dir)
     b, c, h, w = hr.shape
     x = torch.cat([sr, _x_noisy(hr, sr, nz, gamma)], 1)
@@ -108,6 +108,12 @@ def test_adam_update_and_weights_in_use(stepped, golden_dir):
     e2.load_state_dict(new_sd)
     x = torch.randn(1, 6, 32, 32, generator=torch.Generator().manual_seed(3)).cuda()
     nl = torch.tensor([[0.4]]).cuda()
+    if getattr(eng, 'precision', 'f32') == 'f16x3':
+        # the f16x3 forms were re-packed ON THE DEVICE by the optimiser step: same network as host-packed forms
+        # (the upsample convs run the generic kernel until the sub-pixel forms are refreshed: not bitwise, fp32-grade)
+        e2.set_precision('f16x3')
+        d = (eng.unet_forward(x, nl) - e2.unet_forward(x, nl)).abs().max().item()
+        assert d <= 1e-5, d
     for prec in ('f32', 'f16x3'):
         eng.set_precision(prec)
         e2.set_precision(prec)
@@ -183,7 +189,8 @@ def test_train_mode_forward_has_live_dropout():
         assert torch.equal(net(x.cuda(), nl.cuda()).cpu(), ev)          # eval() switches it off again
 
 
-def test_train_step_with_dropout_matches_oracle(golden_dir):
+@pytest.mark.parametrize('prec', ['f32', 'f16x3'])
+def test_train_step_with_dropout_matches_oracle(golden_dir, prec):
     """The optimisation step with live dropout: loss and every gradient against autograd over the oracle fed with
     the masks the engine drew."""
     from fastdiffsr_amd.engine import Engine
@@ -192,7 +199,7 @@ def test_train_step_with_dropout_matches_oracle(golden_dir):
     sd = synth_state_dict(cfg, 0)
     eng = Engine(cfg)
     eng.load_state_dict(sd)
-    eng.set_precision('f32')
+    eng.set_precision(prec)
     eng.set_training(True)
     eng.set_seed(123)
     hr, sr, nz, gamma = _inputs(golden_dir)
