@@ -430,53 +430,86 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p, const i
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
   const int r31 = lane & 31, kh = lane >> 5;
-  for (int tile = t0; tile < t1; ++tile) {
+  // Register prefetch of the NEXT tile's dy tile and raw input halo while the MFMAs of the current one run
+  // (the activation is applied when the registers are stored to LDS): thread -> (channel quad q, pixels i*16 + tid/16).
+  constexpr int NDY = TH * TW * 16 / 256, NIN = (NPIX * 16 + 255) / 256;
+  const int q = tid & 15, prow = tid >> 4;
+  f32x4 rdy[NDY], rin[NIN], rsc = {1.f, 1.f, 1.f, 1.f}, rsh = {0.f, 0.f, 0.f, 0.f};
+  unsigned rmask[NIN];
+  bool rok[NIN];
+  auto prefetch = [&](int tile) {
     int tt = tile;
     const int tx = tt % tilesX;  tt /= tilesX;
     const int ty = tt % tilesY;
     const int n = tt / tilesY;
     const int oy0 = ty * TH, ox0 = tx * TW;
-    __syncthreads();                                       // the previous tile's reads are done
-    // ---- stage dy tile: 128 px x 64 co (zero outside the image / beyond Cout) ----
-    for (int i = tid; i < TH * TW * 16; i += 256) {
-      const int q = i & 15, px = i >> 4;
+#pragma unroll
+    for (int i = 0; i < NDY; ++i) {
+      const int px = i * 16 + prow;
       const int oy = oy0 + px / TW, ox = ox0 + px % TW, co = co0 + q * 4;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (oy < p.Hout && ox < p.Wout && co < p.Cout_s)
         v = *reinterpret_cast<const f32x4*>(p.dy + ((size_t)(n * p.Hout + oy) * p.Wout + ox) * p.Cout_s + co);
-      *reinterpret_cast<f32x4*>(sDy + px * ROW + q * 4) = v;
+      rdy[i] = v;
     }
-    // ---- stage the activated input halo: NPIX px x 64 ci ----
-    for (int i = tid; i < NPIX * 16; i += 256) {
-      const int q = i & 15, hp = i >> 4;
-      const int hy = hp / HWD, hx = hp % HWD;
-      const int iy = oy0 * STRIDE - PAD + hy, ix = ox0 * STRIDE - PAD + hx;
-      const int c = ci0 + q * 4;
+    const int c = ci0 + q * 4;
+    if (p.gn_scale && c < Cin) {
+      rsc = *reinterpret_cast<const f32x4*>(p.gn_scale + (size_t)n * Cin + c);
+      rsh = *reinterpret_cast<const f32x4*>(p.gn_shift + (size_t)n * Cin + c);
+    }
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) {
+      const int hp = i * 16 + prow;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (iy >= 0 && iy < Hsrc && ix >= 0 && ix < Wsrc && c < Cin) {
-        const int sy = UP ? (iy >> 1) : iy, sx = UP ? (ix >> 1) : ix;
-        const float* xs; int Cs, cc;
-        if (c < p.C0) { xs = p.x0; Cs = p.C0; cc = c; } else { xs = p.x1; Cs = p.C1; cc = c - p.C0; }
-        v = *reinterpret_cast<const f32x4*>(xs + ((size_t)(n * p.Hin + sy) * p.Win + sx) * Cs + cc);
-        if (p.gn_scale) {
-          const f32x4 sc = *reinterpret_cast<const f32x4*>(p.gn_scale + (size_t)n * Cin + c);
-          const f32x4 sh = *reinterpret_cast<const f32x4*>(p.gn_shift + (size_t)n * Cin + c);
+      unsigned m = 0x01010101u;
+      bool ok = false;
+      if (hp < NPIX) {
+        const int hy = hp / HWD, hx = hp % HWD;
+        const int iy = oy0 * STRIDE - PAD + hy, ix = ox0 * STRIDE - PAD + hx;
+        if (iy >= 0 && iy < Hsrc && ix >= 0 && ix < Wsrc && c < Cin) {
+          const int sy = UP ? (iy >> 1) : iy, sx = UP ? (ix >> 1) : ix;
+          const float* xs; int Cs, cc;
+          if (c < p.C0) { xs = p.x0; Cs = p.C0; cc = c; } else { xs = p.x1; Cs = p.C1; cc = c - p.C0; }
+          const size_t o = ((size_t)(n * p.Hin + sy) * p.Win + sx) * Cs + cc;
+          v = *reinterpret_cast<const f32x4*>(xs + o);
+          if (p.drop_mask) m = *reinterpret_cast<const unsigned*>(p.drop_mask + o);   // dropout sits between the Swish and the conv (C1 == 0 there)
+          ok = true;
+        }
+      }
+      rin[i] = v;
+      rmask[i] = m;
+      rok[i] = ok;
+    }
+  };
+  auto store = [&]() {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float u = fmaf(v[e], sc[e], sh[e]);
-            v[e] = p.gn_plain ? u : u * sigmoid_f(u);
-          }
-          if (p.drop_mask) {       // dropout sits between the Swish and the conv (C1 == 0 for these layers)
-            const unsigned m = *reinterpret_cast<const unsigned*>(p.drop_mask + ((size_t)(n * p.Hin + sy) * p.Win + sx) * Cs + cc);
+    for (int i = 0; i < NDY; ++i) *reinterpret_cast<f32x4*>(sDy + (i * 16 + prow) * ROW + q * 4) = rdy[i];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = ((m >> (8 * e)) & 0xffu) ? v[e] * p.drop_scale : 0.f;
-          }
+    for (int i = 0; i < NIN; ++i) {
+      const int hp = i * 16 + prow;
+      if (hp >= NPIX) continue;
+      f32x4 v = rin[i];
+      if (rok[i] && p.gn_scale) {            // the conv zero-pads the ACTIVATED tensor
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float u = fmaf(v[e], rsc[e], rsh[e]);
+          v[e] = p.gn_plain ? u : u * sigmoid_f(u);
+        }
+        if (p.drop_mask) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = ((rmask[i] >> (8 * e)) & 0xffu) ? v[e] * p.drop_scale : 0.f;
         }
       }
       *reinterpret_cast<f32x4*>(sIn + hp * ROW + q * 4) = v;
     }
+  };
+  if (t0 < t1) prefetch(t0);
+  for (int tile = t0; tile < t1; ++tile) {
+    __syncthreads();                                       // the previous tile's reads are done
+    store();
     __syncthreads();
-    // ---- 64 pixel pairs: A = dy^T (lane: co = r31, pixel kh of the pair), B = a shifted by the tap ----
+    if (tile + 1 < t1) prefetch(tile + 1);                 // in flight under the MFMAs below
+    // ---- pixel pairs: A = dy^T (lane: co = r31, pixel kh of the pair), B = a shifted by the tap ----
 #pragma unroll 2
     for (int pp = 0; pp < TH * TW / 2; ++pp) {
       // the pair = pixels (x, x + 8) of one tile row: their LDS rows are 8*ROW floats apart = 32 banks,
