@@ -165,13 +165,13 @@ class _StdoutToStderr:
 
 
 def kernel_source_hash():
-    """SHA-256 of the kernel sources: a PMC traffic file under profiles/ is only quoted while it matches."""
+    """SHA-256 of the sources of the SAMPLING kernels (the conv family the traffic figure is about and everything they
+    include): a PMC traffic file under profiles/ is only quoted while it matches."""
     import hashlib
     d = os.path.join(ROOT, 'fastdiffsr_amd', 'csrc')
     h = hashlib.sha256()
-    for f in sorted(os.listdir(d)):
-        if f.endswith(('.hip', '.h')):
-            h.update(f.encode() + b'\0' + open(os.path.join(d, f), 'rb').read() + b'\0')
+    for f in ('fdsr_act_io.h', 'fdsr_conv_h.hip', 'fdsr_conv_up2.hip', 'fdsr_kernels.h', 'fdsr_kernels.hip'):
+        h.update(f.encode() + b'\0' + open(os.path.join(d, f), 'rb').read() + b'\0')
     return h.hexdigest()
 
 
@@ -300,9 +300,15 @@ def run_train(eng, dev, B, S, steps, warmup, rank=0, sync=None, allreduce=None, 
     return dt
 
 
-def train_record(eng, dev, B, S, steps, warmup, precision='f16x3'):
+def train_record(cfg, sd, dev, B, S, steps, warmup, precision='f16x3'):
+    """An engine of its own: optimiser steps move the weights, the sampling engine (and its parity check) must not see that."""
     try:
+        from fastdiffsr_amd.engine import Engine
+        eng = Engine(cfg)
+        eng.load_state_dict(sd)
         dt = run_train(eng, dev, B, S, steps, warmup, precision=precision)
+        del eng
+        torch.cuda.empty_cache()
         ips = B * steps / dt
         # forward + backward = 3 x the forward's 268.31 GFLOP per image (SURVEY 8d), exact fp32 MFMA
         tf = ips * 3 * FLOPS_PER_IMAGE / 20 / 1e12
@@ -457,8 +463,8 @@ def main():
                 'b1_graph': sub_record(eng, dev, 'b1_graph', 'f16x3', 1, S, 10, 2, True,
                                        'configs[0] regime (the reference val loop is B=1, sr_mfe.py:279-284): latency per image, hipGraph'),
             }
-            res['sub_records']['train_step_b32'] = train_record(eng, dev, 32, S, 2, 1, 'f16x3')
-            res['sub_records']['train_step_b32_f32'] = train_record(eng, dev, 32, S, 2, 1, 'f32')
+            res['sub_records']['train_step_b32'] = train_record(cfg, sd, dev, 32, S, 2, 1, 'f16x3')
+            res['sub_records']['train_step_b32_f32'] = train_record(cfg, sd, dev, 32, S, 2, 1, 'f32')
             eng.set_precision(args.precision)
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'], ref = cpu_baseline(cfg, sd)

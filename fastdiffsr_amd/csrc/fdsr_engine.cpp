@@ -1252,6 +1252,7 @@ void fdsr_destroy(fdsr_handle h) {
   if (h->d_nl) (void)hipFree(h->d_nl);
   if (h->d_rng) (void)hipFree(h->d_rng);
   if (h->d_wtq) (void)hipFree(h->d_wtq);
+  if (h->d_hamax) (void)hipFree(h->d_hamax);
   for (float* q : {h->d_master, h->d_grad, h->d_adam_m, h->d_adam_v, h->d_wt, h->d_zero, h->d_hscale})
     if (q) (void)hipFree(q);
   delete h;

@@ -151,6 +151,7 @@ struct fdsr_engine {
   size_t wt_floats = 0;
   std::vector<size_t> wt_off0, wt_off1;   // per weight entry: offsets into d_wt for concat source 0 / 1 (SIZE_MAX: none)
   float* d_hscale = nullptr;          // per weight entry: {2^e, 2^-e} of its f16x3 forms (read by the kernels after device re-packs)
+  unsigned* d_hamax = nullptr;        // scratch of the scale computation: max|w| per weight entry (float bits)
   unsigned char* d_wtq = nullptr;     // transposed, tap-flipped f16x3 fragment forms (input-gradient convolutions in f16x3)
   size_t wtq_bytes = 0;
   std::vector<size_t> wtq_off0, wtq_off1;   // per weight entry (SIZE_MAX: this conv's input gradient stays on the fp32 kernel)

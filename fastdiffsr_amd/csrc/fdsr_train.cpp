@@ -157,6 +157,7 @@ int train_prepare(fdsr_handle h) {
   }
   h->wtq_bytes = qoff;
   HIPCHK(h, hipMalloc((void**)&h->d_wtq, std::max<size_t>(qoff, 256)));
+  HIPCHK(h, hipMalloc((void**)&h->d_hamax, h->weights.size() * sizeof(unsigned)));
   HIPCHK(h, hipMalloc((void**)&h->d_wt, std::max<size_t>(off, 4) * sizeof(float)));
   HIPCHK(h, hipMalloc((void**)&h->d_zero, (size_t)round_up(maxC, 64) * sizeof(float)));
   HIPCHK(h, hipMemset(h->d_zero, 0, (size_t)round_up(maxC, 64) * sizeof(float)));
@@ -194,12 +195,19 @@ int repack_from_master(fdsr_handle h, hipStream_t st, bool forward_forms) {
     }
   }
   // f16x3 forms (forward + transposed), packed on the device with a per-tensor power-of-two scale
+  HIPCHK(h, hipMemsetAsync(h->d_hamax, 0, h->weights.size() * sizeof(unsigned), st));
+  for (int i = 0; i < h->n_schema; ++i) {
+    const WeightEntry& w = h->weights[i];
+    if (w.live && w.sink == WeightEntry::CONV_PACK && w.h_ok)
+      HIPCHK(h, launch_hamax(h->d_master + h->master_off[i], numel(w.shape), h->d_hamax + i, st));
+  }
+  // every slot gets a scale; the slots that are not f16x3 conv weights (amax 0 -> e = 12) are never read
+  HIPCHK(h, launch_hscale_all(h->d_hamax, h->d_hscale, (int)h->weights.size(), st));
   for (int i = 0; i < h->n_schema; ++i) {
     WeightEntry& w = h->weights[i];
     if (!w.live || w.sink != WeightEntry::CONV_PACK || !w.h_ok) continue;
     const float* src = h->d_master + h->master_off[i];
     float* sc2 = h->d_hscale + 2 * (size_t)i;
-    HIPCHK(h, launch_hscale(src, numel(w.shape), sc2, st));
     if (forward_forms)
       HIPCHK(h, launch_pack_conv_h(src, h->d_wq + w.hq_off[PREC_F16X3], sc2, (int)w.shape[0], (int)w.shape[1], w.ks, w.h_WN,
                                    w.h_cout_pad, w.h_cin_pad, 0, 0, 0, st));

@@ -118,8 +118,11 @@ hipError_t launch_pack_conv_f32_t(const float* w, float* packed_t, int Cout, int
                                   int cols_pad, hipStream_t s);
 
 // ---- f16x3 forms on the device (fp32-grade split-f16 MFMA convolutions, fdsr_conv_h.hip) ------------------------
-// scale2[0] = 2^e with e = min(12, floor(log2(32768 / max|w|))) (what pack_weights_h chooses on the host), scale2[1] = 2^-e
-hipError_t launch_hscale(const float* w, size_t n, float* scale2, hipStream_t s);
+// Per-tensor power-of-two scale of the f16x3 forms, e = min(12, floor(log2(32768 / max|w|))) (what pack_weights_h chooses on
+// the host): launch_hamax folds max|w| of one tensor into amax_bits[slot] (bit pattern of a non-negative float; atomicMax
+// is order-independent, so this stays deterministic), launch_hscale_all then writes scale2[slot] = {2^e, 2^-e} for every slot.
+hipError_t launch_hamax(const float* w, size_t n, unsigned* amax_bits, hipStream_t s);
+hipError_t launch_hscale_all(const unsigned* amax_bits, float* scale2, int nslots, hipStream_t s);
 // checkpoint layout [Cout][Cin][ks][ks] -> MFMA B-fragment order [cot][kc][wn][tap][hi|lo][lane] x 16 B (see
 // pack_weights_h in fdsr_engine.cpp), values multiplied by scale2[0].  transposed != 0: the input-gradient form, the
 // conv weight  W'[co' = ci - c_off][ci' = co][tap'] = W[co][ci][T-1-tap'],  co' < rows (the Cin slice of one concat source)

@@ -1053,29 +1053,38 @@ hipError_t launch_pack_conv_f32_t(const float* w, float* packed_t, int Cout, int
 // ---------------------------------------------------------------------------
 // f16x3 weight forms, packed on the device
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) hscale_kernel(const float* __restrict__ w, size_t n, float* __restrict__ scale2) {
-  __shared__ float sm[16];
+__global__ void __launch_bounds__(256) hamax_kernel(const float* __restrict__ w, size_t n, unsigned* __restrict__ amax_bits) {
+  __shared__ float sm[4];
   float m = 0.f;
-  for (size_t i = threadIdx.x; i < n; i += 1024) m = fmaxf(m, fabsf(w[i]));
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = fmaxf(m, fabsf(w[i]));
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
   if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    float amax = 0.f;
-    for (int i = 0; i < 16; ++i) amax = fmaxf(amax, sm[i]);
-    int e = 12;
-    if (amax > 0.f) {
-      const int f = (int)floor(log2(32768.0 / (double)amax));
-      e = f < 12 ? f : 12;
-    }
-    scale2[0] = ldexpf(1.0f, e);
-    scale2[1] = ldexpf(1.0f, -e);
-  }
+  if (threadIdx.x == 0) atomicMax(amax_bits, __builtin_bit_cast(unsigned, fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]))));
 }
 
-hipError_t launch_hscale(const float* w, size_t n, float* scale2, hipStream_t s) {
-  hipLaunchKernelGGL(hscale_kernel, dim3(1), dim3(1024), 0, s, w, n, scale2);
+hipError_t launch_hamax(const float* w, size_t n, unsigned* amax_bits, hipStream_t s) {
+  const unsigned blocks = (unsigned)std::min<size_t>((n + 256 * 16 - 1) / (256 * 16), 512);
+  hipLaunchKernelGGL(hamax_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, s, w, n, amax_bits);
+  return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256) hscale_all_kernel(const unsigned* __restrict__ amax_bits, float* __restrict__ scale2, int nslots) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= nslots) return;
+  const float amax = __builtin_bit_cast(float, amax_bits[i]);
+  int e = 12;
+  if (amax > 0.f) {
+    const int f = (int)floor(log2(32768.0 / (double)amax));
+    e = f < 12 ? f : 12;
+  }
+  scale2[2 * i] = ldexpf(1.0f, e);
+  scale2[2 * i + 1] = ldexpf(1.0f, -e);
+}
+
+hipError_t launch_hscale_all(const unsigned* amax_bits, float* scale2, int nslots, hipStream_t s) {
+  hipLaunchKernelGGL(hscale_all_kernel, dim3((nslots + 255) / 256), dim3(256), 0, s, amax_bits, scale2, nslots);
   return hipGetLastError();
 }
 

@@ -1,8 +1,8 @@
 """The reference's image-folder dataset (FastDiffSR/data/LRHR_dataset.py, data/util.py, data/__init__.py)
-for the val path: `{dataroot}/hr_{r}`, `sr_{l}_{r}` (the bicubic conditioning image), `lr_{l}`, files
-paired by sorted order.  Tensors are what `transform_augment(split='val', min_max=(-1, 1))` gives:
-ToTensor (uint8 / 255, CHW) * 2 - 1.  Training-time flips (util.py:66-75) and the lmdb container are not
-needed on the sampling path: lmdb raises, like the reference does for unknown datatypes.
+`{dataroot}/hr_{r}`, `sr_{l}_{r}` (the bicubic conditioning image), `lr_{l}`, files paired by sorted order.
+Tensors are what `transform_augment(split, min_max=(-1, 1))` gives: ToTensor (uint8 / 255, CHW), in the train split
+ONE RandomHorizontalFlip(p=0.5) decision for the stacked [SR, HR] (and one of its own for LR, util.py:66-88), then
+* 2 - 1.  The lmdb container raises, like the reference does for unknown datatypes.
 
 `cond_from_lr=True` builds SR on the GPU from the LR image instead of reading `sr_*` (bit-identical to the
 reference's offline PIL bicubic, see data.lr_to_sr): the val loop then needs only LR + HR folders."""
@@ -44,8 +44,6 @@ class LRHRDataset(Dataset):
                  need_LR=False, img_mask='no', cond_from_lr=False):
         if datatype != 'img':
             raise NotImplementedError('data_type [{:s}] is not recognized.'.format(str(datatype)))
-        if split == 'train':
-            raise NotImplementedError('training-time augmentation is SURVEY 8f-3; this dataset serves the val path')
         self.l_res, self.r_res, self.split = l_resolution, r_resolution, split
         self.need_LR = need_LR or cond_from_lr
         self.cond_from_lr = cond_from_lr
@@ -68,7 +66,28 @@ class LRHRDataset(Dataset):
             out['LR'] = to_tensor(lr)
             if self.cond_from_lr:
                 out['LR_u8'] = torch.from_numpy(np.array(lr, dtype=np.uint8))
+        if self.split == 'train':
+            # util.py:66-75: hflip(torch.stack([SR, HR])) -- torchvision's RandomHorizontalFlip draws torch.rand(1) once
+            # for the whole stack; util.py:77-88 does the same, separately, for [LR]
+            if torch.rand(1) < 0.5:
+                for k in ('SR', 'HR'):
+                    if k in out:
+                        out[k] = out[k].flip(-1)
+            if 'LR' in out and torch.rand(1) < 0.5:
+                out['LR'] = out['LR'].flip(-1)
+                if 'LR_u8' in out:
+                    out['LR_u8'] = out['LR_u8'].flip(1)
         return out
+
+
+def create_dataloader(dataset, dataset_opt, phase):             # data/__init__.py:7-21
+    from torch.utils.data import DataLoader
+    if phase == 'train':
+        return DataLoader(dataset, batch_size=dataset_opt['batch_size'], shuffle=dataset_opt['use_shuffle'],
+                          num_workers=dataset_opt['num_workers'], pin_memory=True)
+    if phase == 'val':
+        return DataLoader(dataset, batch_size=1, shuffle=False, num_workers=1, pin_memory=True)
+    raise NotImplementedError('Dataloader [{:s}] is not found.'.format(phase))
 
 
 def create_dataset(dataset_opt, phase, cond_from_lr=False):     # data/__init__.py:24-40

@@ -131,6 +131,7 @@ class DDPM:
     def save_network(self, epoch, iter_step):                      # model.py:126-146
         gen_path = os.path.join(self.opt['path']['checkpoint'], 'I{}_E{}_gen.pth'.format(iter_step, epoch))
         opt_path = os.path.join(self.opt['path']['checkpoint'], 'I{}_E{}_opt.pth'.format(iter_step, epoch))
+        os.makedirs(self.opt['path']['checkpoint'], exist_ok=True)   # the reference's parser made it (core/logger.py:37-43)
         sd = self.netG.state_dict()                                # pulls the engine's master copy after optimiser steps
         torch.save(OrderedDict((k, v.cpu()) for k, v in sd.items()), gen_path)
         if self.opt['phase'] == 'train' and self.netG.denoise_fn.engine.trained:

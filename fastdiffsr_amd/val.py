@@ -39,17 +39,20 @@ def _collate(items):
 
 
 def run(opt, batch=1, cond_from_lr=False, precision='f16x3', results=None, max_images=None, rank=0, world=1,
-        save_images=True, log=print, infer=False):
-    """infer=True is the reference's infer.py (:62-110): the same loop, `{step}_{idx}_sr.png` outputs, timing, no metrics."""
+        save_images=True, log=print, infer=False, diffusion=None, step=None, epoch=None):
+    """infer=True is the reference's infer.py (:62-110): the same loop, `{step}_{idx}_sr.png` outputs, timing, no metrics.
+    diffusion: an existing model (the validation pass inside the training loop, sr_mfe.py:122-244); else one is created."""
     val_opt = opt['datasets']['val']
     dataset = create_dataset(val_opt, 'val', cond_from_lr=cond_from_lr)
     n_total = len(dataset) if max_images is None else min(len(dataset), max_images)
     lo, hi = shard_range(n_total, rank, world)
     scale = int(val_opt['r_resolution']) // int(val_opt['l_resolution'])
-    diffusion = create_model(opt)                                                     # sr_mfe.py:60
+    if diffusion is None:
+        diffusion = create_model(opt)                                                 # sr_mfe.py:60
     diffusion.netG.precision = precision
-    diffusion.set_new_noise_schedule(opt['model']['beta_schedule']['val'], schedule_phase='val')   # sr_mfe.py:66-67
-    current_step, current_epoch = diffusion.begin_step, diffusion.begin_epoch
+    diffusion.set_new_noise_schedule(opt['model']['beta_schedule']['val'], schedule_phase='val')   # sr_mfe.py:66-67, :131-132
+    current_step = diffusion.begin_step if step is None else step
+    current_epoch = diffusion.begin_epoch if epoch is None else epoch
     result_path = results or (opt.get('path') or {}).get('results') or 'results'
     if save_images:
         os.makedirs(result_path, exist_ok=True)
