@@ -60,6 +60,7 @@ SYMBOLS = {
     'fdsr_debug_tensor': (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                     C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     'fdsr_set_training': (C.c_int, [C.c_void_p, C.c_int]),
+    'fdsr_set_dropout_seed': (C.c_int, [C.c_void_p, C.c_uint64]),
     'fdsr_debug_dropout_mask': (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                           C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_float)]),
     'fdsr_train_workspace_bytes': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),

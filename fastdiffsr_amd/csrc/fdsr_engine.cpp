@@ -901,7 +901,7 @@ int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, 
         p.part_out = op.no_part ? nullptr : PART(op.dst);   // res_conv output is overwritten in place by block2
         if (dropout_on && op.drop_slot >= 0) {              // Dropout(p) between Swish and this conv (train mode)
           unsigned char* mask = reinterpret_cast<unsigned char*>(ws + sp.drop_off[op.drop_slot]);
-          HIPCHK(h, launch_dropout_mask(mask, (size_t)N * Hi * Wi * op.C0, h->rng_seed, h->drop_step, (unsigned)op.drop_slot,
+          HIPCHK(h, launch_dropout_mask(mask, (size_t)N * Hi * Wi * op.C0, h->drop_seed, h->drop_step, (unsigned)op.drop_slot,
                                         h->cfg.dropout, st));
           const float dscale = 1.0f / (1.0f - h->cfg.dropout);
           if (h->prec == PREC_F32) {           // the fp32 kernel applies the mask in its staging
@@ -1402,6 +1402,8 @@ int fdsr_sample(fdsr_handle h, const float* cond_nchw, const float* noise, float
 int fdsr_set_seed(fdsr_handle h, uint64_t seed) {
   if (!h) return FDSR_E_INVALID;
   h->rng_seed = seed;
+  h->drop_seed = seed;   // one seed call covers both generators unless fdsr_set_dropout_seed overrides it
+  h->drop_step = 0;
   if (h->d_rng) {
     const unsigned long long init[2] = {seed, 0ull};
     HIPCHK(h, hipMemcpy(h->d_rng, init, sizeof(init), hipMemcpyHostToDevice));
@@ -1507,6 +1509,13 @@ int fdsr_set_precision(fdsr_handle h, int mode) {
     h->graphs.clear();
   }
   h->prec = mode;
+  return FDSR_OK;
+}
+
+int fdsr_set_dropout_seed(fdsr_handle h, uint64_t seed) {
+  if (!h) return FDSR_E_INVALID;
+  h->drop_seed = seed;
+  h->drop_step = 0;
   return FDSR_OK;
 }
 

@@ -160,6 +160,7 @@ struct fdsr_engine {
   bool wt_valid = false;              // d_wt matches d_master
   bool training = false;              // .train(): Dropout(p) of block2 is live (unet.py:89-101); fp32 kernels only
   int n_drop_slots = 0;
+  unsigned long long drop_seed = 0;   // key of the dropout masks (fdsr_set_seed / fdsr_set_dropout_seed)
   unsigned drop_step = 0;             // forward passes made in training mode: part of the mask's Philox counter
   bool keep_stats = false;            // forward also stores per-(image, group) mean / rstd of every GroupNorm
   bool h_forms_stale = false;         // 16-bit weight forms lag behind the master copy (after an optimiser step)

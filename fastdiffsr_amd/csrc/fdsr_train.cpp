@@ -405,7 +405,9 @@ int fdsr_train_grads(fdsr_handle h, const float* x_nchw, const float* noise_leve
         q.drop_mask = reinterpret_cast<const unsigned char*>(ws + sp.drop_off[op.drop_slot]);
         q.drop_scale = 1.0f / (1.0f - h->cfg.dropout);
       }
-      HIPCHK(h, launch_wgrad(op.ck, q, st));
+      static const bool f32_wgrad = getenv("FDSR_WGRAD_F32") != nullptr;   // A/B switch: keep the weight gradients exact fp32
+      if (h->prec == PREC_F16X3 && !f32_wgrad) HIPCHK(h, launch_wgrad_h(op.ck, q, st));
+      else HIPCHK(h, launch_wgrad(op.ck, q, st));
     }
     if (op.src0 == h->t_in) continue;                     // no gradient w.r.t. the network input
     // input gradient: on the f16x3 kernels in that mode (where the transposed shape fits them), else exact fp32

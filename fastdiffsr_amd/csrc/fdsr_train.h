@@ -75,6 +75,8 @@ struct WgradParams {
 };
 size_t wgrad_scratch_floats(ConvKind kind, int N, int Hout, int Wout, int Cin, int Cout);
 hipError_t launch_wgrad(ConvKind kind, const WgradParams& p, hipStream_t s);
+// the same in the split-f16 form (three f16 MFMAs per product, fp32 accumulate): FDSR_PREC_F16X3 training steps
+hipError_t launch_wgrad_h(ConvKind kind, const WgradParams& p, hipStream_t s);
 hipError_t train_kernels_init();
 
 // ---- CLAM / SLAM backward (unet.py:123-173) -----------------------------------------------------------------

@@ -593,6 +593,220 @@ hipError_t launch_wgrad(ConvKind kind, const WgradParams& p, hipStream_t s) {
   return hipErrorInvalidValue;
 }
 
+// ---------------------------------------------------------------------------
+// convolution weight gradient, split-f16 ("f16x3") form: v_mfma_f32_32x32x16_f16, three MFMAs per product
+// (hi*hi + hi*lo + lo*hi of dy = dh + dl and a = ah + al), fp32 accumulation, fp64 fold of the slices.
+// ---------------------------------------------------------------------------
+// Pixels are the K dimension and both operands live in HBM pixel-major (NHWC): the MFMA wants, per lane, 8 consecutive
+// PIXELS of one channel.  The tiles are staged as plain [pixel][64 channels] f16 images (hi plane, lo plane; coalesced
+// loads, 8-byte LDS writes) and read with gfx950's transposing LDS read (ds_read_b64_tr_b16: a 16-lane group fetches a
+// 4-pixel x 16-channel block and every lane receives one channel's 4 pixels), two reads per operand half.  A tap only
+// changes the FIRST ROW of the B block, so there is no alignment problem and no shifted copy.  Rows are 128 B; the two
+// 64-byte halves of a row are swapped on rows with bit 1 set, which makes the 4-row blocks bank-conflict free.
+typedef _Float16 th8 __attribute__((ext_vector_type(8)));
+typedef short ts4 __attribute__((ext_vector_type(4)));
+
+template <int KS, int STRIDE, bool UP>
+struct WgHCfg {
+  static constexpr int TH = STRIDE == 2 ? 2 : 4, TW = 16, T = KS * KS;
+  static constexpr int HH = (TH - 1) * STRIDE + KS, HWD = (TW - 1) * STRIDE + KS, NPIX = HH * HWD;
+  static constexpr int PLANE_DY = TH * TW * 128, PLANE_IN = NPIX * 128;     // bytes per plane
+  static constexpr int LDS_BYTES = 2 * PLANE_DY + 2 * PLANE_IN;
+};
+
+__device__ __forceinline__ int tr_img_off(int row, int col) {   // byte offset of (pixel row, channel col) inside a plane
+  return row * 128 + ((col ^ (((row >> 1) & 1) << 5)) << 1);
+}
+
+__device__ __forceinline__ th8 tr_frag(const unsigned char* plane, int row0, int row_step, int col) {
+  // 8 k-values of this lane: rows row0 + {0..3} * row_step (first read) and row0 + {4..7} * row_step (second read);
+  // lane 4q+p of its 16-lane group supplies the address of row q, columns col .. col+3 (col already includes 4p)
+  typedef ts4 __attribute__((address_space(3))) * lds_ts4;
+  const int q = (threadIdx.x >> 2) & 3;
+  const ts4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ts4)(plane + tr_img_off(row0 + q * row_step, col)));
+  const ts4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ts4)(plane + tr_img_off(row0 + (4 + q) * row_step, col)));
+  typedef short ts8 __attribute__((ext_vector_type(8)));
+  const ts8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(th8, v);
+}
+
+template <int KS, int STRIDE, bool UP>
+__global__ void __launch_bounds__(256) wgrad_h_kernel(const WgradParams p, const int nslices, const int ncb, const int nib) {
+  using Cfg = WgHCfg<KS, STRIDE, UP>;
+  constexpr int TH = Cfg::TH, TW = Cfg::TW, T = Cfg::T, HWD = Cfg::HWD, NPIX = Cfg::NPIX, PAD = KS / 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char wsh[];
+  unsigned char* sDyH = wsh;
+  unsigned char* sDyL = wsh + Cfg::PLANE_DY;
+  unsigned char* sInH = wsh + 2 * Cfg::PLANE_DY;
+  unsigned char* sInL = sInH + Cfg::PLANE_IN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wc = wave & 1, wi = wave >> 1;
+  int b = blockIdx.x;
+  const int sl = b % nslices;  b /= nslices;
+  const int ib = b % nib;  b /= nib;
+  const int cb = b;
+  const int co0 = cb * 64, ci0 = ib * 64;
+  const int Cin = p.C0 + p.C1;
+  const int tilesX = (p.Wout + TW - 1) / TW, tilesY = (p.Hout + TH - 1) / TH;
+  const int ntiles = p.N * tilesX * tilesY;
+  const int t0 = (int)((long)sl * ntiles / nslices), t1 = (int)((long)(sl + 1) * ntiles / nslices);
+  const int Hsrc = UP ? p.Hout : p.Hin, Wsrc = UP ? p.Wout : p.Win;
+
+  f32x16 acc[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+  // ---- register prefetch of the next tile (as in wgrad_kernel) ----
+  constexpr int NDY = TH * TW * 16 / 256, NIN = (NPIX * 16 + 255) / 256;
+  const int q4 = tid & 15, prow = tid >> 4;
+  f32x4 rdy[NDY], rin[NIN], rsc = {1.f, 1.f, 1.f, 1.f}, rsh = {0.f, 0.f, 0.f, 0.f};
+  unsigned rmask[NIN];
+  bool rok[NIN];
+  auto prefetch = [&](int tile) {
+    int tt = tile;
+    const int tx = tt % tilesX;  tt /= tilesX;
+    const int ty = tt % tilesY;
+    const int n = tt / tilesY;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+#pragma unroll
+    for (int i = 0; i < NDY; ++i) {
+      const int px = i * 16 + prow;
+      const int oy = oy0 + px / TW, ox = ox0 + px % TW, co = co0 + q4 * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (oy < p.Hout && ox < p.Wout && co < p.Cout_s)
+        v = *reinterpret_cast<const f32x4*>(p.dy + ((size_t)(n * p.Hout + oy) * p.Wout + ox) * p.Cout_s + co);
+      rdy[i] = v;
+    }
+    const int c = ci0 + q4 * 4;
+    if (p.gn_scale && c < Cin) {
+      rsc = *reinterpret_cast<const f32x4*>(p.gn_scale + (size_t)n * Cin + c);
+      rsh = *reinterpret_cast<const f32x4*>(p.gn_shift + (size_t)n * Cin + c);
+    }
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) {
+      const int hp = i * 16 + prow;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      unsigned m = 0x01010101u;
+      bool ok = false;
+      if (hp < NPIX) {
+        const int hy = hp / HWD, hx = hp % HWD;
+        const int iy = oy0 * STRIDE - PAD + hy, ix = ox0 * STRIDE - PAD + hx;
+        if (iy >= 0 && iy < Hsrc && ix >= 0 && ix < Wsrc && c < Cin) {
+          const int sy = UP ? (iy >> 1) : iy, sx = UP ? (ix >> 1) : ix;
+          const float* xs; int Cs, cc;
+          if (c < p.C0) { xs = p.x0; Cs = p.C0; cc = c; } else { xs = p.x1; Cs = p.C1; cc = c - p.C0; }
+          const size_t o = ((size_t)(n * p.Hin + sy) * p.Win + sx) * Cs + cc;
+          v = *reinterpret_cast<const f32x4*>(xs + o);
+          if (p.drop_mask) m = *reinterpret_cast<const unsigned*>(p.drop_mask + o);
+          ok = true;
+        }
+      }
+      rin[i] = v;
+      rmask[i] = m;
+      rok[i] = ok;
+    }
+  };
+  auto put_split = [&](unsigned char* ph, unsigned char* pl, int row, f32x4 v) {
+    // hi = rn_f16(clamp(v)), lo = rn_f16(v - hi): 22 mantissa bits (fdsr_conv_h.hip)
+    typedef _Float16 h4t __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], -65504.f, 65504.f);
+    const h4t hi = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+    const h4t lo = {(_Float16)(v[0] - (float)hi[0]), (_Float16)(v[1] - (float)hi[1]), (_Float16)(v[2] - (float)hi[2]),
+                    (_Float16)(v[3] - (float)hi[3])};
+    const int off = tr_img_off(row, q4 * 4);
+    *reinterpret_cast<h4t*>(ph + off) = hi;
+    *reinterpret_cast<h4t*>(pl + off) = lo;
+  };
+  auto store = [&]() {
+#pragma unroll
+    for (int i = 0; i < NDY; ++i) put_split(sDyH, sDyL, i * 16 + prow, rdy[i]);
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) {
+      const int hp = i * 16 + prow;
+      if (hp >= NPIX) continue;
+      f32x4 v = rin[i];
+      if (rok[i] && p.gn_scale) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float u = fmaf(v[e], rsc[e], rsh[e]);
+          v[e] = p.gn_plain ? u : u * sigmoid_f(u);
+        }
+        if (p.drop_mask) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = ((rmask[i] >> (8 * e)) & 0xffu) ? v[e] * p.drop_scale : 0.f;
+        }
+      }
+      put_split(sInH, sInL, hp, v);
+    }
+  };
+
+  // ---- operand addressing: lane -> (16-lane group g, i = 4q + p); channel column = 32 * wave half + 16 * (g & 1) + 4p,
+  //      first pixel of the 8-pixel run = 8 * (g >> 1)
+  const int g = lane >> 4, pp4 = lane & 3;
+  const int colA = wc * 32 + 16 * (g & 1) + 4 * pp4, colB = wi * 32 + 16 * (g & 1) + 4 * pp4;
+  const int k0 = 8 * (g >> 1);
+
+  if (t0 < t1) prefetch(t0);
+  for (int tile = t0; tile < t1; ++tile) {
+    __syncthreads();
+    store();
+    __syncthreads();
+    if (tile + 1 < t1) prefetch(tile + 1);
+#pragma unroll 1
+    for (int y = 0; y < TH; ++y) {                          // one K-step = one 16-pixel tile row
+      const th8 ah = tr_frag(sDyH, y * TW + k0, 1, colA);
+      const th8 al = tr_frag(sDyL, y * TW + k0, 1, colA);
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const int rb = (y * STRIDE + t / KS) * HWD + k0 * STRIDE + (t % KS);
+        const th8 bh = tr_frag(sInH, rb, STRIDE, colB);
+        const th8 bl = tr_frag(sInL, rb, STRIDE, colB);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
+      }
+    }
+  }
+  const int r31 = lane & 31, kh = lane >> 5;
+  float* dst = p.scratch + ((((size_t)sl * ncb + cb) * nib + ib) * T) * 4096;
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = (i & 3) + 8 * (i >> 2) + 4 * kh;
+      dst[(size_t)t * 4096 + (wc * 32 + row) * 64 + wi * 32 + r31] = acc[t][i];
+    }
+}
+
+template <int KS, int STRIDE, bool UP>
+static hipError_t launch_wgrad_h_t(const WgradParams& p, hipStream_t s) {
+  using Cfg = WgHCfg<KS, STRIDE, UP>;
+  const int Cin = p.C0 + p.C1;
+  const int ncb = (p.Cout + 63) / 64, nib = (Cin + 63) / 64;
+  const int ntiles = p.N * ((p.Wout + Cfg::TW - 1) / Cfg::TW) * ((p.Hout + Cfg::TH - 1) / Cfg::TH);
+  const int ns = wgrad_slices(ntiles, ncb, nib);
+  hipLaunchKernelGGL((wgrad_h_kernel<KS, STRIDE, UP>), dim3(ns * ncb * nib), dim3(256), (size_t)Cfg::LDS_BYTES, s, p, ns, ncb, nib);
+  const size_t total = (size_t)p.Cout * p.Cin_real * Cfg::T;
+  hipLaunchKernelGGL(wgrad_fold_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p.scratch, p.dw, p.Cout, p.Cin_real,
+                     Cfg::T, ns, ncb, nib, total);
+  return hipGetLastError();
+}
+
+// the tiles (4x16, stride 2: 2x16) equal wgrad_kernel's, so the scratch sizing (wgrad_scratch_floats) is shared
+hipError_t launch_wgrad_h(ConvKind kind, const WgradParams& p, hipStream_t s) {
+  if ((p.C0 & 3) || (p.C1 & 3) || (p.Cout_s & 3)) return hipErrorInvalidValue;
+  switch (kind) {
+    case CONV3_S1: return launch_wgrad_h_t<3, 1, false>(p, s);
+    case CONV3_S2: return launch_wgrad_h_t<3, 2, false>(p, s);
+    case CONV3_UP: return launch_wgrad_h_t<3, 1, true>(p, s);
+    case CONV1: return launch_wgrad_h_t<1, 1, false>(p, s);
+  }
+  return hipErrorInvalidValue;
+}
+
 hipError_t train_kernels_init() {
   hipError_t e;
 #define FDSR_WG_INIT(KS, ST, UP)                                                                                      \
@@ -601,6 +815,12 @@ hipError_t train_kernels_init() {
     return e;
   FDSR_WG_INIT(3, 1, false) FDSR_WG_INIT(3, 2, false) FDSR_WG_INIT(3, 1, true) FDSR_WG_INIT(1, 1, false)
 #undef FDSR_WG_INIT
+#define FDSR_WGH_INIT(KS, ST, UP)                                                                                      \
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_h_kernel<KS, ST, UP>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                               (int)WgHCfg<KS, ST, UP>::LDS_BYTES)) != hipSuccess)                                        \
+    return e;
+  FDSR_WGH_INIT(3, 1, false) FDSR_WGH_INIT(3, 2, false) FDSR_WGH_INIT(3, 1, true) FDSR_WGH_INIT(1, 1, false)
+#undef FDSR_WGH_INIT
   return hipSuccess;
 }
 

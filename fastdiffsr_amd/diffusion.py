@@ -90,7 +90,7 @@ class GaussianDiffusion(nn.Module):
         eng.set_precision(self.precision)
         # the reference samples after netG.eval() (model.py:60); in .train() mode its Dropout would be live here too,
         # and so it is (the engine then insists on the fp32 kernels)
-        eng.set_training(self.denoise_fn.training and self.denoise_fn.cfg.dropout > 0)
+        eng.set_training(self.denoise_fn.training and self.denoise_fn.cfg.dropout > 0, seed_from_torch=True)
         if not continous:
             return eng.sample(x, noise, graph=False)
         img, traj = eng.sample(x, noise, want_traj=True, graph=False)
@@ -145,7 +145,7 @@ class GaussianDiffusion(nn.Module):
         eng = unet.engine
         # 'f32' (exact) or 'f16x3' (fp32-grade forward and input gradients; weight gradients stay exact fp32)
         eng.set_precision('f32' if self.precision == 'bf16' else self.precision)
-        eng.set_training(unet.training and unet.cfg.dropout > 0)   # Dropout(p) of block2 is live in .train() mode
+        eng.set_training(unet.training and unet.cfg.dropout > 0, seed_from_torch=True)   # Dropout(p) of block2 is live in .train() mode
         return eng
 
     def optimize_step(self, x_in, lr, betas=(0.9, 0.999), eps=1e-8, noise=None, grad_hook=None, loss_div_batches=1):

@@ -226,9 +226,14 @@ class Engine:
 
     supports_dropout = True
 
-    def set_training(self, on=True):
-        """nn.Module.train()/.eval(): Dropout(p) of block2 live or not (exact-fp32 kernels only when live)."""
+    def set_training(self, on=True, seed_from_torch=False):
+        """nn.Module.train()/.eval(): Dropout(p) of block2 live or not (the fp32-grade precisions only when live).
+        seed_from_torch: key the masks of the coming call by a draw from torch's (CPU) generator, so that a run repeats
+        under torch.manual_seed as the reference's nn.Dropout does."""
         _lib.check(self.h, self.lib.fdsr_set_training(self.h, int(bool(on))))
+        if on and seed_from_torch:
+            seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+            _lib.check(self.h, self.lib.fdsr_set_dropout_seed(self.h, C.c_uint64(seed)))
 
     def dropout_mask(self, block):
         """The multiplicative mask (keep / (1-p)) the last training-mode forward applied in front of `block`'s block2

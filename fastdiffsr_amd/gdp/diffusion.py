@@ -32,7 +32,7 @@ class GaussianDiffusion(_d.GaussianDiffusion):
         self.denoise_fn.sync_weights()
         eng = self.denoise_fn.engine
         eng.set_precision(self.precision)
-        eng.set_training(self.denoise_fn.training and self.denoise_fn.cfg.dropout > 0)
+        eng.set_training(self.denoise_fn.training and self.denoise_fn.cfg.dropout > 0, seed_from_torch=True)
         if not continous:
             return eng.sample(x, noise)[-1]                       # ret_img[-1]: the last image of the batch
         img, traj = eng.sample(x, noise, want_traj=True)

@@ -122,7 +122,7 @@ class UNet(nn.Module):
         # nn.Dropout(p) in block2 is live whenever .training (unet.py:89-101): the engine draws the masks
         # (Philox) and runs the exact-fp32 kernels for such a forward
         live_dropout = self.training and self.cfg.dropout > 0
-        self.engine.set_training(live_dropout)
+        self.engine.set_training(live_dropout, seed_from_torch=True)
         if live_dropout and getattr(self.engine, 'precision', 'f32') == 'bf16':
             self.engine.set_precision('f16x3')       # live dropout needs one of the fp32-grade modes
         return self.engine.unet_forward(x, time)

@@ -200,6 +200,9 @@ int fdsr_profile_end(fdsr_handle h, int* launches, double* conv_ms, double* conv
  * fdsr_debug_dropout_mask gives its offset inside the workspace of the last forward, [N][H][W][C] bytes (1 = keep),
  * and the factor 1/(1-p) kept elements are multiplied by.  `block` is the reference module, e.g. "downs.1". */
 int fdsr_set_training(fdsr_handle h, int on);
+/* Key of the dropout masks alone (fdsr_set_seed sets it too) and restart of the forward count: the facade draws it from
+ * torch's generator before every training-mode call, so runs repeat under torch.manual_seed like the reference's. */
+int fdsr_set_dropout_seed(fdsr_handle h, uint64_t seed);
 int fdsr_debug_dropout_mask(fdsr_handle h, const char* block, const unsigned char** dev_off, int* n, int* hgt, int* wid,
                             int* ch, float* scale);
 

@@ -168,7 +168,7 @@ def test_train_mode_forward_has_live_dropout():
         ev = net(x.cuda(), nl.cuda()).cpu()
         assert (ev - O.unet_forward(tsd, cfg, x, nl)).abs().max().item() <= 1e-4
         net.train()
-        net.engine.set_seed(5)
+        torch.manual_seed(5)
         t1 = net(x.cuda(), nl.cuda()).cpu()
         masks = {b: net.engine.dropout_mask(b).cpu() for b in _res_blocks(cfg)}
         assert len(masks) == 22
@@ -180,11 +180,9 @@ def test_train_mode_forward_has_live_dropout():
         for m in masks.values():
             assert set(torch.unique(m).tolist()) <= {0.0, 1.25}
         t2 = net(x.cuda(), nl.cuda()).cpu()
-        assert (t2 - t1).abs().max().item() > 1e-3                      # fresh masks per forward
-        net.engine.set_seed(6)
-        m6 = net.engine  # different seed -> different masks
-        t3 = net(x.cuda(), nl.cuda()).cpu()
-        assert (t3 - t2).abs().max().item() > 1e-3
+        assert (t2 - t1).abs().max().item() > 1e-3                      # fresh masks per forward (torch's generator moved on)
+        torch.manual_seed(5)
+        assert torch.equal(net(x.cuda(), nl.cuda()).cpu(), t1)          # ... and the same ones under the same torch seed
         net.eval()
         assert torch.equal(net(x.cuda(), nl.cuda()).cpu(), ev)          # eval() switches it off again
 
