@@ -631,7 +631,7 @@ __device__ __forceinline__ th8 tr_frag(const unsigned char* plane, int row0, int
 }
 
 template <int KS, int STRIDE, bool UP>
-__global__ void __launch_bounds__(256) wgrad_h_kernel(const WgradParams p, const int nslices, const int ncb, const int nib) {
+__global__ void __launch_bounds__(256, 2) wgrad_h_kernel(const WgradParams p, const int nslices, const int ncb, const int nib) {
   using Cfg = WgHCfg<KS, STRIDE, UP>;
   constexpr int TH = Cfg::TH, TW = Cfg::TW, T = Cfg::T, HWD = Cfg::HWD, NPIX = Cfg::NPIX, PAD = KS / 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char wsh[];
