@@ -316,7 +316,7 @@ def train_record(cfg, sd, dev, B, S, steps, warmup, precision='f16x3'):
                 'warmup': warmup, 'dtype': precision, 'batch': B,
                 'workload': 'configs[4] per-GPU slice: batch 32, 256x256, q_sample + L1(sum)/(b*c*h*w) (define_G fixes loss_type l1) + '
                             'backward + Adam, Dropout(0.2) live; ' + ('everything exact fp32' if precision == 'f32' else
-                                                                 'forward + input gradients f16x3 (fp32-grade), weight gradients exact fp32'),
+                                                                 'every convolution (forward, input and weight gradients) f16x3 = fp32-grade'),
                 'algorithmic_tflops': tf, 'frac_f32_mfma_peak': tf / PEAK_F32_MFMA}   # priced against the f32 roof in both modes
     except Exception as e:
         return {'error': f'{type(e).__name__}: {e}'}
@@ -417,7 +417,7 @@ def main():
                 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
                 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.precision, 'data': 'synthetic',
                 'config': {'workload': f'BASELINE configs[4] training step: x8 32->256 shapes, batch={Bt}/GPU, 256x256, q_sample + L1(sum)/(b*c*h*w), '
-                                       'Dropout(0.2) live, ' + ('exact fp32' if args.precision == 'f32' else 'f16x3 forward / input gradients + fp32 weight gradients') + '; data parallel = one all-reduce of the 91.6 MB gradient arena per step',
+                                       'Dropout(0.2) live, ' + ('exact fp32' if args.precision == 'f32' else 'every convolution f16x3 (fp32-grade)') + '; data parallel = one all-reduce of the 91.6 MB gradient arena per step',
                            'batch_per_gpu': Bt, 'global_batch': Bt * world, 'parallelism': f'dp{world}'},
                 'algorithmic_tflops_per_gpu': tf, 'frac_f32_mfma_peak': tf / PEAK_F32_MFMA}), flush=True)
         if distributed:

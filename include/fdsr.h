@@ -210,8 +210,8 @@ int fdsr_debug_dropout_mask(fdsr_handle h, const char* block, const unsigned cha
  * DDPM.optimize_parameters (model/model.py:47-57): zero_grad, l_pix = netG(data) = p_losses
  * (fastdiffsr_modules/diffusion.py:242-270), l_pix.sum() / (b*c*h*w), backward, Adam.step.  The engine keeps
  * an fp32 master copy of every executed checkpoint tensor, its gradient and the two Adam moments on the
- * device; the step runs in FDSR_PREC_F32 (everything exact fp32) or FDSR_PREC_F16X3 (forward and input-gradient
- * convolutions fp32-grade on the split-f16 MFMA kernels, weight gradients exact fp32), every reduction in a fixed
+ * device; the step runs in FDSR_PREC_F32 (everything exact fp32) or FDSR_PREC_F16X3 (forward, input-gradient and
+ * weight-gradient convolutions fp32-grade on split-f16 MFMA kernels; everything else fp32), every reduction in a fixed
  * order: a step is bitwise reproducible.  The 44 never-executed tensors of the schema
  * (unet.py:212) get no gradient and are not touched, as in torch. */
 
