@@ -6,10 +6,12 @@ TAG=$1; shift
 R=$(cd $(dirname $0)/.. && pwd); C=$R/fastdiffsr_amd/csrc; O=$C/ab; mkdir -p $O/$TAG
 COMMON="--offload-arch=gfx950 -std=c++17 -fPIC -Wno-unused-result"
 /opt/rocm/bin/hipcc $COMMON -O3 -munsafe-fp-atomics "$@" -c $C/fdsr_kernels.hip -o $O/$TAG/k.o &
+/opt/rocm/bin/hipcc $COMMON -O3 "$@" -c $C/fdsr_train.hip -o $O/$TAG/t.o &
+/opt/rocm/bin/hipcc $COMMON -O2 "$@" -c $C/fdsr_train.cpp -o $O/$TAG/tc.o &
 /opt/rocm/bin/hipcc $COMMON -O3 -fno-slp-vectorize "$@" -c $C/fdsr_conv_h.hip -o $O/$TAG/h.o &
 /opt/rocm/bin/hipcc $COMMON -O3 -fno-slp-vectorize "$@" -c $C/fdsr_conv_up2.hip -o $O/$TAG/u.o &
 /opt/rocm/bin/hipcc $COMMON -O2 -DFDSR_SRC_SHA256=\"variant-$TAG\" "$@" -c $C/fdsr_engine.cpp -o $O/$TAG/e.o &
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $O/$TAG/k.o $O/$TAG/h.o $O/$TAG/u.o $O/$TAG/e.o -o $O/libfdsr_hip_$TAG.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $O/$TAG/k.o $O/$TAG/h.o $O/$TAG/u.o $O/$TAG/e.o $O/$TAG/t.o $O/$TAG/tc.o -o $O/libfdsr_hip_$TAG.so
 rm -rf $O/$TAG
 echo built $O/libfdsr_hip_$TAG.so
