@@ -65,3 +65,42 @@ def test_bench_default_line_is_complete_and_parity_clean():
     if 'psnr_delta_db' in pc:
         assert abs(pc['psnr_delta_db']) <= 0.01 and pc['max_abs_diff_image'] <= 1e-3
     assert len(res['library']['source_sha256']) == 64
+
+
+@pytest.mark.timeout(600)
+def test_bench_train_rccl_path_with_one_rank():
+    """The data-parallel training leg with one rank: the gradient arena wrapped zero-copy as a torch tensor and all-reduced
+    through RCCL between backward and Adam (parallel.allreduce_grads), one JSON line."""
+    env = dict(os.environ)
+    env.update({'FDSR_BENCH_FORCE_DIST': '1', 'RANK': '0', 'LOCAL_RANK': '0', 'WORLD_SIZE': '1',
+                'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(_free_port()), 'HSA_ENABLE_IPC_MODE_LEGACY': '0'})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--train', '--batch', '4', '--steps', '2',
+                        '--warmup', '1'], cwd=ROOT, env=env, capture_output=True, text=True, timeout=540)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    res = json.loads(lines[0])
+    assert res['n_gpus'] == 1 and res['value'] > 0 and res['config']['batch_per_gpu'] == 4
+
+
+def test_grad_arena_is_the_engines_memory():
+    """Engine.grad_arena() shares the engine's gradient memory (no copy): writes through the tensor are what get_grad reads."""
+    import numpy as np
+    import torch
+    from fastdiffsr_amd.arch import UNetConfig
+    from fastdiffsr_amd.engine import Engine
+    from fastdiffsr_amd.synth import synth_state_dict
+    cfg = UNetConfig(in_channel=6, out_channel=3, inner_channel=32, norm_groups=32, channel_mults=(1, 2), attn_res=(16,), res_blocks=1,
+                     dropout=0.0, image_size=32)
+    eng = Engine(cfg)
+    eng.load_state_dict(synth_state_dict(cfg, 1))
+    eng.set_precision('f32')
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 6, 32, 32, generator=g).cuda()
+    eng.train_grads(x, torch.tensor([0.5, 0.7]).cuda(), torch.randn(2, 3, 32, 32, generator=g).cuda(), 'l1', 1e-3)
+    arena = eng.grad_arena()
+    assert arena.is_cuda and arena.dtype == torch.float32 and arena.numel() > 1e5
+    before = eng.get_grad('downs.0.weight').copy()
+    arena.mul_(2.0)                                   # what an all-reduce(sum) over two identical ranks would do
+    torch.cuda.synchronize()
+    assert np.array_equal(eng.get_grad('downs.0.weight'), 2.0 * before)
