@@ -338,6 +338,55 @@ def sub_record(eng, dev, name, precision, B, S, steps, warmup, graph, note):
         return {'error': f'{type(e).__name__}: {e}'}
 
 
+def dist_sub_records(cfg, sd, eng, dev, rank, world, S):
+    """configs[3] and configs[4] at their own per-GPU workloads, measured by ALL ranks of a torch.distributed run (the headline
+    above is configs[1] per GPU): bf16 B=64 + hipGraph sampling (no collective on the data path), and the data-parallel training
+    step at B=32 per GPU (one all-reduce of the gradient arena per step).  Every rank enters every collective here whether or
+    not its own measurement succeeded (a failure is reported as an error record, never as a hang); ranks start together behind
+    a barrier and the time is the max over ranks."""
+    import torch.distributed as dist
+    from fastdiffsr_amd import parallel
+    from fastdiffsr_amd.engine import Engine
+
+    def measure(fn):
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        try:
+            dt, err = fn(), None
+        except Exception as e:
+            dt, err = float('inf'), f'{type(e).__name__}: {e}'
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()), err
+
+    recs = {}
+    steps, warmup = 2, 1
+    dt, err = measure(lambda: run_config(eng, dev, 'bf16', 64, S, steps, warmup, True, 'engine', rank=rank, want_profile=False)[0])
+    if dt != float('inf'):
+        ips = world * 64 * steps / dt
+        recs['bf16_b64_graph'] = {'value': ips, 'unit': 'images/s', 'n_gpus': world, 'ms_per_step': 1e3 * dt / steps, 'steps': steps, 'warmup': warmup,
+                                  'dtype': 'bf16', 'batch_per_gpu': 64, 'global_batch': 64 * world, 'hipgraph': True,
+                                  'workload': 'configs[3]: bf16, batch 64 per GPU sharded over the ranks, 20-step loop as a hipGraph, weights broadcast once'}
+    else:
+        recs['bf16_b64_graph'] = {'error': err or 'failed on another rank'}
+
+    def train():
+        e2 = Engine(cfg)
+        e2.load_state_dict(sd)
+        return run_train(e2, dev, 32, S, steps, warmup, rank=rank, allreduce=parallel.allreduce_grads, precision='f16x3')
+    dt, err = measure(train)
+    torch.cuda.empty_cache()
+    if dt != float('inf'):
+        ips = world * 32 * steps / dt
+        recs['train_step_b32'] = {'value': ips, 'unit': 'images/s (one optimisation step per batch)', 'n_gpus': world, 'ms_per_step': 1e3 * dt / steps,
+                                  'steps': steps, 'warmup': warmup, 'dtype': 'f16x3', 'batch_per_gpu': 32, 'global_batch': 32 * world,
+                                  'workload': 'configs[4]: x8 32->256 shapes, batch 32 per GPU, q_sample + L1(sum)/(b*c*h*w) + backward + Adam, Dropout(0.2) '
+                                              'live, every convolution f16x3; data parallel = one RCCL all-reduce of the 91.6 MB gradient arena per step'}
+    else:
+        recs['train_step_b32'] = {'error': err or 'failed on another rank'}
+    return recs
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -432,6 +481,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    dist_recs = None
+    if distributed and not args.no_sub_records:
+        dist_recs = dist_sub_records(cfg, sd, eng, dev, rank, world, S)
+        eng.set_precision(args.precision)
+
     if rank == 0:
         ips = world * B * args.steps / dt
         version = _lib.load().fdsr_version().decode()
@@ -453,6 +507,8 @@ def main():
                               'broadcast_bytes': int(sum(np.asarray(v).nbytes for v in sd.values()))}
         if prof and prof['conv_ms'] > 0:
             res['roofline'] = conv_roofline(prof, args.precision, B, S, dt)
+        if dist_recs is not None:
+            res['sub_records'] = dist_recs
         if world == 1 and not distributed and not args.no_sub_records:
             # the other arithmetic modes and batch regimes of BASELINE.json, driver-visible in the same line
             res['sub_records'] = {

@@ -27,7 +27,7 @@ def test_bench_rccl_path_with_one_rank():
     env.update({'FDSR_BENCH_FORCE_DIST': '1', 'RANK': '0', 'LOCAL_RANK': '0', 'WORLD_SIZE': '1',
                 'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(_free_port()), 'HSA_ENABLE_IPC_MODE_LEGACY': '0'})
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '1', '--warmup', '1',
-                        '--no-cpu-baseline', '--no-sub-records'], cwd=ROOT, env=env, capture_output=True, text=True, timeout=540)
+                        '--no-cpu-baseline'], cwd=ROOT, env=env, capture_output=True, text=True, timeout=540)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, lines                    # RCCL's banner must not leak onto stdout
@@ -38,6 +38,14 @@ def test_bench_rccl_path_with_one_rank():
     assert w['sha256_after_broadcast'] == w['sha256_rank0_source']    # what RCCL delivered is what rank 0 built
     assert w['broadcast_bytes'] > 90e6                                # the packed fp32 state, one message
     assert 'parallelism' in res['config'] and res['config']['parallelism'].startswith('dp1')
+    # under torch.distributed every rank also measures configs[3] (bf16 B=64/GPU, hipGraph) and configs[4] (data-parallel training
+    # step, B=32/GPU, gradient all-reduce through RCCL): the multi-GPU lines of the driver's scaling run carry them
+    sub = res['sub_records']
+    assert set(sub) == {'bf16_b64_graph', 'train_step_b32'}
+    for k, v in sub.items():
+        assert 'error' not in v, (k, v)
+        assert v['value'] > 0 and v['n_gpus'] == 1
+    assert sub['bf16_b64_graph']['global_batch'] == 64 and sub['train_step_b32']['global_batch'] == 32
 
 
 @pytest.mark.timeout(900)
