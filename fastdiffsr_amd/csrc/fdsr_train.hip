@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 namespace fdsr {
 
@@ -539,17 +540,37 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p, const i
 // dw[co][ci][t] = sum over slices (in order) of scratch[sl][cb][ib][t][co%64][ci%64]
 __global__ void __launch_bounds__(256) wgrad_fold_kernel(const float* __restrict__ scratch, float* __restrict__ dw, int Cout, int Cin_real,
                                                          int T, int nslices, int ncb, int nib, size_t total) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;   // over [Cout][Cin_real][T]
-  if (i >= total) return;
-  const int t = (int)(i % T);
-  size_t r = i / T;
-  const int ci = (int)(r % Cin_real), co = (int)(r / Cin_real);
-  const int cb = co >> 6, ib = ci >> 6;
-  const size_t off = (((size_t)cb * nib + ib) * T + t) * 4096 + (size_t)(co & 63) * 64 + (ci & 63);
+  // One workgroup folds 64 consecutive scratch elements (one row of a 64x64 (co, ci) block of one tap): wave w sums the w-th
+  // quarter of the slices in ascending order (256 contiguous bytes per slice and wave), the four partial sums are added in
+  // wave order -- a fixed association, fp64 -- and the row goes to the checkpoint layout [Cout][Cin][tap].
+  __shared__ double part[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const size_t e = (size_t)blockIdx.x * 64 + lane;              // over [cb][ib][t][co & 63][ci & 63]
   const size_t stride = (size_t)ncb * nib * T * 4096;
+  const int s0 = w * nslices / 4, s1 = (w + 1) * nslices / 4;
+  const float* src = scratch + e;
   double a = 0.0;
-  for (int sl = 0; sl < nslices; ++sl) a += (double)scratch[(size_t)sl * stride + off];
-  dw[i] = (float)a;
+  int sl = s0;
+  for (; sl + 8 <= s1; sl += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(sl + u) * stride];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a += (double)v[u];
+  }
+  for (; sl < s1; ++sl) a += (double)src[(size_t)sl * stride];
+  part[w][lane] = a;
+  __syncthreads();
+  if (w == 0) {
+    const double r = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+    size_t q = e;
+    const int ci = (int)(q & 63);  q >>= 6;
+    const int co = (int)(q & 63);  q >>= 6;
+    const int t = (int)(q % T);  q /= T;
+    const int ib = (int)(q % nib), cb = (int)(q / nib);
+    const int gco = cb * 64 + co, gci = ib * 64 + ci;
+    if (gco < Cout && gci < Cin_real) dw[((size_t)gco * Cin_real + gci) * T + t] = (float)r;
+  }
 }
 
 static int wgrad_slices(int ntiles, int ncb, int nib) {
@@ -577,7 +598,7 @@ static hipError_t launch_wgrad_t(const WgradParams& p, hipStream_t s) {
   hipLaunchKernelGGL((wgrad_kernel<KS, STRIDE, UP>), dim3(ns * ncb * nib), dim3(256), (size_t)Cfg::LDS_FLOATS * sizeof(float), s, p, ns,
                      ncb, nib);
   const size_t total = (size_t)p.Cout * p.Cin_real * Cfg::T;
-  hipLaunchKernelGGL(wgrad_fold_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p.scratch, p.dw, p.Cout, p.Cin_real,
+  hipLaunchKernelGGL(wgrad_fold_kernel, dim3((unsigned)(ncb * nib * Cfg::T * 64)), dim3(256), 0, s, p.scratch, p.dw, p.Cout, p.Cin_real,
                      Cfg::T, ns, ncb, nib, total);
   return hipGetLastError();
 }
@@ -781,6 +802,300 @@ __global__ void __launch_bounds__(256, 2) wgrad_h_kernel(const WgradParams p, co
     }
 }
 
+// ---- the stride-1 form used for almost all of the work: 8 waves, double-buffered tiles ---------------------------------
+// One workgroup per CU (two waves per SIMD): waves 0-3 and 4-7 take the upper and lower four rows of an 8x16-pixel tile of the
+// same 64 (co) x 64 (ci) block, so a tile is 128 K-values per barrier.  The NEXT tile is fetched in four pieces, one per tile
+// row: its global loads are issued before the 27 MFMAs of the row and split / written to the other LDS buffer after them (12
+// staging registers instead of 44, one barrier per tile, the staging VALU of one wave under the MFMAs of its SIMD partner).
+// The B fragments of tap t+1 are read while the MFMAs of tap t run.  The two half-tile accumulators are added through LDS at
+// the end (rows 0-3 + rows 4-7, a fixed order), so the scratch slices and wgrad_fold_kernel are those of the other forms.
+template <int KS, bool UP>
+struct WgH8Cfg {
+  static constexpr int TH = 8, TW = 16, T = KS * KS;
+  static constexpr int HH = TH - 1 + KS, HWD = TW - 1 + KS, NPIX = HH * HWD;
+  static constexpr int PLANE_DY = TH * TW * 128, PLANE_IN = NPIX * 128;     // bytes per plane
+  static constexpr int BUF = 2 * PLANE_DY + 2 * PLANE_IN;
+  static constexpr int RED = T * 4096 * 4;                                  // the final half-tile reduction
+  static constexpr int LDS_BYTES = 2 * BUF > RED ? 2 * BUF : RED;
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+};
+
+__device__ __forceinline__ th8 tr_frag_at(const unsigned char* a) {   // two transposing reads: rows +0..3 and +4..7 of this lane's block
+  typedef ts4 __attribute__((address_space(3))) * lds_ts4;
+  typedef short ts8 __attribute__((ext_vector_type(8)));
+  const ts4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ts4)(a));
+  const ts4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ts4)(a + 4 * 128));   // row + 4: same swizzle
+  const ts8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(th8, v);
+}
+
+template <int KS, bool UP>
+__global__ void __launch_bounds__(512, 2) wgrad_h8_kernel(const WgradParams p, const int nslices, const int ncb, const int nib) {
+  using Cfg = WgH8Cfg<KS, UP>;
+  constexpr int TH = Cfg::TH, TW = Cfg::TW, T = Cfg::T, HH = Cfg::HH, HWD = Cfg::HWD, PAD = KS / 2;
+  static_assert(KS == 3, "the half-tile staging below is laid out for the 3x3 halo");
+  static_assert((2 * HWD) % 4 == 0 && (4 * HWD) % 4 == 0, "the LDS swizzle must not depend on the tile row");
+  extern __shared__ __attribute__((aligned(16))) unsigned char wsh8[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = __builtin_amdgcn_readfirstlane(wave >> 2), wc = wave & 1, wi = (wave >> 1) & 1;
+  int b = blockIdx.x;
+  const int sl = b % nslices;  b /= nslices;
+  const int ib = b % nib;  b /= nib;
+  const int cb = b;
+  const int co0 = cb * 64, ci0 = ib * 64;
+  const int Cin = p.C0 + p.C1;
+  const int tilesX = (p.Wout + TW - 1) / TW, tilesY = (p.Hout + TH - 1) / TH;
+  const int ntiles = p.N * tilesX * tilesY;
+  const int t0 = (int)((long)sl * ntiles / nslices), t1 = (int)((long)(sl + 1) * ntiles / nslices);
+  const int Hsrc = UP ? p.Hout : p.Hin, Wsrc = UP ? p.Wout : p.Win;
+
+  f32x16 acc[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+  // ---- staging: thread -> channel quad q4 and pixel (ry, rx) of a 2-row x 16-column strip.  The next tile is fetched in two
+  // halves; half h = dy rows 4h+ry and 4h+2+ry, halo rows 4h+ry and 4h+2+ry (columns 0..15), plus the halo rows 8+ry (h = 0) or
+  // the two right-hand halo columns (h = 1, threads with prow < 2*HH): every index is a shift or a mask and every LDS address is
+  // a lane base + an immediate.  Global addresses are tensor base (uniform) + a 32-bit byte offset = uniform tile offset + the
+  // lane's offset inside a tile (modular: the halo origin may lie before the image); lanes outside the image read the tensor's
+  // first element instead and are zeroed by the clamp (lim = 0).  The launcher guarantees < 4 GiB tensors.
+  const int q4 = tid & 15, prow = tid >> 4, ry = prow >> 4, rx = prow & 15;
+  const int cdy = co0 + q4 * 4, cin = ci0 + q4 * 4;
+  const bool src0 = ci0 < p.C0;                                      // the 64-channel block lies in one concat source (launcher)
+  const char* xs = reinterpret_cast<const char*>(src0 ? p.x0 : p.x1);
+  const char* dys = reinterpret_cast<const char*>(p.dy);
+  const int Cs = src0 ? p.C0 : p.C1, cc = (src0 ? ci0 : ci0 - p.C0) + q4 * 4;
+  const bool gn = p.gn_scale != nullptr, cin_ok = cin < Cin, cdy_ok = cdy < p.Cout_s;
+  const bool edge_lane = prow < 2 * HH;
+  const int ehy = prow >> 1, ehx = TW + (prow & 1);
+  auto lsrc = [&](int h) { return UP ? ((h - 1) >> 1) : h; };         // halo coordinate -> source coordinate, lane part
+  const unsigned o_dy = (unsigned)((ry * p.Wout + rx) * p.Cout_s + cdy) * 4u;
+  const unsigned o_main = (unsigned)((lsrc(ry) * p.Win + lsrc(rx)) * Cs + cc) * 4u;
+  const unsigned o_edge = (unsigned)((lsrc(ehy) * p.Win + lsrc(ehx)) * Cs + cc) * 4u;
+  const int st_dy = tr_img_off(prow, q4 * 4);                        // + k * 32 rows
+  const int st_in = tr_img_off(ry * HWD + rx, q4 * 4);               // + kk * 2 * HWD rows
+  const int st_edge = tr_img_off(ehy * HWD + ehx, q4 * 4);
+  const unsigned row_dy = (unsigned)(p.Wout * p.Cout_s) * 4u, row_in = (unsigned)(p.Win * Cs) * 4u;   // bytes per image row
+  constexpr int NPV = 5;            // registers of one half: 2 dy, 2 halo strips, 1 extra
+  f32x4 pv[NPV], nsc = {1.f, 1.f, 1.f, 1.f}, nsh = {0.f, 0.f, 0.f, 0.f};
+  unsigned pm[NPV];
+  bool pok[NPV];
+  int toy = 0, tox = 0;             // the tile being fetched
+  unsigned ub_dy = 0, ub_in = 0;    // its uniform byte offsets: dy tile origin, halo origin
+  auto set_tile = [&](int tile) {
+    int tt = tile;
+    tox = (tt % tilesX) * TW;  tt /= tilesX;
+    toy = (tt % tilesY) * TH;
+    const int tn = tt / tilesY;
+    ub_dy = (unsigned)(((tn * p.Hout + toy) * p.Wout + tox) * p.Cout_s) * 4u;
+    ub_in = (unsigned)(((tn * p.Hin + (UP ? toy / 2 : toy - PAD)) * p.Win + (UP ? tox / 2 : tox - PAD)) * Cs) * 4u;
+    if (gn && cin_ok) {
+      nsc = *reinterpret_cast<const f32x4*>(p.gn_scale + (size_t)tn * Cin + cin);
+      nsh = *reinterpret_cast<const f32x4*>(p.gn_shift + (size_t)tn * Cin + cin);
+    }
+  };
+  auto load_dy = [&](int u, int k) {                                  // dy rows 2k + ry
+    const bool ok = toy + 2 * k + ry < p.Hout && tox + rx < p.Wout && cdy_ok;
+    const unsigned off = ok ? ub_dy + o_dy + 2 * k * row_dy : 0u;
+    pv[u] = *reinterpret_cast<const f32x4*>(dys + off);
+    pok[u] = ok;
+  };
+  auto load_in = [&](int u, unsigned o, int rows, int hy, int hx, bool lane_ok) {
+    const bool ok = lane_ok && (unsigned)(toy - PAD + hy) < (unsigned)Hsrc && (unsigned)(tox - PAD + hx) < (unsigned)Wsrc && cin_ok;
+    const unsigned off = ok ? ub_in + o + rows * row_in : 0u;
+    pv[u] = *reinterpret_cast<const f32x4*>(xs + off);
+    if (p.drop_mask) pm[u] = *reinterpret_cast<const unsigned*>(p.drop_mask + (off >> 2));
+    pok[u] = ok;
+  };
+  auto load_half = [&](int h) {
+    load_dy(0, 2 * h);
+    load_dy(1, 2 * h + 1);
+    load_in(2, o_main, UP ? 2 * h : 4 * h, 4 * h + ry, rx, true);
+    load_in(3, o_main, UP ? 2 * h + 1 : 4 * h + 2, 4 * h + 2 + ry, rx, true);
+    if (h == 0) load_in(4, o_main, UP ? 4 : 8, 8 + ry, rx, true);
+    else load_in(4, o_edge, 0, ehy, ehx, edge_lane);
+  };
+  // hi = rn_f16(clamp(v)), lo = rn_f16(v - hi) (22 mantissa bits, as fdsr_conv_h.hip): one packed convert and two
+  // v_fma_mix per pair, lo = f16(fma(hi, -1, v)) rounded once -- bit-identical to the two-step form.  lim = 0 zero-pads.
+  auto put_split = [&](unsigned char* ph, unsigned char* pl, f32x4 v, float lim) {
+    typedef _Float16 h2t __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], -lim, lim);
+    uint2 hi, lo;
+    {
+      const h2t h0 = {(_Float16)v[0], (_Float16)v[1]}, h1 = {(_Float16)v[2], (_Float16)v[3]};
+      hi.x = __builtin_bit_cast(unsigned, h0);
+      hi.y = __builtin_bit_cast(unsigned, h1);
+    }
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo.x) : "v"(hi.x), "v"(v[0]));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo.x) : "v"(hi.x), "v"(v[1]));
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo.y) : "v"(hi.y), "v"(v[2]));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo.y) : "v"(hi.y), "v"(v[3]));
+    *reinterpret_cast<uint2*>(ph) = hi;
+    *reinterpret_cast<uint2*>(pl) = lo;
+  };
+  auto put_in = [&](int u, unsigned char* inH, int off) {
+    f32x4 v = pv[u];
+    if (gn) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], nsc[e], nsh[e]);
+      if (!p.gn_plain) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[e]));
+      }
+      if (p.drop_mask) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = ((pm[u] >> (8 * e)) & 0xffu) ? v[e] * p.drop_scale : 0.f;
+      }
+    }
+    put_split(inH + off, inH + Cfg::PLANE_IN + off, v, pok[u] ? 65504.f : 0.f);   // lim = 0: the conv zero-pads the ACTIVATED tensor
+  };
+  auto store_half = [&](int h, unsigned char* buf) {
+    unsigned char* inH = buf + 2 * Cfg::PLANE_DY;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int off = st_dy + (2 * h + u) * 32 * 128;
+      put_split(buf + off, buf + Cfg::PLANE_DY + off, pv[u], pok[u] ? 65504.f : 0.f);
+    }
+    put_in(2, inH, st_in + (2 * h) * 2 * HWD * 128);
+    put_in(3, inH, st_in + (2 * h + 1) * 2 * HWD * 128);
+    if (h == 0) put_in(4, inH, st_in + 4 * 2 * HWD * 128);
+    else if (edge_lane) put_in(4, inH, st_edge);
+  };
+
+  // ---- operand addressing: lane -> (16-lane group g, q = row inside the 4-row block, p = column quad); channel column =
+  // 32 * wave half + 16 * (g & 1) + 4p, first pixel of the 8-pixel run = 8 * (g >> 1).  The swizzle bit of a read is bit 1 of
+  // its LDS row = bit 1 of (c2 + q), c2 = the row's compile-time part mod 4: one lane base per c2, immediates for the rest.
+  const int g = lane >> 4, pp4 = lane & 3, q = (lane >> 2) & 3;
+  const int k0 = 8 * (g >> 1);
+  const int colAb = (wc * 32 + 16 * (g & 1) + 4 * pp4) * 2, colBb = (wi * 32 + 16 * (g & 1) + 4 * pp4) * 2;
+  const int baseA = (grp * 4 * TW + k0 + q) * 128 + (colAb ^ (((q >> 1) & 1) << 6));
+  int baseB[4];
+#pragma unroll
+  for (int c2 = 0; c2 < 4; ++c2) baseB[c2] = 2 * Cfg::PLANE_DY + (grp * 4 * HWD + k0 + q) * 128 + (colBb ^ ((((c2 + q) >> 1) & 1) << 6));
+
+  auto mfma_row = [&](const unsigned char* cur, int y) {     // one K-step = one 16-pixel row of this half tile: 27 MFMAs
+    const th8 ah = tr_frag_at(cur + baseA + y * TW * 128);
+    const th8 al = tr_frag_at(cur + baseA + y * TW * 128 + Cfg::PLANE_DY);
+    th8 bh[2], bl[2];
+    bh[0] = tr_frag_at(cur + baseB[(y * HWD) & 3] + y * HWD * 128);
+    bl[0] = tr_frag_at(cur + baseB[(y * HWD) & 3] + y * HWD * 128 + Cfg::PLANE_IN);
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      if (t + 1 < T) {
+        const int rr = (y + (t + 1) / KS) * HWD + (t + 1) % KS;      // compile-time part of the LDS row
+        bh[(t + 1) & 1] = tr_frag_at(cur + baseB[rr & 3] + rr * 128);
+        bl[(t + 1) & 1] = tr_frag_at(cur + baseB[rr & 3] + rr * 128 + Cfg::PLANE_IN);
+      }
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[t & 1], acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[t & 1], acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[t & 1], acc[t], 0, 0, 0);
+    }
+  };
+
+  if (t0 < t1) {
+    set_tile(t0);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) { load_half(h); store_half(h, wsh8); }
+  }
+  __syncthreads();
+  // The two waves of a SIMD (w and w + 4) run the same loop half a phase apart: waves 0-3 issue the MFMAs of two rows and then
+  // split the half tile they fetched before them; waves 4-7 split first (a half fetched two rows earlier -- their first half of
+  // the tile after next is fetched under the last two rows) and issue their MFMAs after, so one wave's VALU runs under the
+  // other's MFMAs and every fetch has two MFMA rows of both waves to land (40 KB in flight per CU).
+  if (grp == 0) {
+    for (int tile = t0; tile < t1; ++tile) {
+      const int curoff = ((tile - t0) & 1) ? Cfg::BUF : 0;
+      const unsigned char* cur = wsh8 + curoff;
+      unsigned char* nxt = wsh8 + (Cfg::BUF - curoff);
+      const bool more = tile + 1 < t1;
+      if (more) set_tile(tile + 1);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if (more) load_half(h);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_row(cur, 2 * h);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_row(cur, 2 * h + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) store_half(h, nxt);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();
+    }
+  } else {
+    if (t0 + 1 < t1) { set_tile(t0 + 1); load_half(0); }
+    for (int tile = t0; tile < t1; ++tile) {
+      const int curoff = ((tile - t0) & 1) ? Cfg::BUF : 0;
+      const unsigned char* cur = wsh8 + curoff;
+      unsigned char* nxt = wsh8 + (Cfg::BUF - curoff);
+      const bool more = tile + 1 < t1;
+      if (more) { store_half(0, nxt); load_half(1); }
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_row(cur, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_row(cur, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) store_half(1, nxt);
+      if (tile + 2 < t1) { set_tile(tile + 2); load_half(0); }
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_row(cur, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_row(cur, 3);
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+    }
+  }
+
+  // ---- rows 4-7 (waves 4-7) are added to rows 0-3 through LDS, then one slice goes to the scratch ----
+  const int r31 = lane & 31, kh = lane >> 5;
+  float* red = reinterpret_cast<float*>(wsh8);
+  if (grp == 1) {
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = (i & 3) + 8 * (i >> 2) + 4 * kh;
+        red[t * 4096 + (wc * 32 + row) * 64 + wi * 32 + r31] = acc[t][i];
+      }
+  }
+  __syncthreads();
+  if (grp == 0) {
+    float* dst = p.scratch + ((((size_t)sl * ncb + cb) * nib + ib) * T) * 4096;
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = (i & 3) + 8 * (i >> 2) + 4 * kh;
+        const int o = t * 4096 + (wc * 32 + row) * 64 + wi * 32 + r31;
+        dst[o] = acc[t][i] + red[o];
+      }
+  }
+}
+
+static int wgrad_h8_slices(int ntiles8, int ncb, int nib) {
+  const int blocks = ncb * nib;
+  int s = 512 / blocks;                       // <= two rounds of one workgroup per CU, never a straggler third
+  if (s > ntiles8) s = ntiles8;
+  return s < 1 ? 1 : s;
+}
+
+template <int KS, bool UP>
+static hipError_t launch_wgrad_h8_t(const WgradParams& p, hipStream_t s) {
+  using Cfg = WgH8Cfg<KS, UP>;
+  const int Cin = p.C0 + p.C1;
+  const int ncb = (p.Cout + 63) / 64, nib = (Cin + 63) / 64;
+  const int ntiles = p.N * ((p.Wout + Cfg::TW - 1) / Cfg::TW) * ((p.Hout + Cfg::TH - 1) / Cfg::TH);
+  const int ns = wgrad_h8_slices(ntiles, ncb, nib);     // <= wgrad_slices() of the 4x16 tiling: the scratch is sized for that
+  hipLaunchKernelGGL((wgrad_h8_kernel<KS, UP>), dim3(ns * ncb * nib), dim3(512), (size_t)Cfg::LDS_BYTES, s, p, ns, ncb, nib);
+  const size_t total = (size_t)p.Cout * p.Cin_real * Cfg::T;
+  hipLaunchKernelGGL(wgrad_fold_kernel, dim3((unsigned)(ncb * nib * Cfg::T * 64)), dim3(256), 0, s, p.scratch, p.dw, p.Cout, p.Cin_real,
+                     Cfg::T, ns, ncb, nib, total);
+  return hipGetLastError();
+}
+
 template <int KS, int STRIDE, bool UP>
 static hipError_t launch_wgrad_h_t(const WgradParams& p, hipStream_t s) {
   using Cfg = WgHCfg<KS, STRIDE, UP>;
@@ -790,7 +1105,7 @@ static hipError_t launch_wgrad_h_t(const WgradParams& p, hipStream_t s) {
   const int ns = wgrad_slices(ntiles, ncb, nib);
   hipLaunchKernelGGL((wgrad_h_kernel<KS, STRIDE, UP>), dim3(ns * ncb * nib), dim3(256), (size_t)Cfg::LDS_BYTES, s, p, ns, ncb, nib);
   const size_t total = (size_t)p.Cout * p.Cin_real * Cfg::T;
-  hipLaunchKernelGGL(wgrad_fold_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p.scratch, p.dw, p.Cout, p.Cin_real,
+  hipLaunchKernelGGL(wgrad_fold_kernel, dim3((unsigned)(ncb * nib * Cfg::T * 64)), dim3(256), 0, s, p.scratch, p.dw, p.Cout, p.Cin_real,
                      Cfg::T, ns, ncb, nib, total);
   return hipGetLastError();
 }
@@ -798,11 +1113,16 @@ static hipError_t launch_wgrad_h_t(const WgradParams& p, hipStream_t s) {
 // the tiles (4x16, stride 2: 2x16) equal wgrad_kernel's, so the scratch sizing (wgrad_scratch_floats) is shared
 hipError_t launch_wgrad_h(ConvKind kind, const WgradParams& p, hipStream_t s) {
   if ((p.C0 & 3) || (p.C1 & 3) || (p.Cout_s & 3)) return hipErrorInvalidValue;
+  static const bool four_wave = getenv("FDSR_WGRAD_H4") != nullptr;   // A/B switch: the 4-wave single-buffer form everywhere
+  // the 8-wave form wants a 64-channel block inside one concat source and 32-bit byte offsets; the 4-wave form takes the rest
+  const size_t in_px = (size_t)p.N * p.Hin * p.Win, out_px = (size_t)p.N * p.Hout * p.Wout;
+  const bool seam = (p.C1 > 0 && (p.C0 & 63) != 0) || in_px * (size_t)(p.C0 > p.C1 ? p.C0 : p.C1) * 4 >= (1ull << 32) ||
+                    out_px * (size_t)p.Cout_s * 4 >= (1ull << 32);
   switch (kind) {
-    case CONV3_S1: return launch_wgrad_h_t<3, 1, false>(p, s);
+    case CONV3_S1: return four_wave || seam ? launch_wgrad_h_t<3, 1, false>(p, s) : launch_wgrad_h8_t<3, false>(p, s);
     case CONV3_S2: return launch_wgrad_h_t<3, 2, false>(p, s);
-    case CONV3_UP: return launch_wgrad_h_t<3, 1, true>(p, s);
-    case CONV1: return launch_wgrad_h_t<1, 1, false>(p, s);
+    case CONV3_UP: return four_wave || seam ? launch_wgrad_h_t<3, 1, true>(p, s) : launch_wgrad_h8_t<3, true>(p, s);
+    case CONV1: return launch_wgrad_h_t<1, 1, false>(p, s);   // bandwidth-bound: two small workgroups per CU keep more loads in flight
   }
   return hipErrorInvalidValue;
 }
@@ -821,6 +1141,12 @@ hipError_t train_kernels_init() {
     return e;
   FDSR_WGH_INIT(3, 1, false) FDSR_WGH_INIT(3, 2, false) FDSR_WGH_INIT(3, 1, true) FDSR_WGH_INIT(1, 1, false)
 #undef FDSR_WGH_INIT
+#define FDSR_WGH8_INIT(KS, UP)                                                                                         \
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_h8_kernel<KS, UP>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                               (int)WgH8Cfg<KS, UP>::LDS_BYTES)) != hipSuccess)                                           \
+    return e;
+  FDSR_WGH8_INIT(3, false) FDSR_WGH8_INIT(3, true)
+#undef FDSR_WGH8_INIT
   return hipSuccess;
 }
 
@@ -1123,10 +1449,34 @@ __global__ void __launch_bounds__(256) temb_bwd_image_kernel(const TembBwdParams
     pre[j] = a;
     hv[j] = a / (1.0f + expf(-a));
   }
-  for (int k = tid; k < inner; k += 256) {                  // dt[k] = sum_o dtemb[n][o] * wn[o][k]
-    float a = 0.f;
-    for (int o = 0; o < p.TE; ++o) a = fmaf(p.dtemb[(size_t)n * p.TE + o], p.wn[(size_t)o * inner + k], a);
-    dt[k] = a;
+  {   // dt[k] = sum_o dtemb[n][o] * wn[o][k]: the o range in 256 / inner parts (one per thread group), parts added in order
+    float* dpart = dt + inner;                               // [parts][inner]
+    const int parts = 256 / inner > 0 ? 256 / inner : 1, part = tid / inner, k = tid % inner;
+    if (inner > 256) {                                       // wider than the workgroup: one part, threads stride over k
+      for (int kk = tid; kk < inner; kk += 256) {
+        float a = 0.f;
+        for (int o = 0; o < p.TE; ++o) a = fmaf(p.dtemb[(size_t)n * p.TE + o], p.wn[(size_t)o * inner + kk], a);
+        dpart[kk] = a;
+      }
+    } else if (part < parts) {
+      const int o0 = (int)((long)part * p.TE / parts), o1 = (int)((long)(part + 1) * p.TE / parts);
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      int o = o0;
+      for (; o + 4 <= o1; o += 4) {
+        a0 = fmaf(p.dtemb[(size_t)n * p.TE + o], p.wn[(size_t)o * inner + k], a0);
+        a1 = fmaf(p.dtemb[(size_t)n * p.TE + o + 1], p.wn[(size_t)(o + 1) * inner + k], a1);
+        a2 = fmaf(p.dtemb[(size_t)n * p.TE + o + 2], p.wn[(size_t)(o + 2) * inner + k], a2);
+        a3 = fmaf(p.dtemb[(size_t)n * p.TE + o + 3], p.wn[(size_t)(o + 3) * inner + k], a3);
+      }
+      for (; o < o1; ++o) a0 = fmaf(p.dtemb[(size_t)n * p.TE + o], p.wn[(size_t)o * inner + k], a0);
+      dpart[part * inner + k] = (a0 + a1) + (a2 + a3);
+    }
+    __syncthreads();
+    for (int kk = tid; kk < inner; kk += 256) {
+      float a = 0.f;
+      for (int q = 0; q < parts; ++q) a += dpart[q * inner + kk];
+      dt[kk] = a;
+    }
   }
   __syncthreads();
   float* out = p.scratch + (size_t)n * 11 * inner;
@@ -1201,7 +1551,8 @@ __global__ void __launch_bounds__(256) temb_bwd_param_kernel(const TembBwdParams
 
 hipError_t launch_temb_bwd(const TembBwdParams& p, hipStream_t s) {
   const int inner = p.inner, hid = 4 * inner;
-  hipLaunchKernelGGL(temb_bwd_image_kernel, dim3(p.N), dim3(256), (size_t)(2 * inner + 2 * hid) * sizeof(float), s, p);
+  const int parts = 256 / inner > 0 ? 256 / inner : 1;   // dt partial sums live after dt in LDS
+  hipLaunchKernelGGL(temb_bwd_image_kernel, dim3(p.N), dim3(256), (size_t)(2 * inner + 2 * hid + parts * inner) * sizeof(float), s, p);
   const size_t total = (size_t)p.TE * inner + p.TE + (size_t)inner * hid + inner + (size_t)hid * inner + hid;
   hipLaunchKernelGGL(temb_bwd_param_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, total);
   return hipGetLastError();
