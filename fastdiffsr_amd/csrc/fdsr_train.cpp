@@ -341,12 +341,14 @@ int fdsr_train_grads(fdsr_handle h, const float* x_nchw, const float* noise_leve
   float* loss_dev = reinterpret_cast<float*>(ws + tp.off_loss);
 
   // ---- loss and its gradient ----
-  {
-    size_t g0 = SIZE_MAX;
-    for (size_t t = 0; t < h->tensors.size(); ++t)
-      if (tp.grad_off[t]) g0 = std::min(g0, tp.grad_off[t]);
-    HIPCHK(h, hipMemsetAsync(ws + g0, 0, tp.grad_bytes, st));
-  }
+  // No memset of the gradient tensors: the FIRST contribution to each (the host loop below is the order) is a plain store, later
+  // ones accumulate.  `first(t)` answers that once per tensor; a gradient that is read before anything wrote it is a plan error.
+  std::vector<char> touched(h->tensors.size(), 0);
+  auto first = [&](int t) { const bool f = !touched[t]; touched[t] = 1; return f; };
+  auto grad_bytes_of = [&](int t) {
+    const TensorDesc& td = h->tensors[t];
+    return (size_t)N * (size_t)(H >> td.level) * (W >> td.level) * tensor_channels(h, t) * sizeof(float);
+  };
   HIPCHK(h, hipMemsetAsync(dtemb, 0, (size_t)N * h->TE * sizeof(float), st));
   const float* eps = TP(h->t_eps);
   // f16x3: the gradients that flow through the split-f16 convolutions are kept near 1 by a power-of-two factor
@@ -355,6 +357,7 @@ int fdsr_train_grads(fdsr_handle h, const float* x_nchw, const float* noise_leve
   float gscale = 1.0f;
   if (h->prec == PREC_F16X3 && loss_scale > 0.f) gscale = std::ldexp(1.0f, -(int)std::floor(std::log2((double)loss_scale)));
   HIPCHK(h, launch_loss_grad(eps, target_nchw, GT(h->t_eps), dbl, loss_dev, N, H * W, loss_l2, loss_scale * gscale, st));
+  touched[h->t_eps] = 1;
 
   // ---- backward over the plan ----
   for (int oi = (int)h->ops.size() - 1; oi >= 0; --oi) {
@@ -368,6 +371,8 @@ int fdsr_train_grads(fdsr_handle h, const float* x_nchw, const float* noise_leve
         if (h->ops[k].kind == Op::CLAM) { ca = &h->ops[k]; break; }
       if (!ca) return fail(h, FDSR_E_STATE, "internal: SLAM without CLAM");
       ClamSlamBwdParams c{};
+      if (!touched[op.dst]) return fail(h, FDSR_E_STATE, "internal: gradient read before it was written");
+      if (first(op.src0)) HIPCHK(h, hipMemsetAsync(GT(op.src0), 0, grad_bytes_of(op.src0), st));   // these kernels accumulate
       c.x = TP(op.src0); c.dout = GT(op.dst); c.dx = GT(op.src0);
       c.fc1 = P(ca->fc1); c.fc2 = P(ca->fc2); c.w7 = P(op.w);
       c.dfc1 = DG(ca->fc1); c.dfc2 = DG(ca->fc2); c.dw7 = DG(op.w);
@@ -380,9 +385,10 @@ int fdsr_train_grads(fdsr_handle h, const float* x_nchw, const float* noise_leve
     const WeightEntry& w = h->weights[op.w];
     const int Ho = H >> op.lvl_out, Wo = W >> op.lvl_out, Cin = op.C0 + op.C1, K = conv_K(h, op);
     const float* dy = GT(op.dst);
+    if (!touched[op.dst]) return fail(h, FDSR_E_STATE, "internal: gradient read before it was written");
     // residual (identity): the same gradient flows to the block input
     if (op.res >= 0 && op.res != op.dst)
-      HIPCHK(h, launch_add_slice(dy, GT(op.res), (size_t)N * Ho * Wo, op.Cout, 0, op.Cout, st));
+      HIPCHK(h, launch_add_slice(dy, GT(op.res), (size_t)N * Ho * Wo, op.Cout, 0, op.Cout, first(op.res), st));
     // bias and noise-embedding gradients
     HIPCHK(h, launch_colsum(dy, S, dbl, N, Ho * Wo, K, st));
     if (op.b >= 0) HIPCHK(h, launch_sum_rows(S, N, K, op.Cout, DG(op.b), st));   // db[c] = sum_n S[n][c]
@@ -425,6 +431,8 @@ int fdsr_train_grads(fdsr_handle h, const float* x_nchw, const float* noise_leve
       g.stats = reinterpret_cast<const float*>(ws + sp.gn_stats_off[op.gn_slot]);
       g.gamma = P(op.gamma);
       g.dx0 = GT(op.src0); g.dx1 = GT(op.src1);
+      g.assign0 = first(op.src0) ? 1 : 0;
+      g.assign1 = op.src1 >= 0 && first(op.src1) ? 1 : 0;
       g.dgamma = DG(op.gamma); g.dbeta = DG(op.beta);
       g.scratch = dbl;
       g.N = N; g.HW = Hi * Wi; g.G = G; g.plain = op.gn_plain ? 1 : 0;
@@ -435,13 +443,13 @@ int fdsr_train_grads(fdsr_handle h, const float* x_nchw, const float* noise_leve
       HIPCHK(h, launch_gn_bwd(g, st));
     } else if (op.ck == CONV3_S2) {
       HIPCHK(h, launch_zero_insert(dy, tmpZ, N, Ho, Wo, K, st));
-      if ((rc = dgrad(tmpZ, Hi, Wi, 0, op.C0, GT(op.src0), true))) return rc;
+      if ((rc = dgrad(tmpZ, Hi, Wi, 0, op.C0, GT(op.src0), !first(op.src0)))) return rc;
     } else if (op.ck == CONV3_UP) {
       if ((rc = dgrad(dy, Ho, Wo, 0, op.C0, tmpA, false))) return rc;
-      HIPCHK(h, launch_pool2_add(tmpA, GT(op.src0), N, Hi, Wi, op.C0, st));
+      HIPCHK(h, launch_pool2_add(tmpA, GT(op.src0), N, Hi, Wi, op.C0, first(op.src0), st));
     } else {
-      if ((rc = dgrad(dy, Ho, Wo, 0, op.C0, GT(op.src0), true))) return rc;
-      if (op.C1 > 0 && (rc = dgrad(dy, Ho, Wo, 1, op.C1, GT(op.src1), true))) return rc;
+      if ((rc = dgrad(dy, Ho, Wo, 0, op.C0, GT(op.src0), !first(op.src0)))) return rc;
+      if (op.C1 > 0 && (rc = dgrad(dy, Ho, Wo, 1, op.C1, GT(op.src1), !first(op.src1)))) return rc;
     }
   }
 

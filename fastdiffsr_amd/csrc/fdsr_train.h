@@ -29,10 +29,10 @@ hipError_t launch_scale_inplace(float* x, size_t n, float f, hipStream_t s);
 hipError_t launch_sum_rows(const float* S, int N, int stride, int C, float* out, hipStream_t s);
 // z [N,2H,2W,C] = dy [N,H,W,C] at the even positions, zero elsewhere (the stride-2 conv's transpose)
 hipError_t launch_zero_insert(const float* dy, float* z, int N, int H, int W, int C, hipStream_t s);
-// dx [N,H,W,C] += sum of the 2x2 block of du [N,2H,2W,C]   (nearest x2 upsampling, transposed)
-hipError_t launch_pool2_add(const float* du, float* dx, int N, int H, int W, int C, hipStream_t s);
-// dst[n][p][0..C) += src[n][p][off .. off+C) of a tensor with Cs channels (routes a concat half)
-hipError_t launch_add_slice(const float* src, float* dst, size_t npix, int Cs, int off, int C, hipStream_t s);
+// dx [N,H,W,C] += (assign: =) sum of the 2x2 block of du [N,2H,2W,C]   (nearest x2 upsampling, transposed)
+hipError_t launch_pool2_add(const float* du, float* dx, int N, int H, int W, int C, bool assign, hipStream_t s);
+// dst[n][p][0..C) += (assign: =) src[n][p][off .. off+C) of a tensor with Cs channels (routes a concat half)
+hipError_t launch_add_slice(const float* src, float* dst, size_t npix, int Cs, int off, int C, bool assign, hipStream_t s);
 
 // ---- GroupNorm + Swish backward ------------------------------------------------------------------------------
 // a = swish(u), u = x * scale + shift  (scale = rstd*gamma, shift = beta - mean*scale; x = virtual concat x0|x1)
@@ -46,6 +46,7 @@ struct GnBwdParams {
   const float* stats;             // [N][G][2] (mean, rstd)
   const float* gamma;             // [C]
   float* dx0; float* dx1;         // accumulated (+=); dx1 may be null when C1 == 0
+  int assign0, assign1;           // 1: this is the first contribution to that gradient tensor, store instead of accumulate
   float* dgamma; float* dbeta;    // [C], written (=)
   double* scratch;                // gn_bwd_scratch_doubles()
   int N, HW, G;

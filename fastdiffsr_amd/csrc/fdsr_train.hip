@@ -182,7 +182,7 @@ hipError_t launch_zero_insert(const float* dy, float* z, int N, int H, int W, in
 }
 
 __global__ void __launch_bounds__(256) pool2_add_kernel(const float* __restrict__ du, float* __restrict__ dx, int H, int W, int cq,
-                                                        size_t total) {
+                                                        size_t total, int assign) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;   // over [N][H][W][cq]
   if (i >= total) return;
   const int c4 = (int)(i % cq);
@@ -195,33 +195,33 @@ __global__ void __launch_bounds__(256) pool2_add_kernel(const float* __restrict_
   const float* b = du + (((n * 2 * H + 2 * y) * W2 + 2 * x) * cq + c4) * 4;
   const f32x4 a0 = *reinterpret_cast<const f32x4*>(b), a1 = *reinterpret_cast<const f32x4*>(b + (size_t)cq * 4);
   const f32x4 a2 = *reinterpret_cast<const f32x4*>(b + W2 * cq * 4), a3 = *reinterpret_cast<const f32x4*>(b + (W2 + 1) * cq * 4);
-  f32x4 v = *reinterpret_cast<const f32x4*>(dx + i * 4);
-  v += (a0 + a1) + (a2 + a3);
+  f32x4 v = (a0 + a1) + (a2 + a3);
+  if (!assign) v += *reinterpret_cast<const f32x4*>(dx + i * 4);
   *reinterpret_cast<f32x4*>(dx + i * 4) = v;
 }
 
-hipError_t launch_pool2_add(const float* du, float* dx, int N, int H, int W, int C, hipStream_t s) {
+hipError_t launch_pool2_add(const float* du, float* dx, int N, int H, int W, int C, bool assign, hipStream_t s) {
   if (C & 3) return hipErrorInvalidValue;
   const size_t total = (size_t)N * H * W * (C >> 2);
-  hipLaunchKernelGGL(pool2_add_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, du, dx, H, W, C >> 2, total);
+  hipLaunchKernelGGL(pool2_add_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, du, dx, H, W, C >> 2, total, assign ? 1 : 0);
   return hipGetLastError();
 }
 
 __global__ void __launch_bounds__(256) add_slice_kernel(const float* __restrict__ src, float* __restrict__ dst, int Cs4, int off4,
-                                                        int C4, size_t total) {
+                                                        int C4, size_t total, int assign) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;   // over [npix][C4]
   if (i >= total) return;
   const size_t p = i / C4;
   const int c = (int)(i % C4);
-  f32x4 v = *reinterpret_cast<const f32x4*>(dst + i * 4);
-  v += *reinterpret_cast<const f32x4*>(src + (p * Cs4 + off4 + c) * 4);
+  f32x4 v = *reinterpret_cast<const f32x4*>(src + (p * Cs4 + off4 + c) * 4);
+  if (!assign) v += *reinterpret_cast<const f32x4*>(dst + i * 4);
   *reinterpret_cast<f32x4*>(dst + i * 4) = v;
 }
 
-hipError_t launch_add_slice(const float* src, float* dst, size_t npix, int Cs, int off, int C, hipStream_t s) {
+hipError_t launch_add_slice(const float* src, float* dst, size_t npix, int Cs, int off, int C, bool assign, hipStream_t s) {
   if ((Cs | off | C) & 3) return hipErrorInvalidValue;
   const size_t total = npix * (C >> 2);
-  hipLaunchKernelGGL(add_slice_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, dst, Cs >> 2, off >> 2, C >> 2, total);
+  hipLaunchKernelGGL(add_slice_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, dst, Cs >> 2, off >> 2, C >> 2, total, assign ? 1 : 0);
   return hipGetLastError();
 }
 
@@ -347,8 +347,8 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const GnBwdParams p, 
   const int c = (int)(i % cq) * 4;
   const size_t pix = i / cq;                     // n*HW + p
   const size_t n = pix / p.HW;
-  const float* xs; float* dxs; int Cs, cc;
-  if (c < p.C0) { xs = p.x0; dxs = p.dx0; Cs = p.C0; cc = c; } else { xs = p.x1; dxs = p.dx1; Cs = p.C1; cc = c - p.C0; }
+  const float* xs; float* dxs; int Cs, cc, assign;
+  if (c < p.C0) { xs = p.x0; dxs = p.dx0; Cs = p.C0; cc = c; assign = p.assign0; } else { xs = p.x1; dxs = p.dx1; Cs = p.C1; cc = c - p.C0; assign = p.assign1; }
   const f32x4 x = *reinterpret_cast<const f32x4*>(xs + pix * Cs + cc);
   f32x4 d = *reinterpret_cast<const f32x4*>(p.dA + pix * C + c);
   if (p.drop_mask) {
@@ -358,7 +358,8 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const GnBwdParams p, 
   }
   const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + n * C + c);
   const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + n * C + c);
-  f32x4 o = *reinterpret_cast<const f32x4*>(dxs + pix * Cs + cc);
+  f32x4 o = {0.f, 0.f, 0.f, 0.f};
+  if (!assign) o = *reinterpret_cast<const f32x4*>(dxs + pix * Cs + cc);
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int g = (c + e) / cpg;

@@ -140,6 +140,33 @@ def test_step_is_bitwise_reproducible(golden_dir):
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize('prec', ['f32', 'f16x3'])
+def test_gradients_do_not_depend_on_what_the_workspace_held(golden_dir, prec):
+    """No gradient buffer is zeroed between steps (the first contribution to each stores, later ones accumulate): a step on
+    inputs A after a step on other inputs B must equal, bit for bit, the step on A from a fresh engine."""
+    from fastdiffsr_amd.engine import Engine
+    cfg = UNetConfig(**FASTDIFFSR_UNET)
+    hr, sr, nz, gamma = _inputs(golden_dir)
+    xa = torch.cat([sr, _x_noisy(hr, sr, nz, gamma)], 1).cuda()
+    xb = (xa.flip(0) * 3.0 + 0.5).contiguous()
+    eng = Engine(cfg)
+    eng.load_state_dict(synth_state_dict(cfg, 0))
+    eng.set_precision(prec)
+    names = ['downs.0.weight', 'downs.4.res_block.block1.block.3.weight', 'mid.0.res_block.block2.block.0.bias', 'noise_level_mlp.1.weight',
+             'ups.14.res_block.block2.block.0.weight', 'final_conv.block.3.weight']
+    scale = 1.0 / xa.numel() * 2
+
+    def step(x, nzs):
+        loss = eng.train_grads(x, gamma.cuda(), nzs.cuda(), 'l1', scale)
+        return [loss] + [eng.get_grad(k).copy() for k in names]
+    a1 = step(xa, nz)
+    step(xb, -2.0 * nz)                                    # leaves every gradient tensor full of unrelated values
+    a2 = step(xa, nz)
+    assert a1[0] == a2[0]
+    for k, u, v in zip(names, a1[1:], a2[1:]):
+        assert np.array_equal(u, v), k
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # train mode: nn.Dropout(p) in front of every block2 conv is live (unet.py:89-101)
 # ---------------------------------------------------------------------------------------------------------------
