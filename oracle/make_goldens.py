@@ -472,6 +472,73 @@ def tesr_goldens():
     print('wrote tesr.npz: frames', frames.shape, 'loss', loss.item())
 
 
+def metric_goldens():
+    """(x) the reference's own `ssim` / `calculate_ssim` / `calculate_ergas` (core/metrics.py:103-152) on fixed image pairs.
+    They call cv2.getGaussianKernel, cv2.filter2D and skimage.measure.compare_mse, which this image lacks; the three are
+    supplied here from their published definitions (OpenCV imgproc: the normalised Gaussian exp(-(i-(k-1)/2)^2 / 2 sigma^2);
+    filter2D = correlation, whose border rule cannot matter because the reference keeps [5:-5, 5:-5] of an 11x11 filter;
+    scikit-image 0.14-0.17 compare_mse = mean((a - b)^2) after a float conversion WITHOUT rescaling, accumulated in float64).
+    So tests/golden/metrics_ssim.npz pins the reference's arithmetic around those primitives, not the primitives themselves."""
+    import_reference()
+    from numpy.lib.stride_tricks import sliding_window_view
+
+    def getGaussianKernel(ksize, sigma):
+        x = np.arange(ksize, dtype=np.float64) - (ksize - 1) / 2.0
+        k = np.exp(-(x * x) / (2.0 * sigma * sigma))
+        return (k / k.sum()).reshape(ksize, 1)
+
+    def filter2D(src, ddepth, kernel):
+        assert ddepth == -1
+        kh, kw = kernel.shape
+        pad = ((kh // 2, kh // 2), (kw // 2, kw // 2)) + (((0, 0),) if src.ndim == 3 else ())
+        a = np.pad(src, pad, mode='reflect')               # BORDER_REFLECT_101
+        if src.ndim == 3:
+            return np.stack([np.einsum('ijkl,kl->ij', sliding_window_view(a[..., c], kernel.shape), kernel)
+                             for c in range(src.shape[2])], axis=-1)
+        return np.einsum('ijkl,kl->ij', sliding_window_view(a, kernel.shape), kernel)
+
+    def compare_mse(im1, im2):
+        ft = np.result_type(im1.dtype, im2.dtype, np.float32)
+        return np.mean(np.square(np.asarray(im1, dtype=ft) - np.asarray(im2, dtype=ft)), dtype=np.float64)
+
+    for name in ('cv2', 'skimage', 'skimage.measure', 'lpips', 'matplotlib', 'matplotlib.pyplot', 'torchvision.utils',
+                 'torchvision.transforms', 'core.PerceptualSimilarity'):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules['cv2'].getGaussianKernel = getGaussianKernel
+    sys.modules['cv2'].filter2D = filter2D
+    sys.modules['skimage.measure'].compare_mse = compare_mse
+    sys.modules['skimage'].io = None
+    sys.modules['skimage'].data = None
+    sys.modules['torchvision.utils'].make_grid = None
+    sys.modules['torchvision'].transforms = sys.modules['torchvision.transforms']
+    sys.modules['torchvision'].utils = sys.modules['torchvision.utils']
+    import core
+    core.PerceptualSimilarity = sys.modules['core.PerceptualSimilarity']
+    sys.modules.pop('core.metrics', None)
+    from core import metrics as ref_metrics
+    ref_metrics.compare_mse = compare_mse
+    rng = np.random.default_rng(2024)
+    out = {}
+    yy, xx = np.mgrid[0:48, 0:64]
+    base = (127 + 90 * np.sin(xx / 5.0)[..., None] * np.cos(yy / 7.0)[..., None] + rng.normal(0, 12, (48, 64, 3))).clip(0, 255)
+    cases = {
+        'noisy': (base, base + rng.normal(0, 9, base.shape)),
+        'blur': (base, (base + np.roll(base, 1, 0) + np.roll(base, 1, 1) + np.roll(base, -1, 0)) / 4),
+        'dark': (base, base * 0.6),
+        'same': (base, base.copy()),
+    }
+    for k, (a, b) in cases.items():
+        a8, b8 = a.clip(0, 255).astype(np.uint8), b.clip(0, 255).astype(np.uint8)
+        out[f'{k}/a'], out[f'{k}/b'] = a8, b8
+        out[f'{k}/ssim_rgb'] = np.array(ref_metrics.calculate_ssim(a8, b8), dtype=np.float64)
+        out[f'{k}/ssim_gray'] = np.array(ref_metrics.calculate_ssim(a8[..., 0], b8[..., 0]), dtype=np.float64)
+        out[f'{k}/ssim_1ch'] = np.array(ref_metrics.calculate_ssim(a8[..., :1], b8[..., :1]), dtype=np.float64)
+        out[f'{k}/ergas4'] = np.array(ref_metrics.calculate_ergas(a8, b8, scale=4), dtype=np.float64)
+        out[f'{k}/ergas8'] = np.array(ref_metrics.calculate_ergas(a8, b8, scale=8), dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, 'metrics_ssim.npz'), **out)
+    print({k: float(v) for k, v in out.items() if v.ndim == 0})
+
+
 def config_goldens():
     """(ix) the reference's own option parser (core/logger.py:21-94) on its ten fastdiffsr / ddpm configs:
     what `parse` returns, minus the timestamped `path` subtree.  Pins fastdiffsr_amd.config.load_config."""
@@ -515,6 +582,8 @@ if __name__ == '__main__':
         config_goldens()          # only tests/golden/configs.json
     elif len(sys.argv) > 1 and sys.argv[1] == 'train':
         train_goldens()           # only tests/golden/train_step.npz (reads train_loss.npz)
+    elif len(sys.argv) > 1 and sys.argv[1] == 'metrics':
+        metric_goldens()          # only tests/golden/metrics_ssim.npz
     elif len(sys.argv) > 1 and sys.argv[1] == 'gdp':
         gdp_goldens()             # only tests/golden/gdp.npz
     elif len(sys.argv) > 1 and sys.argv[1] == 'init':
@@ -528,3 +597,4 @@ if __name__ == '__main__':
         tesr_goldens()
         init_goldens()
         gdp_goldens()
+        metric_goldens()

@@ -176,10 +176,26 @@ def test_metrics_vs_reference_goldens(golden_dir):
     assert abs(O.psnr_u8(g['img'], g['img2']) - float(g['psnr'])) < 1e-12
     assert abs(M.calculate_psnr(g['img'], g['img2']) - float(g['psnr'])) < 1e-12
     assert M.calculate_psnr(g['img'], g['img']) == float('inf') == float(g['psnr_same'])
-    # unpinned (reference needs cv2/skimage): sanity only
     assert M.calculate_ssim(g['img'], g['img']) > 0.999999
     assert 0 < M.calculate_ssim(g['img'], g['img2']) < 1
     assert M.calculate_ergas(g['img'], g['img']) == 0.0
+
+
+def test_ssim_ergas_vs_the_references_own_functions(golden_dir):
+    """core/metrics.py:103-152 run from the reference itself on fixed image pairs (tests/golden/metrics_ssim.npz, made by
+    oracle/make_goldens.py `metrics`, which supplies cv2.getGaussianKernel / cv2.filter2D / skimage compare_mse from their
+    published definitions because the image has neither package): the reference's arithmetic around those primitives is
+    pinned -- window, valid crop, constants, the 3-channel branch that scores the whole array three times, ERGAS' mean and
+    channel divisor -- to 1e-12."""
+    from fastdiffsr_amd import metrics as M
+    g = _load(golden_dir, 'metrics_ssim.npz')
+    for case in ('noisy', 'blur', 'dark', 'same'):
+        a, b = g[f'{case}/a'], g[f'{case}/b']
+        assert abs(M.calculate_ssim(a, b) - float(g[f'{case}/ssim_rgb'])) < 1e-12, case
+        assert abs(M.calculate_ssim(a[..., 0], b[..., 0]) - float(g[f'{case}/ssim_gray'])) < 1e-12, case
+        assert abs(M.calculate_ssim(a[..., :1], b[..., :1]) - float(g[f'{case}/ssim_1ch'])) < 1e-12, case
+        assert abs(M.calculate_ergas(a, b, scale=4) - float(g[f'{case}/ergas4'])) < 1e-10, case
+        assert abs(M.calculate_ergas(a, b, scale=8) - float(g[f'{case}/ergas8'])) < 1e-10, case
 
 
 def test_pil_bicubic_restatement(golden_dir):
