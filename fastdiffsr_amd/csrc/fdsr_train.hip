@@ -1076,6 +1076,235 @@ __global__ void __launch_bounds__(512, 2) wgrad_h8_kernel(const WgradParams p, c
   }
 }
 
+// ---- the same with the staging INSIDE the MFMA rows --------------------------------------------------------------------
+// wgrad_h8_kernel's knock-outs say its split / activate / LDS-write stream costs as much as its MFMAs and overlaps them only
+// partly: an in-order wave cannot issue its own VALU while it is blocked in a run of 27 MFMAs.  Here a tile row is ONE basic
+// block: the loads of quarter-piece y+1, the 27 MFMAs of row y with their fragment reads, and the split of piece y (fetched a
+// whole row earlier, so no wait) -- branch-free (GN / DROP are template parameters, the last tile re-fetches itself, the two
+// right-hand halo columns go to a dummy LDS slot on the lanes that do not own one) -- and sched_group_barrier asks for
+// 1 MFMA : 5 VALU : 2 LDS reads per gap.  Two piece register sets (y & 1); both wave groups run the same code.
+#ifndef WG_IL_VALU
+#define WG_IL_VALU 4
+#endif
+#ifndef WG_IL_DSR
+#define WG_IL_DSR 0
+#endif
+template <bool UP, bool GN, bool DROP>
+__global__ void __launch_bounds__(512, 2) wgrad_h8i_kernel(const WgradParams p, const int nslices, const int ncb, const int nib) {
+  using Cfg = WgH8Cfg<3, UP>;
+  constexpr int KS = 3, TH = Cfg::TH, TW = Cfg::TW, T = Cfg::T, HH = Cfg::HH, HWD = Cfg::HWD, PAD = 1;
+  constexpr int DUMMY = 2 * Cfg::BUF;                      // 8 spare bytes per lane-quad above the two buffers (hi), +2 KB (lo)
+  static_assert(2 * Cfg::BUF + 4096 <= 160 * 1024, "room for the dummy slot");
+  extern __shared__ __attribute__((aligned(16))) unsigned char wsh8[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = __builtin_amdgcn_readfirstlane(wave >> 2), wc = wave & 1, wi = (wave >> 1) & 1;
+  int b = blockIdx.x;
+  const int sl = b % nslices;  b /= nslices;
+  const int ib = b % nib;  b /= nib;
+  const int cb = b;
+  const int co0 = cb * 64, ci0 = ib * 64;
+  const int Cin = p.C0 + p.C1;
+  const int tilesX = (p.Wout + TW - 1) / TW, tilesY = (p.Hout + TH - 1) / TH;
+  const int ntiles = p.N * tilesX * tilesY;
+  const int t0 = (int)((long)sl * ntiles / nslices), t1 = (int)((long)(sl + 1) * ntiles / nslices);
+  const int Hsrc = UP ? p.Hout : p.Hin, Wsrc = UP ? p.Wout : p.Win;
+
+  f32x16 acc[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+  if (t0 >= t1) return;                                    // (never: slices <= tiles)
+
+  const int q4 = tid & 15, prow = tid >> 4, ry = prow >> 4, rx = prow & 15;
+  const int cdy = co0 + q4 * 4, cin = ci0 + q4 * 4;
+  const bool src0 = ci0 < p.C0;
+  const char* xs = reinterpret_cast<const char*>(src0 ? p.x0 : p.x1);
+  const char* dys = reinterpret_cast<const char*>(p.dy);
+  const int Cs = src0 ? p.C0 : p.C1, cc = (src0 ? ci0 : ci0 - p.C0) + q4 * 4;
+  const bool cin_ok = cin < Cin, cdy_ok = cdy < p.Cout_s;
+  const bool edge_lane = prow < 2 * HH;
+  const int ehy = prow >> 1, ehx = TW + (prow & 1);
+  auto lsrc = [&](int h) { return UP ? ((h - 1) >> 1) : h; };
+  const unsigned o_dy = (unsigned)((ry * p.Wout + rx) * p.Cout_s + cdy) * 4u;
+  const unsigned o_main = (unsigned)((lsrc(ry) * p.Win + lsrc(rx)) * Cs + cc) * 4u;
+  const unsigned o_edge = (unsigned)((lsrc(ehy) * p.Win + lsrc(ehx)) * Cs + cc) * 4u;
+  const int st_dy = tr_img_off(prow, q4 * 4);
+  const int st_in = 2 * Cfg::PLANE_DY + tr_img_off(ry * HWD + rx, q4 * 4);
+  const int st_edge = 2 * Cfg::PLANE_DY + tr_img_off(ehy * HWD + ehx, q4 * 4);
+  const unsigned row_dy = (unsigned)(p.Wout * p.Cout_s) * 4u, row_in = (unsigned)(p.Win * Cs) * 4u;
+  f32x4 pv[2][3], nsc = {1.f, 1.f, 1.f, 1.f}, nsh = {0.f, 0.f, 0.f, 0.f};
+  unsigned pm[2][3];
+  bool pok[2][3];
+  int toy = 0, tox = 0, tn = 0;
+  unsigned ub_dy = 0, ub_in = 0;
+  auto set_tile = [&](int tile) {
+    int tt = tile;
+    tox = (tt % tilesX) * TW;  tt /= tilesX;
+    toy = (tt % tilesY) * TH;
+    tn = tt / tilesY;
+    ub_dy = (unsigned)(((tn * p.Hout + toy) * p.Wout + tox) * p.Cout_s) * 4u;
+    ub_in = (unsigned)(((tn * p.Hin + (UP ? toy / 2 : toy - PAD)) * p.Win + (UP ? tox / 2 : tox - PAD)) * Cs) * 4u;
+  };
+  auto load_gn = [&]() {
+    if (GN) {
+      const int c = cin_ok ? cin : 0;
+      nsc = *reinterpret_cast<const f32x4*>(p.gn_scale + (size_t)tn * Cin + c);
+      nsh = *reinterpret_cast<const f32x4*>(p.gn_shift + (size_t)tn * Cin + c);
+    }
+  };
+  auto load_in = [&](int set, int u, unsigned o, int rows, int hy, int hx, bool lane_ok) {
+    const bool ok = lane_ok && (unsigned)(toy - PAD + hy) < (unsigned)Hsrc && (unsigned)(tox - PAD + hx) < (unsigned)Wsrc && cin_ok;
+    const unsigned off = ok ? ub_in + o + rows * row_in : 0u;
+    pv[set][u] = *reinterpret_cast<const f32x4*>(xs + off);
+    if (DROP) pm[set][u] = *reinterpret_cast<const unsigned*>(p.drop_mask + (off >> 2));
+    pok[set][u] = ok;
+  };
+  auto load_piece = [&](int set, int j) {                  // quarter j: dy rows 2j+ry, halo rows 2j+ry, + rows 8+ry (j=0) / edge (j=1)
+    {
+      const bool ok = toy + 2 * j + ry < p.Hout && tox + rx < p.Wout && cdy_ok;
+      const unsigned off = ok ? ub_dy + o_dy + 2 * j * row_dy : 0u;
+      pv[set][0] = *reinterpret_cast<const f32x4*>(dys + off);
+      pok[set][0] = ok;
+    }
+    load_in(set, 1, o_main, UP ? j : 2 * j, 2 * j + ry, rx, true);
+    if (j == 0) load_in(set, 2, o_main, UP ? 4 : 8, 8 + ry, rx, true);
+    if (j == 1) load_in(set, 2, o_edge, 0, ehy, ehx, edge_lane);
+  };
+  auto put_split = [&](unsigned char* ph, unsigned char* pl, f32x4 v, float lim) {
+    typedef _Float16 h2t __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], -lim, lim);
+    uint2 hi, lo;
+    {
+      const h2t h0 = {(_Float16)v[0], (_Float16)v[1]}, h1 = {(_Float16)v[2], (_Float16)v[3]};
+      hi.x = __builtin_bit_cast(unsigned, h0);
+      hi.y = __builtin_bit_cast(unsigned, h1);
+    }
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo.x) : "v"(hi.x), "v"(v[0]));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo.x) : "v"(hi.x), "v"(v[1]));
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo.y) : "v"(hi.y), "v"(v[2]));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo.y) : "v"(hi.y), "v"(v[3]));
+    *reinterpret_cast<uint2*>(ph) = hi;
+    *reinterpret_cast<uint2*>(pl) = lo;
+  };
+  auto put_in = [&](int set, int u, unsigned char* buf, int off, int lo_off) {
+    f32x4 v = pv[set][u];
+    if (GN) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], nsc[e], nsh[e]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = v[e] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[e]));
+      if (DROP) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = ((pm[set][u] >> (8 * e)) & 0xffu) ? v[e] * p.drop_scale : 0.f;
+      }
+    }
+    put_split(buf + off, buf + off + lo_off, v, pok[set][u] ? 65504.f : 0.f);
+  };
+  auto store_piece = [&](int set, int j, unsigned char* buf) {
+    put_split(buf + st_dy + j * 32 * 128, buf + Cfg::PLANE_DY + st_dy + j * 32 * 128, pv[set][0], pok[set][0] ? 65504.f : 0.f);
+    put_in(set, 1, buf, st_in + j * 2 * HWD * 128, Cfg::PLANE_IN);
+    if (j == 0) put_in(set, 2, buf, st_in + 4 * 2 * HWD * 128, Cfg::PLANE_IN);
+    if (j == 1) {                                           // lanes without a halo-edge pixel write a dummy slot (no branch)
+      unsigned char* base = edge_lane ? buf + st_edge : wsh8 + DUMMY + (tid & 255) * 8;
+      put_in(set, 2, base, 0, edge_lane ? Cfg::PLANE_IN : 2048);
+    }
+  };
+
+  const int g = lane >> 4, pp4 = lane & 3, q = (lane >> 2) & 3;
+  const int k0 = 8 * (g >> 1);
+  const int colAb = (wc * 32 + 16 * (g & 1) + 4 * pp4) * 2, colBb = (wi * 32 + 16 * (g & 1) + 4 * pp4) * 2;
+  const int baseA = (grp * 4 * TW + k0 + q) * 128 + (colAb ^ (((q >> 1) & 1) << 6));
+  int baseB[4];
+#pragma unroll
+  for (int c2 = 0; c2 < 4; ++c2) baseB[c2] = 2 * Cfg::PLANE_DY + (grp * 4 * HWD + k0 + q) * 128 + (colBb ^ ((((c2 + q) >> 1) & 1) << 6));
+
+  // one tile row: MFMAs + fragment reads; the caller puts the staging of a piece into the same block
+  auto mfma_row = [&](const unsigned char* cur, int y) {
+    const th8 ah = tr_frag_at(cur + baseA + y * TW * 128);
+    const th8 al = tr_frag_at(cur + baseA + y * TW * 128 + Cfg::PLANE_DY);
+    th8 bh[2], bl[2];
+    bh[0] = tr_frag_at(cur + baseB[(y * HWD) & 3] + y * HWD * 128);
+    bl[0] = tr_frag_at(cur + baseB[(y * HWD) & 3] + y * HWD * 128 + Cfg::PLANE_IN);
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      if (t + 1 < T) {
+        const int rr = (y + (t + 1) / KS) * HWD + (t + 1) % KS;
+        bh[(t + 1) & 1] = tr_frag_at(cur + baseB[rr & 3] + rr * 128);
+        bl[(t + 1) & 1] = tr_frag_at(cur + baseB[rr & 3] + rr * 128 + Cfg::PLANE_IN);
+      }
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[t & 1], acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[t & 1], acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[t & 1], acc[t], 0, 0, 0);
+    }
+  };
+  auto interleave = [&]() {                                 // the shape asked of the scheduler for a row block
+#pragma unroll
+    for (int i = 0; i < 27; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // 1 MFMA
+#if WG_IL_DSR
+      __builtin_amdgcn_sched_group_barrier(0x100, WG_IL_DSR, 0);
+#endif
+      __builtin_amdgcn_sched_group_barrier(0x002, WG_IL_VALU, 0);    // VALU per MFMA gap
+    }
+  };
+
+  // prologue: tile t0 staged directly, piece 0 of the next fetch tile in flight
+  set_tile(t0);
+  load_gn();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { load_piece(j & 1, j); store_piece(j & 1, j, wsh8); }
+  {
+    const int f = t0 + 1 < t1 ? t0 + 1 : t1 - 1;
+    set_tile(f);
+    load_gn();
+    load_piece(0, 0);
+  }
+  __syncthreads();
+  for (int tile = t0; tile < t1; ++tile) {
+    const int curoff = ((tile - t0) & 1) ? Cfg::BUF : 0;
+    const unsigned char* cur = wsh8 + curoff;
+    unsigned char* nxt = wsh8 + (Cfg::BUF - curoff);
+#pragma unroll
+    for (int y = 0; y < 4; ++y) {
+      // fetch: piece y+1 of tile+1, or (y = 3) piece 0 of tile+2; convert: piece y of tile+1 (fetched during the previous row)
+      if (y == 3) set_tile(tile + 2 < t1 ? tile + 2 : t1 - 1);
+      load_piece((y + 1) & 1, (y + 1) & 3);
+      mfma_row(cur, y);
+      store_piece(y & 1, y, nxt);
+      if (y == 3) load_gn();                                 // after the last use of this tile's scale / shift
+      interleave();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+  }
+
+  const int r31 = lane & 31, kh = lane >> 5;
+  float* red = reinterpret_cast<float*>(wsh8);
+  if (grp == 1) {
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = (i & 3) + 8 * (i >> 2) + 4 * kh;
+        red[t * 4096 + (wc * 32 + row) * 64 + wi * 32 + r31] = acc[t][i];
+      }
+  }
+  __syncthreads();
+  if (grp == 0) {
+    float* dst = p.scratch + ((((size_t)sl * ncb + cb) * nib + ib) * T) * 4096;
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = (i & 3) + 8 * (i >> 2) + 4 * kh;
+        const int o = t * 4096 + (wc * 32 + row) * 64 + wi * 32 + r31;
+        dst[o] = acc[t][i] + red[o];
+      }
+  }
+}
+
 static int wgrad_h8_slices(int ntiles8, int ncb, int nib) {
   const int blocks = ncb * nib;
   int s = 512 / blocks;                       // <= two rounds of one workgroup per CU, never a straggler third
@@ -1090,6 +1319,14 @@ static hipError_t launch_wgrad_h8_t(const WgradParams& p, hipStream_t s) {
   const int ncb = (p.Cout + 63) / 64, nib = (Cin + 63) / 64;
   const int ntiles = p.N * ((p.Wout + Cfg::TW - 1) / Cfg::TW) * ((p.Hout + Cfg::TH - 1) / Cfg::TH);
   const int ns = wgrad_h8_slices(ntiles, ncb, nib);     // <= wgrad_slices() of the 4x16 tiling: the scratch is sized for that
+  static const bool plain8 = getenv("FDSR_WGRAD_H8") != nullptr;   // A/B switch: the form without the in-row interleave
+  if (!plain8 && KS == 3 && !p.gn_plain) {
+    const size_t lds = (size_t)2 * Cfg::BUF + 4096;
+    const dim3 grid(ns * ncb * nib), block(512);
+    if (!p.gn_scale) hipLaunchKernelGGL((wgrad_h8i_kernel<UP, false, false>), grid, block, lds, s, p, ns, ncb, nib);
+    else if (!p.drop_mask) hipLaunchKernelGGL((wgrad_h8i_kernel<UP, true, false>), grid, block, lds, s, p, ns, ncb, nib);
+    else hipLaunchKernelGGL((wgrad_h8i_kernel<UP, true, true>), grid, block, lds, s, p, ns, ncb, nib);
+  } else
   hipLaunchKernelGGL((wgrad_h8_kernel<KS, UP>), dim3(ns * ncb * nib), dim3(512), (size_t)Cfg::LDS_BYTES, s, p, ns, ncb, nib);
   const size_t total = (size_t)p.Cout * p.Cin_real * Cfg::T;
   hipLaunchKernelGGL(wgrad_fold_kernel, dim3((unsigned)(ncb * nib * Cfg::T * 64)), dim3(256), 0, s, p.scratch, p.dw, p.Cout, p.Cin_real,
@@ -1148,6 +1385,13 @@ hipError_t train_kernels_init() {
     return e;
   FDSR_WGH8_INIT(3, false) FDSR_WGH8_INIT(3, true)
 #undef FDSR_WGH8_INIT
+#define FDSR_WGH8I_INIT(UP, GN, DROP)                                                                                  \
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_h8i_kernel<UP, GN, DROP>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                               2 * WgH8Cfg<3, UP>::BUF + 4096)) != hipSuccess)                                           \
+    return e;
+  FDSR_WGH8I_INIT(false, false, false) FDSR_WGH8I_INIT(false, true, false) FDSR_WGH8I_INIT(false, true, true)
+  FDSR_WGH8I_INIT(true, false, false) FDSR_WGH8I_INIT(true, true, false) FDSR_WGH8I_INIT(true, true, true)
+#undef FDSR_WGH8I_INIT
   return hipSuccess;
 }
 
