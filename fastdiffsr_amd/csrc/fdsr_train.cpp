@@ -389,13 +389,8 @@ int fdsr_train_grads(fdsr_handle h, const float* x_nchw, const float* noise_leve
     // residual (identity): the same gradient flows to the block input
     if (op.res >= 0 && op.res != op.dst)
       HIPCHK(h, launch_add_slice(dy, GT(op.res), (size_t)N * Ho * Wo, op.Cout, 0, op.Cout, first(op.res), st));
-    // bias and noise-embedding gradients
-    HIPCHK(h, launch_colsum(dy, S, dbl, N, Ho * Wo, K, st));
-    if (op.b >= 0) HIPCHK(h, launch_sum_rows(S, N, K, op.Cout, DG(op.b), st));   // db[c] = sum_n S[n][c]
-    if (op.temb_off >= 0)   // rows of S (stride K) -> this block's columns of the [N][TE] table
-      HIPCHK(h, hipMemcpy2DAsync(dtemb + op.temb_off, (size_t)h->TE * sizeof(float), S, (size_t)K * sizeof(float),
-                                 (size_t)op.Cout * sizeof(float), N, hipMemcpyDeviceToDevice, st));
-    // weight gradient
+    // weight gradient; the per-image column sums of dy (bias and noise-embedding gradients) come out of the f16x3 weight-gradient
+    // kernel's own staging of dy where it can produce them, else from a pass of their own
     {
       WgradParams q{};
       q.dy = dy; q.x0 = TP(op.src0); q.x1 = TP(op.src1);
@@ -412,9 +407,19 @@ int fdsr_train_grads(fdsr_handle h, const float* x_nchw, const float* noise_leve
         q.drop_scale = 1.0f / (1.0f - h->cfg.dropout);
       }
       static const bool f32_wgrad = getenv("FDSR_WGRAD_F32") != nullptr;   // A/B switch: keep the weight gradients exact fp32
-      if (h->prec == PREC_F16X3 && !f32_wgrad) HIPCHK(h, launch_wgrad_h(op.ck, q, st));
+      const bool hw = h->prec == PREC_F16X3 && !f32_wgrad;
+      q.colsum = S;
+      if (!(hw && wgrad_h_fuses_colsum(op.ck, q))) {
+        q.colsum = nullptr;
+        HIPCHK(h, launch_colsum(dy, S, dbl, N, Ho * Wo, K, st));
+      }
+      if (hw) HIPCHK(h, launch_wgrad_h(op.ck, q, st));
       else HIPCHK(h, launch_wgrad(op.ck, q, st));
     }
+    if (op.b >= 0) HIPCHK(h, launch_sum_rows(S, N, K, op.Cout, DG(op.b), st));   // db[c] = sum_n S[n][c]
+    if (op.temb_off >= 0)   // rows of S (stride K) -> this block's columns of the [N][TE] table
+      HIPCHK(h, hipMemcpy2DAsync(dtemb + op.temb_off, (size_t)h->TE * sizeof(float), S, (size_t)K * sizeof(float),
+                                 (size_t)op.Cout * sizeof(float), N, hipMemcpyDeviceToDevice, st));
     if (op.src0 == h->t_in) continue;                     // no gradient w.r.t. the network input
     // input gradient: on the f16x3 kernels in that mode (where the transposed shape fits them), else exact fp32
     auto dgrad = [&](const float* dyp, int Hs, int Ws, int src, int Csub, float* outp, bool acc) -> int {

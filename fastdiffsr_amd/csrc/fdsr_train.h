@@ -73,8 +73,12 @@ struct WgradParams {
   int Cout, Cout_s;
   const unsigned char* drop_mask;  // as ConvParams::drop_mask (the activated input is a * keep * drop_scale)
   float drop_scale;
+  float* colsum;                   // launch_wgrad_h only, when wgrad_h_fuses_colsum(): S [N][Cout_s] = per-image column sums of dy
+  float* colsum_part;              // (set by the launcher: per-slice partial sums in the scratch)
 };
 size_t wgrad_scratch_floats(ConvKind kind, int N, int Hout, int Wout, int Cin, int Cout);
+// true when launch_wgrad_h(kind, p) will also write p.colsum (the bias / noise-shift gradient sums launch_colsum computes)
+bool wgrad_h_fuses_colsum(ConvKind kind, const WgradParams& p);
 hipError_t launch_wgrad(ConvKind kind, const WgradParams& p, hipStream_t s);
 // the same in the split-f16 form (three f16 MFMAs per product, fp32 accumulate): FDSR_PREC_F16X3 training steps
 hipError_t launch_wgrad_h(ConvKind kind, const WgradParams& p, hipStream_t s);

@@ -584,9 +584,20 @@ static int wgrad_slices(int ntiles, int ncb, int nib) {
 
 size_t wgrad_scratch_floats(ConvKind kind, int N, int Hout, int Wout, int Cin, int Cout) {
   const int T = kind == CONV1 ? 1 : 9, TH = kind == CONV3_S2 ? 2 : 4;
-  const int ncb = (Cout + 63) / 64, nib = (Cin + 63) / 64;
+  const int ncb = (Cout + 63) / 64, nib = (Cin + 63) / 64, blocks = ncb * nib;
   const int ntiles = N * ((Wout + 15) / 16) * ((Hout + TH - 1) / TH);
-  return (size_t)wgrad_slices(ntiles, ncb, nib) * ncb * nib * T * 4096;
+  size_t need = (size_t)wgrad_slices(ntiles, ncb, nib) * blocks * T * 4096;
+  if (kind == CONV3_S1 || kind == CONV3_UP) {
+    // the 8-wave f16x3 forms (wgrad_h8_plan): up to N * (k0 + 1) <= 512 image-aligned slices, plus their dy column sums
+    int k0 = 512 / (blocks * N);
+    if (k0 < 1) k0 = 1;
+    long ns = (long)N * (k0 + 1);
+    if (ns > 512) ns = (long)N * k0;
+    if (ns > 512) ns = 512;
+    if (ns < 512 / blocks) ns = 512 / blocks;
+    need = std::max(need, (size_t)ns * blocks * T * 4096 + (size_t)ns * ncb * 64);
+  }
+  return need;
 }
 
 template <int KS, int STRIDE, bool UP>
@@ -1134,6 +1145,8 @@ __global__ void __launch_bounds__(512, 2) wgrad_h8i_kernel(const WgradParams p, 
   const int st_edge = 2 * Cfg::PLANE_DY + tr_img_off(ehy * HWD + ehx, q4 * 4);
   const unsigned row_dy = (unsigned)(p.Wout * p.Cout_s) * 4u, row_in = (unsigned)(p.Win * Cs) * 4u;
   f32x4 pv[2][3], nsc = {1.f, 1.f, 1.f, 1.f}, nsh = {0.f, 0.f, 0.f, 0.f};
+  f32x4 cs = {0.f, 0.f, 0.f, 0.f};   // this thread's share of the column sums of dy (bias / noise-shift gradients), real tiles only
+  bool cs_real = true;
   unsigned pm[2][3];
   bool pok[2][3];
   int toy = 0, tox = 0, tn = 0;
@@ -1203,6 +1216,11 @@ __global__ void __launch_bounds__(512, 2) wgrad_h8i_kernel(const WgradParams p, 
     put_split(buf + off, buf + off + lo_off, v, pok[set][u] ? 65504.f : 0.f);
   };
   auto store_piece = [&](int set, int j, unsigned char* buf) {
+    {
+      const bool add = pok[set][0] && cs_real;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) cs[e] += add ? pv[set][0][e] : 0.f;
+    }
     put_split(buf + st_dy + j * 32 * 128, buf + Cfg::PLANE_DY + st_dy + j * 32 * 128, pv[set][0], pok[set][0] ? 65504.f : 0.f);
     put_in(set, 1, buf, st_in + j * 2 * HWD * 128, Cfg::PLANE_IN);
     if (j == 0) put_in(set, 2, buf, st_in + 4 * 2 * HWD * 128, Cfg::PLANE_IN);
@@ -1266,6 +1284,7 @@ __global__ void __launch_bounds__(512, 2) wgrad_h8i_kernel(const WgradParams p, 
     const int curoff = ((tile - t0) & 1) ? Cfg::BUF : 0;
     const unsigned char* cur = wsh8 + curoff;
     unsigned char* nxt = wsh8 + (Cfg::BUF - curoff);
+    cs_real = tile + 1 < t1;                                 // the last tile re-fetches itself: not summed twice
 #pragma unroll
     for (int y = 0; y < 4; ++y) {
       // fetch: piece y+1 of tile+1, or (y = 3) piece 0 of tile+2; convert: piece y of tile+1 (fetched during the previous row)
@@ -1280,6 +1299,24 @@ __global__ void __launch_bounds__(512, 2) wgrad_h8i_kernel(const WgradParams p, 
     __syncthreads();
   }
 
+  // ---- column sums of dy over this slice (one image or part of one): lanes l, l^16, l^32, l^48 share the channel quad ----
+  if (p.colsum_part && ib == 0) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      cs[e] += __shfl_xor(cs[e], 16, 64);
+      cs[e] += __shfl_xor(cs[e], 32, 64);
+    }
+    float* cred = reinterpret_cast<float*>(wsh8);           // [wave][64 channels]
+    if (lane < 16) *reinterpret_cast<f32x4*>(cred + wave * 64 + lane * 4) = cs;
+    __syncthreads();
+    if (tid < 64) {
+      float a = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) a += cred[w * 64 + tid];
+      p.colsum_part[((size_t)sl * ncb + cb) * 64 + tid] = a;
+    }
+    __syncthreads();
+  }
   const int r31 = lane & 31, kh = lane >> 5;
   float* red = reinterpret_cast<float*>(wsh8);
   if (grp == 1) {
@@ -1305,32 +1342,77 @@ __global__ void __launch_bounds__(512, 2) wgrad_h8i_kernel(const WgradParams p, 
   }
 }
 
-static int wgrad_h8_slices(int ntiles8, int ncb, int nib) {
-  const int blocks = ncb * nib;
+// How a stride-1 3x3 (or folded-upsample) f16x3 weight gradient runs.  `colsum`: the in-row kernel also produces the column sums
+// of dy; that wants every slice inside ONE image (ns = N * k), so that S[n][c] is a sum of whole slices.
+struct H8Plan { bool h8, inrow, colsum; int ns, k; };
+static H8Plan wgrad_h8_plan(ConvKind kind, const WgradParams& p) {
+  static const bool four_wave = getenv("FDSR_WGRAD_H4") != nullptr;   // A/B switches: the 4-wave single-buffer form everywhere,
+  static const bool plain8 = getenv("FDSR_WGRAD_H8") != nullptr;      // the 8-wave form without the in-row interleave
+  static const bool no_colsum = getenv("FDSR_WGRAD_NO_COLSUM") != nullptr;
+  H8Plan r{false, false, false, 1, 0};
+  if (kind != CONV3_S1 && kind != CONV3_UP) return r;
+  // the 8-wave forms want a 64-channel block inside one concat source and 32-bit byte offsets; the 4-wave form takes the rest
+  const size_t in_px = (size_t)p.N * p.Hin * p.Win, out_px = (size_t)p.N * p.Hout * p.Wout;
+  const bool seam = (p.C1 > 0 && (p.C0 & 63) != 0) || in_px * (size_t)(p.C0 > p.C1 ? p.C0 : p.C1) * 4 >= (1ull << 32) ||
+                    out_px * (size_t)p.Cout_s * 4 >= (1ull << 32);
+  if (four_wave || seam) return r;
+  r.h8 = true;
+  r.inrow = !plain8 && !p.gn_plain;
+  const int ncb = (p.Cout + 63) / 64, nib = (p.C0 + p.C1 + 63) / 64, blocks = ncb * nib;
+  const int tpi = ((p.Wout + 15) / 16) * ((p.Hout + 7) / 8), ntiles = p.N * tpi;
   int s = 512 / blocks;                       // <= two rounds of one workgroup per CU, never a straggler third
-  if (s > ntiles8) s = ntiles8;
-  return s < 1 ? 1 : s;
+  if (s > ntiles) s = ntiles;
+  r.ns = s < 1 ? 1 : s;
+  if (r.inrow && !no_colsum && p.Cout_s <= ncb * 64) {
+    // slices per image: k0 or k0 + 1, whichever fills whole rounds of 256 workgroups better; within [1, tiles per image]
+    int k0 = 512 / (blocks * p.N);
+    if (k0 < 1) k0 = 1;
+    int best = 0;
+    double beff = -1.0;
+    for (int k = k0; k <= k0 + 1; ++k) {
+      if (k > tpi || p.N * k > 512) continue;
+      const long w = (long)blocks * p.N * k;
+      const double eff = (double)w / (double)(((w + 255) / 256) * 256);
+      if (eff > beff + 1e-9) { beff = eff; best = k; }
+    }
+    if (best > 0) { r.colsum = true; r.k = best; r.ns = p.N * best; }
+  }
+  return r;
+}
+
+bool wgrad_h_fuses_colsum(ConvKind kind, const WgradParams& p) { return wgrad_h8_plan(kind, p).colsum; }
+
+// S[n][c] = the slices of image n added in slice order
+__global__ void __launch_bounds__(256) colsum_slices_kernel(const float* __restrict__ part, float* __restrict__ S, int K, int ncb, int k) {
+  const int c = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
+  if (c >= K) return;
+  double a = 0.0;
+  for (int j = 0; j < k; ++j) a += (double)part[((size_t)(n * k + j) * ncb + (c >> 6)) * 64 + (c & 63)];
+  S[(size_t)n * K + c] = (float)a;
 }
 
 template <int KS, bool UP>
-static hipError_t launch_wgrad_h8_t(const WgradParams& p, hipStream_t s) {
+static hipError_t launch_wgrad_h8_t(const WgradParams& p0, const H8Plan& pl, hipStream_t s) {
   using Cfg = WgH8Cfg<KS, UP>;
+  WgradParams p = p0;
   const int Cin = p.C0 + p.C1;
   const int ncb = (p.Cout + 63) / 64, nib = (Cin + 63) / 64;
-  const int ntiles = p.N * ((p.Wout + Cfg::TW - 1) / Cfg::TW) * ((p.Hout + Cfg::TH - 1) / Cfg::TH);
-  const int ns = wgrad_h8_slices(ntiles, ncb, nib);     // <= wgrad_slices() of the 4x16 tiling: the scratch is sized for that
-  static const bool plain8 = getenv("FDSR_WGRAD_H8") != nullptr;   // A/B switch: the form without the in-row interleave
-  if (!plain8 && KS == 3 && !p.gn_plain) {
+  const int ns = pl.ns;
+  p.colsum_part = pl.colsum && p.colsum ? p.scratch + (size_t)ns * ncb * nib * Cfg::T * 4096 : nullptr;
+  if (pl.inrow) {
     const size_t lds = (size_t)2 * Cfg::BUF + 4096;
     const dim3 grid(ns * ncb * nib), block(512);
     if (!p.gn_scale) hipLaunchKernelGGL((wgrad_h8i_kernel<UP, false, false>), grid, block, lds, s, p, ns, ncb, nib);
     else if (!p.drop_mask) hipLaunchKernelGGL((wgrad_h8i_kernel<UP, true, false>), grid, block, lds, s, p, ns, ncb, nib);
     else hipLaunchKernelGGL((wgrad_h8i_kernel<UP, true, true>), grid, block, lds, s, p, ns, ncb, nib);
-  } else
-  hipLaunchKernelGGL((wgrad_h8_kernel<KS, UP>), dim3(ns * ncb * nib), dim3(512), (size_t)Cfg::LDS_BYTES, s, p, ns, ncb, nib);
+  } else {
+    hipLaunchKernelGGL((wgrad_h8_kernel<KS, UP>), dim3(ns * ncb * nib), dim3(512), (size_t)Cfg::LDS_BYTES, s, p, ns, ncb, nib);
+  }
   const size_t total = (size_t)p.Cout * p.Cin_real * Cfg::T;
   hipLaunchKernelGGL(wgrad_fold_kernel, dim3((unsigned)(ncb * nib * Cfg::T * 64)), dim3(256), 0, s, p.scratch, p.dw, p.Cout, p.Cin_real,
                      Cfg::T, ns, ncb, nib, total);
+  if (p.colsum_part)
+    hipLaunchKernelGGL(colsum_slices_kernel, dim3((p.Cout_s + 255) / 256, p.N), dim3(256), 0, s, p.colsum_part, p.colsum, p.Cout_s, ncb, pl.k);
   return hipGetLastError();
 }
 
@@ -1351,15 +1433,11 @@ static hipError_t launch_wgrad_h_t(const WgradParams& p, hipStream_t s) {
 // the tiles (4x16, stride 2: 2x16) equal wgrad_kernel's, so the scratch sizing (wgrad_scratch_floats) is shared
 hipError_t launch_wgrad_h(ConvKind kind, const WgradParams& p, hipStream_t s) {
   if ((p.C0 & 3) || (p.C1 & 3) || (p.Cout_s & 3)) return hipErrorInvalidValue;
-  static const bool four_wave = getenv("FDSR_WGRAD_H4") != nullptr;   // A/B switch: the 4-wave single-buffer form everywhere
-  // the 8-wave form wants a 64-channel block inside one concat source and 32-bit byte offsets; the 4-wave form takes the rest
-  const size_t in_px = (size_t)p.N * p.Hin * p.Win, out_px = (size_t)p.N * p.Hout * p.Wout;
-  const bool seam = (p.C1 > 0 && (p.C0 & 63) != 0) || in_px * (size_t)(p.C0 > p.C1 ? p.C0 : p.C1) * 4 >= (1ull << 32) ||
-                    out_px * (size_t)p.Cout_s * 4 >= (1ull << 32);
+  const H8Plan pl = wgrad_h8_plan(kind, p);
   switch (kind) {
-    case CONV3_S1: return four_wave || seam ? launch_wgrad_h_t<3, 1, false>(p, s) : launch_wgrad_h8_t<3, false>(p, s);
+    case CONV3_S1: return pl.h8 ? launch_wgrad_h8_t<3, false>(p, pl, s) : launch_wgrad_h_t<3, 1, false>(p, s);
     case CONV3_S2: return launch_wgrad_h_t<3, 2, false>(p, s);
-    case CONV3_UP: return four_wave || seam ? launch_wgrad_h_t<3, 1, true>(p, s) : launch_wgrad_h8_t<3, true>(p, s);
+    case CONV3_UP: return pl.h8 ? launch_wgrad_h8_t<3, true>(p, pl, s) : launch_wgrad_h_t<3, 1, true>(p, s);
     case CONV1: return launch_wgrad_h_t<1, 1, false>(p, s);   // bandwidth-bound: two small workgroups per CU keep more loads in flight
   }
   return hipErrorInvalidValue;
