@@ -364,3 +364,22 @@ def test_autograd_compatible_loss_fills_param_grads():
         y = unet(x, torch.tensor([[0.5]]).cuda())                      # re-uploads the stepped Parameters
     assert np.array_equal(unet.engine.get_weight('downs.0.weight'), named['downs.0.weight'].detach().cpu().numpy())
     assert torch.isfinite(y).all()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize('switch', ['FDSR_WGRAD_H4', 'FDSR_WGRAD_H8', 'FDSR_WGRAD_NO_COLSUM', 'FDSR_WGRAD_F32'])
+def test_every_weight_gradient_kernel_form_meets_the_golden(switch):
+    """The f16x3 step picks its weight-gradient kernel per layer (8-wave in-row with fused column sums by default); the A/B
+    switches force the other forms -- 4-wave, 8-wave without the interleave, separate column-sum pass, exact-fp32 weight
+    gradients -- and each must reproduce the reference's 273 gradients and its Adam update (fresh process: the switches are
+    read once)."""
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env[switch] = '1'
+    here = os.path.abspath(__file__)
+    r = subprocess.run([sys.executable, '-m', 'pytest', here, '-m', 'gpu', '-q', '-x', '-k',
+                        '(test_all_gradients or test_adam_update or test_train_step_with_dropout) and f16x3'],
+                       env=env, capture_output=True, text=True, timeout=840, cwd=os.path.dirname(os.path.dirname(here)))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert ' passed' in r.stdout and 'failed' not in r.stdout
