@@ -1500,6 +1500,11 @@ int fdsr_set_precision(fdsr_handle h, int mode) {
         return fail(h, FDSR_E_INVALID, "bf16 mode needs channel counts that are multiples of 16 (layer %s)", op.name.c_str());
     }
   }
+  if (mode == PREC_F32 && h->f32_forms_stale) {   // f16x3 training steps refreshed only the fp32 forms they read
+    int rc = ensure_f32_forms(h, nullptr);
+    if (rc) return rc;
+    HIPCHK(h, hipDeviceSynchronize());
+  }
   if (mode != PREC_F32 && h->h_forms_stale) {   // optimiser steps moved the master copy: refresh the 16-bit forms
     int rc = fdsr_sync_weight_forms(h);
     if (rc) return rc;

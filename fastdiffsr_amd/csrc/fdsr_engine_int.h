@@ -164,6 +164,9 @@ struct fdsr_engine {
   unsigned drop_step = 0;             // forward passes made in training mode: part of the mask's Philox counter
   bool keep_stats = false;            // forward also stores per-(image, group) mean / rstd of every GroupNorm
   bool h_forms_stale = false;         // 16-bit weight forms lag behind the master copy (after an optimiser step)
+  bool f32_forms_stale = false;       // fp32 conv forms (d_params packs, d_wt) lag: f16x3 training steps refresh only what they read
+  unsigned long long* d_copy_tab = nullptr;   // {src offset, dst offset, count} triples: master -> d_params for the non-conv tensors
+  int n_copy_tab = 0;
 };
 
 namespace fdsr_int {
@@ -184,6 +187,7 @@ int check_ws(fdsr_handle h, void* ws, size_t bytes);
 int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, float nl_scalar, hipStream_t st,
              const float* temb_row = nullptr);
 int pack_weights_h(fdsr_handle h, WeightEntry& w, const float* host);
+int ensure_f32_forms(fdsr_handle h, hipStream_t st);   // fdsr_train.cpp: fp32 conv forms left behind by lazy f16x3 training steps
 // fdsr_train.cpp
 int train_workspace_extra(fdsr_handle h, int N, int H, int W, size_t* bytes);
 

@@ -161,27 +161,43 @@ int train_prepare(fdsr_handle h) {
   HIPCHK(h, hipMalloc((void**)&h->d_wt, std::max<size_t>(off, 4) * sizeof(float)));
   HIPCHK(h, hipMalloc((void**)&h->d_zero, (size_t)round_up(maxC, 64) * sizeof(float)));
   HIPCHK(h, hipMemset(h->d_zero, 0, (size_t)round_up(maxC, 64) * sizeof(float)));
+  {   // the non-conv tensors (GroupNorm affine, biases, MLPs ...) follow the master copy through ONE table-driven copy
+    std::vector<unsigned long long> tab;
+    for (int i = 0; i < h->n_schema; ++i) {
+      const WeightEntry& w = h->weights[i];
+      if (!w.live || w.sink == WeightEntry::CONV_PACK) continue;
+      tab.push_back(h->master_off[i]);
+      tab.push_back(w.dev_off);
+      tab.push_back(numel(w.shape));
+    }
+    h->n_copy_tab = (int)(tab.size() / 3);
+    HIPCHK(h, hipMalloc((void**)&h->d_copy_tab, std::max<size_t>(tab.size(), 3) * sizeof(unsigned long long)));
+    if (!tab.empty()) HIPCHK(h, hipMemcpy(h->d_copy_tab, tab.data(), tab.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+  }
   HIPCHK(h, train_kernels_init());
   h->train_ready = true;
   return FDSR_OK;
 }
 
 // (re-)build every device form the fp32 kernels read from the master copy: after load and after each Adam step
-int repack_from_master(fdsr_handle h, hipStream_t st, bool forward_forms) {
-  for (int i = 0; i < h->n_schema; ++i) {
-    WeightEntry& w = h->weights[i];
-    if (!w.live) continue;
-    const float* src = h->d_master + h->master_off[i];
-    if (forward_forms) {
-      if (w.sink == WeightEntry::CONV_PACK) {
-        HIPCHK(h, launch_pack_conv_f32(src, h->d_params + w.dev_off, (int)w.shape[0], (int)w.shape[1], w.ks, w.cout_pad, w.cin_pad, st));
-      } else {
-        HIPCHK(h, hipMemcpyAsync(h->d_params + w.dev_off, src, numel(w.shape) * sizeof(float), hipMemcpyDeviceToDevice, st));
-      }
+int repack_from_master(fdsr_handle h, hipStream_t st, bool forward_forms, bool all_f32_forms) {
+  // In f16x3 mode a step reads the fp32 conv forms only where the 16-bit kernels cannot run (the packed-input conv, odd
+  // shapes): the others are refreshed when something asks for them (ensure_f32_forms: fp32 mode, fp32 sampling).
+  const bool lazy = h->prec == PREC_F16X3 && !all_f32_forms;
+  bool skipped = false;
+  if (forward_forms) {
+    for (int i = 0; i < h->n_schema; ++i) {
+      WeightEntry& w = h->weights[i];
+      if (!w.live || w.sink != WeightEntry::CONV_PACK) continue;
+      if (lazy && w.h_ok) { skipped = true; continue; }
+      HIPCHK(h, launch_pack_conv_f32(h->d_master + h->master_off[i], h->d_params + w.dev_off, (int)w.shape[0], (int)w.shape[1], w.ks,
+                                     w.cout_pad, w.cin_pad, st));
     }
+    HIPCHK(h, launch_copy_table(h->d_master, h->d_params, h->d_copy_tab, h->n_copy_tab, st));
   }
   for (const Op& op : h->ops) {
     if (op.kind != Op::CONV || op.src0 == h->t_in) continue;
+    if (lazy && h->wtq_off0[op.w] != SIZE_MAX) { skipped = true; continue; }
     const WeightEntry& w = h->weights[op.w];
     const float* src = h->d_master + h->master_off[op.w];
     const int K = conv_K(h, op), Cout = (int)w.shape[0], Cin = (int)w.shape[1];
@@ -231,6 +247,7 @@ int repack_from_master(fdsr_handle h, hipStream_t st, bool forward_forms) {
     }
   }
   h->temb_table_valid = false;
+  h->f32_forms_stale = all_f32_forms ? false : (h->f32_forms_stale || skipped);
   return FDSR_OK;
 }
 
@@ -276,6 +293,11 @@ int train_workspace_extra(fdsr_handle h, int N, int H, int W, size_t* bytes) {
   *bytes = tp.bytes;
   return FDSR_OK;
 }
+// the fp32 conv forms a lazy f16x3 step left behind (see repack_from_master)
+int ensure_f32_forms(fdsr_handle h, hipStream_t st) {
+  if (!h->f32_forms_stale || !h->train_ready) return FDSR_OK;
+  return repack_from_master(h, st, true, true);
+}
 }  // namespace fdsr_int
 
 extern "C" {
@@ -314,8 +336,9 @@ int fdsr_train_grads(fdsr_handle h, const float* x_nchw, const float* noise_leve
   char* ws = reinterpret_cast<char*>(workspace);
   ShapePlan& sp = h->plan;
   // the transposed forms follow the master copy
+  if (h->prec == PREC_F32 && (rc = ensure_f32_forms(h, st))) { h->debug = false; return rc; }
   if (!h->wt_valid) {
-    if ((rc = repack_from_master(h, st, false))) { h->debug = false; return rc; }
+    if ((rc = repack_from_master(h, st, false, false))) { h->debug = false; return rc; }
     h->wt_valid = true;
   }
 
@@ -492,7 +515,7 @@ int fdsr_adam_step(fdsr_handle h, float lr, float beta1, float beta2, float eps,
   hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
   h->adam_t += 1;
   HIPCHK(h, launch_adam(h->d_master, h->d_grad, h->d_adam_m, h->d_adam_v, h->master_floats, lr, beta1, beta2, eps, h->adam_t, st));
-  int rc = repack_from_master(h, st, true);
+  int rc = repack_from_master(h, st, true, false);
   if (rc) return rc;
   h->wt_valid = true;
   h->h_forms_stale = true;

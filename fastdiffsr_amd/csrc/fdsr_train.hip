@@ -138,6 +138,17 @@ __global__ void __launch_bounds__(256) scale_inplace_kernel(float* __restrict__ 
   if (i < n) x[i] *= f;
 }
 
+// dst[tab[3e+1] + i] = src[tab[3e] + i], i < tab[3e+2]: one workgroup per table entry (the small tensors of a model in one launch)
+__global__ void __launch_bounds__(256) copy_table_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                         const unsigned long long* __restrict__ tab) {
+  const unsigned long long so = tab[3 * blockIdx.x], dof = tab[3 * blockIdx.x + 1], n = tab[3 * blockIdx.x + 2];
+  for (unsigned long long i = threadIdx.x; i < n; i += 256) dst[dof + i] = src[so + i];
+}
+hipError_t launch_copy_table(const float* src, float* dst, const unsigned long long* tab, int entries, hipStream_t s) {
+  if (entries > 0) hipLaunchKernelGGL(copy_table_kernel, dim3(entries), dim3(256), 0, s, src, dst, tab);
+  return hipGetLastError();
+}
+
 hipError_t launch_scale_inplace(float* x, size_t n, float f, hipStream_t s) {
   hipLaunchKernelGGL(scale_inplace_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, n, f);
   return hipGetLastError();
