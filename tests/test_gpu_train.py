@@ -383,3 +383,40 @@ def test_every_weight_gradient_kernel_form_meets_the_golden(switch):
                        env=env, capture_output=True, text=True, timeout=840, cwd=os.path.dirname(os.path.dirname(here)))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert ' passed' in r.stdout and 'failed' not in r.stdout
+
+
+@pytest.mark.parametrize('shape', [(3, 40, 56), (2, 72, 48), (5, 32, 32)])
+def test_f16x3_step_on_ragged_shapes_matches_the_exact_fp32_step(shape):
+    """Shapes that are no multiple of any tile (8x16-pixel weight-gradient tiles, 16 / 32-pixel conv tiles), batch sizes that
+    make the image-aligned slices uneven, 32-channel levels that half-fill the 64-channel weight-gradient blocks and concat
+    seams inside a block (the 4-wave fallback): the f16x3 step (split-f16 kernels) against the exact-fp32 step (a different
+    kernel family) of the same engine, every gradient within 1e-4 of its tensor's max."""
+    from fastdiffsr_amd.engine import Engine
+    B, H, W = shape
+    cfg = UNetConfig(in_channel=6, out_channel=3, inner_channel=32, norm_groups=32, channel_mults=(1, 2, 4), attn_res=(16,),
+                     res_blocks=1, dropout=0.0, image_size=32)
+    sd = synth_state_dict(cfg, 7)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, 6, H, W, generator=g).cuda()
+    nl = (torch.rand(B, generator=g) * 0.5 + 0.4).cuda()
+    tgt = torch.randn(B, 3, H, W, generator=g).cuda()
+    grads = {}
+    for prec in ('f32', 'f16x3'):
+        eng = Engine(cfg)
+        eng.load_state_dict(sd)
+        eng.set_precision(prec)
+        loss = eng.train_grads(x, nl, tgt, 'l1', 1.0 / x[:, :3].numel())
+        grads[prec] = (loss, {k: eng.get_grad(k).copy() for k, _, live in eng.schema() if live})
+    assert abs(grads['f32'][0] - grads['f16x3'][0]) <= 1e-5 * abs(grads['f32'][0])
+    # (with 32 groups over 32 channels a bias or noise shift in front of a GroupNorm has an exactly zero gradient: what either
+    # step reports there is rounding noise, ~1e-6 of the typical gradient -- hence the absolute floor)
+    gmax = max(float(np.abs(a).max()) for a in grads['f32'][1].values())
+    worst = 0.0
+    for k, a in grads['f32'][1].items():
+        b = grads['f16x3'][1][k]
+        scale = float(np.abs(a).max())
+        d = float(np.abs(a - b).max())
+        assert d <= 1e-4 * scale + 1e-6 * gmax, (k, d, scale, gmax)
+        if scale > 1e-3 * gmax:
+            worst = max(worst, d / scale)
+    print(f'ragged {shape}: worst relative gradient difference {worst:.2e} (tensors above 1e-3 of the largest gradient)')
