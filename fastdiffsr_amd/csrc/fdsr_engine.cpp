@@ -1253,6 +1253,7 @@ void fdsr_destroy(fdsr_handle h) {
   if (h->d_rng) (void)hipFree(h->d_rng);
   if (h->d_wtq) (void)hipFree(h->d_wtq);
   if (h->d_hamax) (void)hipFree(h->d_hamax);
+  if (h->d_copy_tab) (void)hipFree(h->d_copy_tab);
   for (float* q : {h->d_master, h->d_grad, h->d_adam_m, h->d_adam_v, h->d_wt, h->d_zero, h->d_hscale})
     if (q) (void)hipFree(q);
   delete h;
