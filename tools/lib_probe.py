@@ -17,7 +17,7 @@ cond, noise = synth_inputs(B, 256, 256, 20)
 c, n = cond.cuda(), noise.cuda()
 out = torch.empty(B, 3, 256, 256, device='cuda')
 e.sample(c, n, out=out); torch.cuda.synchronize()
-for rep in range(2):
+for rep in range(int(os.environ.get("REPS", 6))):
     t0 = time.perf_counter()
     for _ in range(4):
         e.sample(c, n, out=out)
