@@ -208,6 +208,10 @@ def conv_roofline(prof, precision, B, S, dt_total, round_tag='r02'):
          # the engine brackets the conv launches of every 4th diffusion step with HIP
          # events (5 of 20 steps): <1 % overhead in the timed region, measured 2.6 % with all
          'timed_steps_of_20': n_timed}
+    if precision != 'f32':
+        # (until round 2's last change these launches did not contain the 1x1 res_convs: their time sat outside the family)
+        r['launch_set'] = ('every 3x3 conv launch; in the 16-bit modes the 14 1x1 res_convs of a forward ride inside their '
+                           "block2 launches (ConvParams::xr0): their FLOPs, bytes and time are in these figures")
     if dt_total:
         r['conv_time_share'] = prof['conv_ms'] * 1e-3 * (20 / n_timed) / dt_total
     return r

@@ -62,8 +62,9 @@ struct ConvHCfg {
   static_assert(TH % WM == 0, "TH must be a multiple of WM");
 };
 
-template <int KS, int STRIDE, bool UP, int TH, int WN, int PREC, int KSUB>
+template <int KS, int STRIDE, bool UP, int TH, int WN, int PREC, int KSUB, bool RIDER = false>
 __global__ void __launch_bounds__(512, 2) conv_mfma_h_kernel(const ConvParams p) {
+  static_assert(!RIDER || (KS == 3 && STRIDE == 1 && !UP && KSUB == 1), "the rider rides the stride-1 3x3 kernels");
   using Cfg = ConvHCfg<KS, STRIDE, UP, TH, WN, PREC, KSUB>;
   constexpr int TW = Cfg::TW, KC = Cfg::KC, NP = Cfg::NP, ROWB = Cfg::ROWB, PAD = Cfg::PAD, HWD = Cfg::HWD;
   constexpr int NPIX = Cfg::NPIX, WM = Cfg::WM, BN = Cfg::BN, MB = Cfg::MB, RPP = Cfg::RPP, NIN = Cfg::NIN, T = Cfg::T, Q4 = Cfg::Q4, NW = Cfg::NW;
@@ -119,15 +120,24 @@ __global__ void __launch_bounds__(512, 2) conv_mfma_h_kernel(const ConvParams p)
   }
 
   using IO = ActIO<PREC>;
-  typename IO::Quad rin[NIN];
+  typedef typename IO::Quad Quad;
+  Quad rin[NIN];
+  Quad rin2[RIDER ? NIN : 1];   // second prefetch set: the short rider chunks fetch two chunks ahead
   f32x4 rsc = {1.f, 1.f, 1.f, 1.f}, rsh = {0.f, 0.f, 0.f, 0.f};
-  auto prefetch = [&](int kc) {
-    const int cbase = kc * KC;
+  const int nk = p.Cin_pad / KC;               // main chunks; chunks nk .. nk + nkr - 1 are the rider's (raw second input, centre tap)
+  auto prefetch_to = [&](int kc, Quad* rin) {
+    int cbase = kc * KC;
     const float* base;
     int Cs, cc;
-    if (cbase < p.C0) { base = p.x0; Cs = p.C0; cc = cbase + q * 4; }
+    bool g = gn;
+    if (RIDER && kc >= nk) {
+      cbase -= nk * KC;
+      g = false;
+      if (cbase < p.Cr0) { base = p.xr0; Cs = p.Cr0; cc = cbase + q * 4; }
+      else { base = p.xr1; Cs = p.Cr1; cc = cbase - p.Cr0 + q * 4; }
+    } else if (cbase < p.C0) { base = p.x0; Cs = p.C0; cc = cbase + q * 4; }
     else { base = p.x1; Cs = p.C1; cc = cbase - p.C0 + q * 4; }
-    if (gn) {   // per-(image, channel) GroupNorm scale/shift travel with the input prefetch
+    if (g) {   // per-(image, channel) GroupNorm scale/shift travel with the input prefetch
       rsc = *reinterpret_cast<const f32x4*>(p.gn_scale + (size_t)n * Cin + cbase + q * 4);
       rsh = *reinterpret_cast<const f32x4*>(p.gn_shift + (size_t)n * Cin + cbase + q * 4);
     }
@@ -135,13 +145,14 @@ __global__ void __launch_bounds__(512, 2) conv_mfma_h_kernel(const ConvParams p)
     for (int i = 0; i < NIN; ++i)   // branch-free: padding / unused rows read pixel 0 and are zeroed in stage()
       rin[i] = IO::load4(base, (size_t)(in_pix[i] < 0 ? 0 : in_pix[i]) * Cs + cc);
   };
-  auto stage = [&](int kc, unsigned char* buf) {
+  auto prefetch = [&](int kc) { prefetch_to(kc, rin); };
+  auto stage_from = [&](int kc, unsigned char* buf, const Quad* rin) {
     const f32x4 sc = rsc, sh = rsh;
 #pragma unroll
     for (int i = 0; i < NIN; ++i) {
       if (NIN * RPP > NPIX && i == NIN - 1 && row0 + i * RPP >= NPIX) continue;   // only the last pass can overrun
       f32x4 v = IO::widen(rin[i]);
-      if (gn) {
+      if (gn && !(RIDER && kc >= nk)) {
         v = v * sc + sh;
         if (!p.gn_plain) { v.x = silu_h(v.x); v.y = silu_h(v.y); v.z = silu_h(v.z); v.w = silu_h(v.w); }
       }
@@ -164,14 +175,17 @@ __global__ void __launch_bounds__(512, 2) conv_mfma_h_kernel(const ConvParams p)
       }
     }
   };
+  auto stage = [&](int kc, unsigned char* buf) { stage_from(kc, buf, rin); };
 
   // ---- weight fragments: [cot][kc][wn][tap][plane][lane] x 16 B, loaded straight to VGPRs ----
   const uint4* wq = reinterpret_cast<const uint4*>(p.wq);
-  const int nk = p.Cin_pad / KC;
+  const int nkt = RIDER ? nk + p.nkr : nk;
   uint4 Bf[T][NP];
   auto load_b_tap = [&](int kc, int tap) {
     const int ts = tap / KSUB, sub = tap % KSUB;   // packed per 16-channel block: [cot][kc16][wn][spatial tap]
     const uint4* src = wq + ((((size_t)cot * (nk * KSUB) + kc * KSUB + sub) * WN + wn) * (KS * KS) + ts) * (NP * 64) + lane;
+    if (RIDER && kc >= nk)   // the 1x1 conv's own fragments [cot][kc16][wn]: one tap, into slot 0
+      src = reinterpret_cast<const uint4*>(p.wq_r) + (((size_t)cot * p.nkr + (kc - nk)) * WN + wn) * (NP * 64) + lane;
 #pragma unroll
     for (int pl = 0; pl < NP; ++pl) Bf[tap][pl] = src[pl * 64];
   };
@@ -191,9 +205,10 @@ __global__ void __launch_bounds__(512, 2) conv_mfma_h_kernel(const ConvParams p)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[mb][i] = 0.f;
 
-  const int kc0 = ksi * nk / SK, kc1 = (ksi + 1) * nk / SK;   // this slice's chunks
+  const int kc0 = ksi * nkt / SK, kc1 = (ksi + 1) * nkt / SK;   // this slice's chunks
 #pragma unroll
-  for (int tap = 0; tap < T; ++tap) load_b_tap(kc0, tap);
+  for (int tap = 0; tap < T; ++tap)
+    if (tap == 0 || !(RIDER && kc0 >= nk)) load_b_tap(kc0, tap);
   prefetch(kc0);
   stage(kc0, sBuf0);
   if (kc0 + 1 < kc1) prefetch(kc0 + 1);
@@ -214,10 +229,13 @@ __global__ void __launch_bounds__(512, 2) conv_mfma_h_kernel(const ConvParams p)
         Af[slot][mb][pl] = *reinterpret_cast<const uint4*>(arow[mb] + aoff + 32 * pl);
   };
 
-  for (int kc = kc0; kc < kc1; ++kc) {
+  // main chunks: all taps of 16 GroupNorm'ed channels
+  const int kcm = RIDER ? (kc1 < nk ? kc1 : nk) : kc1;
+  for (int kc = kc0; kc < kcm; ++kc) {
     unsigned char* cur = ((kc - kc0) & 1) ? sBuf1 : sBuf0;
     unsigned char* nxt = ((kc - kc0) & 1) ? sBuf0 : sBuf1;
     const bool more = kc + 1 < kc1;
+    const bool next_rider = RIDER && kc + 1 >= nk;
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) arow[mb] = cur + abase[mb];
     load_a(0, 0);
@@ -236,13 +254,55 @@ __global__ void __launch_bounds__(512, 2) conv_mfma_h_kernel(const ConvParams p)
           acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8, ahi), __builtin_bit_cast(b8, Bf[tap][0]), acc[mb], 0, 0, 0);
         }
       }
-      if (more) load_b_tap(kc + 1, tap);             // same registers, next chunk
+      if (more && (tap == 0 || !next_rider)) load_b_tap(kc + 1, tap);   // same registers, next chunk
       if (tap == T / 2 && more) {                    // mid-chunk: fill the other halo buffer
         stage(kc + 1, nxt);
         if (kc + 2 < kc1) prefetch(kc + 2);
       }
     }
     __syncthreads();
+  }
+  if (RIDER && kc1 > nk) {
+    // rider chunks: 16 raw channels of the second input each, centre tap only, the 1x1 conv's fragments in slot 0
+    if (kc0 < nk) {   // the accumulators leave the main conv's weight scale for the rider's (a power of two: exact)
+      const float ratio = (p.w_inv_scale_dev ? *p.w_inv_scale_dev : p.w_inv_scale) / (p.w_inv_scale_r_dev ? *p.w_inv_scale_r_dev : p.w_inv_scale_r);
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) acc[mb] *= ratio;
+    }
+    // A rider chunk is short (MB x 3 MFMAs): its input is fetched TWO chunks ahead, into two register sets that alternate
+    // (on entry `rin` holds chunk k0 + 1, as the main loop leaves it; the weight registers of taps 1..8 are free by now).
+    const int k0 = kc0 > nk ? kc0 : nk;
+    if (k0 + 2 < kc1) prefetch_to(k0 + 2, rin2);
+    auto rider_chunk = [&](int kc, Quad* r1, Quad* r2) {   // r1 holds chunk kc + 1, r2 chunk kc + 2
+      unsigned char* cur = ((kc - kc0) & 1) ? sBuf1 : sBuf0;
+      unsigned char* nxt = ((kc - kc0) & 1) ? sBuf0 : sBuf1;
+      (void)r2;
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) arow[mb] = cur + abase[mb];
+      load_a(0, T / 2);
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        const uint4 ahi = Af[0][mb][0];
+        if (PREC == PREC_F16X3) {
+          const uint4 alo = Af[0][mb][NP - 1];
+          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, alo), __builtin_bit_cast(h8, Bf[0][0]), acc[mb], 0, 0, 0);
+          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, ahi), __builtin_bit_cast(h8, Bf[0][NP - 1]), acc[mb], 0, 0, 0);
+          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, ahi), __builtin_bit_cast(h8, Bf[0][0]), acc[mb], 0, 0, 0);
+        } else {
+          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8, ahi), __builtin_bit_cast(b8, Bf[0][0]), acc[mb], 0, 0, 0);
+        }
+      }
+      if (kc + 1 < kc1) {
+        load_b_tap(kc + 1, 0);
+        stage_from(kc + 1, nxt, r1);
+        if (kc + 3 < kc1) prefetch_to(kc + 3, r1);
+      }
+      __syncthreads();
+    };
+    for (int kc = k0; kc < kc1; kc += 2) {
+      rider_chunk(kc, rin, rin2);
+      if (kc + 1 < kc1) rider_chunk(kc + 1, rin2, rin);
+    }
   }
 
   // ---- epilogue.  Interior tiles take a branch-free path: per-element bounds branches make the
@@ -253,10 +313,17 @@ __global__ void __launch_bounds__(512, 2) conv_mfma_h_kernel(const ConvParams p)
   float add = 0.f;
   if (cok) {
     add = p.bias[co];
+    if (RIDER) add += p.bias_r[co];
     if (p.temb) add += p.temb[(size_t)n * p.temb_stride + p.temb_off + co];
   }
   float s1 = 0.f, s2 = 0.f;
-  const float winv = p.w_inv_scale_dev ? *p.w_inv_scale_dev : p.w_inv_scale;   // uniform: a scalar load
+  const float winv_m = p.w_inv_scale_dev ? *p.w_inv_scale_dev : p.w_inv_scale;   // uniform: a scalar load
+  const float winv = RIDER ? (p.w_inv_scale_r_dev ? *p.w_inv_scale_r_dev : p.w_inv_scale_r) : winv_m;
+  if (RIDER && kc1 <= nk) {   // (split K) a slice that never reached the rider chunks: bring it to the rider's scale too
+    const float ratio = winv_m / winv;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) acc[mb] *= ratio;
+  }
   const bool interior = (oy0 + TH <= p.Hout) && (ox0 + TW <= p.Wout) && (co0 + BN <= p.Cout);
   if (SK > 1) {   // raw partial accumulators; bias, shift, residual and statistics happen in the reduce
     float* sb = p.kscratch + (size_t)ksi * p.N * p.Hout * p.Wout * p.Cout;
@@ -372,6 +439,7 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const ConvParams p, 
   f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
   if (g < groups) {
     f32x4 add = *reinterpret_cast<const f32x4*>(p.bias + cbase + c4 * 4);
+    if (p.xr0) add += *reinterpret_cast<const f32x4*>(p.bias_r + cbase + c4 * 4);
     if (p.temb) add += *reinterpret_cast<const f32x4*>(p.temb + (size_t)n * p.temb_stride + p.temb_off + cbase + c4 * 4);
     const size_t slice = (size_t)p.N * p.Hout * p.Wout * p.Cout;
     for (int px = g; px < 64; px += groups) {
@@ -381,7 +449,7 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const ConvParams p, 
       f32x4 a = *reinterpret_cast<const f32x4*>(p.kscratch + o);
 #pragma unroll 4
       for (int s = 1; s < p.ksplit; ++s) a += *reinterpret_cast<const f32x4*>(p.kscratch + s * slice + o);
-      a = a * (p.w_inv_scale_dev ? *p.w_inv_scale_dev : p.w_inv_scale) + add;
+      a = a * (p.xr0 ? (p.w_inv_scale_r_dev ? *p.w_inv_scale_r_dev : p.w_inv_scale_r) : (p.w_inv_scale_dev ? *p.w_inv_scale_dev : p.w_inv_scale)) + add;
       if (p.out_bf16) {   // bf16 mode: residual and output are bf16 tensors
         if (p.res) a += ActIO<PREC_BF16>::widen(ActIO<PREC_BF16>::load4(p.res, o));
         uint2 pk;
@@ -415,10 +483,10 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const ConvParams p, 
   }
 }
 
-template <int KS, int STRIDE, bool UP, int TH, int WN, int PREC, int KSUB>
+template <int KS, int STRIDE, bool UP, int TH, int WN, int PREC, int KSUB, bool RIDER = false>
 static hipError_t launch_h_t(const ConvParams& p, hipStream_t s, int* tiles) {
   using Cfg = ConvHCfg<KS, STRIDE, UP, TH, WN, PREC, KSUB>;
-  auto kfn = conv_mfma_h_kernel<KS, STRIDE, UP, TH, WN, PREC, KSUB>;
+  auto kfn = conv_mfma_h_kernel<KS, STRIDE, UP, TH, WN, PREC, KSUB, RIDER>;
   const size_t lds = (size_t)2 * Cfg::BUF_BYTES;
   const int tilesX = (p.Wout + Cfg::TW - 1) / Cfg::TW, tilesY = (p.Hout + TH - 1) / TH;
   if (tiles) *tiles = tilesX * tilesY;
@@ -436,9 +504,9 @@ static hipError_t launch_h_t(const ConvParams& p, hipStream_t s, int* tiles) {
   return hipGetLastError();
 }
 
-template <int KS, int STRIDE, bool UP, int TH, int WN, int PREC, int KSUB>
+template <int KS, int STRIDE, bool UP, int TH, int WN, int PREC, int KSUB, bool RIDER = false>
 static hipError_t init_h_t() {
-  auto kfn = conv_mfma_h_kernel<KS, STRIDE, UP, TH, WN, PREC, KSUB>;
+  auto kfn = conv_mfma_h_kernel<KS, STRIDE, UP, TH, WN, PREC, KSUB, RIDER>;
   return hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
@@ -454,6 +522,10 @@ static hipError_t init_h_t() {
   X(1, 1, false, 16, 1, 1) X(1, 1, false, 8, 1, 1) X(1, 1, false, 4, 8, 1) X(1, 1, false, 2, 8, 1)                       \
   X(1, 1, false, 8, 4, 4) X(1, 1, false, 4, 4, 4) X(1, 1, false, 8, 2, 4) X(1, 1, false, 4, 2, 4)                         \
   X(1, 1, false, 8, 1, 4) X(1, 1, false, 4, 8, 4) X(1, 1, false, 2, 8, 4)
+
+// the stride-1 3x3 shapes, again with a 1x1 rider: XR(TH, WN)
+#define FDSR_CONVH_RIDER_SHAPES(XR) \
+  XR(8, 4) XR(4, 4) XR(16, 2) XR(8, 2) XR(4, 2) XR(16, 1) XR(8, 1) XR(4, 8) XR(2, 8)
 
 // Output-channel split of the workgroup (weights are packed per WN, so this depends on the layer only).
 void conv_h_config(ConvKind kind, int Cout, int* TH, int* WN) {
@@ -508,6 +580,16 @@ hipError_t launch_conv_h(ConvKind kind, int prec, const ConvParams& p, hipStream
   TH = pick_th(kind, WN, ksub, p);
   const int ks = kind == CONV1 ? 1 : 3, stride = kind == CONV3_S2 ? 2 : 1;
   const bool up = kind == CONV3_UP;
+  if (p.xr0) {   // 3x3 stride-1 with a 1x1 rider
+    if (kind != CONV3_S1) return hipErrorInvalidValue;
+#define XR(TH_, WN_)                                                                                     \
+    if (TH == TH_ && WN == WN_)                                                                          \
+      return prec == PREC_F16X3 ? launch_h_t<3, 1, false, TH_, WN_, PREC_F16X3, 1, true>(p, s, tiles)     \
+                                : launch_h_t<3, 1, false, TH_, WN_, PREC_BF16, 1, true>(p, s, tiles);
+    FDSR_CONVH_RIDER_SHAPES(XR)
+#undef XR
+    return hipErrorInvalidValue;
+  }
 #define X(KS_, ST_, UP_, TH_, WN_, KSUB_)                                                                \
   if (ks == KS_ && stride == ST_ && up == UP_ && TH == TH_ && WN == WN_ && ksub == KSUB_) {               \
     return prec == PREC_F16X3 ? launch_h_t<KS_, ST_, UP_, TH_, WN_, PREC_F16X3, KSUB_>(p, s, tiles)       \
@@ -525,6 +607,11 @@ hipError_t kernels_h_init() {
   if ((e = init_h_t<KS_, ST_, UP_, TH_, WN_, PREC_BF16, KSUB_>()) != hipSuccess) return e;
   FDSR_CONVH_SHAPES(X)
 #undef X
+#define XR(TH_, WN_)                                                                                    \
+  if ((e = init_h_t<3, 1, false, TH_, WN_, PREC_F16X3, 1, true>()) != hipSuccess) return e;              \
+  if ((e = init_h_t<3, 1, false, TH_, WN_, PREC_BF16, 1, true>()) != hipSuccess) return e;
+  FDSR_CONVH_RIDER_SHAPES(XR)
+#undef XR
   return hipSuccess;
 }
 

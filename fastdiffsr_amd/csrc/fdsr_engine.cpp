@@ -152,6 +152,7 @@ int finish_plan(fdsr_handle h, const std::string mlp_keys[4], int row_len) {
     const Op& op = h->ops[i];
     auto use = [&](int t) { if (t >= 0) h->tensors[t].last_use = (int)i; };
     use(op.src0); use(op.src1); use(op.res);
+    if (op.rider >= 0) { use(h->ops[op.rider].src0); use(h->ops[op.rider].src1); }   // the fused launch reads the res_conv input itself
     if (op.aux >= 0) {
       if (h->tensors[op.aux].first_def < 0) h->tensors[op.aux].first_def = (int)i;
       h->tensors[op.aux].last_use = (int)i;
@@ -278,16 +279,19 @@ int build_plan(fdsr_handle h) {
     h->tensors[k1.dst].need_part = true;
     h->ops.push_back(s2);
     const int out = new_tensor(h, Cout, lvl, with_attn ? r : p);
-    int res_src = x0;
+    int res_src = x0, kr_idx = -1;
     if (wr >= 0) {   // res_conv 1x1 on the raw (concatenated) input, written into `out` first
       Op kr; kr.kind = Op::CONV; kr.name = r + ".res_conv"; kr.ck = CONV1; kr.src0 = x0; kr.src1 = x1; kr.C0 = C0; kr.C1 = C1;
       kr.Cout = Cout; kr.lvl_in = kr.lvl_out = lvl; kr.w = wr; kr.b = br; kr.dst = out; kr.no_part = true;
+      kr_idx = (int)h->ops.size();
+      kr.rider_of = kr_idx + 1;   // block2 comes next: on the 16-bit kernels it can carry this conv as a rider (run_unet)
       h->ops.push_back(kr);
       res_src = out;
     }
     Op k2; k2.kind = Op::CONV; k2.name = r + ".block2"; k2.ck = CONV3_S1; k2.src0 = k1.dst; k2.C0 = Cout; k2.Cout = Cout;
     k2.lvl_in = k2.lvl_out = lvl; k2.gn_slot = s2.gn_slot; k2.gamma = g2; k2.beta = b2; k2.w = w2; k2.b = c2; k2.res = res_src;
     k2.dst = out;
+    k2.rider = kr_idx;
     if (c.dropout > 0.f) k2.drop_slot = h->n_drop_slots++;   // block2 = Block(dim_out, dim_out, dropout=dropout), unet.py:112
     h->ops.push_back(k2);
     int result = out;
@@ -882,6 +886,20 @@ int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, 
         break;
       }
       case Op::CONV: {
+        // ResnetBlock's res_conv as a rider of block2 (16-bit kernels, sampling): one launch, no round trip of its output
+        // through HBM.  Measured same-box: every res_conv fused is as good as or better than fusing only the bandwidth-bound
+        // ones (FDSR_RIDER=1: full-resolution level + input widths up to the output width), at every batch size;
+        // FDSR_RIDER=0 turns it off.
+        auto rides = [&](const Op& k2) -> bool {
+          static const int mode = getenv("FDSR_RIDER") ? atoi(getenv("FDSR_RIDER")) : 2;
+          if (mode == 0 || k2.rider < 0 || h->prec == PREC_F32 || h->keep_stats) return false;
+          const Op& kr = h->ops[k2.rider];
+          const WeightEntry &w2 = h->weights[k2.w], &wr = h->weights[kr.w];
+          if (!w2.h_ok || !wr.h_ok || wr.h_WN != w2.h_WN || wr.h_cout_pad != w2.h_cout_pad) return false;
+          return mode == 2 || k2.lvl_out == 0 || kr.C0 + kr.C1 <= k2.Cout;
+        };
+        if (op.rider_of >= 0 && rides(h->ops[op.rider_of])) break;
+        const bool ridden = op.rider >= 0 && rides(op);
         ConvParams p{};
         const WeightEntry& w = h->weights[op.w];
         p.x0 = TP(op.src0);
@@ -893,6 +911,17 @@ int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, 
         p.temb_off = op.temb_off >= 0 ? op.temb_off : 0;
         p.res = TP(op.res);
         p.out = TP(op.dst);
+        if (ridden) {
+          const Op& kr = h->ops[op.rider];
+          const WeightEntry& wr = h->weights[kr.w];
+          p.res = nullptr;
+          p.xr0 = TP(kr.src0); p.xr1 = TP(kr.src1); p.Cr0 = kr.C0; p.Cr1 = kr.C1;
+          p.nkr = wr.h_cin_pad / 16;
+          p.wq_r = h->d_wq + wr.hq_off[h->prec];
+          p.bias_r = P(kr.b);
+          p.w_inv_scale_r = wr.h_inv_scale[h->prec];
+          if (h->prec == PREC_F16X3) p.w_inv_scale_r_dev = h->d_hscale + 2 * (size_t)kr.w + 1;
+        }
         if (op.gn_slot >= 0) {
           p.gn_scale = reinterpret_cast<const float*>(ws + sp.gn_off[op.gn_slot]);
           p.gn_shift = p.gn_scale + (size_t)N * (op.C0 + op.C1);
@@ -954,10 +983,12 @@ int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, 
         if (timed) {
           HIPCHK(h, hipEventRecord(h->ev_pool[h->ev_used++], st));
           double f = conv_flops(op, N, H, W);
+          if (ridden) f += conv_flops(h->ops[op.rider], N, H, W);
           if (op.src0 == h->t_in) f *= (double)h->cfg.in_channel / h->CP;
           h->prof_flops += f;
           // algorithmic bytes: input read once + output written once
           h->prof_bytes += 4.0 * N * ((double)Hi * Wi * (op.C0 + op.C1) + (double)p.Hout * p.Wout * op.Cout);
+          if (ridden) h->prof_bytes += 4.0 * N * (double)Hi * Wi * (h->ops[op.rider].C0 + h->ops[op.rider].C1);
         }
         break;
       }

@@ -63,6 +63,8 @@ struct Op {
   int heads = 1;          // ATTN
   bool force_generic = false;   // CONV3_UP with a GroupNorm prologue: not the sub-pixel kernel
   int drop_slot = -1;     // block2 conv with Dropout(p > 0) in front of it (unet.py:89-101): index of its keep-mask
+  int rider = -1;         // block2 conv: index of the res_conv op it can absorb as a 1x1 rider (ConvParams::xr0); that op: rider_of
+  int rider_of = -1;
 };
 
 struct ShapePlan {

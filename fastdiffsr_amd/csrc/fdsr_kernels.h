@@ -46,6 +46,16 @@ struct ConvParams {
   // keep is a byte per element of the input tensor (dropout_mask_kernel); fp32 kernel only.
   const unsigned char* drop_mask;   // [N][Hin][Win][C0] or null
   float drop_scale;
+  // "rider" (16-bit 3x3 stride-1 kernels only): a 1x1 convolution over a second, raw input (xr0 | xr1) accumulated into the same
+  // output tile -- ResnetBlock's out = block2(h) + res_conv(x) (unet.py:104-120) in one launch, without the round trip of the
+  // res_conv output through HBM.  Its weights are the 1x1 conv's own fragments (same WN), its bias is added in the epilogue.
+  const float* xr0;      // null: no rider
+  const float* xr1;
+  int Cr0, Cr1, nkr;     // nkr: 16-channel chunks of the rider (its fragment stride)
+  const void* wq_r;
+  const float* bias_r;
+  float w_inv_scale_r;               // the rider's accumulator un-scaling; the accumulator is brought to THIS scale when the
+  const float* w_inv_scale_r_dev;    // K loop passes from the main chunks to the rider chunks (powers of two: exact)
 };
 
 enum Precision { PREC_F32 = 0, PREC_F16X3 = 1, PREC_BF16 = 2 };
