@@ -889,10 +889,10 @@ int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, 
         // ResnetBlock's res_conv as a rider of block2 (16-bit kernels, sampling): one launch, no round trip of its output
         // through HBM.  Measured same-box: every res_conv fused is as good as or better than fusing only the bandwidth-bound
         // ones (FDSR_RIDER=1: full-resolution level + input widths up to the output width), at every batch size;
-        // FDSR_RIDER=0 turns it off.
+        // FDSR_RIDER=0 turns it off.  Training forwards ride too (the backward never reads the res_conv output).
         auto rides = [&](const Op& k2) -> bool {
           static const int mode = getenv("FDSR_RIDER") ? atoi(getenv("FDSR_RIDER")) : 2;
-          if (mode == 0 || k2.rider < 0 || h->prec == PREC_F32 || h->keep_stats) return false;
+          if (mode == 0 || k2.rider < 0 || h->prec == PREC_F32) return false;
           const Op& kr = h->ops[k2.rider];
           const WeightEntry &w2 = h->weights[k2.w], &wr = h->weights[kr.w];
           if (!w2.h_ok || !wr.h_ok || wr.h_WN != w2.h_WN || wr.h_cout_pad != w2.h_cout_pad) return false;
