@@ -345,3 +345,21 @@ def test_infer_size_512(full):
         report(f'512x512 forward {prec}: max|d|={d:.3e}')
         assert d <= TOL_FWD
     eng.set_precision('f32')
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize('mode', ['0', '1'])
+def test_res_conv_as_its_own_launch_or_riding_by_rule(mode):
+    """By default every ResnetBlock res_conv rides inside block2's 3x3 launch on the 16-bit kernels (ConvParams::xr0);
+    FDSR_RIDER=0 keeps it a launch of its own, =1 lets only the bandwidth-bound ones ride.  Each setting must meet the same
+    layer-by-layer and 20-step-loop bounds against the oracle in f16x3 and bf16 (fresh process: the switch is read once)."""
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env['FDSR_RIDER'] = mode
+    here = os.path.abspath(__file__)
+    r = subprocess.run([sys.executable, '-m', 'pytest', here, '-m', 'gpu', '-q', '-x', '-k',
+                        'test_precision_modes_layerwise_and_loop or test_other_architectures'],
+                       env=env, capture_output=True, text=True, timeout=840, cwd=os.path.dirname(os.path.dirname(here)))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert ' passed' in r.stdout and 'failed' not in r.stdout
