@@ -186,6 +186,7 @@ __global__ void __launch_bounds__(512, 2) conv_up2_h_kernel(const ConvParams p) 
   // ---- epilogue: out[(2(oy0+row)+py)][2(ox0+col)+px], + bias (+ temb), GN partials of the output ----
   const int co = co0 + wn * 32 + r31;
   const bool cok = co < p.Cout;
+  const float winv = p.w_inv_scale_dev ? *p.w_inv_scale_dev : p.w_inv_scale;   // device value: forms re-packed after optimiser steps
   float add = 0.f;
   if (cok) {
     add = p.bias[co];
@@ -202,7 +203,7 @@ __global__ void __launch_bounds__(512, 2) conv_up2_h_kernel(const ConvParams p) 
       for (int px = 0; px < 2; ++px)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          const float v = acc[mb][px][i] * p.w_inv_scale + add;
+          const float v = acc[mb][px][i] * winv + add;
           IO::store1(p.out, rowp + (size_t)(2 * ((i & 3) + 8 * (i >> 2)) + px) * p.Cout, v);   // bf16 mode: bf16 activation
           s1 += v;
           s2 += v * v;
@@ -217,7 +218,7 @@ __global__ void __launch_bounds__(512, 2) conv_up2_h_kernel(const ConvParams p) 
         for (int i = 0; i < 16; ++i) {
           const int sy = oy0 + wm + mb * WM, sx = ox0 + (i & 3) + 8 * (i >> 2) + 4 * h;
           if (cok && sy < p.Hin && sx < p.Win) {
-            const float v = acc[mb][px][i] * p.w_inv_scale + add;
+            const float v = acc[mb][px][i] * winv + add;
             IO::store1(p.out, ((size_t)(n * p.Hout + 2 * sy + py) * p.Wout + 2 * sx + px) * p.Cout + co, v);
             s1 += v;
             s2 += v * v;

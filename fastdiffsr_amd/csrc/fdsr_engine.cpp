@@ -966,8 +966,9 @@ int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, 
           if (h->prec == PREC_F16X3) p.w_inv_scale_dev = h->d_hscale + 2 * (size_t)op.w + 1;
           static const bool no_up2 = getenv("FDSR_NO_UP2") != nullptr;
           // (after optimiser steps the sub-pixel forms lag until fdsr_sync_weight_forms: training forwards use the generic kernel)
-          if (op.ck == CONV3_UP && !no_up2 && !op.force_generic && !h->h_forms_stale && !h->keep_stats) {
-            p.w_inv_scale_dev = nullptr;
+          const bool up2_dev = h->prec == PREC_F16X3 && h->up2_dev_fresh;   // re-packed on the device by the last optimiser step
+          if (op.ck == CONV3_UP && !no_up2 && !op.force_generic && (!h->h_forms_stale || up2_dev)) {
+            p.w_inv_scale_dev = up2_dev ? h->d_up2_inv + op.w : nullptr;
             p.wq = h->d_wq + w.up2_off[h->prec];
             p.w_inv_scale = w.up2_inv_scale[h->prec];
             HIPCHK(h, launch_conv_up2_h(h->prec, p, st, &nt));
@@ -1285,6 +1286,7 @@ void fdsr_destroy(fdsr_handle h) {
   if (h->d_wtq) (void)hipFree(h->d_wtq);
   if (h->d_hamax) (void)hipFree(h->d_hamax);
   if (h->d_copy_tab) (void)hipFree(h->d_copy_tab);
+  if (h->d_up2_inv) (void)hipFree(h->d_up2_inv);
   for (float* q : {h->d_master, h->d_grad, h->d_adam_m, h->d_adam_v, h->d_wt, h->d_zero, h->d_hscale})
     if (q) (void)hipFree(q);
   delete h;
@@ -1338,6 +1340,7 @@ int fdsr_load_weight(fdsr_handle h, const char* key, const float* host, const in
   }
   w.loaded = true;
   h->wt_valid = false;
+  h->up2_dev_fresh = false;   // this tensor's sub-pixel form is host-packed again (own scale)
   h->temb_table_valid = false;
   for (auto& g : h->graphs) (void)hipGraphExecDestroy(g.exec);   // weights are baked by address only, but be safe
   h->graphs.clear();

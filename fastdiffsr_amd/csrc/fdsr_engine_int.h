@@ -166,6 +166,8 @@ struct fdsr_engine {
   unsigned drop_step = 0;             // forward passes made in training mode: part of the mask's Philox counter
   bool keep_stats = false;            // forward also stores per-(image, group) mean / rstd of every GroupNorm
   bool h_forms_stale = false;         // 16-bit weight forms lag behind the master copy (after an optimiser step)
+  float* d_up2_inv = nullptr;         // per weight entry: un-scaling of its device-packed sub-pixel (upsample) form
+  bool up2_dev_fresh = false;         // the f16x3 sub-pixel forms were re-packed on the device after the last optimiser step
   bool f32_forms_stale = false;       // fp32 conv forms (d_params packs, d_wt) lag: f16x3 training steps refresh only what they read
   unsigned long long* d_copy_tab = nullptr;   // {src offset, dst offset, count} triples: master -> d_params for the non-conv tensors
   int n_copy_tab = 0;

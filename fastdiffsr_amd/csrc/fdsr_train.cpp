@@ -158,6 +158,7 @@ int train_prepare(fdsr_handle h) {
   h->wtq_bytes = qoff;
   HIPCHK(h, hipMalloc((void**)&h->d_wtq, std::max<size_t>(qoff, 256)));
   HIPCHK(h, hipMalloc((void**)&h->d_hamax, h->weights.size() * sizeof(unsigned)));
+  HIPCHK(h, hipMalloc((void**)&h->d_up2_inv, h->weights.size() * sizeof(float)));
   HIPCHK(h, hipMalloc((void**)&h->d_wt, std::max<size_t>(off, 4) * sizeof(float)));
   HIPCHK(h, hipMalloc((void**)&h->d_zero, (size_t)round_up(maxC, 64) * sizeof(float)));
   HIPCHK(h, hipMemset(h->d_zero, 0, (size_t)round_up(maxC, 64) * sizeof(float)));
@@ -224,10 +225,15 @@ int repack_from_master(fdsr_handle h, hipStream_t st, bool forward_forms, bool a
     if (!w.live || w.sink != WeightEntry::CONV_PACK || !w.h_ok) continue;
     const float* src = h->d_master + h->master_off[i];
     float* sc2 = h->d_hscale + 2 * (size_t)i;
-    if (forward_forms)
+    if (forward_forms) {
       HIPCHK(h, launch_pack_conv_h(src, h->d_wq + w.hq_off[PREC_F16X3], sc2, (int)w.shape[0], (int)w.shape[1], w.ks, w.h_WN,
                                    w.h_cout_pad, w.h_cin_pad, 0, 0, 0, st));
+      if (w.ck == CONV3_UP)   // and the sub-pixel form the upsample convs run on
+        HIPCHK(h, launch_pack_conv_up2_h(src, h->d_wq + w.up2_off[PREC_F16X3], sc2, h->d_up2_inv + i, (int)w.shape[0], (int)w.shape[1],
+                                         w.h_WN, w.h_cout_pad, w.h_cin_pad, st));
+    }
   }
+  if (forward_forms) h->up2_dev_fresh = true;
   for (const Op& op : h->ops) {
     if (op.kind != Op::CONV || op.src0 == h->t_in || h->wtq_off0[op.w] == SIZE_MAX) continue;
     const WeightEntry& w = h->weights[op.w];
@@ -602,6 +608,7 @@ int fdsr_sync_weight_forms(fdsr_handle h) {
     if (rc) return rc;
   }
   h->h_forms_stale = false;
+  h->up2_dev_fresh = false;   // the host-packed sub-pixel forms (own scale) are current again
   return FDSR_OK;
 }
 

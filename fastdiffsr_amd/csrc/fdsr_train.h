@@ -137,6 +137,9 @@ hipError_t launch_hscale_all(const unsigned* amax_bits, float* scale2, int nslot
 // conv weight  W'[co' = ci - c_off][ci' = co][tap'] = W[co][ci][T-1-tap'],  co' < rows (the Cin slice of one concat source)
 hipError_t launch_pack_conv_h(const float* w, void* frags, const float* scale2, int Cout, int Cin, int ks, int WN, int cout_pad,
                               int cin_pad, int transposed, int c_off, int rows, hipStream_t s);
+// the sub-pixel form of an upsample conv (fdsr_conv_up2.hip) from the fp32 master weights, scale = scale2[0] / 4; *inv_out = its inverse
+hipError_t launch_pack_conv_up2_h(const float* w, void* frags, const float* scale2, float* inv_out, int Cout, int Cin, int WN, int cout_pad,
+                                  int cin_pad, hipStream_t s);
 // a[n][p][c] = swish(x*scale + shift) * keep * drop_scale: the dropped activation of block2 materialised, for the f16x3
 // forward (the 16-bit conv kernel then reads it raw; its staging has no spare registers for the mask)
 hipError_t launch_gn_silu_drop(const float* x, const float* gn_scale, const float* gn_shift, const unsigned char* mask, float drop_scale,

@@ -2032,6 +2032,61 @@ __global__ void __launch_bounds__(256) pack_conv_h_kernel(const float* __restric
   frags[(fidx * 2 + 1) * 64 + l] = b;             // plane 1 = lo
 }
 
+// Sub-pixel form of Upsample(nearest x2) + Conv3x3 (pack_weights_h in fdsr_engine.cpp): per output parity (py, px) and source
+// offset (a, b) the 3x3 taps that land there are pre-summed; fragments [cot][kc][wn][py][px*4+a*2+b][plane][lane] x 16 B.  A sum
+// of up to four taps is at most 4 max|w|, so the scale is the 3x3 form's divided by 4 (inv_out = its inverse, for the epilogue).
+__global__ void __launch_bounds__(256) pack_conv_up2_h_kernel(const float* __restrict__ w, uint4* __restrict__ frags,
+                                                              const float* __restrict__ scale2, float* __restrict__ inv_out, int Cout,
+                                                              int Cin, int WN, int nk, size_t total) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;   // over [cot][kc][wn][py][slot][lane]
+  if (i == 0) *inv_out = scale2[1] * 4.0f;
+  if (i >= total) return;
+  const int l = (int)(i & 63);
+  size_t f = i >> 6;
+  const int slot = (int)(f & 7);  f >>= 3;
+  const int py = (int)(f & 1);  f >>= 1;
+  const int wn = (int)(f % WN);  f /= WN;
+  const int kc = (int)(f % nk);
+  const int cot = (int)(f / nk);
+  const int px = slot >> 2, a = (slot >> 1) & 1, b = slot & 1;
+  // taps of parity par that land on source offset o: par 0: {0} | {1,2}; par 1: {0,1} | {2}
+  const int y0 = py == 0 ? (a == 0 ? 0 : 1) : (a == 0 ? 0 : 2), y1 = py == 0 ? (a == 0 ? 0 : 2) : (a == 0 ? 1 : 2);
+  const int x0 = px == 0 ? (b == 0 ? 0 : 1) : (b == 0 ? 0 : 2), x1 = px == 0 ? (b == 0 ? 0 : 2) : (b == 0 ? 1 : 2);
+  const int co = cot * 32 * WN + wn * 32 + (l & 31);
+  const float scale = scale2[0] * 0.25f;
+  unsigned short hi[8], lo[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = kc * 16 + 8 * (l >> 5) + j;
+    float v = 0.f;
+    if (co < Cout && k < Cin) {
+      const float* wp = w + ((size_t)co * Cin + k) * 9;
+      for (int ky = y0; ky <= y1; ++ky)
+        for (int kx = x0; kx <= x1; ++kx) v += wp[ky * 3 + kx];
+    }
+    const float vs = v * scale;
+    const _Float16 h = (_Float16)vs;
+    const _Float16 lw = (_Float16)(vs - (float)h);
+    hi[j] = __builtin_bit_cast(unsigned short, h);
+    lo[j] = __builtin_bit_cast(unsigned short, lw);
+  }
+  const size_t fidx = (i >> 6);
+  uint4 ua, ub;
+  ua.x = hi[0] | ((unsigned)hi[1] << 16); ua.y = hi[2] | ((unsigned)hi[3] << 16); ua.z = hi[4] | ((unsigned)hi[5] << 16); ua.w = hi[6] | ((unsigned)hi[7] << 16);
+  ub.x = lo[0] | ((unsigned)lo[1] << 16); ub.y = lo[2] | ((unsigned)lo[3] << 16); ub.z = lo[4] | ((unsigned)lo[5] << 16); ub.w = lo[6] | ((unsigned)lo[7] << 16);
+  frags[(fidx * 2) * 64 + l] = ua;
+  frags[(fidx * 2 + 1) * 64 + l] = ub;
+}
+
+hipError_t launch_pack_conv_up2_h(const float* w, void* frags, const float* scale2, float* inv_out, int Cout, int Cin, int WN, int cout_pad,
+                                  int cin_pad, hipStream_t s) {
+  const int ncot = cout_pad / (32 * WN), nk = cin_pad / 16;
+  const size_t total = (size_t)ncot * nk * WN * 16 * 64;
+  hipLaunchKernelGGL(pack_conv_up2_h_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, reinterpret_cast<uint4*>(frags), scale2,
+                     inv_out, Cout, Cin, WN, nk, total);
+  return hipGetLastError();
+}
+
 hipError_t launch_pack_conv_h(const float* w, void* frags, const float* scale2, int Cout, int Cin, int ks, int WN, int cout_pad,
                               int cin_pad, int transposed, int c_off, int rows, hipStream_t s) {
   const int T = ks * ks, BN = 32 * WN, ncot = cout_pad / BN, nk = cin_pad / 16;
