@@ -391,6 +391,62 @@ def dist_sub_records(cfg, sd, eng, dev, rank, world, S):
     return recs
 
 
+def gather_rank_times(dt, dev):
+    """Every rank's own time for the same timed region -> (max over ranks, list per rank).  The max is the job's time
+    (barrier-bracketed region); the list exposes a straggler."""
+    import torch.distributed as dist
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    all_t = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(all_t, t)
+    ts = [float(x.item()) for x in all_t]
+    return max(ts), ts
+
+
+def per_rank_stats(ts, units_per_rank):
+    v = [units_per_rank / t for t in ts]
+    return {'min': min(v), 'max': max(v), 'mean': sum(v) / len(v), 'unit': 'images/s per rank', 'ranks': len(v)}
+
+
+def free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        return so.getsockname()[1]
+
+
+def rank_env(base, rank, world, port):
+    """Environment of rank `rank` of a one-node job: what torch.distributed.run would have set."""
+    env = dict(base)
+    env.update({'RANK': str(rank), 'LOCAL_RANK': str(rank), 'WORLD_SIZE': str(world), 'LOCAL_WORLD_SIZE': str(world),
+                'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port), 'FDSR_BENCH_CHILD': '1'})
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC: RCCL needs it on this driver
+    return env
+
+
+def launch_ranks(n, argv, visible=None, popen=None, script=None):
+    """`python bench.py --gpus N` without torchrun: this process -- which has NOT touched the GPU (no torch.cuda call that
+    initialises HIP; device_count() does not) -- starts N fresh child processes, one per GPU, relays rank 0's single JSON
+    line on stdout (every other rank's stdout goes to stderr) and returns the worst child exit code.  Never an exec."""
+    import subprocess
+    if visible is None:
+        visible = torch.cuda.device_count()
+    if visible < n:
+        print(f'bench.py: --gpus {n} but only {visible} device(s) visible', file=sys.stderr)
+        return 2
+    popen = popen or subprocess.Popen
+    port = free_port()
+    procs = []
+    for r in range(n):
+        procs.append(popen([sys.executable, script or os.path.abspath(__file__)] + list(argv), env=rank_env(os.environ, r, n, port),
+                           stdout=(None if r == 0 else sys.stderr)))
+    rc = 0
+    for p in procs:
+        c = p.wait()
+        if c != 0:
+            rc = c if rc == 0 or abs(c) > abs(rc) else rc
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -413,12 +469,16 @@ def main():
                          "randn_like per step; tensor: a pre-drawn [T,B,3,H,W] tensor resident in HBM (the parity-run form)")
     args = ap.parse_args()
 
+    if 'WORLD_SIZE' not in os.environ and (args.gpus > 1 or os.environ.get('FDSR_BENCH_FORCE_DIST') == '1'):
+        # not under torch.distributed.run: start the ranks ourselves (before anything here initialises the GPU)
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     # FDSR_BENCH_FORCE_DIST=1: take the RCCL path (init, weight broadcast, barrier, max-reduce) with one rank too
     distributed = world > 1 or os.environ.get('FDSR_BENCH_FORCE_DIST') == '1'
-    if args.gpus != world and distributed:
+    if args.gpus != world:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
 
     import torch.distributed as dist
@@ -458,10 +518,9 @@ def main():
         Bt = args.batch if args.batch != 16 else 32
         hook = parallel.allreduce_grads if distributed else None
         dt = run_train(eng, dev, Bt, S, args.steps, args.warmup, rank=rank, sync=sync, allreduce=hook, precision=args.precision)
+        rank_ts = [dt]
         if distributed:
-            t = torch.tensor([dt], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
+            dt, rank_ts = gather_rank_times(dt, dev)
         if rank == 0:
             ips = world * Bt * args.steps / dt
             tf = ips / world * 3 * FLOPS_PER_IMAGE / 20 / 1e12
@@ -472,6 +531,8 @@ def main():
                 'config': {'workload': f'BASELINE configs[4] training step: x8 32->256 shapes, batch={Bt}/GPU, 256x256, q_sample + L1(sum)/(b*c*h*w), '
                                        'Dropout(0.2) live, ' + ('exact fp32' if args.precision == 'f32' else 'every convolution f16x3 (fp32-grade)') + '; data parallel = one all-reduce of the 91.6 MB gradient arena per step',
                            'batch_per_gpu': Bt, 'global_batch': Bt * world, 'parallelism': f'dp{world}'},
+                'per_rank': per_rank_stats(rank_ts, Bt * args.steps),
+                'world_size_reported_by_backend': dist.get_world_size() if distributed else 1,
                 'algorithmic_tflops_per_gpu': tf, 'frac_f32_mfma_peak': tf / PEAK_F32_MFMA}), flush=True)
         if distributed:
             dist.destroy_process_group()
@@ -480,10 +541,9 @@ def main():
     # independent per-GPU batch (weak scaling): rank r samples its own B images
     dt, out, prof, _ = run_config(eng, dev, args.precision, B, S, args.steps, args.warmup, args.graph, args.noise,
                                   rank=rank, sync=sync, want_profile=not args.no_profile)
+    rank_ts = [dt]
     if distributed:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt, rank_ts = gather_rank_times(dt, dev)
 
     dist_recs = None
     if distributed and not args.no_sub_records:
@@ -502,6 +562,8 @@ def main():
                        'batch_per_gpu': B, 'global_batch': B * world, 'timesteps': 20, 'noise': ('drawn in the loop by the engine (Philox4x32-10)' if args.noise == 'engine'
                                                   else 'pre-drawn tensor in HBM'), 'hipgraph': bool(args.graph),
                        'parallelism': f'dp{world} (independent batches, weights broadcast once)'},
+            'per_rank': per_rank_stats(rank_ts, B * args.steps),
+            'world_size_reported_by_backend': dist.get_world_size() if distributed else 1,
             'whole_path_tflops': ips / world * FLOPS_PER_IMAGE / 1e12,
             'whole_path': whole_path(ips / world, args.precision),
             'library': {'version': version.split(' FDSR_SRC_SHA256=')[0], 'source_sha256': version.rsplit('=', 1)[-1]},

@@ -57,6 +57,7 @@ SYMBOLS = {
     'fdsr_tensor2img_u8': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                      C.c_void_p]),
     'fdsr_set_debug': (C.c_int, [C.c_void_p, C.c_int]),
+    'fdsr_debug_option': (C.c_int, [C.c_char_p, C.c_longlong]),
     'fdsr_debug_tensor': (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                     C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     'fdsr_set_training': (C.c_int, [C.c_void_p, C.c_int]),
@@ -97,6 +98,13 @@ def load():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def debug_option(name, value):
+    """Launcher A/B options (include/fdsr.h: fdsr_debug_option); process-wide."""
+    rc = load().fdsr_debug_option(name.encode(), int(value))
+    if rc != 0:
+        raise FdsrError(rc, f'unknown debug option {name!r}')
 
 
 def check(handle, rc):

@@ -548,15 +548,13 @@ static int pick_th(ConvKind kind, int WN, int ksub, const ConvParams& p) {
     if (ksub > 1 && th > 8) continue;          // LDS: 64-channel rows
     const long wgs = (long)p.N * tilesX * ((p.Hout + th - 1) / th) * nco;
     best = th;
-    static const long min_wgs = getenv("FDSR_TH_MIN_WGS") ? atol(getenv("FDSR_TH_MIN_WGS")) : 256;   // one workgroup per CU
-    if (wgs >= min_wgs) break;
+    if (wgs >= g_tun.th_min_wgs) break;   // default 256: one workgroup per CU
   }
   return best;
 }
 
 int conv_h_ksplit(ConvKind kind, int N, int Hout, int Wout, int Cout, int Cout_pad, int Cin_pad, int C0, int C1) {
-  static const bool off = getenv("FDSR_NO_SPLITK") != nullptr;
-  if (off || kind == CONV3_UP || (Cout & 3) || Cout > 1024) return 1;
+  if (!g_tun.splitk || kind == CONV3_UP || (Cout & 3) || Cout > 1024) return 1;
   int TH, WN;
   conv_h_config(kind, Cout, &TH, &WN);
   const int ksub = (kind == CONV1 && Cin_pad % 64 == 0 && (C1 == 0 || C0 % 64 == 0)) ? 4 : 1;
@@ -565,7 +563,7 @@ int conv_h_ksplit(ConvKind kind, int N, int Hout, int Wout, int Cout, int Cout_p
   TH = pick_th(kind, WN, ksub, p);
   const long wgs = (long)N * ((Wout + 31) / 32) * ((Hout + TH - 1) / TH) * (Cout_pad / (32 * WN));
   const int nk = Cin_pad / (16 * ksub);
-  static const int target = getenv("FDSR_SK_TARGET") ? atoi(getenv("FDSR_SK_TARGET")) : 256;
+  const int target = g_tun.sk_target;
   if (wgs >= target) return 1;
   // enough slices to give every CU a workgroup, at least two chunks per slice
   const int sk = (int)std::min<long>(std::min(16, nk / 2), (target + wgs - 1) / wgs);

@@ -710,6 +710,7 @@ int make_shape_plan(fdsr_handle h, int N, int H, int W, ShapePlan* sp) {
   if (N < 1 || H < down || W < down || H % down || W % down)
     return fail(h, FDSR_E_INVALID, "batch>=1 and H,W multiples of %d required (got %d,%d,%d)", down, N, H, W);
   sp->N = N; sp->H = H; sp->W = W; sp->debug = h->debug;
+  sp->tun_epoch = g_tun.epoch;
   size_t off = 0;
   sp->gn_off.assign(h->n_gn_slots, 0);
   for (const Op& op : h->ops)
@@ -827,7 +828,7 @@ int make_shape_plan(fdsr_handle h, int N, int H, int W, ShapePlan* sp) {
 
 int get_plan(fdsr_handle h, int N, int H, int W) {
   if (h->plan.N == N && h->plan.H == H && h->plan.W == W && h->plan.debug == h->debug && h->plan.training == h->training &&
-      h->plan.bytes)
+      h->plan.tun_epoch == g_tun.epoch && h->plan.bytes)
     return FDSR_OK;
   ShapePlan sp;
   int rc = make_shape_plan(h, N, H, W, &sp);
@@ -891,7 +892,7 @@ int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, 
         // ones (FDSR_RIDER=1: full-resolution level + input widths up to the output width), at every batch size;
         // FDSR_RIDER=0 turns it off.  Training forwards ride too (the backward never reads the res_conv output).
         auto rides = [&](const Op& k2) -> bool {
-          static const int mode = getenv("FDSR_RIDER") ? atoi(getenv("FDSR_RIDER")) : 2;
+          const int mode = g_tun.rider;
           if (mode == 0 || k2.rider < 0 || h->prec == PREC_F32) return false;
           const Op& kr = h->ops[k2.rider];
           const WeightEntry &w2 = h->weights[k2.w], &wr = h->weights[kr.w];
@@ -931,7 +932,7 @@ int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, 
         if (dropout_on && op.drop_slot >= 0) {              // Dropout(p) between Swish and this conv (train mode)
           unsigned char* mask = reinterpret_cast<unsigned char*>(ws + sp.drop_off[op.drop_slot]);
           HIPCHK(h, launch_dropout_mask(mask, (size_t)N * Hi * Wi * op.C0, h->drop_seed, h->drop_step, (unsigned)op.drop_slot,
-                                        h->cfg.dropout, st));
+                                        h->cfg.dropout, st, (size_t)g_tun.drop_image_offset * Hi * Wi * op.C0));
           const float dscale = 1.0f / (1.0f - h->cfg.dropout);
           if (h->prec == PREC_F32) {           // the fp32 kernel applies the mask in its staging
             p.drop_mask = mask;
@@ -964,7 +965,7 @@ int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, 
           p.Cin_pad = w.h_cin_pad;
           p.Cout_pad = w.h_cout_pad;
           if (h->prec == PREC_F16X3) p.w_inv_scale_dev = h->d_hscale + 2 * (size_t)op.w + 1;
-          static const bool no_up2 = getenv("FDSR_NO_UP2") != nullptr;
+          const bool no_up2 = !g_tun.up2;
           // (after optimiser steps the sub-pixel forms lag until fdsr_sync_weight_forms: training forwards use the generic kernel)
           const bool up2_dev = h->prec == PREC_F16X3 && h->up2_dev_fresh;   // re-packed on the device by the last optimiser step
           if (op.ck == CONV3_UP && !no_up2 && !op.force_generic && (!h->h_forms_stale || up2_dev)) {
@@ -1411,6 +1412,11 @@ int fdsr_sample(fdsr_handle h, const float* cond_nchw, const float* noise, float
   const bool use_graph = (flags & FDSR_SAMPLE_GRAPH) && !h->profiling;
   if (!use_graph) return sample_body(h, cond_nchw, noise, out_nchw, traj_nchw, batch, height, width, ws, st);
 
+  if (h->graphs_epoch != g_tun.epoch) {   // graphs captured under other launcher options
+    for (auto& g : h->graphs) (void)hipGraphExecDestroy(g.exec);
+    h->graphs.clear();
+    h->graphs_epoch = g_tun.epoch;
+  }
   for (auto& g : h->graphs)
     if (g.cond == cond_nchw && g.noise == noise && g.out == out_nchw && g.traj == traj_nchw && g.ws == workspace &&
         g.N == batch && g.H == height && g.W == width) {
@@ -1536,6 +1542,8 @@ int fdsr_set_precision(fdsr_handle h, int mode) {
     }
   }
   if (mode == PREC_F32 && h->f32_forms_stale) {   // f16x3 training steps refreshed only the fp32 forms they read
+    // the optimiser step that left them stale may still be queued on a non-blocking stream the NULL stream does not order after
+    HIPCHK(h, hipDeviceSynchronize());
     int rc = ensure_f32_forms(h, nullptr);
     if (rc) return rc;
     HIPCHK(h, hipDeviceSynchronize());
@@ -1582,6 +1590,10 @@ int fdsr_debug_dropout_mask(fdsr_handle h, const char* block, const unsigned cha
       return FDSR_OK;
     }
   return fail(h, FDSR_E_KEY, "no dropout in front of block '%s'", block);
+}
+
+int fdsr_debug_option(const char* name, long long value) {
+  return set_tunable(name, value) == 0 ? FDSR_OK : FDSR_E_INVALID;
 }
 
 int fdsr_set_debug(fdsr_handle h, int on) {

@@ -70,6 +70,7 @@ struct Op {
 struct ShapePlan {
   int N = 0, H = 0, W = 0;
   bool debug = false;
+  unsigned tun_epoch = 0;          // fdsr::g_tun.epoch the plan was made under
   size_t bytes = 0;
   size_t off_temb = 0, off_gate = 0, off_splitk = 0;
   std::vector<int> op_ksplit;      // per op: K-loop split factor of a 16-bit conv at this shape (1 = none)
@@ -141,6 +142,7 @@ struct fdsr_engine {
   size_t ev_used = 0;
   double prof_flops = 0, prof_bytes = 0;
   std::vector<GraphEntry> graphs;
+  unsigned graphs_epoch = 0;
   // ---- training state (fdsr_train.cpp) ----
   float* d_master = nullptr;          // every live checkpoint tensor in checkpoint layout, concatenated in schema order
   std::vector<size_t> master_off;     // per weight entry: float offset into d_master (SIZE_MAX: dead / synthetic)

@@ -60,6 +60,28 @@ struct ConvParams {
 
 enum Precision { PREC_F32 = 0, PREC_F16X3 = 1, PREC_BF16 = 2 };
 
+// Debug / A-B options of the launchers (fdsr_debug_option in include/fdsr.h).  Process-wide, never read from the
+// environment: a library behind a C ABI must not change numerics paths because of a stray variable.  `epoch` moves with
+// every change, so that cached workspace plans and captured graphs made under other settings are dropped.
+struct Tunables {
+  int rider = 2;            // ResnetBlock res_conv inside block2's launch: 0 never, 1 bandwidth-bound ones only, 2 always
+  int up2 = 1;              // sub-pixel form of Upsample + conv3x3 (0: the generic folded-upsample kernel)
+  long th_min_wgs = 256;    // conv tile rows: the largest tile that still gives this many workgroups
+  int splitk = 1;           // split the K loop of small grids over workgroups
+  int sk_target = 256;      // ... up to this many workgroups
+  int wgrad_form = 0;       // f16x3 weight gradients: 0 default (8-wave in-row), 1 4-wave everywhere, 2 8-wave without the interleave
+  int wgrad_colsum = 1;     // column sums of dy fused into the in-row weight-gradient kernel
+  int wgrad_f32 = 0;        // f16x3 steps keep exact-fp32 weight gradients
+  long long wgrad_big_bytes = 1ll << 32;   // tensors from this size on take the 4-wave weight-gradient kernel (64-bit offsets)
+  int wino = 1;             // Winograd F(2x2,3x3) form of the stride-1 3x3 convs in f16x3 (0: direct everywhere)
+  long wino_min_wgs = 256;  // ... only for launches with at least this many workgroups
+  int sat_guard = 1;        // f16x3: sticky device flag when a RAW conv input exceeds the f16 range
+  int drop_image_offset = 0;   // tests: the batch is images [offset, offset + N) of a larger one (its dropout masks follow)
+  unsigned epoch = 0;
+};
+extern Tunables g_tun;
+int set_tunable(const char* name, long long value);   // 0 ok, -1 unknown name
+
 enum ConvKind { CONV3_S1 = 0, CONV3_S2 = 1, CONV3_UP = 2, CONV1 = 3 };
 
 // KC (K-chunk) / BN (Cout tile) the launcher will use for this shape; the packer
@@ -141,7 +163,7 @@ hipError_t launch_slam(const float* x, float* scratch, const float* w7 /*[2][7][
 // Dropout keep-mask of one block: byte e = 1 with probability 1-p, a pure function of (seed, step, slot, e)
 // (Philox4x32-10), so a run can be repeated and the mask inspected (fdsr_debug_dropout_mask).
 hipError_t launch_dropout_mask(unsigned char* mask, size_t n, unsigned long long seed, unsigned step, unsigned slot, float p,
-                               hipStream_t s);
+                               hipStream_t s, size_t first_elem = 0);
 
 // layout changes at the boundary
 hipError_t launch_nchw_to_nhwc(const float* src, float* dst, int N, int Csrc, int H, int W,

@@ -19,6 +19,8 @@
 // update, layout changes at the boundary) is HBM-bound streaming code.
 #include "fdsr_kernels.h"
 
+#include <string>
+
 namespace fdsr {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -442,6 +444,28 @@ hipError_t launch_gn_finalize(const GnFinalizeParams& p, hipStream_t s) {
   return hipGetLastError();
 }
 
+Tunables g_tun;
+
+int set_tunable(const char* name, long long v) {
+  const std::string n(name ? name : "");
+  if (n == "rider") g_tun.rider = (int)v;
+  else if (n == "up2") g_tun.up2 = (int)v;
+  else if (n == "th_min_wgs") g_tun.th_min_wgs = (long)v;
+  else if (n == "splitk") g_tun.splitk = (int)v;
+  else if (n == "sk_target") g_tun.sk_target = (int)v;
+  else if (n == "wgrad_form") g_tun.wgrad_form = (int)v;
+  else if (n == "wgrad_colsum") g_tun.wgrad_colsum = (int)v;
+  else if (n == "wgrad_f32") g_tun.wgrad_f32 = (int)v;
+  else if (n == "wgrad_big_bytes") g_tun.wgrad_big_bytes = v;
+  else if (n == "wino") g_tun.wino = (int)v;
+  else if (n == "wino_min_wgs") g_tun.wino_min_wgs = (long)v;
+  else if (n == "sat_guard") g_tun.sat_guard = (int)v;
+  else if (n == "drop_image_offset") g_tun.drop_image_offset = (int)v;
+  else return -1;
+  ++g_tun.epoch;
+  return 0;
+}
+
 int conv_max_tiles(int H, int W) {
   // f32 kernel: 8x16 tiles; 16-bit kernels: TH x 32 with TH >= 2
   const int a = ((H + 7) / 8) * ((W + 15) / 16), b = ((H + 1) / 2) * ((W + 31) / 32);
@@ -812,10 +836,11 @@ hipError_t launch_rng_advance(unsigned long long* rng, hipStream_t s) {
 
 // four keep bytes per Philox call: byte e of quad i = (word e >= p * 2^32)
 __global__ void __launch_bounds__(256) dropout_mask_kernel(unsigned* __restrict__ mask4, size_t nquads, unsigned long long seed,
-                                                           unsigned step, unsigned slot, unsigned thresh) {
+                                                           unsigned step, unsigned slot, unsigned thresh, size_t quad0) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= nquads) return;
-  unsigned c0 = (unsigned)i, c1 = (unsigned)(i >> 32), c2 = slot, c3 = step;
+  const size_t gi = i + quad0;   // counter = position in the FULL batch (a shard of a larger batch draws its own images' masks)
+  unsigned c0 = (unsigned)gi, c1 = (unsigned)(gi >> 32), c2 = slot, c3 = step;
   unsigned k0 = (unsigned)seed ^ 0x44524F50u /* 'DROP' */, k1 = (unsigned)(seed >> 32);
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
@@ -827,13 +852,13 @@ __global__ void __launch_bounds__(256) dropout_mask_kernel(unsigned* __restrict_
 }
 
 hipError_t launch_dropout_mask(unsigned char* mask, size_t n, unsigned long long seed, unsigned step, unsigned slot, float p,
-                               hipStream_t s) {
-  if (n & 3) return hipErrorInvalidValue;
+                               hipStream_t s, size_t first_elem) {
+  if ((n & 3) || (first_elem & 3)) return hipErrorInvalidValue;
   const double t = (double)p * 4294967296.0;
   const unsigned thresh = t >= 4294967295.0 ? 0xffffffffu : (unsigned)t;
   const size_t nq = n >> 2;
   hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, reinterpret_cast<unsigned*>(mask), nq, seed,
-                     step, slot, thresh);
+                     step, slot, thresh, first_elem >> 2);
   return hipGetLastError();
 }
 

@@ -330,21 +330,25 @@ int fdsr_train_grads(fdsr_handle h, const float* x_nchw, const float* noise_leve
   if ((rc = train_prepare(h))) return rc;
   hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
   const int N = batch, H = height, W = width, G = h->cfg.norm_groups;
-  h->debug = true;
+  // keep mode for the forward of this call only: the caller's own fdsr_set_debug / statistics settings come back on every exit path
+  struct KeepMode {
+    fdsr_handle h; bool debug, keep;
+    explicit KeepMode(fdsr_handle hh) : h(hh), debug(hh->debug), keep(hh->keep_stats) { h->debug = true; }
+    void restore() { h->debug = debug; h->keep_stats = keep; }
+    ~KeepMode() { restore(); }
+  } keep_mode(h);
   rc = get_plan(h, N, H, W);
-  if (rc) { h->debug = false; return rc; }
+  if (rc) return rc;
   TrainPlan tp;
-  if ((rc = make_train_plan(h, N, H, W, &tp))) { h->debug = false; return rc; }
-  if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 255) || workspace_bytes < tp.bytes) {
-    h->debug = false;
+  if ((rc = make_train_plan(h, N, H, W, &tp))) return rc;
+  if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 255) || workspace_bytes < tp.bytes)
     return fail(h, FDSR_E_WORKSPACE, "training workspace too small or misaligned: %zu < %zu bytes", workspace_bytes, tp.bytes);
-  }
   char* ws = reinterpret_cast<char*>(workspace);
   ShapePlan& sp = h->plan;
   // the transposed forms follow the master copy
-  if (h->prec == PREC_F32 && (rc = ensure_f32_forms(h, st))) { h->debug = false; return rc; }
+  if (h->prec == PREC_F32 && (rc = ensure_f32_forms(h, st))) return rc;
   if (!h->wt_valid) {
-    if ((rc = repack_from_master(h, st, false, false))) { h->debug = false; return rc; }
+    if ((rc = repack_from_master(h, st, false, false))) return rc;
     h->wt_valid = true;
   }
 
@@ -353,8 +357,7 @@ int fdsr_train_grads(fdsr_handle h, const float* x_nchw, const float* noise_leve
   HIPCHK(h, launch_nchw_to_nhwc(x_nchw, xin, N, h->cfg.in_channel, H, W, h->CP, 0, 1, st));
   h->keep_stats = true;
   rc = run_unet(h, N, H, W, ws, noise_level, 0.f, st);
-  h->keep_stats = false;
-  h->debug = false;
+  keep_mode.restore();
   if (rc) return rc;
 
   auto P = [&](int widx) -> const float* { return widx >= 0 ? h->d_params + h->weights[widx].dev_off : nullptr; };
@@ -435,7 +438,7 @@ int fdsr_train_grads(fdsr_handle h, const float* x_nchw, const float* noise_leve
         q.drop_mask = reinterpret_cast<const unsigned char*>(ws + sp.drop_off[op.drop_slot]);
         q.drop_scale = 1.0f / (1.0f - h->cfg.dropout);
       }
-      static const bool f32_wgrad = getenv("FDSR_WGRAD_F32") != nullptr;   // A/B switch: keep the weight gradients exact fp32
+      const bool f32_wgrad = g_tun.wgrad_f32 != 0;   // A/B option: keep the weight gradients exact fp32
       const bool hw = h->prec == PREC_F16X3 && !f32_wgrad;
       q.colsum = S;
       if (!(hw && wgrad_h_fuses_colsum(op.ck, q))) {
@@ -587,7 +590,11 @@ int fdsr_set_optimizer_state(fdsr_handle h, const char* key, const float* exp_av
 // across ranks in place (RCCL all-reduce over xGMI) between fdsr_train_grads and fdsr_adam_step.
 int fdsr_grad_arena(fdsr_handle h, float** dev_ptr, size_t* count) {
   if (!h || !dev_ptr || !count) return fail(h, FDSR_E_INVALID, "null argument");
-  if (!h->d_grad) return fail(h, FDSR_E_STATE, "fdsr_train_grads has not run yet");
+  if (!h->d_grad) {   // a data-parallel rank with an empty shard asks for the arena before it ever ran a step: allocate (zeroed)
+    int rc = check_ready(h, false);
+    if (rc) return rc;
+    if ((rc = train_prepare(h))) return rc;
+  }
   *dev_ptr = h->d_grad;
   *count = h->master_floats;
   return FDSR_OK;

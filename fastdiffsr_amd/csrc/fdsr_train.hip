@@ -1357,15 +1357,15 @@ __global__ void __launch_bounds__(512, 2) wgrad_h8i_kernel(const WgradParams p, 
 // of dy; that wants every slice inside ONE image (ns = N * k), so that S[n][c] is a sum of whole slices.
 struct H8Plan { bool h8, inrow, colsum; int ns, k; };
 static H8Plan wgrad_h8_plan(ConvKind kind, const WgradParams& p) {
-  static const bool four_wave = getenv("FDSR_WGRAD_H4") != nullptr;   // A/B switches: the 4-wave single-buffer form everywhere,
-  static const bool plain8 = getenv("FDSR_WGRAD_H8") != nullptr;      // the 8-wave form without the in-row interleave
-  static const bool no_colsum = getenv("FDSR_WGRAD_NO_COLSUM") != nullptr;
+  const bool four_wave = g_tun.wgrad_form == 1;   // A/B options (fdsr_debug_option): the 4-wave single-buffer form everywhere,
+  const bool plain8 = g_tun.wgrad_form == 2;      // the 8-wave form without the in-row interleave
+  const bool no_colsum = !g_tun.wgrad_colsum;
   H8Plan r{false, false, false, 1, 0};
   if (kind != CONV3_S1 && kind != CONV3_UP) return r;
   // the 8-wave forms want a 64-channel block inside one concat source and 32-bit byte offsets; the 4-wave form takes the rest
   const size_t in_px = (size_t)p.N * p.Hin * p.Win, out_px = (size_t)p.N * p.Hout * p.Wout;
-  const bool seam = (p.C1 > 0 && (p.C0 & 63) != 0) || in_px * (size_t)(p.C0 > p.C1 ? p.C0 : p.C1) * 4 >= (1ull << 32) ||
-                    out_px * (size_t)p.Cout_s * 4 >= (1ull << 32);
+  const bool seam = (p.C1 > 0 && (p.C0 & 63) != 0) || in_px * (size_t)(p.C0 > p.C1 ? p.C0 : p.C1) * 4 >= (size_t)g_tun.wgrad_big_bytes ||
+                    out_px * (size_t)p.Cout_s * 4 >= (size_t)g_tun.wgrad_big_bytes;
   if (four_wave || seam) return r;
   r.h8 = true;
   r.inrow = !plain8 && !p.gn_plain;

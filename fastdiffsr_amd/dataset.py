@@ -69,14 +69,16 @@ class LRHRDataset(Dataset):
         if self.split == 'train':
             # util.py:66-75: hflip(torch.stack([SR, HR])) -- torchvision's RandomHorizontalFlip draws torch.rand(1) once
             # for the whole stack; util.py:77-88 does the same, separately, for [LR]
-            if torch.rand(1) < 0.5:
+            flip_hr = bool(torch.rand(1) < 0.5)
+            if flip_hr:
                 for k in ('SR', 'HR'):
                     if k in out:
                         out[k] = out[k].flip(-1)
             if 'LR' in out and torch.rand(1) < 0.5:
                 out['LR'] = out['LR'].flip(-1)
-                if 'LR_u8' in out:
-                    out['LR_u8'] = out['LR_u8'].flip(1)
+            # the conditioning image built later from LR_u8 stands in for SR: it must mirror with HR, not with LR's own draw
+            if 'LR_u8' in out and flip_hr:
+                out['LR_u8'] = out['LR_u8'].flip(1)
         return out
 
 

@@ -141,27 +141,39 @@ class GaussianDiffusion(nn.Module):
 
     def _engine_for_training(self):
         unet = self.denoise_fn
-        unet.sync_weights()
+        unet.sync_weights(for_training=True)
         eng = unet.engine
-        # 'f32' (exact) or 'f16x3' (fp32-grade forward and input gradients; weight gradients stay exact fp32)
+        # 'f32' (everything exact fp32) or 'f16x3' (every convolution -- forward, input and weight gradients -- fp32-grade on
+        # split-f16 MFMAs)
         eng.set_precision('f32' if self.precision == 'bf16' else self.precision)
         eng.set_training(unet.training and unet.cfg.dropout > 0, seed_from_torch=True)   # Dropout(p) of block2 is live in .train() mode
         return eng
 
-    def optimize_step(self, x_in, lr, betas=(0.9, 0.999), eps=1e-8, noise=None, grad_hook=None, loss_div_batches=1):
+    def optimize_step(self, x_in, lr, betas=(0.9, 0.999), eps=1e-8, noise=None, grad_hook=None, global_batch=None):
         """DDPM.optimize_parameters (model/model.py:47-57) entirely on the device: forward, loss / (b*c*h*w),
-        backward, Adam on the engine's master copy.  Returns l_pix (python float).  grad_hook(engine) runs between
-        backward and the optimiser (data-parallel all-reduce of the gradient arena, parallel.allreduce_grads)."""
-        x6, gamma, noise = self._training_batch(x_in, noise)
+        backward, Adam on the engine's master copy.  Returns the SUMMED loss of this rank's samples divided by the
+        global element count (a python float; summed over ranks it is the reference's l_pix).  grad_hook(engine) runs
+        between backward and the optimiser (data-parallel all-reduce of the gradient arena, parallel.allreduce_grads).
+
+        Data parallel: `global_batch` is the number of samples of the WHOLE step over all ranks -- every rank divides by
+        global_batch*c*h*w and the all-reduce SUMS the arenas, so per-sample weights are right for ragged shards too; a
+        rank whose shard is empty (b == 0) contributes a zero arena and still takes part in the all-reduce."""
         b, c, h, w = x_in['HR'].shape
+        gb = int(global_batch) if global_batch is not None else int(b)
+        if gb < 1:
+            raise ValueError('optimize_step: the global batch is empty')
         eng = self._engine_for_training()
-        # data parallel: every rank divides by the GLOBAL element count, the all-reduce then SUMS the arenas
-        loss = eng.train_grads(x6, gamma, noise, self.loss_type, 1.0 / (int(b * c * h * w) * int(loss_div_batches)))
+        if b > 0:
+            x6, gamma, noise = self._training_batch(x_in, noise)
+            loss = eng.train_grads(x6, gamma, noise, self.loss_type, 1.0 / (gb * int(c * h * w)))
+        else:
+            eng.zero_grads(x_in['HR'].device)
+            loss = 0.0
         if grad_hook is not None:
             grad_hook(eng)
         eng.adam_step(lr, betas, eps)
         self.denoise_fn._engine_ahead = True
-        return loss / int(b * c * h * w)
+        return loss / (gb * int(c * h * w))
 
     def forward(self, x, *args, **kwargs):                        # :272-273
         return self.p_losses(x, *args, **kwargs)

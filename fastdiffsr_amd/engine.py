@@ -51,6 +51,9 @@ class Engine:
 
     # -- schema / weights ---------------------------------------------------
     def schema(self):
+        """(key, shape, live) of every checkpoint tensor; fixed at fdsr_create, so it is read once."""
+        if getattr(self, '_schema_cache', None) is not None:
+            return self._schema_cache
         out = []
         n = self.lib.fdsr_num_weights(self.h)
         buf = C.create_string_buffer(256)
@@ -59,6 +62,8 @@ class Engine:
         for i in range(n):
             _lib.check(self.h, self.lib.fdsr_weight_info(self.h, i, buf, 256, shape, C.byref(nd), C.byref(live)))
             out.append((buf.value.decode(), tuple(int(shape[k]) for k in range(nd.value)), bool(live.value)))
+        self._schema_cache = out
+        self._shape_of = {k: sh for k, sh, _ in out}
         return out
 
     def load_weight(self, key, value):
@@ -203,6 +208,10 @@ class Engine:
         self._keep = (x, nl, target)
         return float(loss.value)
 
+    def zero_grads(self, device='cuda'):
+        """A zero gradient arena (a data-parallel rank whose shard of the batch is empty still joins the all-reduce)."""
+        self.grad_arena().zero_()
+
     def adam_step(self, lr, betas=(0.9, 0.999), eps=1e-8):
         st = torch.cuda.current_stream().cuda_stream
         _lib.check(self.h, self.lib.fdsr_adam_step(self.h, C.c_float(lr), C.c_float(betas[0]), C.c_float(betas[1]), C.c_float(eps),
@@ -210,7 +219,8 @@ class Engine:
         self.trained = True
 
     def _fetch(self, fn, key):
-        shape = {k: s for k, s, _ in self.schema()}[key]
+        self.schema()
+        shape = self._shape_of[key]
         a = np.empty(shape, dtype=np.float32)
         _lib.check(self.h, fn(self.h, key.encode(), a.ctypes.data_as(C.c_void_p)))
         return a
@@ -247,7 +257,8 @@ class Engine:
 
     def optimizer_state(self, key):
         """(exp_avg, exp_avg_sq, step) of torch.optim.Adam for one executed tensor."""
-        shape = {k: s for k, s, _ in self.schema()}[key]
+        self.schema()
+        shape = self._shape_of[key]
         m, v, step = np.empty(shape, np.float32), np.empty(shape, np.float32), C.c_int()
         torch.cuda.synchronize()
         _lib.check(self.h, self.lib.fdsr_get_optimizer_state(self.h, key.encode(), m.ctypes.data_as(C.c_void_p),

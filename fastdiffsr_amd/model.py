@@ -28,8 +28,22 @@ class DDPM:
         self.set_new_noise_schedule(opt['model']['beta_schedule']['train'], schedule_phase='train')
         if opt['phase'] == 'train':
             self.netG.train()
-            if opt['model'].get('finetune_norm'):                  # model.py:25-35 looks for 'transformer' parameters:
-                raise NotImplementedError('finetune_norm: this UNet has no transformer parameters')   # none exist
+            if opt['model'].get('finetune_norm'):                  # model.py:25-35
+                # the reference freezes every parameter, then un-freezes (and zero-fills) those whose name contains
+                # 'transformer', and hands only those to Adam.  No denoiser of this repository (nor of the reference's
+                # four model dirs) has such a parameter, so the reference builds Adam over an EMPTY list, which torch
+                # refuses ("optimizer got an empty parameter list"): same error, same moment.
+                optim_params = []
+                for k, v in self.netG.named_parameters():
+                    v.requires_grad = False
+                    if k.find('transformer') >= 0:
+                        v.requires_grad = True
+                        v.data.zero_()
+                        optim_params.append(v)
+                        logger.info('Params [{:s}] initialized to 0 and will optimize.'.format(k))
+                if not optim_params:
+                    raise ValueError('optimizer got an empty parameter list')
+                raise NotImplementedError('finetune_norm with transformer parameters: the engine optimises the whole UNet')
             # torch.optim.Adam(netG.parameters(), lr) (model.py:37-38) lives in the engine: its state is the
             # (exp_avg, exp_avg_sq) pair kept beside the fp32 master copy of every executed tensor
             self.lr = float(opt['train']['optimizer']['lr'])
@@ -56,8 +70,11 @@ class DDPM:
         from . import parallel
         world = parallel.world_size()
         hook = parallel.allreduce_grads if world > 1 else None
-        l_pix = self.netG.optimize_step(self.data, self.lr, self.betas, self.adam_eps, grad_hook=hook, loss_div_batches=world)
-        self.log_dict['l_pix'] = parallel.mean_over_ranks(l_pix) if world > 1 else l_pix
+        b = int(self.data['HR'].shape[0])
+        # the divisor is the GLOBAL sample count (ragged or empty shards included): one tiny all-reduce
+        gb = parallel.sum_over_ranks(b) if world > 1 else b
+        l_pix = self.netG.optimize_step(self.data, self.lr, self.betas, self.adam_eps, grad_hook=hook, global_batch=int(gb))
+        self.log_dict['l_pix'] = parallel.sum_over_ranks(l_pix) if world > 1 else l_pix
 
     def get_current_log(self):                                     # model.py:94-95
         return self.log_dict

@@ -73,6 +73,36 @@ def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+def _coll_device():
+    return 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
+
+
+def sum_over_ranks(value):
+    t = torch.tensor([float(value)], dtype=torch.float64, device=_coll_device())
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+def broadcast_module_(module, src=0):
+    """Make every rank's copy of `module` (parameters AND buffers) rank `src`'s, in place: ONE packed broadcast.
+    Data-parallel training from scratch needs it -- each rank's init_weights draws from its own RNG, and the replicas
+    only stay in lockstep if they start equal (the reference's nn.DataParallel re-replicates from device 0 every
+    forward, networks.py:116-118)."""
+    ts = [t for t in list(module.parameters()) + list(module.buffers()) if t.is_floating_point()]
+    if not ts:
+        return module
+    dev = _coll_device()
+    flat = torch.cat([t.detach().reshape(-1).to(device=dev, dtype=torch.float32) for t in ts])
+    dist.broadcast(flat, src=src)
+    off = 0
+    with torch.no_grad():
+        for t in ts:
+            n = t.numel()
+            t.copy_(flat[off:off + n].view_as(t).to(device=t.device, dtype=t.dtype))
+            off += n
+    return module
+
+
 def mean_over_ranks(value):
     t = torch.tensor([float(value)], dtype=torch.float64, device='cuda' if dist.get_backend() == 'nccl' else 'cpu')
     dist.all_reduce(t, op=dist.ReduceOp.SUM)

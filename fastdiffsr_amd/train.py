@@ -36,6 +36,12 @@ def run(opt, precision='f16x3', rank=0, world=1, log=print, val_batch=1, max_val
         create_dataloader(train_set, train_opt, 'train')
     diffusion = create_model(opt)                                                      # sr_mfe.py:81
     diffusion.netG.precision = precision
+    if world > 1:
+        # every rank ran init_weights / default inits on its OWN torch RNG: start the replicas from rank 0's weights
+        # (resumed runs load the same checkpoint everywhere; the broadcast is then a no-op in value)
+        from .parallel import broadcast_module_
+        broadcast_module_(diffusion.netG, src=0)
+        diffusion.netG.denoise_fn.sync_weights(force=True)
     current_step, current_epoch = diffusion.begin_step, diffusion.begin_epoch
     n_iter = opt['train']['n_iter']
     if (opt.get('path') or {}).get('resume_state'):

@@ -85,11 +85,18 @@ class UNet(nn.Module):
 
     def _param_version(self):
         ts = list(self.parameters()) + list(self.buffers())
-        return tuple(p._version for p in ts) + tuple(id(p.data) for p in ts)
+        return tuple((p._version, p.data_ptr()) for p in ts)
 
-    def sync_weights(self, force=False):
-        """Upload parameters to the engine if they changed since the last upload."""
-        if self._engine_ahead:          # the engine's optimiser moved the weights: the module follows, not leads
+    def sync_weights(self, force=False, for_training=False):
+        """Upload parameters to the engine if they changed since the last upload.
+
+        After device-side optimiser steps the ENGINE holds the newest weights (`_engine_ahead`).  The training path
+        (`for_training`) then touches nothing: no pull, no upload -- the Parameters are refreshed lazily, by
+        state_dict() / pull_weights() / the next sampling call.  Only when somebody wrote to the Parameters in the
+        meantime (their version counters moved) does the module lead again."""
+        if self._engine_ahead:
+            if for_training and not force and self._param_version() == self._uploaded_version:
+                return
             self.pull_weights()
         ver = self._param_version()
         if force or ver != self._uploaded_version:

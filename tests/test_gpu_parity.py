@@ -351,12 +351,12 @@ def test_infer_size_512(full):
 @pytest.mark.parametrize('mode', ['0', '1'])
 def test_res_conv_as_its_own_launch_or_riding_by_rule(mode):
     """By default every ResnetBlock res_conv rides inside block2's 3x3 launch on the 16-bit kernels (ConvParams::xr0);
-    FDSR_RIDER=0 keeps it a launch of its own, =1 lets only the bandwidth-bound ones ride.  Each setting must meet the same
-    layer-by-layer and 20-step-loop bounds against the oracle in f16x3 and bf16 (fresh process: the switch is read once)."""
+    the debug option rider=0 keeps it a launch of its own, =1 lets only the bandwidth-bound ones ride.  Each setting must meet
+    the same layer-by-layer and 20-step-loop bounds against the oracle in f16x3 and bf16 (a fresh process per setting)."""
     import subprocess
     import sys
     env = dict(os.environ)
-    env['FDSR_RIDER'] = mode
+    env['FDSR_TEST_DEBUG_OPTION'] = f'rider={mode}'
     here = os.path.abspath(__file__)
     r = subprocess.run([sys.executable, '-m', 'pytest', here, '-m', 'gpu', '-q', '-x', '-k',
                         'test_precision_modes_layerwise_and_loop or test_other_architectures'],

@@ -23,9 +23,9 @@ def _free_port():
 
 @pytest.mark.timeout(600)
 def test_bench_rccl_path_with_one_rank():
-    env = dict(os.environ)
-    env.update({'FDSR_BENCH_FORCE_DIST': '1', 'RANK': '0', 'LOCAL_RANK': '0', 'WORLD_SIZE': '1',
-                'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(_free_port()), 'HSA_ENABLE_IPC_MODE_LEGACY': '0'})
+    # no RANK / WORLD_SIZE here: bench.py's own launcher (the path `--gpus N` takes without torchrun) starts the rank process
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT')}
+    env.update({'FDSR_BENCH_FORCE_DIST': '1', 'HSA_ENABLE_IPC_MODE_LEGACY': '0'})
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '1', '--warmup', '1',
                         '--no-cpu-baseline'], cwd=ROOT, env=env, capture_output=True, text=True, timeout=540)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
@@ -33,6 +33,8 @@ def test_bench_rccl_path_with_one_rank():
     assert len(lines) == 1, lines                    # RCCL's banner must not leak onto stdout
     res = json.loads(lines[0])
     assert res['n_gpus'] == 1 and res['scaling'] == 'weak' and res['unit'] == 'images/s'
+    assert res['world_size_reported_by_backend'] == 1 and res['per_rank']['ranks'] == 1
+    assert abs(res['per_rank']['min'] - res['value']) < 1e-6 * res['value']
     assert res['value'] > 0 and res['value'] == res['value']          # finite (bench asserts isfinite(out) itself)
     w = res['weights']
     assert w['sha256_after_broadcast'] == w['sha256_rank0_source']    # what RCCL delivered is what rank 0 built
@@ -79,9 +81,9 @@ def test_bench_default_line_is_complete_and_parity_clean():
 def test_bench_train_rccl_path_with_one_rank():
     """The data-parallel training leg with one rank: the gradient arena wrapped zero-copy as a torch tensor and all-reduced
     through RCCL between backward and Adam (parallel.allreduce_grads), one JSON line."""
-    env = dict(os.environ)
-    env.update({'FDSR_BENCH_FORCE_DIST': '1', 'RANK': '0', 'LOCAL_RANK': '0', 'WORLD_SIZE': '1',
-                'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(_free_port()), 'HSA_ENABLE_IPC_MODE_LEGACY': '0'})
+    # no RANK / WORLD_SIZE here: bench.py's own launcher (the path `--gpus N` takes without torchrun) starts the rank process
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT')}
+    env.update({'FDSR_BENCH_FORCE_DIST': '1', 'HSA_ENABLE_IPC_MODE_LEGACY': '0'})
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--train', '--batch', '4', '--steps', '2',
                         '--warmup', '1'], cwd=ROOT, env=env, capture_output=True, text=True, timeout=540)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]

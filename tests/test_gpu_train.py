@@ -367,16 +367,17 @@ def test_autograd_compatible_loss_fills_param_grads():
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize('switch', ['FDSR_WGRAD_H4', 'FDSR_WGRAD_H8', 'FDSR_WGRAD_NO_COLSUM', 'FDSR_WGRAD_F32'])
-def test_every_weight_gradient_kernel_form_meets_the_golden(switch):
+@pytest.mark.parametrize('option', [('wgrad_form', 1), ('wgrad_form', 2), ('wgrad_colsum', 0), ('wgrad_f32', 1), ('wgrad_big_bytes', 1 << 20)])
+def test_every_weight_gradient_kernel_form_meets_the_golden(option):
     """The f16x3 step picks its weight-gradient kernel per layer (8-wave in-row with fused column sums by default); the A/B
-    switches force the other forms -- 4-wave, 8-wave without the interleave, separate column-sum pass, exact-fp32 weight
-    gradients -- and each must reproduce the reference's 273 gradients and its Adam update (fresh process: the switches are
-    read once)."""
+    options (fdsr_debug_option) force the other forms -- 4-wave, 8-wave without the interleave, separate column-sum pass,
+    exact-fp32 weight gradients, and the ">= 4 GiB tensor" fallback (threshold lowered to 1 MiB: every large layer takes the
+    64-bit-offset kernel) -- and each must reproduce the reference's 273 gradients and its Adam update (a fresh process per
+    option, so that nothing else in this session runs under it)."""
     import subprocess
     import sys
     env = dict(os.environ)
-    env[switch] = '1'
+    env['FDSR_TEST_DEBUG_OPTION'] = f'{option[0]}={option[1]}'
     here = os.path.abspath(__file__)
     r = subprocess.run([sys.executable, '-m', 'pytest', here, '-m', 'gpu', '-q', '-x', '-k',
                         '(test_all_gradients or test_adam_update or test_train_step_with_dropout) and f16x3'],
