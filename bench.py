@@ -464,6 +464,8 @@ def main():
     ap.add_argument('--train', action='store_true',
                     help='time optimisation steps (forward + loss + backward + Adam, BASELINE configs[4]) instead of sampling; '
                          'the metric is then images/s through one training step')
+    ap.add_argument('--debug-option', action='append', default=[], metavar='NAME=VALUE',
+                    help='launcher A/B option (include/fdsr.h: fdsr_debug_option), e.g. wino=0; repeatable; recorded in the line')
     ap.add_argument('--noise', default='engine', choices=['engine', 'tensor'],
                     help="engine: N(0,1) drawn inside the timed loop by the engine (Philox), as the reference draws "
                          "randn_like per step; tensor: a pre-drawn [T,B,3,H,W] tensor resident in HBM (the parity-run form)")
@@ -490,6 +492,9 @@ def main():
 
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
+    for item in args.debug_option:
+        k, v = item.split('=')
+        _lib.debug_option(k, int(v))
     cfg = UNetConfig(**FASTDIFFSR_UNET)
     # weights: rank 0 builds the random-init UNet, ONE RCCL broadcast replicates it
     sd = synth_state_dict(cfg, 0) if rank == 0 else None
@@ -568,6 +573,8 @@ def main():
             'whole_path': whole_path(ips / world, args.precision),
             'library': {'version': version.split(' FDSR_SRC_SHA256=')[0], 'source_sha256': version.rsplit('=', 1)[-1]},
         }
+        if args.debug_option:
+            res['debug_options'] = list(args.debug_option)
         if distributed:   # every rank loaded what rank 0 broadcast: its hash is checked against rank 0's own arrays
             res['weights'] = {'sha256_rank0_source': weights_sha_rank0, 'sha256_after_broadcast': state_dict_sha256(sd),
                               'broadcast_bytes': int(sum(np.asarray(v).nbytes for v in sd.values()))}

@@ -99,6 +99,11 @@ hipError_t launch_conv_h(ConvKind kind, int prec, const ConvParams& p, hipStream
 // workspace planner and the launcher agree.  Only grids that would leave most of the 256 CUs idle split.
 int conv_h_ksplit(ConvKind kind, int N, int Hout, int Wout, int Cout, int Cout_pad, int Cin_pad, int C0, int C1);
 hipError_t kernels_h_init();
+// Winograd F(2x2,3x3) form of the stride-1 3x3 convs (fdsr_conv_wino.hip; f16x3 only): transformed weights U = G g G^T packed
+// [cot][kc][role][nu][plane][lane] x 16 B (role = position row xi | cout half << 2).  conv_wino_ok: does this launch take it?
+bool conv_wino_ok(ConvKind kind, int prec, const ConvParams& p);
+hipError_t launch_conv_wino_h(const ConvParams& p, hipStream_t s, int* tiles_per_image);
+hipError_t kernels_wino_init();
 // Upsample(nearest x2)+Conv3x3 in sub-pixel form (fdsr_conv_up2.hip): four 2x2 convs on the source grid
 // with pre-summed weights packed [cot][kc][wn][py][px*4+a*2+b][plane][lane] x 16 B.
 hipError_t launch_conv_up2_h(int prec, const ConvParams& p, hipStream_t s, int* tiles_per_image);
