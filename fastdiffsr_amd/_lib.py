@@ -29,6 +29,13 @@ class FdsrError(RuntimeError):
         self.code = code
 
 
+class FdsrSaturated(FdsrError):
+    """f16x3: a raw convolution input left the f16 range (FDSR_E_SATURATED): the call's output is not fp32-grade."""
+
+
+FDSR_E_SATURATED = -6
+
+
 _lib = None
 
 # name -> (restype, argtypes); every symbol include/fdsr.h declares
@@ -58,6 +65,7 @@ SYMBOLS = {
                                      C.c_void_p]),
     'fdsr_set_debug': (C.c_int, [C.c_void_p, C.c_int]),
     'fdsr_debug_option': (C.c_int, [C.c_char_p, C.c_longlong]),
+    'fdsr_check_saturation': (C.c_int, [C.c_void_p, C.c_void_p]),
     'fdsr_debug_tensor': (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                     C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     'fdsr_set_training': (C.c_int, [C.c_void_p, C.c_int]),

@@ -10,6 +10,13 @@ typedef float f32x4_io __attribute__((ext_vector_type(4)));
 // activations in HBM: fp32 (f32 / f16x3 modes) or bf16 (bf16 mode)
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned v) { return __builtin_bit_cast(float, v << 16); }
 __device__ __forceinline__ unsigned short f32_to_bf16_bits(float v) { return __builtin_bit_cast(unsigned short, (__bf16)v); }
+// f16x3 range guard: the hi/lo split clamps every staged value to the f16 range.  GroupNorm'ed inputs are re-scaled before the
+// split, but a RAW conv input (res_conv, down/upsample convs, the rider's chunks) beyond +-65504 would be clamped SILENTLY:
+// the staging paths of raw inputs raise a sticky device flag instead (fdsr_check_saturation reads and clears it).
+__device__ __forceinline__ void sat_check(int* flag, f32x4_io v, float lim) {
+  const float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+  if (m > lim) *flag = 1;
+}
 template <int PREC> struct ActIO;
 template <> struct ActIO<PREC_F16X3> {
   typedef f32x4_io Quad;   // four consecutive channels as loaded

@@ -155,6 +155,8 @@ __global__ void __launch_bounds__(512, 2) conv_mfma_h_kernel(const ConvParams p)
       if (gn && !(RIDER && kc >= nk)) {
         v = v * sc + sh;
         if (!p.gn_plain) { v.x = silu_h(v.x); v.y = silu_h(v.y); v.z = silu_h(v.z); v.w = silu_h(v.w); }
+      } else if (PREC == PREC_F16X3 && p.sat_flag) {
+        sat_check(p.sat_flag, v, 65504.f);             // a raw input the split below would clamp: tell the host
       }
       const float keep = in_pix[i] >= 0 ? 1.f : 0.f;   // conv zero-pads the ACTIVATED tensor
       const float lim = in_pix[i] >= 0 ? 65504.f : 0.f;   // f16 range clamp and zero padding in one med3

@@ -99,6 +99,7 @@ __global__ void __launch_bounds__(512, 2) conv_up2_h_kernel(const ConvParams p) 
       const float lim = in_pix[i] >= 0 ? 65504.f : 0.f;
       unsigned char* dst = buf + (row0 + i * RPP) * ROWB + q * 8;
       if (PREC == PREC_F16X3) {
+        if (p.sat_flag) sat_check(p.sat_flag, v, 65504.f);   // raw input (no GroupNorm in front of the upsample conv)
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], -lim, lim);   // padding: lim = 0
         h4 hi = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};

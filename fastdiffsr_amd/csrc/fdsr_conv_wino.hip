@@ -23,6 +23,7 @@
 // blockIdx -> (cout block, tile): workgroups of one XCD (blockIdx & 7) share ONE 64-cout block, so an XCD's 4 MiB L2
 // holds Cin x 4 KB of transformed weights (2 MB at Cin = 512) instead of the whole layer (8 MB).
 #include "fdsr_kernels.h"
+#include "fdsr_act_io.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -130,6 +131,7 @@ __global__ void __launch_bounds__(512, 2) conv_wino_h_kernel(const ConvParams p)
       }
       // the conv zero-pads the ACTIVATED tensor (lim = 0); |V| <= 4 max|a| must stay inside the f16 range after the transform
       const float lim = in_pix[i] >= 0 ? 16376.f : 0.f;
+      if (p.sat_flag) sat_check(p.sat_flag, v, 16376.f);
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], -lim, lim);
       *reinterpret_cast<f32x4*>(buf + (row0 + i * 128) * W_RAWB + q * 16) = v;

@@ -695,6 +695,8 @@ int ensure_device(fdsr_handle h) {
     std::vector<float> ones(h->weights.size() * 2, 1.0f);
     HIPCHK(h, hipMemcpy(h->d_hscale, ones.data(), ones.size() * sizeof(float), hipMemcpyHostToDevice));
   }
+  HIPCHK(h, hipMalloc((void**)&h->d_sat, 64));
+  HIPCHK(h, hipMemset(h->d_sat, 0, 64));
   if (h->wq_bytes) {
     HIPCHK(h, hipMalloc((void**)&h->d_wq, h->wq_bytes));
     HIPCHK(h, hipMemset(h->d_wq, 0, h->wq_bytes));
@@ -975,6 +977,7 @@ int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, 
           HIPCHK(h, hipEventRecord(h->ev_pool[h->ev_used++], st));
         }
         if (h->prec != PREC_F32 && w.h_ok) {
+          p.sat_flag = (h->prec == PREC_F16X3 && g_tun.sat_guard) ? h->d_sat : nullptr;
           p.wq = h->d_wq + w.hq_off[h->prec];
           p.w_inv_scale = w.h_inv_scale[h->prec];
           p.Cin_pad = w.h_cin_pad;
@@ -1348,6 +1351,7 @@ void fdsr_destroy(fdsr_handle h) {
   for (auto e : h->ev_pool) (void)hipEventDestroy(e);
   if (h->d_params) (void)hipFree(h->d_params);
   if (h->d_wq) (void)hipFree(h->d_wq);
+  if (h->d_sat) (void)hipFree(h->d_sat);
   if (h->d_temb_table) (void)hipFree(h->d_temb_table);
   if (h->d_nl) (void)hipFree(h->d_nl);
   if (h->d_rng) (void)hipFree(h->d_rng);
@@ -1657,6 +1661,19 @@ int fdsr_debug_dropout_mask(fdsr_handle h, const char* block, const unsigned cha
       return FDSR_OK;
     }
   return fail(h, FDSR_E_KEY, "no dropout in front of block '%s'", block);
+}
+
+int fdsr_check_saturation(fdsr_handle h, void* hip_stream) {
+  if (!h) return FDSR_E_INVALID;
+  if (!h->d_sat) return FDSR_OK;
+  hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+  int flag = 0;
+  HIPCHK(h, hipMemcpyAsync(&flag, h->d_sat, sizeof flag, hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  if (!flag) return FDSR_OK;
+  HIPCHK(h, hipMemsetAsync(h->d_sat, 0, sizeof flag, st));
+  return fail(h, FDSR_E_SATURATED, "f16x3: a raw convolution input exceeded the f16 range (+-65504) and was clamped; "
+                                   "re-run this call with fdsr_set_precision(FDSR_PREC_F32)");
 }
 
 int fdsr_debug_option(const char* name, long long value) {

@@ -56,6 +56,7 @@ struct ConvParams {
   const float* bias_r;
   float w_inv_scale_r;               // the rider's accumulator un-scaling; the accumulator is brought to THIS scale when the
   const float* w_inv_scale_r_dev;    // K loop passes from the main chunks to the rider chunks (powers of two: exact)
+  int* sat_flag;                     // f16x3: set to 1 when a RAW input value exceeds the f16 range (null: no check)
 };
 
 enum Precision { PREC_F32 = 0, PREC_F16X3 = 1, PREC_BF16 = 2 };

@@ -14,6 +14,18 @@ from torch import nn
 from .schedule import schedule_buffers, sampling_scalars
 
 
+_warned_saturated = False
+
+
+def _warn_saturated_once():
+    global _warned_saturated
+    if not _warned_saturated:
+        import warnings
+        warnings.warn('fastdiffsr_amd: a raw convolution input exceeded the f16 range in f16x3 mode; this call was re-run on the '
+                      'exact-fp32 kernels (set netG.precision = "f32" to avoid the double work)', RuntimeWarning)
+        _warned_saturated = True
+
+
 class _EngineLoss(torch.autograd.Function):
     """loss = p_losses(...) with the engine's backward pass behind autograd: backward() copies the engine's
     gradients (scaled by the incoming gradient of the loss, e.g. 1 / (b*c*h*w)) into the Parameters' .grad."""
@@ -91,9 +103,21 @@ class GaussianDiffusion(nn.Module):
         # the reference samples after netG.eval() (model.py:60); in .train() mode its Dropout would be live here too,
         # and so it is (the engine then insists on the fp32 kernels)
         eng.set_training(self.denoise_fn.training and self.denoise_fn.cfg.dropout > 0, seed_from_torch=True)
+        from . import _lib
+        try:
+            res = eng.sample(x, noise, want_traj=bool(continous), graph=False)
+        except _lib.FdsrSaturated:
+            # a raw conv input left the f16 range (checkpoints with very large residual streams): the exact-fp32 kernels
+            # have no such limit.  With engine-drawn noise the re-run draws fresh noise (as a second call would).
+            _warn_saturated_once()
+            eng.set_precision('f32')
+            try:
+                res = eng.sample(x, noise, want_traj=bool(continous), graph=False)
+            finally:
+                eng.set_precision(self.precision)
         if not continous:
-            return eng.sample(x, noise, graph=False)
-        img, traj = eng.sample(x, noise, want_traj=True, graph=False)
+            return res
+        img, traj = res
         inter = (1 | (T // 10))                                   # :195
         frames = [self.res2img(x, x)]                             # ret_img[0] = res2img(x_in, x_in) (:215-216)
         for k, t in enumerate(reversed(range(T))):

@@ -40,6 +40,10 @@ class Engine:
         self._gstream = None
         self.trained = False            # at least one optimiser step ran (there is optimiser state to save)
         self.T = 0
+        self.precision = 'f32'
+        # f16x3 range guard (include/fdsr.h: fdsr_check_saturation): after every sample / unet_forward in f16x3 the engine
+        # asks whether a raw conv input left the f16 range and raises FdsrSaturated if so (one stream synchronisation per call)
+        self.check_saturation = True
 
     def __del__(self):
         try:
@@ -130,7 +134,16 @@ class Engine:
         _lib.check(self.h, self.lib.fdsr_unet_forward(self.h, _ptr(x), _ptr(nl), _ptr(out), B, H, W, _ptr(ws), ws.numel(),
                                                       C.c_void_p(st)))
         self._keep = (x, nl)
+        self._saturation_check(st)
         return out
+
+    def _saturation_check(self, stream):
+        if self.precision != 'f16x3' or not self.check_saturation:
+            return
+        rc = self.lib.fdsr_check_saturation(self.h, C.c_void_p(stream))
+        if rc == _lib.FDSR_E_SATURATED:
+            raise _lib.FdsrSaturated(rc, self.lib.fdsr_last_error(self.h).decode())
+        _lib.check(self.h, rc)
 
     def sample(self, cond, noise=None, want_traj=False, graph=False, out=None, traj=None):
         """noise: [T,B,3,H,W] (parity runs: the reference's draws), or None: the engine draws
@@ -158,9 +171,12 @@ class Engine:
             self._gstream.wait_stream(cur)
             _lib.check(self.h, self.lib.fdsr_sample(*args, C.c_void_p(self._gstream.cuda_stream), flags))
             cur.wait_stream(self._gstream)
+            self._keep = (cond, noise, out, traj)
+            self._saturation_check(self._gstream.cuda_stream)
         else:
             _lib.check(self.h, self.lib.fdsr_sample(*args, C.c_void_p(cur.cuda_stream), flags))
-        self._keep = (cond, noise, out, traj)
+            self._keep = (cond, noise, out, traj)
+            self._saturation_check(cur.cuda_stream)
         return (out, traj) if want_traj else out
 
     def set_seed(self, seed):

@@ -43,6 +43,7 @@ extern "C" {
 #define FDSR_E_STATE (-3)     /* weights / schedule missing                */
 #define FDSR_E_WORKSPACE (-4) /* workspace too small or misaligned         */
 #define FDSR_E_HIP (-5)       /* HIP runtime error (see fdsr_last_error)   */
+#define FDSR_E_SATURATED (-6) /* f16x3: a raw conv input left the f16 range (fdsr_check_saturation) */
 
 #define FDSR_MAX_MULTS 8
 
@@ -175,6 +176,13 @@ int fdsr_tensor2img_u8(fdsr_handle h, const float* src_nchw, uint8_t* dst_nhwc, 
  * The first call for a new (in,out) size builds its coefficient tables (synchronous upload). */
 int fdsr_resize_bicubic_u8(fdsr_handle h, const uint8_t* src_nhwc, int batch, int in_h, int in_w, int out_h,
                            int out_w, uint8_t* tmp, uint8_t* dst_u8_nhwc, float* dst_f32_nchw, void* hip_stream);
+
+/* f16x3 range guard.  The split-f16 arithmetic clamps every operand to +-65504.  GroupNorm'ed conv inputs are re-scaled
+ * before the split, but a RAW input (ResnetBlock res_conv, Down/Upsample convs: unet.py:66-83,112) beyond that range would be
+ * clamped silently; the kernels raise a sticky device flag instead.  This call synchronises `hip_stream`, reads and clears the
+ * flag: FDSR_OK, or FDSR_E_SATURATED if any fdsr_sample / fdsr_unet_forward since the last check clamped a raw input (their
+ * outputs are then not fp32-grade: re-run them after fdsr_set_precision(FDSR_PREC_F32), which has no such limit). */
+int fdsr_check_saturation(fdsr_handle h, void* hip_stream);
 
 /* -- introspection for parity tests and bench.py -------------------------- */
 /* Debug / A-B options of the launchers (process-wide; nothing in the library reads the environment).  Names:

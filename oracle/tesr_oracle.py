@@ -12,7 +12,8 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from fastdiffsr_amd.arch import UNetConfig, build_layers
+from fastdiffsr_amd.arch import UNetConfig   # the hyper-parameter record only (type of `cfg`)
+from oracle.layers import wiring as build_layers   # the oracle's own wiring table
 from oracle.fdsr_oracle import block, noise_level_mlp, resnet_block
 from oracle.sr3_oracle import self_attention
 

@@ -89,3 +89,61 @@ def test_activation_plane_scale(scale, prec):
     d, worst = _layerwise(sd, cfg, x, nl, prec)
     print(f'plane scale {scale:.0e} (max|downs.0| {top:.3e}) [{prec}]: final max|d| {d:.3e}; worst layer {worst[1]} '
           f'at {worst[0]:.3e} x max(1,|ref|)')
+
+
+def test_f16x3_saturation_guard_residual_stream_at_1e5():
+    """A residual stream at 1e5 (> 65504) read RAW by the res_convs and the down/upsample convs.  Before the guard the split-f16
+    staging clamped it silently and the layers after it were wrong with no signal (documented below by switching the guard off);
+    with the guard the C ABI reports FDSR_E_SATURATED for the call, and the facade re-runs it on the exact-fp32 kernels:
+    within 1e-4 * max(1, |ref|) of the oracle."""
+    import warnings
+    from fastdiffsr_amd import _lib
+    from fastdiffsr_amd.engine import Engine
+    from fastdiffsr_amd.unet import UNet
+    from oracle import fdsr_oracle as O
+    cfg = UNetConfig(**CFG)
+    sd = synth_state_dict(cfg, 0)
+    sd['downs.0.weight'] = sd['downs.0.weight'] * np.float32(3.0e4)     # first plane / first skips reach ~1.5e5
+    sd['downs.0.bias'] = sd['downs.0.bias'] * np.float32(3.0e4)
+    x = torch.randn(2, 6, 64, 64, generator=torch.Generator().manual_seed(2)).clamp(-3, 3)
+    nl = torch.tensor([[0.05], [0.6]])
+    cap = {}
+    with torch.no_grad():
+        ref = O.unet_forward(O.to_torch_sd(sd), cfg, x, nl, capture=cap)
+    assert cap['downs.0'].abs().max().item() > 1.0e5
+    scale = max(1.0, ref.abs().max().item())
+    eng = Engine(cfg)
+    eng.load_state_dict(sd)
+    eng.set_precision('f16x3')
+    # (1) the engine reports it
+    with pytest.raises(_lib.FdsrSaturated) as ei:
+        eng.unet_forward(x.cuda(), nl.cuda())
+    assert ei.value.code == _lib.FDSR_E_SATURATED
+    # (2) what used to happen silently: clamped raw inputs, a wrong answer, no error
+    eng.check_saturation = False
+    bad = eng.unet_forward(x.cuda(), nl.cuda()).cpu()
+    assert (bad - ref).abs().max().item() > 1e-3 * scale
+    eng.check_saturation = True
+    # (3) the flag is sticky until read, then clear: a clean input afterwards passes
+    with pytest.raises(_lib.FdsrSaturated):
+        eng.unet_forward(x.cuda(), nl.cuda())
+    # (4) the exact-fp32 mode has no such limit
+    eng.set_precision('f32')
+    assert (eng.unet_forward(x.cuda(), nl.cuda()).cpu() - ref).abs().max().item() <= TOL * scale
+    # (5) the facade: warns once, re-runs the call in f32, stays in f16x3 for the next call
+    net = UNet(in_channel=6, out_channel=3, norm_groups=32, inner_channel=64, channel_mults=(1, 2, 4, 4), attn_res=(16,),
+               res_blocks=2, dropout=0.2, image_size=64)
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    net = net.cuda().eval()
+    net.engine.set_precision('f16x3')
+    with torch.no_grad(), warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        got = net(x.cuda(), nl.cuda()).cpu()
+    assert (got - ref).abs().max().item() <= TOL * scale
+    assert net.engine.precision == 'f16x3'
+    # a network whose activations stay in range never trips it
+    sd0 = synth_state_dict(cfg, 0)
+    e2 = Engine(cfg)
+    e2.load_state_dict(sd0)
+    e2.set_precision('f16x3')
+    e2.unet_forward(x.cuda(), nl.cuda())

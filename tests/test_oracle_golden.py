@@ -334,3 +334,22 @@ def test_gdp_oracle_matches_reference(golden_dir):
         loss = GO.p_losses(sd, cfg, tab, torch.from_numpy(g['hr']), torch.from_numpy(g['sr']), torch.from_numpy(g['loss_t']),
                            torch.from_numpy(g['loss_noise']))
     assert abs(loss.item() - float(g['loss'])) <= 1e-5 * abs(float(g['loss']))
+
+
+def test_oracle_wiring_table_is_its_own_and_agrees_with_the_products():
+    """oracle/layers.py derives the module list from the reference's constructor on its own; the product's arch.build_layers is a
+    second, independent derivation.  They must agree for every architecture the tests use (the goldens pin both)."""
+    from fastdiffsr_amd.arch import UNetConfig, FASTDIFFSR_UNET, build_layers
+    from oracle import layers as OL
+    import oracle.fdsr_oracle as O
+    assert O.build_layers is OL.wiring
+    cfgs = [UNetConfig(**FASTDIFFSR_UNET),
+            UNetConfig(inner_channel=32, channel_mults=(1, 2, 4, 4), attn_res=(16,), res_blocks=2, image_size=32),
+            UNetConfig(inner_channel=32, channel_mults=(1, 2), attn_res=(16,), res_blocks=1, image_size=16),
+            UNetConfig(inner_channel=64, channel_mults=(1, 2, 4, 8, 8), attn_res=(16,), res_blocks=2, image_size=256, variant='ddpm'),
+            UNetConfig(inner_channel=32, channel_mults=(1, 2, 4), attn_res=(8, 16), res_blocks=1, image_size=32, variant='tesr')]
+    for cfg in cfgs:
+        a, b = OL.wiring(cfg), build_layers(cfg)
+        assert len(a) == len(b)
+        for x, y in zip(a, b):
+            assert (x.kind, x.name, x.cin, x.cout, bool(x.with_attn), x.cskip) == (y.kind, y.name, y.cin, y.cout, bool(y.with_attn), y.cskip)
