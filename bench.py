@@ -60,9 +60,9 @@ def cpu_model():
     return 'unknown'
 
 
-def cpu_baseline(cfg, sd, budget_s=24.0):
+def cpu_baseline(cfg, sd, budget_s=32.0, images=3):
     """The oracle (CPU restatement of the reference loop) timed on the host cores, on a BOUNDED sample
-    (BASELINE.md section 3): after one warm-up UNet forward, full 20-step loops of 256x256 images at B=1 -- two
+    (BASELINE.md section 3): after one warm-up UNet forward, full 20-step loops of 256x256 images at B=1 -- three
     images, or as many reverse steps as fit in ~budget_s (every step costs the same: one UNet forward + the
     posterior update) -- then ONE B=4 UNet forward (the reference gains nothing from batching on CPU).
     images/s = 1 / (20 * mean step time).  Reported baseline only."""
@@ -74,12 +74,12 @@ def cpu_baseline(cfg, sd, budget_s=24.0):
     torch.set_num_threads(threads)
     tsd = O.to_torch_sd(sd)
     tab = O.schedule_tables(FASTDIFFSR_SCHEDULE_VAL)
-    cond, noise = synth_inputs(2, 256, 256, 20)
+    cond, noise = synth_inputs(images, 256, 256, 20)
     first = None
     with torch.no_grad():
         O.unet_forward(tsd, cfg, torch.cat([cond[:1], noise[0, :1]], 1), torch.full((1, 1), 0.5))   # warm-up
         steps, t0 = 0, time.perf_counter()
-        for i in range(2):
+        for i in range(images):
             c, nz = cond[i:i + 1], noise[:, i:i + 1]
             img, k = nz[0], 0
             for t in reversed(range(20)):
@@ -175,13 +175,13 @@ def kernel_source_hash():
     return h.hexdigest()
 
 
-def conv_roofline(prof, precision, B, S, dt_total, round_tag='r02'):
+def conv_roofline(prof, precision, B, S, dt_total, round_tag='r03'):
     """Roofline of the dominant kernel family = every 3x3 convolution launch (implicit-GEMM MFMA kernels incl. the
     sub-pixel upsample form and the 6-channel input conv): algorithmic FLOPs / HIP-event time around those launches."""
     ach = prof['conv_flops'] / (prof['conv_ms'] * 1e-3) / 1e12
     peak = PEAK_F32_MFMA if precision == 'f32' else PEAK_16BIT_MFMA
     passes = 3 if precision == 'f16x3' else 1     # MFMA products issued per algorithmic product
-    kern = 'conv_mfma_f32_kernel' if precision == 'f32' else 'conv_mfma_h_kernel'
+    kern = 'conv_mfma_f32_kernel' if precision == 'f32' else ('conv_wino_h_kernel + conv_mfma_h_kernel' if precision == 'f16x3' else 'conv_mfma_h_kernel')
     # HBM bytes per launch of the SAME launch set (3x3 family), from rocprofv3 --pmc passes of this command kept
     # under profiles/ (separate FETCH_SIZE / WRITE_SIZE runs, gfx950 x2 read correction: tools/pmc_traffic.py).
     # Quoted only while the file was measured on these very kernel sources; otherwise null.
@@ -208,10 +208,13 @@ def conv_roofline(prof, precision, B, S, dt_total, round_tag='r02'):
          # the engine brackets the conv launches of every 4th diffusion step with HIP
          # events (5 of 20 steps): <1 % overhead in the timed region, measured 2.6 % with all
          'timed_steps_of_20': n_timed}
+    if precision == 'f16x3':
+        r['executed_note'] = ('executed_tflops prices every product at 3 MFMA passes of the DIRECT form; launches that take the Winograd '
+                              'F(2x2,3x3) form (stride-1 3x3, grids >= 256 workgroups) issue 16/36 of those MFMAs for the same algorithmic FLOPs')
     if precision != 'f32':
         # (until round 2's last change these launches did not contain the 1x1 res_convs: their time sat outside the family)
-        r['launch_set'] = ('every 3x3 conv launch; in the 16-bit modes the 14 1x1 res_convs of a forward ride inside their '
-                           "block2 launches (ConvParams::xr0): their FLOPs, bytes and time are in these figures")
+        r['launch_set'] = ('every 3x3 conv launch; 1x1 res_convs that ride inside a direct block2 launch (ConvParams::xr0) have their '
+                           'FLOPs, bytes and time in these figures; behind a Winograd block2 launch the res_conv is a launch of its own, outside them')
     if dt_total:
         r['conv_time_share'] = prof['conv_ms'] * 1e-3 * (20 / n_timed) / dt_total
     return r
@@ -304,6 +307,21 @@ def run_train(eng, dev, B, S, steps, warmup, rank=0, sync=None, allreduce=None, 
     return dt
 
 
+def train_roofline(ips_per_gpu, precision):
+    """The optimisation step against the MFMA roof of its arithmetic: forward + input gradients + weight gradients = 3 x the
+    forward's 268.31 GFLOP per image, every one of them a convolution of the same family.  f16x3 issues three f16
+    MFMAs per product on the 2.5 PF pipe; exact fp32 runs v_mfma_f32_32x32x2_f32 (157.3 TF).  Whole-step figure: time of
+    the complete step (loss, GroupNorm backward, Adam included), not of the conv launches alone."""
+    tf = ips_per_gpu * 3 * FLOPS_PER_IMAGE / 20 / 1e12
+    peak = PEAK_F32_MFMA if precision == 'f32' else PEAK_16BIT_MFMA
+    passes = 3 if precision == 'f16x3' else 1
+    fam = ('conv_mfma_f32_kernel (forward, input gradients) + wgrad_kernel (weight gradients)' if precision == 'f32' else
+           'conv_mfma_h_kernel (forward, input gradients) + wgrad_h8i_kernel / wgrad_h_kernel (weight gradients)')
+    return {'bound': 'mfma', 'kernel': fam, 'achieved': tf, 'peak': peak, 'unit': 'TFLOP/s', 'frac': tf / peak,
+            'mfma_passes_per_product': passes, 'executed_tflops': tf * passes, 'frac_executed': tf * passes / peak, 'traffic': None,
+            'scope': 'whole optimisation step (algorithmic conv FLOPs of forward + backward / step time)'}
+
+
 def train_record(cfg, sd, dev, B, S, steps, warmup, precision='f16x3'):
     """An engine of its own: optimiser steps move the weights, the sampling engine (and its parity check) must not see that."""
     try:
@@ -321,7 +339,7 @@ def train_record(cfg, sd, dev, B, S, steps, warmup, precision='f16x3'):
                 'workload': 'configs[4] per-GPU slice: batch 32, 256x256, q_sample + L1(sum)/(b*c*h*w) (define_G fixes loss_type l1) + '
                             'backward + Adam, Dropout(0.2) live; ' + ('everything exact fp32' if precision == 'f32' else
                                                                  'every convolution (forward, input and weight gradients) f16x3 = fp32-grade'),
-                'algorithmic_tflops': tf, 'frac_f32_mfma_peak': tf / PEAK_F32_MFMA}   # priced against the f32 roof in both modes
+                'algorithmic_tflops': tf, 'roofline': train_roofline(ips, precision)}
     except Exception as e:
         return {'error': f'{type(e).__name__}: {e}'}
 
@@ -538,7 +556,7 @@ def main():
                            'batch_per_gpu': Bt, 'global_batch': Bt * world, 'parallelism': f'dp{world}'},
                 'per_rank': per_rank_stats(rank_ts, Bt * args.steps),
                 'world_size_reported_by_backend': dist.get_world_size() if distributed else 1,
-                'algorithmic_tflops_per_gpu': tf, 'frac_f32_mfma_peak': tf / PEAK_F32_MFMA}), flush=True)
+                'algorithmic_tflops_per_gpu': tf, 'roofline': train_roofline(ips / world, args.precision)}), flush=True)
         if distributed:
             dist.destroy_process_group()
         return

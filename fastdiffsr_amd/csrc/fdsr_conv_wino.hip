@@ -27,6 +27,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 namespace fdsr {
 
@@ -60,6 +61,9 @@ __device__ __forceinline__ void split_store(unsigned char* dst, f32x4 v) {
 }
 
 }  // namespace
+
+// Perf-only knock-out builds (tools/build_wino_variant.sh -DWINO_KO_...): remove one part of the kernel to price it; results are garbage.
+#define WINO_SINK4(u) asm volatile("" ::"v"((u).x), "v"((u).y), "v"((u).z), "v"((u).w))
 
 __global__ void __launch_bounds__(512, 2) conv_wino_h_kernel(const ConvParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_w[];
@@ -207,24 +211,38 @@ __global__ void __launch_bounds__(512, 2) conv_wino_h_kernel(const ConvParams p)
     unsigned char* cur = (kc & 1) ? sRaw1 : sRaw0;
     unsigned char* nxt = (kc & 1) ? sRaw0 : sRaw1;
     const bool more = kc + 1 < nk;
+#ifndef WINO_KO_T
     transform(cur);
+#endif
     __syncthreads();          // V complete
+#ifndef WINO_KO_A
     load_a(0, 0);
+#endif
 #pragma unroll
     for (int nu = 0; nu < 4; ++nu) {
+#ifndef WINO_KO_A
       if (nu + 1 < 4) load_a((nu + 1) & 1, nu + 1);
+#endif
 #pragma unroll
       for (int tb = 0; tb < 2; ++tb) {
         const uint4 ahi = Af[nu & 1][tb][0], alo = Af[nu & 1][tb][1];
+#ifndef WINO_KO_M
         acc[nu][tb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, alo), __builtin_bit_cast(h8, Bf[nu][0]), acc[nu][tb], 0, 0, 0);
         acc[nu][tb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, ahi), __builtin_bit_cast(h8, Bf[nu][1]), acc[nu][tb], 0, 0, 0);
         acc[nu][tb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, ahi), __builtin_bit_cast(h8, Bf[nu][0]), acc[nu][tb], 0, 0, 0);
+#else
+        WINO_SINK4(ahi); WINO_SINK4(alo); WINO_SINK4(Bf[nu][0]); WINO_SINK4(Bf[nu][1]);
+#endif
       }
+#ifndef WINO_KO_B
       if (more) load_b(kc + 1, nu);   // same registers, next chunk
+#endif
+#ifndef WINO_KO_STAGE
       if (nu == 1 && more) {          // mid-phase: activate and store the next chunk's halo, fetch the one after
         stage(nxt);
         if (kc + 2 < nk) prefetch(kc + 2);
       }
+#endif
     }
     __syncthreads();          // V free again; next halo complete
   }
@@ -292,11 +310,315 @@ __global__ void __launch_bounds__(512, 2) conv_wino_h_kernel(const ConvParams p)
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Second form of the same kernel ("half-tile pipeline", the default): the measured first form spends its chunk time in
+// SERIAL phases -- transform (VALU + LDS), barrier, MFMAs with the halo staging in the middle, barrier: 17 % MFMA busy,
+// 17 VALU per MFMA (profiles/r03_wino_knockouts.txt).  Here every barrier interval holds BOTH kinds of work and the two
+// waves of a SIMD run them in opposite order, so one wave's MFMAs cover its partner's VALU / LDS work:
+//   phase A(k): MFMAs on tile block 0 of chunk k  |  transform tile block 1 of chunk k -> V1; stage items 1, 2 of chunk k+1
+//   phase B(k): MFMAs on tile block 1 of chunk k  |  transform tile block 0 of chunk k+1 -> V0; stage item 0 of chunk k+2
+// (waves 0-3: transform / staging first, then MFMAs; waves 4-7: MFMAs first).  V is two 32-tile halves, each written in
+// one phase and read in the next; the fp32 halo stays double-buffered.  Fewer VALU per element: hi/lo split as one
+// packed convert + two v_fma_mix per pair, wave-uniform roles in SGPRs (scalar branches), no range check (the input is
+// GroupNorm'ed), halo rows padded to 1536 B so that the transform reads of a (tile row, tile row + 1) lane pair fall on
+// the same banks modulo 64 words -- every ds_read_b128 group of 16 lanes covers 8 tile columns x 2 channel quads.
+namespace {
+constexpr int W2_RAWROW = 1536;                          // bytes per halo row (18 pixels x 80 B = 1440, padded)
+constexpr int W2_RAW_BYTES = W_HW * W2_RAWROW;           // 27648
+constexpr int W2_LDS = W_Z_BYTES > W_V_BYTES + 2 * W2_RAW_BYTES ? W_Z_BYTES : W_V_BYTES + 2 * W2_RAW_BYTES;
+
+// hi = rn_f16(v), lo = rn_f16(v - hi): one packed convert and two v_fma_mix per pair (lo = f16(fma(hi, -1, v)), rounded once:
+// bit-identical to the two-step form); hi at dst, lo at dst + 32
+__device__ __forceinline__ void split_store2(unsigned char* dst, f32x4 v) {
+  typedef _Float16 h2t __attribute__((ext_vector_type(2)));
+  uint2 hi, lo;
+  {
+    const h2t h0 = {(_Float16)v[0], (_Float16)v[1]}, h1 = {(_Float16)v[2], (_Float16)v[3]};
+    hi.x = __builtin_bit_cast(unsigned, h0);
+    hi.y = __builtin_bit_cast(unsigned, h1);
+  }
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo.x) : "v"(hi.x), "v"(v[0]));
+  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo.x) : "v"(hi.x), "v"(v[1]));
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo.y) : "v"(hi.y), "v"(v[2]));
+  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo.y) : "v"(hi.y), "v"(v[3]));
+  *reinterpret_cast<uint2*>(dst) = hi;
+  *reinterpret_cast<uint2*>(dst + 32) = lo;
+}
+}  // namespace
+
+__global__ void __launch_bounds__(512, 2) conv_wino2_h_kernel(const ConvParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_w[];
+  unsigned char* sV = smem_w;
+  unsigned char* sRaw0 = smem_w + W_V_BYTES;
+  unsigned char* sRaw1 = sRaw0 + W2_RAW_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: roles below live in SGPRs
+  const int Cin = p.C0 + p.C1;
+  const int nk = p.Cin_pad >> 4;
+  const int nco = p.Cout_pad >> 6;
+  const int tilesX = p.Wout >> 4, ntile = tilesX * (p.Hout >> 4);
+  int cot, sp;
+  {
+    const int b = blockIdx.x;
+    if (nco <= 8 && (8 % nco) == 0 && (gridDim.x & 7) == 0) {   // one cout block per XCD (round-robin dispatch: XCD = b & 7)
+      const int xcd = b & 7, k = b >> 3, per = 8 / nco;
+      cot = xcd % nco;
+      sp = k * per + xcd / nco;
+    } else {
+      cot = b % nco;
+      sp = b / nco;
+    }
+  }
+  const int n = sp / ntile, tl = sp % ntile;
+  const int oy0 = (tl / tilesX) * 16, ox0 = (tl % tilesX) * 16, co0 = cot * 64;
+
+  // ---- halo staging: thread -> (pixel row0 + 128 i, channel quad q), i = 0..2 ----
+  const int q = tid & 3, row0 = tid >> 2;
+  int in_pix[W_NIN], raw_off[W_NIN];
+#pragma unroll
+  for (int i = 0; i < W_NIN; ++i) {
+    const int pix = row0 + i * 128;
+    int v = -2, ro = 0;
+    if (pix < W_NPIX) {
+      const int hy = pix / W_HW, hx = pix % W_HW;
+      const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+      const bool ok = iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
+      v = ok ? (n * p.Hin + iy) * p.Win + ix : -1;
+      ro = hy * W2_RAWROW + hx * W_RAWB + q * 16;
+    }
+    in_pix[i] = v;
+    raw_off[i] = ro;
+  }
+  const bool has2 = row0 + 2 * 128 < W_NPIX;   // the third pass covers 68 of the 128 pixel rows
+  f32x4 rin[W_NIN];
+  f32x4 rsc, rsh;
+  auto load_scsh = [&](int kc) {
+    rsc = *reinterpret_cast<const f32x4*>(p.gn_scale + (size_t)n * Cin + kc * 16 + q * 4);
+    rsh = *reinterpret_cast<const f32x4*>(p.gn_shift + (size_t)n * Cin + kc * 16 + q * 4);
+  };
+  auto prefetch_item = [&](int i, int kc) {
+    const int cbase = kc * 16;
+    const float* base;
+    int Cs, cc;
+    if (cbase < p.C0) { base = p.x0; Cs = p.C0; cc = cbase + q * 4; }
+    else { base = p.x1; Cs = p.C1; cc = cbase - p.C0 + q * 4; }
+    rin[i] = *reinterpret_cast<const f32x4*>(base + (size_t)(in_pix[i] < 0 ? 0 : in_pix[i]) * Cs + cc);   // padding reads pixel 0, zeroed below
+  };
+  auto stage_item = [&](int i, unsigned char* buf) {
+    if (i == 2 && !has2) return;
+    f32x4 v = rin[i] * rsc + rsh;
+    v.x = silu_w(v.x); v.y = silu_w(v.y); v.z = silu_w(v.z); v.w = silu_w(v.w);
+    const float lim = in_pix[i] >= 0 ? 16376.f : 0.f;   // zero padding of the ACTIVATED tensor; |V| <= 4 max|a| stays inside f16
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], -lim, lim);
+    *reinterpret_cast<f32x4*>(buf + raw_off[i]) = v;
+  };
+
+  // ---- transformed-weight fragments: [cot][kc][wave][nu][plane][lane] x 16 B ----
+  const uint4* wq = reinterpret_cast<const uint4*>(p.wq) + ((size_t)cot * nk * 8 + wave) * (4 * 2 * 64) + lane;
+  uint4 Bf[4][2];
+  auto load_b = [&](int kc, int nu) {
+    const uint4* src = wq + (size_t)kc * (8 * 4 * 2 * 64) + nu * (2 * 64);
+    Bf[nu][0] = src[0];
+    Bf[nu][1] = src[64];
+  };
+
+  // ---- input transform roles: lane = {ty[1:0], cq[0], tx[2:0]}, wave = {xi_t[1:0], cq[1]}; one item = (tile of a 32-tile half,
+  // 4 channels, position row xi_t): 2 halo rows x 4 columns in, 4 positions out ----
+  const int t_tx = lane & 7, t_ty = lane >> 4, t_cq = ((lane >> 3) & 1) | ((wave & 1) << 1);
+  const int xi_t = wave >> 1;
+  const int ra_off = (xi_t == 0 ? 0 : 1) * W2_RAWROW, rb_off = (xi_t == 3 ? 3 : 2) * W2_RAWROW;   // rows (0,2) (1,2) (1,2) (1,3)
+  const int t_rd = (2 * t_ty) * W2_RAWROW + (2 * t_tx) * W_RAWB + t_cq * 16;                       // + tb * 8 rows
+  const int t_wr = ((xi_t * 4) * W_TT + t_ty * 8 + t_tx) * W_ROWB + t_cq * 8;                      // + tb * 32 tiles
+  auto transform = [&](int tb, const unsigned char* raw) {
+    const unsigned char* ra = raw + t_rd + tb * (8 * W2_RAWROW) + ra_off;
+    const unsigned char* rb = raw + t_rd + tb * (8 * W2_RAWROW) + rb_off;
+    // column by column (few live registers: the accumulators and weight fragments leave ~90 VGPRs): R[c] = row combination of
+    // column c, outputs V0 = R0 - R2, V1 = R1 + R2, V2 = R2 - R1, V3 = R1 - R3 leave as soon as their columns are in
+    auto col = [&](int c) -> f32x4 {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(ra + c * W_RAWB);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(rb + c * W_RAWB);
+      return xi_t == 1 ? a + b : (xi_t == 2 ? b - a : a - b);      // d1 + d2 | d2 - d1 | d0 - d2, d1 - d3  (xi_t is wave-uniform)
+    };
+    unsigned char* dst = sV + t_wr + tb * (32 * W_ROWB);
+    const f32x4 R0 = col(0), R2 = col(2);
+    split_store2(dst + 0 * (W_TT * W_ROWB), R0 - R2);
+    const f32x4 R1 = col(1);
+    split_store2(dst + 1 * (W_TT * W_ROWB), R1 + R2);
+    split_store2(dst + 2 * (W_TT * W_ROWB), R2 - R1);
+    const f32x4 R3 = col(3);
+    split_store2(dst + 3 * (W_TT * W_ROWB), R1 - R3);
+  };
+
+  // ---- MFMA roles: position row xi = wave & 3, cout half = wave >> 2 (also the stagger group) ----
+  const int xi = wave & 3, chalf = wave >> 2;
+  const int r31 = lane & 31, kh = lane >> 5;
+  const unsigned char* abase = sV + ((xi * 4) * W_TT + r31) * W_ROWB + 16 * kh;
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int nu = 0; nu < 4; ++nu)
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[nu][tb][i] = 0.f;
+
+  uint4 Af[2][2];   // [slot][plane]
+  auto load_a = [&](int slot, int nu, int tb) {
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+      Af[slot][pl] = *reinterpret_cast<const uint4*>(abase + (nu * W_TT + tb * 32) * W_ROWB + 32 * pl);
+  };
+  // 12 MFMAs on tile block tb of the current chunk; reload: fetch the next chunk's fragments into the same registers
+  auto mfma_part = [&](auto tb_tag, int kc_next, bool reload) {
+    constexpr int tb = decltype(tb_tag)::value;
+    load_a(0, 0, tb);
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu) {
+      if (nu + 1 < 4) load_a((nu + 1) & 1, nu + 1, tb);
+      const uint4 ahi = Af[nu & 1][0], alo = Af[nu & 1][1];
+      acc[nu][tb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, alo), __builtin_bit_cast(h8, Bf[nu][0]), acc[nu][tb], 0, 0, 0);
+      acc[nu][tb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, ahi), __builtin_bit_cast(h8, Bf[nu][1]), acc[nu][tb], 0, 0, 0);
+      acc[nu][tb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, ahi), __builtin_bit_cast(h8, Bf[nu][0]), acc[nu][tb], 0, 0, 0);
+      if (reload) load_b(kc_next, nu);
+    }
+  };
+  using TB0 = std::integral_constant<int, 0>;
+  using TB1 = std::integral_constant<int, 1>;
+
+  // ---- prologue: chunk 0 staged whole, its tile block 0 transformed; chunk 1 fetched, its item 0 staged ----
+#pragma unroll
+  for (int nu = 0; nu < 4; ++nu) load_b(0, nu);
+  load_scsh(0);
+#pragma unroll
+  for (int i = 0; i < W_NIN; ++i) prefetch_item(i, 0);
+#pragma unroll
+  for (int i = 0; i < W_NIN; ++i) stage_item(i, sRaw0);
+  if (nk > 1) {
+    load_scsh(1);
+#pragma unroll
+    for (int i = 0; i < W_NIN; ++i) prefetch_item(i, 1);
+  }
+  __syncthreads();
+  transform(0, sRaw0);
+  if (nk > 1) {
+    stage_item(0, sRaw1);
+    if (nk > 2) prefetch_item(0, 2);
+  }
+  __syncthreads();
+
+  for (int kc = 0; kc < nk; ++kc) {
+    unsigned char* cur = (kc & 1) ? sRaw1 : sRaw0;
+    unsigned char* nxt = (kc & 1) ? sRaw0 : sRaw1;
+    const bool more = kc + 1 < nk, more2 = kc + 2 < nk;
+    // ---- phase A ----
+    auto t_a = [&]() {
+      transform(1, cur);
+      if (more) {
+        stage_item(1, nxt);
+        stage_item(2, nxt);
+        if (more2) {
+          prefetch_item(1, kc + 2);
+          prefetch_item(2, kc + 2);
+          load_scsh(kc + 2);
+        }
+      }
+    };
+    // (sched_barrier: the two parts of a phase stay apart in a wave's own stream -- interleaving them makes their registers live together)
+    // ONE copy of the MFMA part between two guarded copies of the other part (an if / else over whole phases made the register
+    // allocator spill > 100 VGPRs)
+    if (chalf == 0) t_a();
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_part(TB0{}, 0, false);
+    __builtin_amdgcn_sched_barrier(0);
+    if (chalf != 0) t_a();
+    __syncthreads();
+    // ---- phase B ----
+    auto t_b = [&]() {
+      if (more) transform(0, nxt);
+      if (more2) {
+        stage_item(0, cur);
+        if (kc + 3 < nk) prefetch_item(0, kc + 3);
+      }
+    };
+    if (chalf == 0) t_b();
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_part(TB1{}, kc + 1, more);
+    __builtin_amdgcn_sched_barrier(0);
+    if (chalf != 0) t_b();
+    __syncthreads();
+  }
+
+  // ---- epilogue (as the first form): fold the position row over nu, rows meet in LDS ----
+  {
+    float* z = reinterpret_cast<float*>(smem_w);
+    const int cz = chalf * 32 + r31;
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int tile = tb * 32 + (i & 3) + 8 * (i >> 2) + 4 * kh;
+        const float m0 = acc[0][tb][i], m1 = acc[1][tb][i], m2 = acc[2][tb][i], m3 = acc[3][tb][i];
+        z[(((xi * 2 + 0) * W_TT + tile) * W_ZROWB >> 2) + cz] = m0 + m1 + m2;
+        z[(((xi * 2 + 1) * W_TT + tile) * W_ZROWB >> 2) + cz] = m1 - m2 - m3;
+      }
+  }
+  __syncthreads();
+  const float winv = p.w_inv_scale_dev ? *p.w_inv_scale_dev : p.w_inv_scale;
+  const int cqo = tid & 15, pp0 = tid >> 4;
+  const int co = co0 + cqo * 4;
+  f32x4 add = *reinterpret_cast<const f32x4*>(p.bias + co);
+  if (p.temb) add += *reinterpret_cast<const f32x4*>(p.temb + (size_t)n * p.temb_stride + p.temb_off + co);
+  f32x4 rv[8], yv[8];
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int pp = pp0 + it * 32, py = pp >> 4, px = pp & 15;
+    const size_t o = ((size_t)(n * p.Hout + oy0 + py) * p.Wout + ox0 + px) * p.Cout + co;
+    rv[it] = p.res ? *reinterpret_cast<const f32x4*>(p.res + o) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int pp = pp0 + it * 32, py = pp >> 4, px = pp & 15;
+    const int tile = (py >> 1) * 8 + (px >> 1), i = py & 1, j = px & 1;
+    const unsigned char* zb = smem_w + ((size_t)j * W_TT + tile) * W_ZROWB + cqo * 16;
+    const f32x4 z0 = *reinterpret_cast<const f32x4*>(zb + (size_t)(0 + i) * 2 * W_TT * W_ZROWB);
+    const f32x4 z1 = *reinterpret_cast<const f32x4*>(zb + (size_t)(1 + i) * 2 * W_TT * W_ZROWB);
+    const f32x4 z2 = *reinterpret_cast<const f32x4*>(zb + (size_t)(2 + i) * 2 * W_TT * W_ZROWB);
+    const f32x4 y = i == 0 ? (z0 + z1) + z2 : (z0 - z1) - z2;
+    yv[it] = y * winv + add + rv[it];
+  }
+  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int pp = pp0 + it * 32, py = pp >> 4, px = pp & 15;
+    const size_t o = ((size_t)(n * p.Hout + oy0 + py) * p.Wout + ox0 + px) * p.Cout + co;
+    *reinterpret_cast<f32x4*>(p.out + o) = yv[it];
+    s1 += yv[it];
+    s2 += yv[it] * yv[it];
+  }
+  if (p.part_out) {
+    __syncthreads();
+    f32x4* sred = reinterpret_cast<f32x4*>(smem_w);
+    sred[(pp0 * 16 + cqo) * 2 + 0] = s1;
+    sred[(pp0 * 16 + cqo) * 2 + 1] = s2;
+    __syncthreads();
+    if (tid < 16) {
+      f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
+      for (int g = 0; g < 32; ++g) { a += sred[(g * 16 + tid) * 2 + 0]; b += sred[(g * 16 + tid) * 2 + 1]; }
+      float* dst = p.part_out + (((size_t)n * ntile + tl) * p.Cout + co0 + tid * 4) * 2;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { dst[2 * e] = a[e]; dst[2 * e + 1] = b[e]; }
+    }
+  }
+}
+
 // Which launches take the Winograd form: stride-1 3x3, f16x3, 16-pixel-aligned maps, whole 64-cout blocks, 16-aligned concat
 // halves, and a grid that fills the chip (small grids keep the direct kernel with its K split).
 bool conv_wino_ok(ConvKind kind, int prec, const ConvParams& p) {
   if (!g_tun.wino || kind != CONV3_S1 || prec != PREC_F16X3) return false;
-  if (p.xr0 || p.drop_mask || p.ksplit > 1) return false;
+  if (p.xr0 || p.drop_mask || p.ksplit > 1 || p.gn_plain) return false;
   if ((p.Hout & 15) || (p.Wout & 15) || p.Hin != p.Hout || p.Win != p.Wout) return false;
   if ((p.Cout & 63) || (p.C0 & 15) || (p.C1 & 15) || p.C0 + p.C1 < 16) return false;
   const long wgs = (long)p.N * (p.Hout >> 4) * (p.Wout >> 4) * (p.Cout >> 6);
@@ -310,12 +632,17 @@ hipError_t launch_conv_wino_h(const ConvParams& p, hipStream_t s, int* tiles) {
   q.Cin_pad = p.C0 + p.C1;     // 16-aligned halves: no channel padding in this form
   q.Cout_pad = p.Cout;
   const int nwg = p.N * ntile * (p.Cout >> 6);
-  hipLaunchKernelGGL(conv_wino_h_kernel, dim3(nwg), dim3(512), (size_t)W_LDS, s, q);
+  if (g_tun.wino == 1 || !p.gn_scale)   // debug option wino = 1: the first (serial-phase) form, kept for A/B; it also takes raw inputs
+    hipLaunchKernelGGL(conv_wino_h_kernel, dim3(nwg), dim3(512), (size_t)W_LDS, s, q);
+  else
+    hipLaunchKernelGGL(conv_wino2_h_kernel, dim3(nwg), dim3(512), (size_t)W2_LDS, s, q);
   return hipGetLastError();
 }
 
 hipError_t kernels_wino_init() {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino2_h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
 }  // namespace fdsr

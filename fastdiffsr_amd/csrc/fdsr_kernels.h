@@ -74,7 +74,8 @@ struct Tunables {
   int wgrad_colsum = 1;     // column sums of dy fused into the in-row weight-gradient kernel
   int wgrad_f32 = 0;        // f16x3 steps keep exact-fp32 weight gradients
   long long wgrad_big_bytes = 1ll << 32;   // tensors from this size on take the 4-wave weight-gradient kernel (64-bit offsets)
-  int wino = 1;             // Winograd F(2x2,3x3) form of the stride-1 3x3 convs in f16x3 (0: direct everywhere)
+  int wino = 2;             // Winograd F(2x2,3x3) form of the stride-1 3x3 convs in f16x3: 2 half-tile pipeline (default), 1 first
+                            // (serial-phase) form, 0 direct everywhere
   long wino_min_wgs = 256;  // ... only for launches with at least this many workgroups
   int sat_guard = 1;        // f16x3: sticky device flag when a RAW conv input exceeds the f16 range
   int drop_image_offset = 0;   // tests: the batch is images [offset, offset + N) of a larger one (its dropout masks follow)

@@ -27,14 +27,16 @@ def full():
     return cfg, eng, sd
 
 
-@pytest.fixture()
-def forced():
-    """Winograd for every eligible launch regardless of the grid size; restored afterwards."""
+@pytest.fixture(params=[2, 1], ids=['half-tile-pipeline', 'serial-phases'])
+def forced(request):
+    """Winograd for every eligible launch regardless of the grid size, in both forms of the kernel (2: the default half-tile
+    pipeline, 1: the first, serial-phase form kept for A/B); restored afterwards."""
     from fastdiffsr_amd import _lib
     _lib.debug_option('wino_min_wgs', 1)
-    yield
+    _lib.debug_option('wino', request.param)
+    yield request.param
     _lib.debug_option('wino_min_wgs', 256)
-    _lib.debug_option('wino', 1)
+    _lib.debug_option('wino', 2)
 
 
 @pytest.mark.timeout(900)
@@ -65,7 +67,7 @@ def test_layerwise_forced_winograd_vs_oracle(full, forced):
     # the direct kernels on the same input: same function, another kernel family => close, but not bitwise
     _lib.debug_option('wino', 0)
     out_d = eng.unet_forward(x.cuda(), nl.cuda())
-    _lib.debug_option('wino', 1)
+    _lib.debug_option('wino', forced)
     eng.set_debug(False)
     dd = (out_d - out).abs().max().item()
     assert 0.0 < dd <= 2e-5, dd
@@ -109,7 +111,7 @@ def test_b16_256_default_path_is_winograd_and_matches_direct(full):
     try:
         b = eng.unet_forward(x, nl)
     finally:
-        _lib.debug_option('wino', 1)
+        _lib.debug_option('wino', 2)
     dd = (a - b).abs().max().item()
     assert 0.0 < dd <= 2e-5, dd
     with torch.no_grad():

@@ -168,3 +168,207 @@ if __name__ == '__main__':
     assert worst < 1e-9
     print('index maps consistent')
     print('split-f16 numerics (direct x3, winograd x3) relative to max|out|:', numerics())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# second form (conv_wino2_h_kernel): half-tile pipeline.  Emulates the phase schedule thread by thread with an LDS model that
+# flags any address written and read in the same barrier interval (a race), any read of a never-written address, and checks
+# the result against the direct correlation.
+# ---------------------------------------------------------------------------------------------------------------------
+RAWROW = 1536
+V_BYTES = 16 * TT * ROWB
+RAW2 = HW * RAWROW
+
+
+class LDS:
+    def __init__(self):
+        self.mem, self.w, self.r = {}, set(), set()
+
+    def write(self, adr, val):
+        assert adr not in self.w, f'two writes to {adr} in one phase'
+        self.w.add(adr)
+        self.mem[adr] = val
+
+    def read(self, adr):
+        self.r.add(adr)
+        return self.mem[adr]
+
+    def barrier(self):
+        assert not (self.w & self.r), f'race: {len(self.w & self.r)} addresses written and read in one phase'
+        self.w, self.r = set(), set()
+
+
+def run_wg2(x, w, oy0, ox0, cot):
+    H, W, Cin = x.shape
+    nk = Cin // 16
+    fr = pack_u(w)
+    lds = LDS()
+    sV, sRaw = 0, [V_BYTES, V_BYTES + RAW2]
+    T = range(512)
+    q = [t & 3 for t in T]; row0 = [t >> 2 for t in T]
+    in_pix, raw_off = {}, {}
+    for t in T:
+        for i in range(3):
+            pix = row0[t] + 128 * i
+            v, ro = -2, 0
+            if pix < HW * HW:
+                hy, hx = divmod(pix, HW)
+                iy, ix = oy0 - 1 + hy, ox0 - 1 + hx
+                v = (iy, ix) if (0 <= iy < H and 0 <= ix < W) else -1
+                ro = hy * RAWROW + hx * RAWB + q[t] * 16
+            in_pix[t, i], raw_off[t, i] = v, ro
+    rin = {}
+
+    def prefetch_item(t, i, kc):
+        v = in_pix[t, i]
+        pos = v if isinstance(v, tuple) else (0, 0)
+        rin[t, i] = x[pos[0], pos[1], kc * 16 + 4 * q[t]: kc * 16 + 4 * q[t] + 4].copy()
+
+    def stage_item(t, i, buf):
+        if i == 2 and not (row0[t] + 256 < HW * HW):
+            return
+        v = rin[t, i] if isinstance(in_pix[t, i], tuple) else np.zeros(4)
+        lds.write(buf + raw_off[t, i], v)
+
+    def transform(t, tb, raw):
+        lane, wave = t & 63, t >> 6
+        t_tx, t_ty, t_cq = lane & 7, lane >> 4, ((lane >> 3) & 1) | ((wave & 1) << 1)
+        xi_t = wave >> 1
+        ra_off = (0 if xi_t == 0 else 1) * RAWROW
+        rb_off = (3 if xi_t == 3 else 2) * RAWROW
+        t_rd = (2 * t_ty) * RAWROW + (2 * t_tx) * RAWB + t_cq * 16
+        t_wr = ((xi_t * 4) * TT + t_ty * 8 + t_tx) * ROWB + t_cq * 8
+        ra = raw + t_rd + tb * (8 * RAWROW) + ra_off
+        rb = raw + t_rd + tb * (8 * RAWROW) + rb_off
+
+        def col(c):
+            a, b = lds.read(ra + c * RAWB), lds.read(rb + c * RAWB)
+            return a + b if xi_t == 1 else (b - a if xi_t == 2 else a - b)
+        dst = sV + t_wr + tb * (32 * ROWB)
+        R0, R2 = col(0), col(2)
+        lds.write(dst + 0 * (TT * ROWB), R0 - R2)
+        R1 = col(1)
+        lds.write(dst + 1 * (TT * ROWB), R1 + R2)
+        lds.write(dst + 2 * (TT * ROWB), R2 - R1)
+        R3 = col(3)
+        lds.write(dst + 3 * (TT * ROWB), R1 - R3)
+
+    acc = np.zeros((8, 4, 2, 64, 16))
+    Bf = {}
+
+    def load_b(wave, kc, nu):
+        Bf[wave, nu] = fr[cot, kc, wave, nu].copy()      # [lane][8]
+
+    def mfma_part(wave, tb, kc_next, reload):
+        xi = wave & 3
+        for nu in range(4):
+            A = np.zeros((32, 16)); B = np.zeros((16, 32))
+            for lane in range(64):
+                r31, kh = lane & 31, lane >> 5
+                adr = sV + ((xi * 4) * TT + r31) * ROWB + 16 * kh + (nu * TT + tb * 32) * ROWB
+                A[r31, 8 * kh: 8 * kh + 8] = np.concatenate([lds.read(adr), lds.read(adr + 8)])
+                B[8 * kh: 8 * kh + 8, r31] = Bf[wave, nu][lane]
+            C = A @ B
+            for lane in range(64):
+                r31, kh = lane & 31, lane >> 5
+                for i in range(16):
+                    acc[wave, nu, tb, lane, i] += C[(i & 3) + 8 * (i >> 2) + 4 * kh, r31]
+            if reload:
+                load_b(wave, kc_next, nu)
+
+    # prologue
+    for wave in range(8):
+        for nu in range(4):
+            load_b(wave, 0, nu)
+    for t in T:
+        for i in range(3):
+            prefetch_item(t, i, 0)
+    for t in T:
+        for i in range(3):
+            stage_item(t, i, sRaw[0])
+    if nk > 1:
+        for t in T:
+            for i in range(3):
+                prefetch_item(t, i, 1)
+    lds.barrier()
+    for t in T:
+        transform(t, 0, sRaw[0])
+        if nk > 1:
+            stage_item(t, 0, sRaw[1])
+            if nk > 2:
+                prefetch_item(t, 0, 2)
+    lds.barrier()
+    for kc in range(nk):
+        cur, nxt = sRaw[kc & 1], sRaw[(kc + 1) & 1]
+        more, more2 = kc + 1 < nk, kc + 2 < nk
+
+        def t_a(t):
+            transform(t, 1, cur)
+            if more:
+                stage_item(t, 1, nxt); stage_item(t, 2, nxt)
+                if more2:
+                    prefetch_item(t, 1, kc + 2); prefetch_item(t, 2, kc + 2)
+
+        def t_b(t):
+            if more:
+                transform(t, 0, nxt)
+            if more2:
+                stage_item(t, 0, cur)
+                if kc + 3 < nk:
+                    prefetch_item(t, 0, kc + 3)
+        # phase A: any interleaving of the two wave groups is allowed inside a phase -> run group 1's MFMAs first, then everything else
+        for wave in range(4, 8):
+            mfma_part(wave, 0, 0, False)
+        for t in T:
+            t_a(t)
+        for wave in range(0, 4):
+            mfma_part(wave, 0, 0, False)
+        lds.barrier()
+        for wave in range(4, 8):
+            mfma_part(wave, 1, kc + 1, more)
+        for t in T:
+            t_b(t)
+        for wave in range(0, 4):
+            mfma_part(wave, 1, kc + 1, more)
+        lds.barrier()
+    z = {}
+    for wave in range(8):
+        xi, chalf = wave & 3, wave >> 2
+        for lane in range(64):
+            r31, kh = lane & 31, lane >> 5
+            cz = chalf * 32 + r31
+            for tb in range(2):
+                for i in range(16):
+                    tile = tb * 32 + (i & 3) + 8 * (i >> 2) + 4 * kh
+                    m = acc[wave, :, tb, lane, i]
+                    z[((xi * 2 + 0) * TT + tile) * ZROWB // 4 + cz] = m[0] + m[1] + m[2]
+                    z[((xi * 2 + 1) * TT + tile) * ZROWB // 4 + cz] = m[1] - m[2] - m[3]
+    out = np.zeros((16, 16, 64))
+    for tid in range(512):
+        cqo, pp0 = tid & 15, tid >> 4
+        for it in range(8):
+            pp = pp0 + it * 32
+            py, px = pp >> 4, pp & 15
+            tile, i, j = (py >> 1) * 8 + (px >> 1), py & 1, px & 1
+            zb = (j * TT + tile) * ZROWB + cqo * 16
+            zs = [np.array([z[(zb + (k + i) * 2 * TT * ZROWB) // 4 + e] for e in range(4)]) for k in range(3)]
+            out[py, px, cqo * 4: cqo * 4 + 4] = (zs[0] + zs[1]) + zs[2] if i == 0 else (zs[0] - zs[1]) - zs[2]
+    return out
+
+
+def check_v2():
+    rng = np.random.default_rng(2)
+    for Cin in (16, 32, 48, 80):
+        x = rng.standard_normal((32, 32, Cin))
+        w = rng.standard_normal((128, Cin, 3, 3)).astype(np.float32)
+        ref = direct(x, w)
+        for (oy0, ox0, cot) in [(0, 0, 0), (16, 16, 1)]:
+            got = run_wg2(x, w, oy0, ox0, cot)
+            d = np.abs(got - ref[oy0:oy0 + 16, ox0:ox0 + 16, cot * 64:cot * 64 + 64]).max()
+            print(f'v2 Cin={Cin} workgroup ({oy0},{ox0},cot {cot}): max|emulated - direct| = {d:.3e}')
+            assert d < 1e-9
+    print('v2 schedule: no LDS race, index maps consistent')
+
+
+if __name__ == '__main__':
+    check_v2()
