@@ -35,6 +35,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -326,7 +327,9 @@ __global__ void __launch_bounds__(512, 2) conv_wino_h_kernel(const ConvParams p)
 namespace {
 constexpr int W2_RAWROW = 1536;                          // bytes per halo row (18 pixels x 80 B = 1440, padded)
 constexpr int W2_RAW_BYTES = W_HW * W2_RAWROW;           // 27648
-constexpr int W2_LDS = W_Z_BYTES > W_V_BYTES + 2 * W2_RAW_BYTES ? W_Z_BYTES : W_V_BYTES + 2 * W2_RAW_BYTES;
+constexpr int W2_MAXCIN = 1024;                          // GroupNorm scale / shift of the whole input live in LDS: 8 B per channel
+constexpr int W2_SS_OFF = W_V_BYTES + 2 * W2_RAW_BYTES;  // 137216
+constexpr int W2_LDS = W2_SS_OFF + W2_MAXCIN * 8;        // 145408 (> the epilogue's exchange image, 139264)
 
 // hi = rn_f16(v), lo = rn_f16(v - hi): one packed convert and two v_fma_mix per pair (lo = f16(fma(hi, -1, v)), rounded once:
 // bit-identical to the two-step form); hi at dst, lo at dst + 32
@@ -347,11 +350,31 @@ __device__ __forceinline__ void split_store2(unsigned char* dst, f32x4 v) {
 }
 }  // namespace
 
+#ifdef WINO_STAMPS
+// Diagnostic build only (tools/build_wino_variant.sh -DWINO_STAMPS): s_memtime stamps of waves 0 and 4 of the first 256 workgroups
+// of ONE layer (Cin = WINO_STAMP_CIN, Cout = WINO_STAMP_COUT) at the phase boundaries; read back by fdsr_diag_wino_stamps.
+__device__ unsigned long long g_w2_stamps[256][2][128];
+#define W2_STAMP()                                                                                                   \
+  do {                                                                                                               \
+    if (stamp_on && si < 128) g_w2_stamps[blockIdx.x][wave >> 2][si] = __builtin_amdgcn_s_memtime();                 \
+    ++si;                                                                                                            \
+  } while (0)
+#ifdef WINO_STAMPS_FINE
+#define W2_FSTAMP() W2_STAMP()
+#else
+#define W2_FSTAMP() do {} while (0)
+#endif
+#else
+#define W2_STAMP() do {} while (0)
+#define W2_FSTAMP() do {} while (0)
+#endif
+
 __global__ void __launch_bounds__(512, 2) conv_wino2_h_kernel(const ConvParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_w[];
   unsigned char* sV = smem_w;
   unsigned char* sRaw0 = smem_w + W_V_BYTES;
   unsigned char* sRaw1 = sRaw0 + W2_RAW_BYTES;
+  float* sSS = reinterpret_cast<float*>(smem_w + W2_SS_OFF);   // scale[Cin] | shift[Cin] of image n
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: roles below live in SGPRs
@@ -359,6 +382,11 @@ __global__ void __launch_bounds__(512, 2) conv_wino2_h_kernel(const ConvParams p
   const int nk = p.Cin_pad >> 4;
   const int nco = p.Cout_pad >> 6;
   const int tilesX = p.Wout >> 4, ntile = tilesX * (p.Hout >> 4);
+#ifdef WINO_STAMPS
+  int si = 0;
+  const bool stamp_on = lane == 0 && (wave & 3) == 0 && blockIdx.x < 256 && Cin == WINO_STAMP_CIN && p.Cout == WINO_STAMP_COUT;
+#endif
+  W2_STAMP();
   int cot, sp;
   {
     const int b = blockIdx.x;
@@ -393,22 +421,31 @@ __global__ void __launch_bounds__(512, 2) conv_wino2_h_kernel(const ConvParams p
   }
   const bool has2 = row0 + 2 * 128 < W_NPIX;   // the third pass covers 68 of the 128 pixel rows
   f32x4 rin[W_NIN];
-  f32x4 rsc, rsh;
-  auto load_scsh = [&](int kc) {
-    rsc = *reinterpret_cast<const f32x4*>(p.gn_scale + (size_t)n * Cin + kc * 16 + q * 4);
-    rsh = *reinterpret_cast<const f32x4*>(p.gn_shift + (size_t)n * Cin + kc * 16 + q * 4);
-  };
+  // per-(image, channel) GroupNorm scale / shift: read from LDS where they are used (no registers held across phases, and no
+  // vector-memory wait that would drag the in-flight halo prefetch with it: vmcnt counts in issue order)
+  for (int c4 = tid; c4 < (Cin >> 2); c4 += 512) {
+    *reinterpret_cast<f32x4*>(sSS + c4 * 4) = *reinterpret_cast<const f32x4*>(p.gn_scale + (size_t)n * Cin + c4 * 4);
+    *reinterpret_cast<f32x4*>(sSS + Cin + c4 * 4) = *reinterpret_cast<const f32x4*>(p.gn_shift + (size_t)n * Cin + c4 * 4);
+  }
   auto prefetch_item = [&](int i, int kc) {
     const int cbase = kc * 16;
     const float* base;
     int Cs, cc;
     if (cbase < p.C0) { base = p.x0; Cs = p.C0; cc = cbase + q * 4; }
     else { base = p.x1; Cs = p.C1; cc = cbase - p.C0 + q * 4; }
+    // (hand-placed s_waitcnt vmcnt over inline-asm loads was tried here: no faster -- the phases are not waiting for memory --
+    // and wrong at B = 16, 256 x 256: the compiler moves asm outputs before the data has landed.  Plain loads, counted by the compiler.)
     rin[i] = *reinterpret_cast<const f32x4*>(base + (size_t)(in_pix[i] < 0 ? 0 : in_pix[i]) * Cs + cc);   // padding reads pixel 0, zeroed below
   };
-  auto stage_item = [&](int i, unsigned char* buf) {
+  f32x4 ssc, ssh;
+  auto load_ss = [&](int kc) {
+    ssc = *reinterpret_cast<const f32x4*>(sSS + kc * 16 + q * 4);
+    ssh = *reinterpret_cast<const f32x4*>(sSS + Cin + kc * 16 + q * 4);
+  };
+  auto stage_item = [&](int i, int kc, unsigned char* buf) {
+    (void)kc;
     if (i == 2 && !has2) return;
-    f32x4 v = rin[i] * rsc + rsh;
+    f32x4 v = rin[i] * ssc + ssh;
     v.x = silu_w(v.x); v.y = silu_w(v.y); v.z = silu_w(v.z); v.w = silu_w(v.w);
     const float lim = in_pix[i] >= 0 ? 16376.f : 0.f;   // zero padding of the ACTIVATED tensor; |V| <= 4 max|a| stays inside f16
 #pragma unroll
@@ -417,10 +454,10 @@ __global__ void __launch_bounds__(512, 2) conv_wino2_h_kernel(const ConvParams p
   };
 
   // ---- transformed-weight fragments: [cot][kc][wave][nu][plane][lane] x 16 B ----
-  const uint4* wq = reinterpret_cast<const uint4*>(p.wq) + ((size_t)cot * nk * 8 + wave) * (4 * 2 * 64) + lane;
-  uint4 Bf[4][2];
+  const u32x4* wq = reinterpret_cast<const u32x4*>(p.wq) + ((size_t)cot * nk * 8 + wave) * (4 * 2 * 64) + lane;
+  u32x4 Bf[4][2];
   auto load_b = [&](int kc, int nu) {
-    const uint4* src = wq + (size_t)kc * (8 * 4 * 2 * 64) + nu * (2 * 64);
+    const u32x4* src = wq + (size_t)kc * (8 * 4 * 2 * 64) + nu * (2 * 64);
     Bf[nu][0] = src[0];
     Bf[nu][1] = src[64];
   };
@@ -429,27 +466,36 @@ __global__ void __launch_bounds__(512, 2) conv_wino2_h_kernel(const ConvParams p
   // 4 channels, position row xi_t): 2 halo rows x 4 columns in, 4 positions out ----
   const int t_tx = lane & 7, t_ty = lane >> 4, t_cq = ((lane >> 3) & 1) | ((wave & 1) << 1);
   const int xi_t = wave >> 1;
-  const int ra_off = (xi_t == 0 ? 0 : 1) * W2_RAWROW, rb_off = (xi_t == 3 ? 3 : 2) * W2_RAWROW;   // rows (0,2) (1,2) (1,2) (1,3)
+  // row combination of B^T d as ONE fma, R = a + s b: (a, b, s) = (d0, d2, -1) (d1, d2, +1) (d2, d1, -1) (d1, d3, -1) for xi_t = 0..3
+  const int ra_off = (xi_t == 0 ? 0 : (xi_t == 2 ? 2 : 1)) * W2_RAWROW, rb_off = (xi_t == 3 ? 3 : (xi_t == 2 ? 1 : 2)) * W2_RAWROW;
+  const float t_s = xi_t == 1 ? 1.f : -1.f;
   const int t_rd = (2 * t_ty) * W2_RAWROW + (2 * t_tx) * W_RAWB + t_cq * 16;                       // + tb * 8 rows
   const int t_wr = ((xi_t * 4) * W_TT + t_ty * 8 + t_tx) * W_ROWB + t_cq * 8;                      // + tb * 32 tiles
-  auto transform = [&](int tb, const unsigned char* raw) {
+  // One item in two steps, so that every LDS read of a phase's transform / staging part goes out before anything waits: ONE LDS
+  // round trip per part (column by column the compiler waited out three, plus one per staged item for scale / shift).
+  f32x4 ta[4], tb_[4];
+  auto t_load = [&](int tb, const unsigned char* raw) {
     const unsigned char* ra = raw + t_rd + tb * (8 * W2_RAWROW) + ra_off;
     const unsigned char* rb = raw + t_rd + tb * (8 * W2_RAWROW) + rb_off;
-    // column by column (few live registers: the accumulators and weight fragments leave ~90 VGPRs): R[c] = row combination of
-    // column c, outputs V0 = R0 - R2, V1 = R1 + R2, V2 = R2 - R1, V3 = R1 - R3 leave as soon as their columns are in
-    auto col = [&](int c) -> f32x4 {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(ra + c * W_RAWB);
-      const f32x4 b = *reinterpret_cast<const f32x4*>(rb + c * W_RAWB);
-      return xi_t == 1 ? a + b : (xi_t == 2 ? b - a : a - b);      // d1 + d2 | d2 - d1 | d0 - d2, d1 - d3  (xi_t is wave-uniform)
-    };
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      ta[c] = *reinterpret_cast<const f32x4*>(ra + c * W_RAWB);
+      tb_[c] = *reinterpret_cast<const f32x4*>(rb + c * W_RAWB);
+    }
+  };
+  auto t_compute = [&](int tb) {
     unsigned char* dst = sV + t_wr + tb * (32 * W_ROWB);
-    const f32x4 R0 = col(0), R2 = col(2);
+    const f32x4 R0 = tb_[0] * t_s + ta[0], R2 = tb_[2] * t_s + ta[2];
     split_store2(dst + 0 * (W_TT * W_ROWB), R0 - R2);
-    const f32x4 R1 = col(1);
+    const f32x4 R1 = tb_[1] * t_s + ta[1];
     split_store2(dst + 1 * (W_TT * W_ROWB), R1 + R2);
     split_store2(dst + 2 * (W_TT * W_ROWB), R2 - R1);
-    const f32x4 R3 = col(3);
+    const f32x4 R3 = tb_[3] * t_s + ta[3];
     split_store2(dst + 3 * (W_TT * W_ROWB), R1 - R3);
+  };
+  auto transform = [&](int tb, const unsigned char* raw) {
+    t_load(tb, raw);
+    t_compute(tb);
   };
 
   // ---- MFMA roles: position row xi = wave & 3, cout half = wave >> 2 (also the stagger group) ----
@@ -465,91 +511,152 @@ __global__ void __launch_bounds__(512, 2) conv_wino2_h_kernel(const ConvParams p
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[nu][tb][i] = 0.f;
 
-  uint4 Af[2][2];   // [slot][plane]
-  auto load_a = [&](int slot, int nu, int tb) {
-#pragma unroll
-    for (int pl = 0; pl < 2; ++pl)
-      Af[slot][pl] = *reinterpret_cast<const uint4*>(abase + (nu * W_TT + tb * 32) * W_ROWB + 32 * pl);
-  };
-  // 12 MFMAs on tile block tb of the current chunk; reload: fetch the next chunk's fragments into the same registers
-  auto mfma_part = [&](auto tb_tag, int kc_next, bool reload) {
+  // 12 MFMAs on tile block tb of the current chunk: all eight A-fragment reads go out first (the compiler otherwise re-uses one
+  // register quad and waits out the LDS latency in front of every MFMA group); RELOAD: the next chunk's weight fragments into
+  // the same registers right after their last use -- unconditionally (the last chunk re-reads its own), so that every
+  // vector-memory operation of the loop sits in straight-line code and the waits the compiler inserts are counted, not vmcnt(0)
+  u32x4 Af[4][2] = {};
+  auto mfma_part = [&](auto tb_tag, auto reload_tag, int kc_next) {
     constexpr int tb = decltype(tb_tag)::value;
-    load_a(0, 0, tb);
+    constexpr bool RELOAD = decltype(reload_tag)::value;
+#ifndef WINO_KO_A
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl)
+        Af[nu][pl] = *reinterpret_cast<const u32x4*>(abase + (nu * W_TT + tb * 32) * W_ROWB + 32 * pl);
+#endif
+    W2_FSTAMP();      // A reads issued
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int nu = 0; nu < 4; ++nu) {
-      if (nu + 1 < 4) load_a((nu + 1) & 1, nu + 1, tb);
-      const uint4 ahi = Af[nu & 1][0], alo = Af[nu & 1][1];
+      const u32x4 ahi = Af[nu][0], alo = Af[nu][1];
+#ifndef WINO_KO_M
       acc[nu][tb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, alo), __builtin_bit_cast(h8, Bf[nu][0]), acc[nu][tb], 0, 0, 0);
       acc[nu][tb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, ahi), __builtin_bit_cast(h8, Bf[nu][1]), acc[nu][tb], 0, 0, 0);
       acc[nu][tb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, ahi), __builtin_bit_cast(h8, Bf[nu][0]), acc[nu][tb], 0, 0, 0);
-      if (reload) load_b(kc_next, nu);
+#else
+      WINO_SINK4(ahi); WINO_SINK4(alo); WINO_SINK4(Bf[nu][0]); WINO_SINK4(Bf[nu][1]);
+#endif
+#ifndef WINO_KO_B
+      if (RELOAD) load_b(kc_next, nu);
+#endif
     }
   };
   using TB0 = std::integral_constant<int, 0>;
   using TB1 = std::integral_constant<int, 1>;
 
-  // ---- prologue: chunk 0 staged whole, its tile block 0 transformed; chunk 1 fetched, its item 0 staged ----
-#pragma unroll
-  for (int nu = 0; nu < 4; ++nu) load_b(0, nu);
-  load_scsh(0);
+  // ---- prologue: chunk 0 staged whole, its tile block 0 transformed; chunk 1 fetched, its item 0 staged.  The vector-memory
+  // operations go out in the order the loop keeps (items 1, 2 | weight fragments | item 0), so that the wait counts the compiler
+  // derives at the loop head are those of the steady state ----
 #pragma unroll
   for (int i = 0; i < W_NIN; ++i) prefetch_item(i, 0);
+  __syncthreads();          // scale / shift are in LDS
+  load_ss(0);
 #pragma unroll
-  for (int i = 0; i < W_NIN; ++i) stage_item(i, sRaw0);
-  if (nk > 1) {
-    load_scsh(1);
+  for (int i = 0; i < W_NIN; ++i) stage_item(i, 0, sRaw0);
+  {
+    const int k1 = nk > 1 ? 1 : 0, k2 = nk > 2 ? 2 : nk - 1;
+    prefetch_item(0, k1);
+    prefetch_item(1, k1);
+    prefetch_item(2, k1);
 #pragma unroll
-    for (int i = 0; i < W_NIN; ++i) prefetch_item(i, 1);
+    for (int nu = 0; nu < 4; ++nu) load_b(0, nu);
+    __syncthreads();
+    load_ss(k1);
+    transform(0, sRaw0);
+    stage_item(0, k1, sRaw1);
+    prefetch_item(0, k2);
   }
   __syncthreads();
-  transform(0, sRaw0);
-  if (nk > 1) {
-    stage_item(0, sRaw1);
-    if (nk > 2) prefetch_item(0, 2);
-  }
-  __syncthreads();
+  W2_STAMP();      // [1] prologue done
 
-  for (int kc = 0; kc < nk; ++kc) {
-    unsigned char* cur = (kc & 1) ? sRaw1 : sRaw0;
-    unsigned char* nxt = (kc & 1) ? sRaw0 : sRaw1;
-    const bool more = kc + 1 < nk, more2 = kc + 2 < nk;
-    // ---- phase A ----
-    auto t_a = [&]() {
-      transform(1, cur);
-      if (more) {
-        stage_item(1, nxt);
-        stage_item(2, nxt);
-        if (more2) {
-          prefetch_item(1, kc + 2);
-          prefetch_item(2, kc + 2);
-          load_scsh(kc + 2);
-        }
-      }
-    };
-    // (sched_barrier: the two parts of a phase stay apart in a wave's own stream -- interleaving them makes their registers live together)
-    // ONE copy of the MFMA part between two guarded copies of the other part (an if / else over whole phases made the register
-    // allocator spill > 100 VGPRs)
-    if (chalf == 0) t_a();
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_part(TB0{}, 0, false);
-    __builtin_amdgcn_sched_barrier(0);
-    if (chalf != 0) t_a();
-    __syncthreads();
-    // ---- phase B ----
-    auto t_b = [&]() {
-      if (more) transform(0, nxt);
-      if (more2) {
-        stage_item(0, cur);
-        if (kc + 3 < nk) prefetch_item(0, kc + 3);
-      }
-    };
-    if (chalf == 0) t_b();
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_part(TB1{}, kc + 1, more);
-    __builtin_amdgcn_sched_barrier(0);
-    if (chalf != 0) t_b();
-    __syncthreads();
-  }
+  // The loop body is branch-free: past the end, chunk indices are clamped (the tail re-stages and re-fetches the last chunk into
+  // buffers nobody reads any more), and every vector-memory operation sits in straight-line code, so the waits the compiler
+  // inserts are counted (vmcnt completes in issue order: a wait for a weight fragment must not drag a younger HBM fetch along).
+  // Two copies of the loop, one per wave group: the MFMA part and the transform / staging part of a phase in opposite order.
+  auto run_loop = [&](auto first_tag) {
+    // MODE 1 / 0: this copy of the loop runs the transform part first / last; MODE 2: one copy of the loop for both groups, the
+    // transform part guarded in front of and behind the MFMA part
+    constexpr int MODE = (int)decltype(first_tag)::value;
+    for (int kc = 0; kc < nk; ++kc) {
+      unsigned char* cur = (kc & 1) ? sRaw1 : sRaw0;
+      unsigned char* nxt = (kc & 1) ? sRaw0 : sRaw1;
+      const int kc1 = kc + 1 < nk ? kc + 1 : nk - 1, kc2 = kc + 2 < nk ? kc + 2 : nk - 1, kc3 = kc + 3 < nk ? kc + 3 : nk - 1;
+      // ---- phase A: MFMAs on tile block 0 | tile block 1 transformed, items 1, 2 of the next chunk staged ----
+      auto t_a = [&]() {
+#ifndef WINO_KO_T
+        t_load(1, cur);
+#endif
+#ifndef WINO_KO_STAGE
+        load_ss(kc1);
+#endif
+        W2_FSTAMP();      // LDS reads issued
+        __builtin_amdgcn_sched_barrier(0);
+#ifndef WINO_KO_T
+        t_compute(1);
+#endif
+        W2_FSTAMP();      // transform written
+        __builtin_amdgcn_sched_barrier(0);
+#ifndef WINO_KO_STAGE
+        stage_item(1, kc1, nxt);
+        W2_FSTAMP();
+        __builtin_amdgcn_sched_barrier(0);
+        stage_item(2, kc1, nxt);
+#endif
+      };
+      if (MODE == 1 || (MODE == 2 && chalf == 0)) t_a();
+      W2_STAMP();
+      __builtin_amdgcn_sched_barrier(0);          // the two parts stay apart in a wave's own stream (register pressure)
+      mfma_part(TB0{}, std::false_type{}, 0);
+      W2_STAMP();
+      __builtin_amdgcn_sched_barrier(0);
+      if (MODE == 0 || (MODE == 2 && chalf != 0)) t_a();
+#ifndef WINO_KO_STAGE
+      prefetch_item(1, kc2);
+      prefetch_item(2, kc2);
+#endif
+      W2_STAMP();
+      __syncthreads();
+      W2_STAMP();
+      // ---- phase B: MFMAs on tile block 1 | tile block 0 of the next chunk transformed, item 0 of the one after staged ----
+      auto t_b = [&](auto after_reload) {
+#ifndef WINO_KO_T
+        t_load(0, nxt);
+#endif
+#ifndef WINO_KO_STAGE
+        load_ss(kc2);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+#ifndef WINO_KO_T
+        t_compute(0);
+#endif
+#ifndef WINO_KO_STAGE
+        (void)after_reload;
+        stage_item(0, kc2, cur);
+#endif
+      };
+      if (MODE == 1 || (MODE == 2 && chalf == 0)) t_b(std::false_type{});
+      W2_STAMP();
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_part(TB1{}, std::true_type{}, kc1);
+      W2_STAMP();
+      __builtin_amdgcn_sched_barrier(0);
+      if (MODE == 0 || (MODE == 2 && chalf != 0)) t_b(std::true_type{});
+#ifndef WINO_KO_STAGE
+      prefetch_item(0, kc3);                      // after this phase's weight-fragment loads (see above)
+#endif
+      W2_STAMP();
+      __syncthreads();
+      W2_STAMP();
+    }
+  };
+#ifdef WINO2_TWO_LOOPS
+  if (chalf == 0) run_loop(std::integral_constant<int, 1>{});
+  else run_loop(std::integral_constant<int, 0>{});
+#else
+  run_loop(std::integral_constant<int, 2>{});
+#endif
 
   // ---- epilogue (as the first form): fold the position row over nu, rows meet in LDS ----
   {
@@ -565,7 +672,9 @@ __global__ void __launch_bounds__(512, 2) conv_wino2_h_kernel(const ConvParams p
         z[(((xi * 2 + 1) * W_TT + tile) * W_ZROWB >> 2) + cz] = m1 - m2 - m3;
       }
   }
+  W2_STAMP();      // Z written
   __syncthreads();
+  W2_STAMP();
   const float winv = p.w_inv_scale_dev ? *p.w_inv_scale_dev : p.w_inv_scale;
   const int cqo = tid & 15, pp0 = tid >> 4;
   const int co = co0 + cqo * 4;
@@ -599,28 +708,46 @@ __global__ void __launch_bounds__(512, 2) conv_wino2_h_kernel(const ConvParams p
     s2 += yv[it] * yv[it];
   }
   if (p.part_out) {
+    // lanes l, l ^ 16, l ^ 32 of a wave hold the same cout quad (4 pixel groups per wave): fold them in a fixed order, then the 8 waves
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      s1[e] += __shfl_xor(s1[e], 16, 64); s2[e] += __shfl_xor(s2[e], 16, 64);
+      s1[e] += __shfl_xor(s1[e], 32, 64); s2[e] += __shfl_xor(s2[e], 32, 64);
+    }
     __syncthreads();
-    f32x4* sred = reinterpret_cast<f32x4*>(smem_w);
-    sred[(pp0 * 16 + cqo) * 2 + 0] = s1;
-    sred[(pp0 * 16 + cqo) * 2 + 1] = s2;
+    f32x4* sred = reinterpret_cast<f32x4*>(smem_w);    // [8 waves][16 quads][2]
+    if (lane < 16) {
+      sred[(wave * 16 + lane) * 2 + 0] = s1;
+      sred[(wave * 16 + lane) * 2 + 1] = s2;
+    }
     __syncthreads();
     if (tid < 16) {
       f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
-      for (int g = 0; g < 32; ++g) { a += sred[(g * 16 + tid) * 2 + 0]; b += sred[(g * 16 + tid) * 2 + 1]; }
+#pragma unroll
+      for (int g = 0; g < 8; ++g) { a += sred[(g * 16 + tid) * 2 + 0]; b += sred[(g * 16 + tid) * 2 + 1]; }
       float* dst = p.part_out + (((size_t)n * ntile + tl) * p.Cout + co0 + tid * 4) * 2;
 #pragma unroll
       for (int e = 0; e < 4; ++e) { dst[2 * e] = a[e]; dst[2 * e + 1] = b[e]; }
     }
   }
+  W2_STAMP();      // end
 }
 
 // Which launches take the Winograd form: stride-1 3x3, f16x3, 16-pixel-aligned maps, whole 64-cout blocks, 16-aligned concat
 // halves, and a grid that fills the chip (small grids keep the direct kernel with its K split).
-bool conv_wino_ok(ConvKind kind, int prec, const ConvParams& p) {
+bool conv_wino_ok(ConvKind kind, int prec, const ConvParams& p, bool has_rider) {
   if (!g_tun.wino || kind != CONV3_S1 || prec != PREC_F16X3) return false;
+  // Where the form pays (same-box per-layer timings at B = 16, profiles/r03_wino_per_layer.txt): the kernel is LDS-bound at about
+  // the direct kernel's speed, so it wins only where the direct one is at its worst -- the 32 x 32 maps (-18 %) and the widest
+  // concatenated inputs (-3 .. -7 %) -- and never where it would cost a ResnetBlock its res_conv rider (the 1x1 comes back as a
+  // launch of its own).  Debug option wino_all = 1 lifts the rule (tests run every layer through the form).
+  if (!g_tun.wino_all) {
+    const bool small_map = (long)p.Hout * p.Wout <= 1024;
+    if (!(small_map || (!has_rider && p.C0 + p.C1 >= 384))) return false;
+  }
   if (p.xr0 || p.drop_mask || p.ksplit > 1 || p.gn_plain) return false;
   if ((p.Hout & 15) || (p.Wout & 15) || p.Hin != p.Hout || p.Win != p.Wout) return false;
-  if ((p.Cout & 63) || (p.C0 & 15) || (p.C1 & 15) || p.C0 + p.C1 < 16) return false;
+  if ((p.Cout & 63) || (p.C0 & 15) || (p.C1 & 15) || p.C0 + p.C1 < 16 || p.C0 + p.C1 > 1024) return false;
   const long wgs = (long)p.N * (p.Hout >> 4) * (p.Wout >> 4) * (p.Cout >> 6);
   return wgs >= g_tun.wino_min_wgs;
 }
@@ -638,6 +765,12 @@ hipError_t launch_conv_wino_h(const ConvParams& p, hipStream_t s, int* tiles) {
     hipLaunchKernelGGL(conv_wino2_h_kernel, dim3(nwg), dim3(512), (size_t)W2_LDS, s, q);
   return hipGetLastError();
 }
+
+#ifdef WINO_STAMPS
+extern "C" int fdsr_diag_wino_stamps(unsigned long long* dst, size_t count) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_w2_stamps), count * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 hipError_t kernels_wino_init() {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -905,7 +905,7 @@ int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, 
           ConvParams t{};
           t.N = N; t.Hin = H >> k.lvl_in; t.Win = W >> k.lvl_in; t.Hout = H >> k.lvl_out; t.Wout = W >> k.lvl_out;
           t.C0 = k.C0; t.C1 = k.C1; t.Cout = k.Cout;
-          return conv_wino_ok(k.ck, h->prec, t);
+          return conv_wino_ok(k.ck, h->prec, t, k.rider >= 0 && g_tun.rider != 0);
         };
         auto rides = [&](const Op& k2) -> bool {
           const int mode = g_tun.rider;

@@ -77,6 +77,7 @@ struct Tunables {
   int wino = 2;             // Winograd F(2x2,3x3) form of the stride-1 3x3 convs in f16x3: 2 half-tile pipeline (default), 1 first
                             // (serial-phase) form, 0 direct everywhere
   long wino_min_wgs = 256;  // ... only for launches with at least this many workgroups
+  int wino_all = 0;         // ... 0: only the layers where it measured faster (conv_wino_ok); 1: every eligible launch
   int sat_guard = 1;        // f16x3: sticky device flag when a RAW conv input exceeds the f16 range
   int drop_image_offset = 0;   // tests: the batch is images [offset, offset + N) of a larger one (its dropout masks follow)
   unsigned epoch = 0;
@@ -103,7 +104,7 @@ int conv_h_ksplit(ConvKind kind, int N, int Hout, int Wout, int Cout, int Cout_p
 hipError_t kernels_h_init();
 // Winograd F(2x2,3x3) form of the stride-1 3x3 convs (fdsr_conv_wino.hip; f16x3 only): transformed weights U = G g G^T packed
 // [cot][kc][role][nu][plane][lane] x 16 B (role = position row xi | cout half << 2).  conv_wino_ok: does this launch take it?
-bool conv_wino_ok(ConvKind kind, int prec, const ConvParams& p);
+bool conv_wino_ok(ConvKind kind, int prec, const ConvParams& p, bool has_rider);
 hipError_t launch_conv_wino_h(const ConvParams& p, hipStream_t s, int* tiles_per_image);
 hipError_t kernels_wino_init();
 // Upsample(nearest x2)+Conv3x3 in sub-pixel form (fdsr_conv_up2.hip): four 2x2 convs on the source grid

@@ -33,9 +33,11 @@ def forced(request):
     pipeline, 1: the first, serial-phase form kept for A/B); restored afterwards."""
     from fastdiffsr_amd import _lib
     _lib.debug_option('wino_min_wgs', 1)
+    _lib.debug_option('wino_all', 1)
     _lib.debug_option('wino', request.param)
     yield request.param
     _lib.debug_option('wino_min_wgs', 256)
+    _lib.debug_option('wino_all', 0)
     _lib.debug_option('wino', 2)
 
 
@@ -96,12 +98,15 @@ def test_loop_forced_winograd_vs_oracle(full, forced):
 
 
 @pytest.mark.timeout(900)
-def test_b16_256_default_path_is_winograd_and_matches_direct(full):
-    """BASELINE configs[1] (B=16, 256x256): the form is the default there.  One UNet forward against the direct kernels
-    (both fp32-grade: <= 2e-5 apart, not bitwise), bitwise rerun, and image 0 of the batch against the oracle's B=1 forward."""
+@pytest.mark.parametrize('everywhere', [0, 1], ids=['default-rule', 'every-eligible-layer'])
+def test_b16_256_default_path_is_winograd_and_matches_direct(full, everywhere):
+    """BASELINE configs[1] (B=16, 256x256): by default the layers where the form measured faster take it (the 32 x 32 maps, the
+    widest concat inputs), with wino_all every eligible layer.  One UNet forward against the direct kernels (both fp32-grade:
+    <= 2e-5 apart, not bitwise), bitwise rerun, and image 0 of the batch against the oracle's B=1 forward."""
     from fastdiffsr_amd import _lib
     from oracle import fdsr_oracle as O
     cfg, eng, sd = full
+    _lib.debug_option('wino_all', everywhere)
     gen = torch.Generator().manual_seed(9)
     x = torch.randn(16, 6, 256, 256, generator=gen).cuda()
     nl = (torch.rand(16, 1, generator=gen) * 0.9 + 0.05).cuda()
@@ -114,6 +119,7 @@ def test_b16_256_default_path_is_winograd_and_matches_direct(full):
         _lib.debug_option('wino', 2)
     dd = (a - b).abs().max().item()
     assert 0.0 < dd <= 2e-5, dd
+    _lib.debug_option('wino_all', 0)
     with torch.no_grad():
         ref = O.unet_forward(O.to_torch_sd(sd), cfg, x[:1].cpu(), nl[:1].cpu())
     assert (a[:1].cpu() - ref).abs().max().item() <= TOL_FWD

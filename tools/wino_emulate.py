@@ -276,60 +276,56 @@ def run_wg2(x, w, oy0, ox0, cot):
             if reload:
                 load_b(wave, kc_next, nu)
 
-    # prologue
-    for wave in range(8):
-        for nu in range(4):
-            load_b(wave, 0, nu)
+    # prologue (the kernel's order: items of chunk 0, stage, items of chunk 1, weight fragments, transform, item 0 of chunk 2)
     for t in T:
         for i in range(3):
             prefetch_item(t, i, 0)
+    lds.barrier()
     for t in T:
         for i in range(3):
             stage_item(t, i, sRaw[0])
-    if nk > 1:
-        for t in T:
-            for i in range(3):
-                prefetch_item(t, i, 1)
+    k1, k2 = (1 if nk > 1 else 0), (2 if nk > 2 else nk - 1)
+    for t in T:
+        for i in range(3):
+            prefetch_item(t, i, k1)
+    for wave in range(8):
+        for nu in range(4):
+            load_b(wave, 0, nu)
     lds.barrier()
     for t in T:
         transform(t, 0, sRaw[0])
-        if nk > 1:
-            stage_item(t, 0, sRaw[1])
-            if nk > 2:
-                prefetch_item(t, 0, 2)
+        stage_item(t, 0, sRaw[1])
+        prefetch_item(t, 0, k2)
     lds.barrier()
     for kc in range(nk):
         cur, nxt = sRaw[kc & 1], sRaw[(kc + 1) & 1]
-        more, more2 = kc + 1 < nk, kc + 2 < nk
+        kc1, kc2, kc3 = min(kc + 1, nk - 1), min(kc + 2, nk - 1), min(kc + 3, nk - 1)
 
         def t_a(t):
             transform(t, 1, cur)
-            if more:
-                stage_item(t, 1, nxt); stage_item(t, 2, nxt)
-                if more2:
-                    prefetch_item(t, 1, kc + 2); prefetch_item(t, 2, kc + 2)
+            stage_item(t, 1, nxt); stage_item(t, 2, nxt)
 
         def t_b(t):
-            if more:
-                transform(t, 0, nxt)
-            if more2:
-                stage_item(t, 0, cur)
-                if kc + 3 < nk:
-                    prefetch_item(t, 0, kc + 3)
-        # phase A: any interleaving of the two wave groups is allowed inside a phase -> run group 1's MFMAs first, then everything else
+            transform(t, 0, nxt)
+            stage_item(t, 0, cur)
+        # any interleaving of the two wave groups is allowed inside a phase: run group 1's MFMAs first, then all transforms, then group 0's
         for wave in range(4, 8):
             mfma_part(wave, 0, 0, False)
         for t in T:
             t_a(t)
         for wave in range(0, 4):
             mfma_part(wave, 0, 0, False)
+        for t in T:
+            prefetch_item(t, 1, kc2); prefetch_item(t, 2, kc2)
         lds.barrier()
         for wave in range(4, 8):
-            mfma_part(wave, 1, kc + 1, more)
+            mfma_part(wave, 1, kc1, True)
         for t in T:
             t_b(t)
         for wave in range(0, 4):
-            mfma_part(wave, 1, kc + 1, more)
+            mfma_part(wave, 1, kc1, True)
+        for t in T:
+            prefetch_item(t, 0, kc3)
         lds.barrier()
     z = {}
     for wave in range(8):
