@@ -269,8 +269,8 @@ def run_config(eng, dev, precision, B, S, steps, warmup, graph, noise_mode, rank
 
 
 def run_train(eng, dev, B, S, steps, warmup, rank=0, sync=None, allreduce=None, precision='f16x3'):
-    """Time `steps` optimisation steps (BASELINE configs[4], "training step"): q_sample in torch (pointwise), then
-    forward + L1 loss / (b*c*h*w) + backward + Adam on the device, exact fp32, Dropout(0.2) live as in .train() mode.
+    """Time `steps` optimisation steps (BASELINE configs[4], "training step"): noise draw + img2res + q_sample + forward + L1 loss /
+    (b*c*h*w) + backward + Adam, all in the engine (no ATen kernel in the timed region), Dropout(0.2) live as in .train() mode.
     Returns seconds.  A "step" = one optimizer step over one batch of B synthetic 256x256 HR/SR pairs per GPU."""
     g = torch.Generator().manual_seed(777 + rank)
     hr = (torch.rand(B, 3, S, S, generator=g) * 2 - 1).to(dev)
@@ -283,13 +283,13 @@ def run_train(eng, dev, B, S, steps, warmup, rank=0, sync=None, allreduce=None, 
         def sync():
             torch.cuda.synchronize(dev)
 
+    rs = np.random.RandomState(555 + rank)
+
     def one():
-        gamma = torch.rand(B, device=dev) * 0.5 + 0.4                      # continuous sqrt(alpha_bar) per sample
-        noise = torch.randn(B, 3, S, S, device=dev)
-        x_start = ((hr - sr) * 2.0).clamp(-1, 1)                            # img2res (diffusion.py:283-289)
-        gg = gamma.view(-1, 1, 1, 1)
-        x_noisy = gg * x_start + (1 - gg ** 2).sqrt() * noise               # q_sample (:233-241)
-        loss = eng.train_grads(torch.cat([sr, x_noisy], 1), gamma, noise, 'l1', 1.0 / (B * 3 * S * S * world))
+        # the whole step is the engine's: gamma is drawn on the host as the reference draws it (numpy, diffusion.py:246-256: B
+        # floats), the noise inside the engine (Philox), and img2res + q_sample + cat run in the kernel that writes the packed input
+        gamma = torch.from_numpy(rs.uniform(0.4, 0.9, size=B).astype(np.float32)).to(dev, non_blocking=True)
+        loss = eng.train_grads_pairs(hr, sr, gamma, None, 'l1', 1.0 / (B * 3 * S * S * world))
         if allreduce is not None:
             allreduce(eng)
         eng.adam_step(1e-4)

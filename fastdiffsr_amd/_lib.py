@@ -75,6 +75,8 @@ SYMBOLS = {
     'fdsr_train_workspace_bytes': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
     'fdsr_train_grads': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.POINTER(C.c_float), C.c_int,
                                    C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'fdsr_train_grads_pairs': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.POINTER(C.c_float),
+                                         C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     'fdsr_adam_step': (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     'fdsr_get_weight': (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p]),
     'fdsr_get_grad': (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p]),

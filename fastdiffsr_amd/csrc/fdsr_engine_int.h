@@ -194,6 +194,7 @@ int fail(fdsr_handle h, int code, const char* fmt, ...);
 int get_plan(fdsr_handle h, int N, int H, int W);
 int check_ready(fdsr_handle h, bool need_schedule);
 int check_ws(fdsr_handle h, void* ws, size_t bytes);
+int ensure_rng(fdsr_handle h);
 int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, float nl_scalar, hipStream_t st,
              const float* temb_row = nullptr);
 int pack_weights_h(fdsr_handle h, WeightEntry& w, const float* host);

@@ -31,7 +31,7 @@ struct TrainPlan {
   std::vector<size_t> grad_off;         // per tensor: its gradient [N][HW][C] (eps: 8 channels)
   size_t grad_bytes = 0;                // all gradient tensors (one memset)
   size_t off_tmpA = 0, off_tmpZ = 0, off_S = 0, off_dtemb = 0, off_dwn = 0, off_dbn = 0, off_dbl = 0, off_wg = 0, off_csb = 0,
-         off_tb = 0, off_loss = 0, off_deps = 0;
+         off_tb = 0, off_loss = 0, off_deps = 0, off_noise = 0;
   size_t bytes = 0;                     // total workspace (forward plan + extras)
 };
 
@@ -83,6 +83,8 @@ int make_train_plan(fdsr_handle h, int N, int H, int W, TrainPlan* tp) {
   tp->off_csb = take(csb);
   tp->off_tb = take((size_t)N * 11 * h->cfg.inner_channel * sizeof(float));
   tp->off_loss = take(256);
+  tp->off_noise = off;                  // the target noise of a step whose noise the engine draws itself (fdsr_train_grads_pairs)
+  off += align_up((size_t)N * 3 * H * W * sizeof(float), 256);
   tp->bytes = off;
   return FDSR_OK;
 }
@@ -318,10 +320,15 @@ int fdsr_train_workspace_bytes(fdsr_handle h, int batch, int height, int width, 
   return train_workspace_extra(h, batch, height, width, bytes);
 }
 
-int fdsr_train_grads(fdsr_handle h, const float* x_nchw, const float* noise_level, const float* target_nchw, int loss_l2,
-                     float loss_scale, float* loss_host, int batch, int height, int width, void* workspace, size_t workspace_bytes,
-                     void* hip_stream) {
-  if (!h || !x_nchw || !noise_level || !target_nchw) return fail(h, FDSR_E_INVALID, "null argument");
+}  // extern "C"
+
+namespace {
+// The step behind both entry points.  x_nchw != null: the packed network input is given ([B,6,H,W], cat([SR, x_noisy])).
+// Otherwise (hr, sr): img2res + q_sample + cat (diffusion.py:233-241, :283-289, :257-263) run here, in the kernel that writes
+// the packed NHWC input; target_nchw == null then means: the engine draws the noise itself.
+int train_grads_impl(fdsr_handle h, const float* x_nchw, const float* hr_nchw, const float* sr_nchw, const float* noise_level,
+                     const float* target_nchw, int loss_l2, float loss_scale, float* loss_host, int batch, int height, int width,
+                     void* workspace, size_t workspace_bytes, void* hip_stream) {
   if (h->prec == PREC_BF16)
     return fail(h, FDSR_E_INVALID, "the training step runs the fp32-grade kernels: fdsr_set_precision(FDSR_PREC_F32 or FDSR_PREC_F16X3) first");
   if (h->cfg.in_channel != 6 || h->cfg.out_channel != 3) return fail(h, FDSR_E_INVALID, "training needs in_channel=6, out_channel=3");
@@ -354,7 +361,18 @@ int fdsr_train_grads(fdsr_handle h, const float* x_nchw, const float* noise_leve
 
   // ---- forward, keeping every activation and the GroupNorm statistics ----
   float* xin = reinterpret_cast<float*>(ws + sp.tensor_off[h->t_in]);
-  HIPCHK(h, launch_nchw_to_nhwc(x_nchw, xin, N, h->cfg.in_channel, H, W, h->CP, 0, 1, st));
+  if (x_nchw) {
+    HIPCHK(h, launch_nchw_to_nhwc(x_nchw, xin, N, h->cfg.in_channel, H, W, h->CP, 0, 1, st));
+  } else {
+    if (!target_nchw) {   // nobody supplied the noise: draw it (Philox, keyed by fdsr_set_seed and the count of such steps)
+      if ((rc = ensure_rng(h))) return rc;
+      float* nz = reinterpret_cast<float*>(ws + tp.off_noise);
+      HIPCHK(h, launch_rng_advance(h->d_rng, st));
+      HIPCHK(h, launch_randn_plane(h->d_rng, nz, N, H * W, 0, st));
+      target_nchw = nz;
+    }
+    HIPCHK(h, launch_qsample_pack(hr_nchw, sr_nchw, noise_level, target_nchw, xin, N, H * W, h->CP, st));
+  }
   h->keep_stats = true;
   rc = run_unet(h, N, H, W, ws, noise_level, 0.f, st);
   keep_mode.restore();
@@ -516,6 +534,26 @@ int fdsr_train_grads(fdsr_handle h, const float* x_nchw, const float* noise_leve
     HIPCHK(h, hipStreamSynchronize(st));
   }
   return FDSR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fdsr_train_grads(fdsr_handle h, const float* x_nchw, const float* noise_level, const float* target_nchw, int loss_l2,
+                     float loss_scale, float* loss_host, int batch, int height, int width, void* workspace, size_t workspace_bytes,
+                     void* hip_stream) {
+  if (!h || !x_nchw || !noise_level || !target_nchw) return fail(h, FDSR_E_INVALID, "null argument");
+  return train_grads_impl(h, x_nchw, nullptr, nullptr, noise_level, target_nchw, loss_l2, loss_scale, loss_host, batch, height, width,
+                          workspace, workspace_bytes, hip_stream);
+}
+
+int fdsr_train_grads_pairs(fdsr_handle h, const float* hr_nchw, const float* sr_nchw, const float* gamma, const float* noise_nchw,
+                           int loss_l2, float loss_scale, float* loss_host, int batch, int height, int width, void* workspace,
+                           size_t workspace_bytes, void* hip_stream) {
+  if (!h || !hr_nchw || !sr_nchw || !gamma) return fail(h, FDSR_E_INVALID, "null argument");
+  return train_grads_impl(h, nullptr, hr_nchw, sr_nchw, gamma, noise_nchw, loss_l2, loss_scale, loss_host, batch, height, width,
+                          workspace, workspace_bytes, hip_stream);
 }
 
 int fdsr_adam_step(fdsr_handle h, float lr, float beta1, float beta2, float eps, void* hip_stream) {

@@ -19,6 +19,11 @@ size_t loss_partial_count(size_t npix);
 hipError_t launch_loss_grad(const float* eps, const float* target, float* deps8, double* partial, float* loss_out, int N, int HW,
                             int l2, float scale, hipStream_t s);
 
+// ---- network input of a training step: xin [N,H,W,CP] = [SR | gamma * img2res(HR, SR) + sqrt(1 - gamma^2) * noise | 0 ...] from NCHW
+// HR, SR, noise and the per-sample gamma [N] (diffusion.py:233-263); bit-identical to the op-by-op torch tensor
+hipError_t launch_qsample_pack(const float* hr, const float* sr, const float* gamma, const float* noise, float* xin, int N, int HW,
+                               int CP, hipStream_t s);
+
 // ---- small helpers -----------------------------------------------------------------------------------------
 // S[n][c] = sum over the pixels of image n of dy[n][p][c]   (bias / noise-shift gradients); fixed order
 hipError_t launch_colsum(const float* dy, float* S, double* scratch, int N, int HW, int C, hipStream_t s);

@@ -36,6 +36,39 @@ __device__ __forceinline__ float sigmoid_f(float v) { return 1.0f / (1.0f + expf
 }  // namespace
 
 // ---------------------------------------------------------------------------
+// network input of a training step, formed on the device: img2res (diffusion.py:283-289), q_sample (:233-241) and
+// cat([SR, x_noisy], dim=1) (:257-263) in the kernel that writes the packed NHWC input.  Separately rounded products and
+// sums (no contraction), so the tensor is bit-identical to the one torch forms op by op.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) qsample_pack_kernel(const float* __restrict__ hr, const float* __restrict__ sr,
+                                                           const float* __restrict__ gamma, const float* __restrict__ noise,
+                                                           float* __restrict__ xin, int HW, int CP, size_t npix) {
+  const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= npix) return;
+  const size_t n = p / HW, hw = p % HW;
+  const float g = gamma[n];
+  const float sg = __fsqrt_rn(__fsub_rn(1.0f, __fmul_rn(g, g)));   // (1 - gamma ** 2).sqrt()
+  float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const size_t i = (n * 3 + c) * HW + hw;
+    const float s = sr[i];
+    const float xs = fminf(fmaxf(__fmul_rn(__fsub_rn(hr[i], s), 2.0f), -1.0f), 1.0f);   // img2res: ((hr - sr) * 2).clamp(-1, 1)
+    o[c] = s;
+    o[3 + c] = __fadd_rn(__fmul_rn(g, xs), __fmul_rn(sg, noise[i]));                    // gamma * x_start + sqrt(1 - gamma^2) * noise
+  }
+  float* dst = xin + p * CP;
+  for (int c = 0; c < CP; ++c) dst[c] = c < 8 ? o[c] : 0.f;
+}
+
+hipError_t launch_qsample_pack(const float* hr, const float* sr, const float* gamma, const float* noise, float* xin, int N, int HW,
+                               int CP, hipStream_t s) {
+  const size_t npix = (size_t)N * HW;
+  hipLaunchKernelGGL(qsample_pack_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, hr, sr, gamma, noise, xin, HW, CP, npix);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // loss
 // ---------------------------------------------------------------------------
 size_t loss_partial_count(size_t npix) { return (npix + 255) / 256; }

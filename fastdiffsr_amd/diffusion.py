@@ -188,8 +188,14 @@ class GaussianDiffusion(nn.Module):
             raise ValueError('optimize_step: the global batch is empty')
         eng = self._engine_for_training()
         if b > 0:
-            x6, gamma, noise = self._training_batch(x_in, noise)
-            loss = eng.train_grads(x6, gamma, noise, self.loss_type, 1.0 / (gb * int(c * h * w)))
+            # the RNG draws are the reference's (numpy for t and gamma, torch for the noise: diffusion.py:246-259); img2res,
+            # q_sample and the channel concat happen in the engine's input kernel (bit-identical to _training_batch's tensors)
+            hr, sr = x_in['HR'].float().contiguous(), x_in['SR'].float().contiguous()
+            t = np.random.randint(1, self.num_timesteps + 1)
+            gamma = torch.FloatTensor(np.random.uniform(self.sqrt_alphas_cumprod_prev[t - 1], self.sqrt_alphas_cumprod_prev[t],
+                                                        size=b)).to(hr.device)
+            noise = torch.randn_like(hr) if noise is None else noise
+            loss = eng.train_grads_pairs(hr, sr, gamma, noise.contiguous(), self.loss_type, 1.0 / (gb * int(c * h * w)))
         else:
             eng.zero_grads(x_in['HR'].device)
             loss = 0.0

@@ -224,6 +224,30 @@ class Engine:
         self._keep = (x, nl, target)
         return float(loss.value)
 
+    def train_grads_pairs(self, hr, sr, gamma, noise=None, loss_type='l1', loss_scale=1.0):
+        """The same step from the training pair (include/fdsr.h: fdsr_train_grads_pairs): img2res, q_sample and the channel concat
+        happen in the engine's input kernel; noise=None: the engine draws the target noise itself (Philox, set_seed)."""
+        hr, sr = self._check_input(hr, 'hr'), self._check_input(sr, 'sr')
+        B, _, H, W = hr.shape
+        g = self._check_input(gamma.to(hr.device), 'gamma').reshape(-1)
+        if g.numel() != B or tuple(sr.shape) != (B, 3, H, W) or tuple(hr.shape) != (B, 3, H, W):
+            raise ValueError('hr / sr must be [B,3,H,W] and gamma [B]')
+        if noise is not None:
+            noise = self._check_input(noise, 'noise')
+            if tuple(noise.shape) != (B, 3, H, W):
+                raise ValueError('noise must be [B,3,H,W]')
+        need = self.train_workspace_bytes(B, H, W)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != hr.device:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=hr.device)
+        ws, loss = self._ws, C.c_float()
+        st = torch.cuda.current_stream(hr.device).cuda_stream
+        _lib.check(self.h, self.lib.fdsr_train_grads_pairs(self.h, _ptr(hr), _ptr(sr), _ptr(g), _ptr(noise), {'l1': 0, 'l2': 1}[loss_type],
+                                                           C.c_float(float(loss_scale)), C.byref(loss), B, H, W, _ptr(ws), ws.numel(),
+                                                           C.c_void_p(st)))
+        self._keep = (hr, sr, g, noise)
+        return float(loss.value)
+
     def zero_grads(self, device='cuda'):
         """A zero gradient arena (a data-parallel rank whose shard of the batch is empty still joins the all-reduce)."""
         self.grad_arena().zero_()

@@ -421,3 +421,34 @@ def test_f16x3_step_on_ragged_shapes_matches_the_exact_fp32_step(shape):
         if scale > 1e-3 * gmax:
             worst = max(worst, d / scale)
     print(f'ragged {shape}: worst relative gradient difference {worst:.2e} (tensors above 1e-3 of the largest gradient)')
+
+
+@pytest.mark.parametrize('prec', ['f32', 'f16x3'])
+def test_step_from_the_training_pair_equals_the_step_from_torch_formed_inputs(golden_dir, prec):
+    """fdsr_train_grads_pairs forms img2res + q_sample + cat([SR, x_noisy]) in the engine's input kernel (diffusion.py:233-263):
+    same loss and same gradients, bit for bit, as the step on the tensor torch forms op by op; with noise=None the engine draws
+    the target itself (fresh per step, repeatable under set_seed)."""
+    from fastdiffsr_amd.engine import Engine
+    cfg = UNetConfig(**FASTDIFFSR_UNET)
+    sd = synth_state_dict(cfg, 0)
+    hr, sr, nz, gamma = _inputs(golden_dir)
+    b, c, h, w = hr.shape
+    scale = 1.0 / (b * c * h * w)
+    eng = Engine(cfg)
+    eng.load_state_dict(sd)
+    eng.set_precision(prec)
+    x = torch.cat([sr, _x_noisy(hr, sr, nz, gamma)], 1)
+    l_a = eng.train_grads(x.cuda(), gamma.cuda(), nz.cuda(), 'l1', scale)
+    g_a = {k: eng.get_grad(k).copy() for k, _, live in eng.schema() if live}
+    l_b = eng.train_grads_pairs(hr.cuda(), sr.cuda(), gamma.cuda(), nz.cuda(), 'l1', scale)
+    assert l_a == l_b
+    for k, v in g_a.items():
+        assert np.array_equal(eng.get_grad(k), v), k
+    # engine-drawn noise: finite, different from step to step, the same again under the same seed
+    eng.set_seed(7)
+    l1 = eng.train_grads_pairs(hr.cuda(), sr.cuda(), gamma.cuda(), None, 'l1', scale)
+    l2 = eng.train_grads_pairs(hr.cuda(), sr.cuda(), gamma.cuda(), None, 'l1', scale)
+    eng.set_seed(7)
+    l3 = eng.train_grads_pairs(hr.cuda(), sr.cuda(), gamma.cuda(), None, 'l1', scale)
+    assert np.isfinite([l1, l2]).all() and l1 != l2 and l1 == l3
+    assert abs(l1 / (b * c * h * w) - 0.8) < 0.3          # ~E|N(0,1) - eps| of an untrained network
