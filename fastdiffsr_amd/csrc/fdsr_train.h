@@ -20,7 +20,7 @@ hipError_t launch_loss_grad(const float* eps, const float* target, float* deps8,
                             int l2, float scale, hipStream_t s);
 
 // ---- network input of a training step: xin [N,H,W,CP] = [SR | gamma * img2res(HR, SR) + sqrt(1 - gamma^2) * noise | 0 ...] from NCHW
-// HR, SR, noise and the per-sample gamma [N] (diffusion.py:233-263); bit-identical to the op-by-op torch tensor
+// HR, SR, noise and the per-sample gamma [N] (diffusion.py:233-263); the arithmetic of the op-by-op torch tensor
 hipError_t launch_qsample_pack(const float* hr, const float* sr, const float* gamma, const float* noise, float* xin, int N, int HW,
                                int CP, hipStream_t s);
 

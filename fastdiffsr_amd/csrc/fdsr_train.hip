@@ -38,7 +38,7 @@ __device__ __forceinline__ float sigmoid_f(float v) { return 1.0f / (1.0f + expf
 // ---------------------------------------------------------------------------
 // network input of a training step, formed on the device: img2res (diffusion.py:283-289), q_sample (:233-241) and
 // cat([SR, x_noisy], dim=1) (:257-263) in the kernel that writes the packed NHWC input.  Separately rounded products and
-// sums (no contraction), so the tensor is bit-identical to the one torch forms op by op.
+// sums (no contraction), the same arithmetic as the tensor torch forms op by op.
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) qsample_pack_kernel(const float* __restrict__ hr, const float* __restrict__ sr,
                                                            const float* __restrict__ gamma, const float* __restrict__ noise,

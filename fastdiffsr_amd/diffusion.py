@@ -189,7 +189,7 @@ class GaussianDiffusion(nn.Module):
         eng = self._engine_for_training()
         if b > 0:
             # the RNG draws are the reference's (numpy for t and gamma, torch for the noise: diffusion.py:246-259); img2res,
-            # q_sample and the channel concat happen in the engine's input kernel (bit-identical to _training_batch's tensors)
+            # q_sample and the channel concat happen in the engine's input kernel (the arithmetic of _training_batch's tensors)
             hr, sr = x_in['HR'].float().contiguous(), x_in['SR'].float().contiguous()
             t = np.random.randint(1, self.num_timesteps + 1)
             gamma = torch.FloatTensor(np.random.uniform(self.sqrt_alphas_cumprod_prev[t - 1], self.sqrt_alphas_cumprod_prev[t],

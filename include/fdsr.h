@@ -246,7 +246,7 @@ int fdsr_train_grads(fdsr_handle h, const float* x_nchw, const float* noise_leve
                      int loss_l2, float loss_scale, float* loss_host, int batch, int height, int width,
                      void* workspace, size_t workspace_bytes, void* hip_stream);
 /* The same step from the training pair itself: img2res (diffusion.py:283-289), q_sample (:233-241) and cat([SR, x_noisy]) (:257-263)
- * run in the kernel that writes the packed network input (bit-identical to the tensor torch forms op by op).  hr / sr / noise:
+ * run in the kernel that writes the packed network input (the arithmetic of the tensor torch forms op by op: separately rounded products and sums).  hr / sr / noise:
  * [B,3,H,W] NCHW fp32 device pointers, gamma: [B] (the continuous sqrt(alpha_bar) per sample, :246-256).  noise == NULL: the
  * engine draws N(0,1) itself (Philox, fdsr_set_seed) and uses it as the target. */
 int fdsr_train_grads_pairs(fdsr_handle h, const float* hr_nchw, const float* sr_nchw, const float* gamma, const float* noise_nchw,
