@@ -416,10 +416,10 @@ __global__ void __launch_bounds__(512, 2) conv_wino2_h_kernel(const ConvParams p
       v = ok ? (n * p.Hin + iy) * p.Win + ix : -1;
       ro = hy * W2_RAWROW + hx * W_RAWB + q * 16;
     }
+    if (pix >= W_NPIX) ro = 18 * W_RAWB + q * 16;   // no third item on this lane: a dummy slot in the padding of halo row 0 (bytes 1440..1503)
     in_pix[i] = v;
     raw_off[i] = ro;
   }
-  const bool has2 = row0 + 2 * 128 < W_NPIX;   // the third pass covers 68 of the 128 pixel rows
   f32x4 rin[W_NIN];
   // per-(image, channel) GroupNorm scale / shift: read from LDS where they are used (no registers held across phases, and no
   // vector-memory wait that would drag the in-flight halo prefetch with it: vmcnt counts in issue order)
@@ -444,7 +444,6 @@ __global__ void __launch_bounds__(512, 2) conv_wino2_h_kernel(const ConvParams p
   };
   auto stage_item = [&](int i, int kc, unsigned char* buf) {
     (void)kc;
-    if (i == 2 && !has2) return;
     f32x4 v = rin[i] * ssc + ssh;
     v.x = silu_w(v.x); v.y = silu_w(v.y); v.z = silu_w(v.z); v.w = silu_w(v.w);
     const float lim = in_pix[i] >= 0 ? 16376.f : 0.f;   // zero padding of the ACTIVATED tensor; |V| <= 4 max|a| stays inside f16
@@ -651,11 +650,94 @@ __global__ void __launch_bounds__(512, 2) conv_wino2_h_kernel(const ConvParams p
       W2_STAMP();
     }
   };
-#ifdef WINO2_TWO_LOOPS
+#if defined(WINO2_TWO_LOOPS)
   if (chalf == 0) run_loop(std::integral_constant<int, 1>{});
   else run_loop(std::integral_constant<int, 0>{});
+#elif !defined(WINO2_INTERLEAVED)
+  run_loop(std::integral_constant<int, 2>{});      // the form used: one loop, the transform part guarded in front of / behind the MFMA part
 #else
-  run_loop(std::integral_constant<int, 2>{});
+  // Third shape of the loop (-DWINO2_INTERLEAVED; measured 3 % SLOWER than the guarded form, 10.13 vs 9.80 ms for the 44 launches of
+  // a B=16 forward, insensitive to the VALU count per gap: kept for reference only).  Both waves of a SIMD run the SAME stream, and
+  // inside it every MFMA is followed by its share of the phase's VALU work.  The timeline of the guarded form (profiles/r03_wino_phase_timeline.txt) shows why the stagger
+  // is not enough: the transform / staging part is ~3x longer than the MFMA part, so for most of a phase BOTH waves of a SIMD are in
+  // it and the matrix pipe idles -- the loop is VALU-issue-bound (~140 instructions per wave and phase), and an MFMA costs the
+  // issuing wave only 8 of its 32 cycles.  One basic block per phase (branch-free: lanes without a third halo item stage into a
+  // dummy slot); sched_group_barrier asks for 1 MFMA : W2_IL_VALU VALU per gap, with the LDS reads up front and the writes trailing.
+#ifndef W2_IL_VALU
+#define W2_IL_VALU 11
+#endif
+  auto interleave = [&]() {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);            // LDS reads run a gap or two ahead of their use
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);            // 1 MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, W2_IL_VALU, 0);   // its share of the VALU work
+      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);            // an LDS write when one is ready
+    }
+  };
+  u32x4 Ai[2][2];   // A fragments of position nu in slot nu & 1: read one position ahead
+  auto read_a = [&](int nu, int tb) {
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+      Ai[nu & 1][pl] = *reinterpret_cast<const u32x4*>(abase + (nu * W_TT + tb * 32) * W_ROWB + 32 * pl);
+  };
+  auto mfma3 = [&](int nu, auto tb_tag) {
+    constexpr int tb = decltype(tb_tag)::value;
+    const u32x4 ahi = Ai[nu & 1][0], alo = Ai[nu & 1][1];
+    acc[nu][tb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, alo), __builtin_bit_cast(h8, Bf[nu][0]), acc[nu][tb], 0, 0, 0);
+    acc[nu][tb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, ahi), __builtin_bit_cast(h8, Bf[nu][1]), acc[nu][tb], 0, 0, 0);
+    acc[nu][tb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, ahi), __builtin_bit_cast(h8, Bf[nu][0]), acc[nu][tb], 0, 0, 0);
+  };
+  // one phase in the order its values are wanted: A(0), columns 0 and 2 -> V0 | A(1), column 1 -> V1, V2 | A(2), column 3 -> V3 |
+  // A(3), staging; the MFMAs of position nu sit between the reads of nu + 1 and the VALU work that follows
+  auto phase = [&](auto tb_tag, int ttb, const unsigned char* traw, int kss, auto second_stage) {
+    constexpr int tb = decltype(tb_tag)::value;
+    const unsigned char* ra = traw + t_rd + ttb * (8 * W2_RAWROW) + ra_off;
+    const unsigned char* rb = traw + t_rd + ttb * (8 * W2_RAWROW) + rb_off;
+    unsigned char* dst = sV + t_wr + ttb * (32 * W_ROWB);
+    auto col = [&](int c) -> f32x4 {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(ra + c * W_RAWB);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(rb + c * W_RAWB);
+      return b * t_s + a;
+    };
+    read_a(0, tb);
+    const f32x4 R0 = col(0), R2 = col(2);
+    load_ss(kss);
+    read_a(1, tb);
+    mfma3(0, tb_tag);
+    split_store2(dst + 0 * (W_TT * W_ROWB), R0 - R2);
+    const f32x4 R1 = col(1);
+    read_a(2, tb);
+    mfma3(1, tb_tag);
+    split_store2(dst + 1 * (W_TT * W_ROWB), R1 + R2);
+    split_store2(dst + 2 * (W_TT * W_ROWB), R2 - R1);
+    const f32x4 R3 = col(3);
+    read_a(3, tb);
+    mfma3(2, tb_tag);
+    split_store2(dst + 3 * (W_TT * W_ROWB), R1 - R3);
+    second_stage(0);
+    mfma3(3, tb_tag);
+    second_stage(1);
+    interleave();
+  };
+  for (int kc = 0; kc < nk; ++kc) {
+    unsigned char* cur = (kc & 1) ? sRaw1 : sRaw0;
+    unsigned char* nxt = (kc & 1) ? sRaw0 : sRaw1;
+    const int kc1 = kc + 1 < nk ? kc + 1 : nk - 1, kc2 = kc + 2 < nk ? kc + 2 : nk - 1, kc3 = kc + 3 < nk ? kc + 3 : nk - 1;
+    // ---- phase A: 12 MFMAs on tile block 0 | tile block 1 transformed, items 1, 2 of the next chunk staged ----
+    phase(TB0{}, 1, cur, kc1, [&](int part) { stage_item(part ? 2 : 1, kc1, nxt); });
+    __builtin_amdgcn_sched_barrier(0);
+    prefetch_item(1, kc2);
+    prefetch_item(2, kc2);
+    __syncthreads();
+    // ---- phase B: 12 MFMAs on tile block 1 | tile block 0 of the next chunk transformed, item 0 of the one after staged ----
+    phase(TB1{}, 0, nxt, kc2, [&](int part) { if (part == 0) stage_item(0, kc2, cur); });
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu) load_b(kc1, nu);    // same registers, next chunk (the last chunk re-reads its own)
+    prefetch_item(0, kc3);
+    __syncthreads();
+  }
 #endif
 
   // ---- epilogue (as the first form): fold the position row over nu, rows meet in LDS ----
