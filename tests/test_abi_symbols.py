@@ -67,3 +67,21 @@ def test_header_is_plain_c99_and_demo_links(tmp_path):
     out = subprocess.run(['ldd', demo], capture_output=True, text=True).stdout
     assert 'libfdsr_hip.so' in out and 'not found' not in out.split('libfdsr_hip.so')[1].split('\n')[0]
     assert 'torch' not in out and 'python' not in out
+
+
+def test_debug_options_are_an_abi_call_not_environment():
+    """Launcher A/B options go through fdsr_debug_option (host-only, no GPU needed): known names are accepted, unknown ones are
+    FDSR_E_INVALID, and no kernel / engine source reads the environment."""
+    from fastdiffsr_amd import _lib
+    lib = _lib.load()
+    defaults = {'rider': 2, 'up2': 1, 'splitk': 1, 'sk_target': 256, 'th_min_wgs': 256, 'wino': 2, 'wino_all': 0, 'wino_min_wgs': 256,
+                'wgrad_form': 0, 'wgrad_colsum': 1, 'wgrad_f32': 0, 'wgrad_big_bytes': 1 << 32, 'sat_guard': 1, 'drop_image_offset': 0}
+    for name, value in defaults.items():          # every documented name is accepted (set to its default)
+        assert lib.fdsr_debug_option(name.encode(), value) == 0, name
+    assert lib.fdsr_debug_option(b'no_such_option', 1) == -1          # FDSR_E_INVALID
+    with pytest.raises(_lib.FdsrError):
+        _lib.debug_option('no_such_option', 1)
+    csrc = os.path.join(ROOT, 'fastdiffsr_amd', 'csrc')
+    for f in os.listdir(csrc):
+        if f.endswith(('.hip', '.cpp', '.h')):
+            assert 'getenv' not in open(os.path.join(csrc, f)).read(), f
