@@ -166,6 +166,13 @@ class _OracleEngine:
         self.flat = torch.cat([self.leaves[k].grad.reshape(-1) for k in self.keys])
         return float(loss)
 
+    def train_grads_pairs(self, hr, sr, gamma, noise, loss_type, scale):
+        """What fdsr_train_grads_pairs does on the device: img2res + q_sample + cat (diffusion.py:233-263), then the step."""
+        x_start = ((hr - sr) * 2.0).clamp(-1, 1)
+        g = gamma.view(-1, 1, 1, 1)
+        x6 = torch.cat([sr, g * x_start + (1 - g ** 2).sqrt() * noise], 1)
+        return self.train_grads(x6, gamma, noise, loss_type, scale)
+
     def zero_grads(self, device=None):
         if self.keys is None:       # the key set does not depend on the data: derive it from a dry run
             self.keys = _OracleEngine._live_keys
@@ -225,14 +232,20 @@ def _driver_worker(rank, world, port, batches, q):
         t = np.random.randint(1, 21)
         gam_full = np.random.uniform(sqrt_prev[t - 1], sqrt_prev[t], size=B)
 
-        def tb(x_in, noise=None, lo=lo, hi=hi, gam_full=gam_full, full_noise=full_noise):
-            x_start = netG.img2res(x_in['HR'], x_in['SR'])
-            gamma = torch.FloatTensor(gam_full[lo:hi]).view(-1, 1)
-            nz = full_noise[lo:hi]
-            return torch.cat([x_in['SR'], netG.q_sample(x_start, gamma.view(-1, 1, 1, 1), nz)], 1).contiguous(), gamma, nz.contiguous()
-        netG._training_batch = tb
+        # optimize_step draws t and gamma with numpy and the noise with torch.randn_like (the reference's RNG, diffusion.py:246-259):
+        # here every rank must see ITS SLICE of the global draws, so the three calls are patched for the step
+        from unittest import mock
+        patches = [mock.patch.object(np.random, 'randint', lambda a, b, t=t: t),
+                   mock.patch.object(np.random, 'uniform', lambda lo_, hi_, size=None, g=gam_full[lo:hi]: g.copy()),
+                   mock.patch.object(torch, 'randn_like', lambda x, nz=full_noise[lo:hi]: nz.clone())]
+        for pt in patches:
+            pt.start()
         ddpm.data = {'HR': hr[lo:hi], 'SR': sr[lo:hi]}
-        ddpm.optimize_parameters()
+        try:
+            ddpm.optimize_parameters()
+        finally:
+            for pt in patches:
+                pt.stop()
         logs.append(ddpm.log_dict['l_pix'])
         if step == 0:
             first = dict(B=B, hr=hr, sr=sr, gam=gam_full, noise=full_noise, arena=eng.flat.clone())
