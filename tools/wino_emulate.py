@@ -368,3 +368,140 @@ def check_v2():
 
 if __name__ == '__main__':
     check_v2()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# fourth form (conv_wino4_h_kernel): 256-thread workgroups of 32 tiles (8 x 16 pixels) x 64 couts, wave = position row with both
+# cout halves, serial phases (transform | barrier | MFMAs + staging | barrier)
+# ---------------------------------------------------------------------------------------------------------------------
+def run_wg4(x, w, oy0, ox0, cot):
+    H, W, Cin = x.shape
+    nk = Cin // 16
+    fr = pack_u(w)
+    lds = LDS()
+    TT4, HH4 = 32, 10
+    sV, sRaw = 0, [16 * TT4 * ROWB, 16 * TT4 * ROWB + HH4 * RAWROW]
+    T = range(256)
+    q = [t & 3 for t in T]; row0 = [t >> 2 for t in T]
+    in_pix, raw_off = {}, {}
+    for t in T:
+        for i in range(3):
+            pix = row0[t] + 64 * i
+            v, ro = -2, 18 * RAWB + q[t] * 16
+            if pix < HH4 * HW:
+                hy, hx = divmod(pix, HW)
+                iy, ix = oy0 - 1 + hy, ox0 - 1 + hx
+                v = (iy, ix) if (0 <= iy < H and 0 <= ix < W) else -1
+                ro = hy * RAWROW + hx * RAWB + q[t] * 16
+            in_pix[t, i], raw_off[t, i] = v, ro
+    rin = {}
+
+    def prefetch(t, kc):
+        for i in range(3):
+            v = in_pix[t, i]
+            pos = v if isinstance(v, tuple) else (0, 0)
+            rin[t, i] = x[pos[0], pos[1], kc * 16 + 4 * q[t]: kc * 16 + 4 * q[t] + 4].copy()
+
+    def stage(t, buf):
+        for i in range(3):
+            v = rin[t, i] if isinstance(in_pix[t, i], tuple) else np.zeros(4)
+            adr = buf + raw_off[t, i]
+            if in_pix[t, i] == -2:
+                lds.mem[adr] = v          # dummy slot: several lanes write it, nobody reads it
+            else:
+                lds.write(adr, v)
+
+    def transform(t, raw):
+        lane, wave = t & 63, t >> 6
+        t_tx, t_ty, t_cq = lane & 7, lane >> 4, ((lane >> 3) & 1) | ((wave & 1) << 1)
+        t_rd = (2 * t_ty) * RAWROW + (2 * t_tx) * RAWB + t_cq * 16
+        for j in range(2):
+            xi_t = (wave >> 1) * 2 + j
+            ra_off = (0 if xi_t == 0 else (2 if xi_t == 2 else 1)) * RAWROW
+            rb_off = (3 if xi_t == 3 else (1 if xi_t == 2 else 2)) * RAWROW
+            t_s = 1.0 if xi_t == 1 else -1.0
+            a = [lds.read(raw + t_rd + ra_off + c * RAWB) for c in range(4)]
+            b = [lds.read(raw + t_rd + rb_off + c * RAWB) for c in range(4)]
+            R = [b[c] * t_s + a[c] for c in range(4)]
+            dst = sV + ((xi_t * 4) * TT4 + t_ty * 8 + t_tx) * ROWB + t_cq * 8
+            for nu, o in enumerate((R[0] - R[2], R[1] + R[2], R[2] - R[1], R[1] - R[3])):
+                lds.write(dst + nu * (TT4 * ROWB), o)
+
+    acc = np.zeros((4, 4, 2, 64, 16))          # [wave][nu][cout half][lane][i]
+    for t in T:
+        prefetch(t, 0)
+    lds.barrier()
+    for t in T:
+        stage(t, sRaw[0])
+    for t in T:
+        prefetch(t, 1 if nk > 1 else 0)
+    lds.barrier()
+    for kc in range(nk):
+        cur, nxt = sRaw[kc & 1], sRaw[(kc + 1) & 1]
+        kc1, kc2 = min(kc + 1, nk - 1), min(kc + 2, nk - 1)
+        for t in T:
+            transform(t, cur)
+        lds.barrier()
+        for wave in range(4):
+            xi = wave
+            for nu in range(4):
+                A = np.zeros((32, 16))
+                for lane in range(64):
+                    r31, kh = lane & 31, lane >> 5
+                    adr = sV + ((xi * 4) * TT4 + r31) * ROWB + 16 * kh + (nu * TT4) * ROWB
+                    A[r31, 8 * kh: 8 * kh + 8] = np.concatenate([lds.read(adr), lds.read(adr + 8)])
+                for ch in range(2):
+                    B = np.zeros((16, 32))
+                    for lane in range(64):
+                        r31, kh = lane & 31, lane >> 5
+                        B[8 * kh: 8 * kh + 8, r31] = fr[cot, kc, xi | (ch << 2), nu, lane]
+                    C = A @ B
+                    for lane in range(64):
+                        r31, kh = lane & 31, lane >> 5
+                        for i in range(16):
+                            acc[wave, nu, ch, lane, i] += C[(i & 3) + 8 * (i >> 2) + 4 * kh, r31]
+        for t in T:
+            stage(t, nxt)
+            prefetch(t, kc2)
+        lds.barrier()
+    z = {}
+    for wave in range(4):
+        xi = wave
+        for lane in range(64):
+            r31, kh = lane & 31, lane >> 5
+            for ch in range(2):
+                cz = ch * 32 + r31
+                for i in range(16):
+                    tile = (i & 3) + 8 * (i >> 2) + 4 * kh
+                    m = acc[wave, :, ch, lane, i]
+                    z[((xi * 2 + 0) * TT4 + tile) * ZROWB // 4 + cz] = m[0] + m[1] + m[2]
+                    z[((xi * 2 + 1) * TT4 + tile) * ZROWB // 4 + cz] = m[1] - m[2] - m[3]
+    out = np.zeros((8, 16, 64))
+    for tid in range(256):
+        cqo, pp0 = tid & 15, tid >> 4
+        for it in range(8):
+            pp = pp0 + it * 16
+            py, px = pp >> 4, pp & 15
+            tile, i, j = (py >> 1) * 8 + (px >> 1), py & 1, px & 1
+            zb = (j * TT4 + tile) * ZROWB + cqo * 16
+            zs = [np.array([z[(zb + (k + i) * 2 * TT4 * ZROWB) // 4 + e] for e in range(4)]) for k in range(3)]
+            out[py, px, cqo * 4: cqo * 4 + 4] = (zs[0] + zs[1]) + zs[2] if i == 0 else (zs[0] - zs[1]) - zs[2]
+    return out
+
+
+def check_v4():
+    rng = np.random.default_rng(3)
+    for Cin in (16, 48):
+        x = rng.standard_normal((32, 32, Cin))
+        w = rng.standard_normal((128, Cin, 3, 3)).astype(np.float32)
+        ref = direct(x, w)
+        for (oy0, ox0, cot) in [(0, 0, 0), (8, 16, 1), (24, 0, 1)]:
+            got = run_wg4(x, w, oy0, ox0, cot)
+            d = np.abs(got - ref[oy0:oy0 + 8, ox0:ox0 + 16, cot * 64:cot * 64 + 64]).max()
+            print(f'v4 Cin={Cin} workgroup ({oy0},{ox0},cot {cot}): max|emulated - direct| = {d:.3e}')
+            assert d < 1e-9
+    print('v4 schedule: no LDS race, index maps consistent')
+
+
+if __name__ == '__main__':
+    check_v4()
