@@ -42,7 +42,7 @@ namespace {
 constexpr int W_TT = 64;                       // tiles per workgroup: 8 x 8 tiles of 2 x 2 outputs
 constexpr int W_HW = 18;                       // halo width / height in pixels
 constexpr int W_NPIX = W_HW * W_HW;            // 324
-constexpr int W_ROWB = 80;                     // raw: 16 fp32 channels... no: see W_RAWB; V row: [16 hi | 16 lo | 16 B pad]
+constexpr int W_ROWB = 80;                     // V row of one (position, tile): [16 hi | 16 lo | 16 B pad]
 constexpr int W_RAWB = 80;                     // raw halo pixel: 16 fp32 = 64 B + 16 B pad (odd number of 16-byte slots)
 constexpr int W_V_BYTES = 16 * W_TT * W_ROWB;  // 81920
 constexpr int W_RAW_BYTES = W_NPIX * W_RAWB;   // 25920
