@@ -1018,7 +1018,7 @@ int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, 
         break;
       }
       case Op::ATTN: {
-        HIPCHK(h, launch_self_attention(TP(op.src0), TP(op.aux), TP(op.dst), N, Hi * Wi, op.C0, op.heads, st));
+        HIPCHK(h, launch_self_attention(TP(op.src0), TP(op.aux), TP(op.dst), N, Hi * Wi, op.C0, op.heads, st, h->prec == PREC_BF16));
         break;
       }
       case Op::POOL2: {
@@ -1605,9 +1605,10 @@ int fdsr_set_precision(fdsr_handle h, int mode) {
   if (!h || mode < 0 || mode > 2) return fail(h, FDSR_E_INVALID, "precision mode must be 0 (f32), 1 (f16x3) or 2 (bf16)");
   if (mode == PREC_BF16) {
     // bf16 mode stores activations as bf16: every conv but the packed-input one must run on the 16-bit
-    // kernels, and the attention kernels of the SR3 variant read fp32
+    // kernels (attention has its own bf16 pair); the materialised resampling kernels of the GDP variant read fp32
     for (const Op& op : h->ops) {
-      if (op.kind == Op::ATTN) return fail(h, FDSR_E_INVALID, "bf16 mode is not available for the SR3 / TESR variants (fp32 attention kernels)");
+      if (op.kind == Op::POOL2 || op.kind == Op::UP2X)
+        return fail(h, FDSR_E_INVALID, "bf16 mode is not available for the GDP variant (fp32 resampling kernels)");
       if (op.kind == Op::CONV && !h->weights[op.w].h_ok && op.src0 != h->t_in)
         return fail(h, FDSR_E_INVALID, "bf16 mode needs channel counts that are multiples of 16 (layer %s)", op.name.c_str());
     }

@@ -183,7 +183,8 @@ hipError_t launch_nhwc_to_nchw(const float* src, float* dst, int N, int C, int H
 // S (scratch [N][HW][HW]) = softmax(Q K^T / sqrt(C)), O [N][HW][C] = S V.
 // heads > 1 (GDP AttentionBlock, QKVAttentionLegacy, gdp_modules/unet.py:461-488): qkv channels are laid out
 // [head][q | k | v][C/heads]; every head attends on its own, scores / sqrt(C/heads).  heads == 1: [q | k | v][C].
-hipError_t launch_self_attention(const float* qkv, float* S, float* O, int N, int HW, int C, int heads, hipStream_t s);
+// act_bf16: qkv and O hold bf16 (the bf16 precision mode); scores / softmax stay fp32 either way
+hipError_t launch_self_attention(const float* qkv, float* S, float* O, int N, int HW, int C, int heads, hipStream_t s, int act_bf16 = 0);
 size_t attn_scratch_floats(int N, int HW, int heads);
 // 2x2 average pool of x (optionally of swish(x*scale + shift), the activated GroupNorm output) and nearest x2
 // upsampling, materialised: the up/down ResBlocks of GDP resample h AND the skip input (gdp_modules/unet.py:369-376)

@@ -1063,7 +1063,7 @@ __global__ void __launch_bounds__(64) attn_scores_kernel(const float* __restrict
   }
 }
 
-// rows of pitch HWp >= HW (multiple of 8); the pad columns are written as exact zeros
+// rows of pitch HWp >= HW (multiple of 16); the pad columns are written as exact zeros
 __global__ void __launch_bounds__(256) softmax_rows_kernel(float* __restrict__ S, int HW, int HWp, size_t rows) {
   const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -1106,17 +1106,84 @@ __global__ void __launch_bounds__(64) attn_pv_kernel(const float* __restrict__ P
 }
 
 // S: scratch of attn_scratch_floats(N, HW, heads) floats
-size_t attn_scratch_floats(int N, int HW, int heads) { return (size_t)N * heads * HW * ((HW + 7) / 8 * 8); }
+size_t attn_scratch_floats(int N, int HW, int heads) { return (size_t)N * heads * HW * ((HW + 15) / 16 * 16); }
 
-hipError_t launch_self_attention(const float* qkv, float* S, float* O, int N, int HW, int C, int heads, hipStream_t s) {
+// ---- bf16 mode (activations stored as bf16): Q K^T and P V on v_mfma_f32_32x32x16_bf16 -- the "MFMA bf16 QK^T.V contraction" of
+// BASELINE.json's north_star, for the siblings that do attend (ddpm_modules/unet.py:99, tesr_modules).  Scores and the softmax stay
+// fp32; P is rounded to bf16 as it enters the second product; O is stored as bf16.
+typedef __bf16 bfrag8 __attribute__((ext_vector_type(8)));
+__global__ void __launch_bounds__(64) attn_scores_bf16_kernel(const unsigned short* __restrict__ qkv, float* __restrict__ S, int HW, int HWp,
+                                                              int C, int heads, float inv_div) {
+  const int lane = threadIdx.x, r31 = lane & 31, h = lane >> 5;
+  const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32, bh = blockIdx.z, b = bh / heads, hd = bh % heads;
+  const int ch = C / heads;
+  int qo, ko, vo;
+  attn_offsets(C, heads, hd, qo, ko, vo);
+  const unsigned short* base = qkv + (size_t)b * HW * 3 * C;
+  const unsigned short* qrow = base + (size_t)min(m0 + r31, HW - 1) * 3 * C + qo + 8 * h;   // A[i = query][k = 8 h + j]
+  const unsigned short* krow = base + (size_t)min(n0 + r31, HW - 1) * 3 * C + ko + 8 * h;   // B[k = 8 h + j][j = key]
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  for (int k = 0; k < ch; k += 16) {
+    const uint4 a = *reinterpret_cast<const uint4*>(qrow + k);
+    const uint4 bb = *reinterpret_cast<const uint4*>(krow + k);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bfrag8, a), __builtin_bit_cast(bfrag8, bb), acc, 0, 0, 0);
+  }
+  const int col = n0 + r31;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int row = m0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+    if (row < HW && col < HW) S[((size_t)bh * HW + row) * HWp + col] = acc[i] * inv_div;
+  }
+}
+
+__global__ void __launch_bounds__(64) attn_pv_bf16_kernel(const float* __restrict__ P, const unsigned short* __restrict__ qkv,
+                                                          unsigned short* __restrict__ O, int HW, int HWp, int C, int heads) {
+  const int lane = threadIdx.x, r31 = lane & 31, h = lane >> 5;
+  const int ch = C / heads, nblk = ch / 32;
+  const int hd = blockIdx.x / nblk, n0 = (blockIdx.x % nblk) * 32, m0 = blockIdx.y * 32, b = blockIdx.z;
+  int qo, ko, vo;
+  attn_offsets(C, heads, hd, qo, ko, vo);
+  const float* prow = P + ((size_t)(b * heads + hd) * HW + min(m0 + r31, HW - 1)) * HWp + 8 * h;   // A[i = query][k = key 8 h + j]
+  const unsigned short* vcol = qkv + (size_t)b * HW * 3 * C + vo + n0 + r31;                       // B[k = key][j = channel]
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  for (int k = 0; k < HWp; k += 16) {                       // HWp is a multiple of 16; pad keys carry P == 0
+    const f32x4 p0 = *reinterpret_cast<const f32x4*>(prow + k), p1 = *reinterpret_cast<const f32x4*>(prow + k + 4);
+    bfrag8 a, bv;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { a[j] = (__bf16)p0[j]; a[4 + j] = (__bf16)p1[j]; }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      bv[j] = __builtin_bit_cast(__bf16, vcol[(size_t)min(k + 8 * h + j, HW - 1) * 3 * C]);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bv, acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int row = m0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+    if (row < HW) O[((size_t)b * HW + row) * C + hd * ch + n0 + r31] = __builtin_bit_cast(unsigned short, (__bf16)acc[i]);
+  }
+}
+
+hipError_t launch_self_attention(const float* qkv, float* S, float* O, int N, int HW, int C, int heads, hipStream_t s, int act_bf16) {
   if (heads < 1 || C % heads || (C / heads) % 32) return hipErrorInvalidValue;
-  const int HWp = (HW + 7) / 8 * 8, ch = C / heads;
+  const int HWp = (HW + 15) / 16 * 16, ch = C / heads;
   // QKVAttentionLegacy scales q and k by ch^-1/4 each (gdp_modules/unet.py:480-483); SelfAttention divides by sqrt(C)
   const float inv_div = 1.0f / sqrtf((float)ch);
-  hipLaunchKernelGGL(attn_scores_kernel, dim3((HW + 31) / 32, (HW + 31) / 32, N * heads), dim3(64), 0, s, qkv, S, HW, HWp, C, heads, inv_div);
   const size_t rows = (size_t)N * heads * HW;
+  const dim3 gs((HW + 31) / 32, (HW + 31) / 32, N * heads), gp(C / 32, (HW + 31) / 32, N);
+  if (act_bf16) {
+    const unsigned short* q16 = reinterpret_cast<const unsigned short*>(qkv);
+    hipLaunchKernelGGL(attn_scores_bf16_kernel, gs, dim3(64), 0, s, q16, S, HW, HWp, C, heads, inv_div);
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, S, HW, HWp, rows);
+    hipLaunchKernelGGL(attn_pv_bf16_kernel, gp, dim3(64), 0, s, S, q16, reinterpret_cast<unsigned short*>(O), HW, HWp, C, heads);
+    return hipGetLastError();
+  }
+  hipLaunchKernelGGL(attn_scores_kernel, gs, dim3(64), 0, s, qkv, S, HW, HWp, C, heads, inv_div);
   hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, S, HW, HWp, rows);
-  hipLaunchKernelGGL(attn_pv_kernel, dim3(C / 32, (HW + 31) / 32, N), dim3(64), 0, s, S, qkv, O, HW, HWp, C, heads);
+  hipLaunchKernelGGL(attn_pv_kernel, gp, dim3(64), 0, s, S, qkv, O, HW, HWp, C, heads);
   return hipGetLastError();
 }
 

@@ -51,6 +51,45 @@ def test_sr3_unet_and_loop_vs_reference_goldens(golden_dir, prec):
     assert np.abs(img.cpu().numpy() - ref[-2:]).max() <= 1e-3
 
 
+def test_sr3_bf16_mode_vs_reference_goldens(golden_dir):
+    """bf16 mode for the attending sibling: bf16 activations, bf16 MFMA convolutions, QK^T and PV on
+    v_mfma_f32_32x32x16_bf16 with fp32 scores / softmax.  Judged like the flagship's bf16 mode."""
+    from fastdiffsr_amd.engine import Engine
+    from fastdiffsr_amd.schedule import schedule_buffers, sampling_scalars
+    from oracle import fdsr_oracle as O, sr3_oracle as S
+    from test_gpu_parity import report
+    g = np.load(os.path.join(golden_dir, 'sr3.npz'))
+    cfg = UNetConfig(**CFG)
+    sd = synth_state_dict(cfg, 5)
+    eng = Engine(cfg)
+    eng.load_state_dict(sd)
+    eng.set_precision('bf16')
+    x = torch.from_numpy(g['x'])
+    cap = {}
+    with torch.no_grad():
+        S.unet_forward(O.to_torch_sd(sd), cfg, x, torch.tensor([3, 999]), capture=cap)
+    eng.set_debug(True)
+    out = eng.unet_forward(x.cuda(), torch.tensor([3., 999.]).cuda()).cpu().numpy()
+    worst = 0.0
+    for L in build_layers(cfg):
+        scale = max(1.0, cap[L.name].abs().max().item())
+        d = (eng.debug_tensor(L.name).cpu() - cap[L.name]).abs().max().item()
+        worst = max(worst, d / scale)
+        assert d <= 0.25 * scale, (L.name, d)
+    eng.set_debug(False)
+    d_eps = np.abs(out - g['eps_t']).max()
+    bufs, sp = schedule_buffers(SCHED)
+    eng.set_schedule(sampling_scalars(bufs, sp))
+    cond, noise = torch.from_numpy(g['cond']).cuda(), torch.from_numpy(g['noise']).cuda()
+    img = eng.sample(cond, noise).cpu()
+    ref = torch.from_numpy(g['continous'][-2:])
+    d_img = (img - ref).abs().max().item()
+    psnr = min(O.psnr_u8(O.tensor2img_u8(img[i]), O.tensor2img_u8(ref[i])) for i in range(2))
+    report(f'sr3 bf16: worst layer {worst:.3e} of range, eps max|d|={d_eps:.3e}, x_0 max|d|={d_img:.3e}, '
+           f'PSNR(x_0 bf16, x_0 reference)={psnr:.2f} dB')
+    assert d_eps <= 0.05 and psnr >= 40.0
+
+
 def test_sr3_facade_and_reference_config():
     """define_G(which_model_G='ddpm') with the reference's SR3 config (6 levels, attention at 16x16 and in mid),
     strict checkpoint exchange, one forward at 64x64 against the oracle."""
