@@ -1023,11 +1023,11 @@ int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, 
       }
       case Op::POOL2: {
         const float* sc = op.gn_slot >= 0 ? reinterpret_cast<const float*>(ws + sp.gn_off[op.gn_slot]) : nullptr;
-        HIPCHK(h, launch_pool2(TP(op.src0), sc, sc ? sc + (size_t)N * op.C0 : nullptr, TP(op.dst), N, Hi, Wi, op.C0, st));
+        HIPCHK(h, launch_pool2(TP(op.src0), sc, sc ? sc + (size_t)N * op.C0 : nullptr, TP(op.dst), N, Hi, Wi, op.C0, st, h->prec == PREC_BF16));
         break;
       }
       case Op::UP2X:
-        HIPCHK(h, launch_upsample2(TP(op.src0), TP(op.dst), N, Hi, Wi, op.C0, st));
+        HIPCHK(h, launch_upsample2(TP(op.src0), TP(op.dst), N, Hi, Wi, op.C0, st, h->prec == PREC_BF16));
         break;
       case Op::CLAM:
         HIPCHK(h, launch_clam_gate(TP(op.src0), N, Hi * Wi, op.C0, P(op.fc1), P(op.fc2), op.C0 / 16, gate, st,
@@ -1605,10 +1605,8 @@ int fdsr_set_precision(fdsr_handle h, int mode) {
   if (!h || mode < 0 || mode > 2) return fail(h, FDSR_E_INVALID, "precision mode must be 0 (f32), 1 (f16x3) or 2 (bf16)");
   if (mode == PREC_BF16) {
     // bf16 mode stores activations as bf16: every conv but the packed-input one must run on the 16-bit
-    // kernels (attention has its own bf16 pair); the materialised resampling kernels of the GDP variant read fp32
+    // kernels (attention and the GDP resampling kernels have bf16 forms of their own)
     for (const Op& op : h->ops) {
-      if (op.kind == Op::POOL2 || op.kind == Op::UP2X)
-        return fail(h, FDSR_E_INVALID, "bf16 mode is not available for the GDP variant (fp32 resampling kernels)");
       if (op.kind == Op::CONV && !h->weights[op.w].h_ok && op.src0 != h->t_in)
         return fail(h, FDSR_E_INVALID, "bf16 mode needs channel counts that are multiples of 16 (layer %s)", op.name.c_str());
     }

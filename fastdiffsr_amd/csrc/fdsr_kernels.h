@@ -189,8 +189,8 @@ size_t attn_scratch_floats(int N, int HW, int heads);
 // 2x2 average pool of x (optionally of swish(x*scale + shift), the activated GroupNorm output) and nearest x2
 // upsampling, materialised: the up/down ResBlocks of GDP resample h AND the skip input (gdp_modules/unet.py:369-376)
 hipError_t launch_pool2(const float* x, const float* gn_scale, const float* gn_shift, float* out, int N, int H, int W, int C,
-                        hipStream_t s);   // x [N,H,W,C] -> out [N,H/2,W/2,C]
-hipError_t launch_upsample2(const float* x, float* out, int N, int H, int W, int C, hipStream_t s);   // -> [N,2H,2W,C]
+                        hipStream_t s, int act_bf16 = 0);   // x [N,H,W,C] -> out [N,H/2,W/2,C]
+hipError_t launch_upsample2(const float* x, float* out, int N, int H, int W, int C, hipStream_t s, int act_bf16 = 0);   // -> [N,2H,2W,C]
 
 // tensor2img of the val loop (core/metrics.py:16-42): NCHW fp32 -> HWC uint8
 hipError_t launch_tensor2img_u8(const float* src, unsigned char* dst, int N, int C, int H, int W, float lo, float hi,

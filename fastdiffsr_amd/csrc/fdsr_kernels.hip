@@ -18,6 +18,7 @@
 // Everything else on the path (GroupNorm statistics, CLAM/SLAM, the posterior
 // update, layout changes at the boundary) is HBM-bound streaming code.
 #include "fdsr_kernels.h"
+#include "fdsr_act_io.h"
 
 #include <string>
 
@@ -1190,8 +1191,11 @@ hipError_t launch_self_attention(const float* qkv, float* S, float* O, int N, in
 // ---------------------------------------------------------------------------
 // materialised resampling of the GDP up/down ResBlocks
 // ---------------------------------------------------------------------------
+// PREC: PREC_F16X3 = fp32 activations (f32 and f16x3 modes), PREC_BF16 = bf16 activations
+template <int PREC>
 __global__ void __launch_bounds__(256) pool2_kernel(const float* __restrict__ x, const float* __restrict__ sc, const float* __restrict__ sh,
                                                     float* __restrict__ out, int H, int W, int cq, size_t total) {
+  using IO = ActIO<PREC>;
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;   // over [N][H/2][W/2][cq]
   if (i >= total) return;
   const int c4 = (int)(i % cq);
@@ -1211,7 +1215,7 @@ __global__ void __launch_bounds__(256) pool2_kernel(const float* __restrict__ x,
   for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
     for (int dx = 0; dx < 2; ++dx) {
-      f32x4 v = *reinterpret_cast<const f32x4*>(x + (((n * H + 2 * oy + dy) * W + 2 * ox + dx) * cq + c4) * 4);
+      f32x4 v = IO::widen(IO::load4(x, (((n * H + 2 * oy + dy) * W + 2 * ox + dx) * cq + c4) * 4));
       if (sc) {
         v = v * a + b;
 #pragma unroll
@@ -1219,18 +1223,29 @@ __global__ void __launch_bounds__(256) pool2_kernel(const float* __restrict__ x,
       }
       acc += v;
     }
-  *reinterpret_cast<f32x4*>(out + i * 4) = acc * 0.25f;
+  acc = acc * 0.25f;
+  if (PREC == PREC_BF16) {
+    uint2 pk;
+    pk.x = (unsigned)f32_to_bf16_bits(acc[0]) | ((unsigned)f32_to_bf16_bits(acc[1]) << 16);
+    pk.y = (unsigned)f32_to_bf16_bits(acc[2]) | ((unsigned)f32_to_bf16_bits(acc[3]) << 16);
+    *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(out) + i * 4) = pk;
+  } else {
+    *reinterpret_cast<f32x4*>(out + i * 4) = acc;
+  }
 }
 
 hipError_t launch_pool2(const float* x, const float* gn_scale, const float* gn_shift, float* out, int N, int H, int W, int C,
-                        hipStream_t s) {
+                        hipStream_t s, int act_bf16) {
   if ((C & 3) || (H & 1) || (W & 1)) return hipErrorInvalidValue;
   const size_t total = (size_t)N * (H >> 1) * (W >> 1) * (C >> 2);
-  hipLaunchKernelGGL(pool2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, gn_scale, gn_shift, out, H, W, C >> 2, total);
+  const dim3 grid((unsigned)((total + 255) / 256));
+  if (act_bf16) hipLaunchKernelGGL(pool2_kernel<PREC_BF16>, grid, dim3(256), 0, s, x, gn_scale, gn_shift, out, H, W, C >> 2, total);
+  else hipLaunchKernelGGL(pool2_kernel<PREC_F16X3>, grid, dim3(256), 0, s, x, gn_scale, gn_shift, out, H, W, C >> 2, total);
   return hipGetLastError();
 }
 
-__global__ void __launch_bounds__(256) upsample2_kernel(const float* __restrict__ x, float* __restrict__ out, int H, int W, int cq,
+template <typename Q>   // Q: four consecutive channels as stored (f32x4, or uint2 = 4 x bf16)
+__global__ void __launch_bounds__(256) upsample2_kernel(const Q* __restrict__ x, Q* __restrict__ out, int H, int W, int cq,
                                                         size_t total) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;   // over [N][2H][2W][cq]
   if (i >= total) return;
@@ -1240,13 +1255,17 @@ __global__ void __launch_bounds__(256) upsample2_kernel(const float* __restrict_
   r /= (2 * W);
   const int oy = (int)(r % (2 * H));
   const size_t n = r / (2 * H);
-  *reinterpret_cast<f32x4*>(out + i * 4) = *reinterpret_cast<const f32x4*>(x + (((n * H + (oy >> 1)) * W + (ox >> 1)) * cq + c4) * 4);
+  out[i] = x[((n * H + (oy >> 1)) * W + (ox >> 1)) * cq + c4];
 }
 
-hipError_t launch_upsample2(const float* x, float* out, int N, int H, int W, int C, hipStream_t s) {
+hipError_t launch_upsample2(const float* x, float* out, int N, int H, int W, int C, hipStream_t s, int act_bf16) {
   if (C & 3) return hipErrorInvalidValue;
   const size_t total = (size_t)N * 2 * H * 2 * W * (C >> 2);
-  hipLaunchKernelGGL(upsample2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, out, H, W, C >> 2, total);
+  const dim3 grid((unsigned)((total + 255) / 256));
+  if (act_bf16)
+    hipLaunchKernelGGL(upsample2_kernel<uint2>, grid, dim3(256), 0, s, reinterpret_cast<const uint2*>(x), reinterpret_cast<uint2*>(out), H, W, C >> 2, total);
+  else
+    hipLaunchKernelGGL(upsample2_kernel<f32x4>, grid, dim3(256), 0, s, reinterpret_cast<const f32x4*>(x), reinterpret_cast<f32x4*>(out), H, W, C >> 2, total);
   return hipGetLastError();
 }
 

@@ -154,8 +154,8 @@ int fdsr_randn(fdsr_handle h, float* dst_nchw, int batch, int height, int width,
  *   FDSR_PREC_F16X3  fp32-grade: operands split hi/lo into two f16, three f16 MFMAs per product,
  *                    fp32 accumulate (stays inside the 1e-3 parity bound)
  *   FDSR_PREC_BF16   one bf16 MFMA per product and bf16 activations in HBM (BASELINE config 3; judged on
- *                    PSNR delta).  Needs 16-aligned channel counts; the SR3 / TESR variants run their attention on
- *                    bf16 MFMA kernels (fp32 scores and softmax); refused for the GDP variant (FDSR_E_INVALID). */
+ *                    PSNR delta).  Needs 16-aligned channel counts (FDSR_E_INVALID otherwise); the SR3 / TESR / GDP variants
+ *                    run their attention on bf16 MFMA kernels (fp32 scores and softmax). */
 #define FDSR_PREC_F32 0
 #define FDSR_PREC_F16X3 1
 #define FDSR_PREC_BF16 2

@@ -293,11 +293,7 @@ def test_error_paths(full):
         Engine(UNetConfig(in_channel=6, out_channel=3, inner_channel=24, norm_groups=8, channel_mults=(1, 2), res_blocks=1))
     e4 = Engine(UNetConfig(in_channel=6, out_channel=3, inner_channel=32, channel_mults=(1, 2), attn_res=(16,), res_blocks=1,
                            image_size=32, variant='ddpm'))
-    e4.set_precision('bf16')            # the attention-bearing siblings have bf16 attention kernels (test_gpu_sr3.py)
-    e5 = Engine(UNetConfig(in_channel=6, out_channel=3, inner_channel=64, channel_mults=(1, 2), attn_res=(16,), res_blocks=1,
-                           image_size=32, variant='gdp'))
-    with pytest.raises(_lib.FdsrError, match='GDP'):
-        e5.set_precision('bf16')
+    e4.set_precision('bf16')            # every variant has a bf16 mode (attention on bf16 MFMA: test_gpu_sr3.py, _tesr, _gdp)
     e2 = Engine(cfg)
     with pytest.raises(_lib.FdsrError):                                            # weights missing
         e2.unet_forward(torch.zeros(1, 6, 32, 32).cuda(), torch.zeros(1).cuda())
