@@ -90,6 +90,38 @@ def test_sr3_bf16_mode_vs_reference_goldens(golden_dir):
     assert d_eps <= 0.05 and psnr >= 40.0
 
 
+@pytest.mark.parametrize('size', [(24, 24), (24, 40)])
+def test_attention_token_counts_off_the_tile_grid(size):
+    """Token counts that are not multiples of the 32-query tiles or of the 16-key MFMA step (36 / 60 tokens at the attn_res level,
+    9 / 15 in `mid`): the clamped loads, the zero pad keys and the masked stores of both attention kernel pairs, against the oracle --
+    f32 and f16x3 at 1e-4, bf16 inside its range bound."""
+    from fastdiffsr_amd.engine import Engine
+    from oracle import fdsr_oracle as O, sr3_oracle as S
+    H, W = size
+    cfg = UNetConfig(in_channel=6, out_channel=3, inner_channel=32, norm_groups=32, channel_mults=(1, 2, 2, 4),
+                     attn_res=(H // 4,), res_blocks=1, dropout=0.0, image_size=H, variant='ddpm')
+    sd = synth_state_dict(cfg, 21)
+    eng = Engine(cfg)
+    eng.load_state_dict(sd)
+    x = torch.randn(2, 6, H, W, generator=torch.Generator().manual_seed(4))
+    t = torch.tensor([7, 640])
+    cap = {}
+    with torch.no_grad():
+        ref = S.unet_forward(O.to_torch_sd(sd), cfg, x, t, capture=cap)
+    attn_layers = [L.name for L in build_layers(cfg) if L.with_attn]
+    assert attn_layers
+    for prec, tol in (('f32', 1e-4), ('f16x3', 1e-4), ('bf16', 0.25)):
+        eng.set_precision(prec)
+        eng.set_debug(True)
+        out = eng.unet_forward(x.cuda(), t.float().cuda()).cpu()
+        for name in attn_layers:
+            scale = max(1.0, cap[name].abs().max().item())
+            d = (eng.debug_tensor(name).cpu() - cap[name]).abs().max().item()
+            assert d <= tol * scale, (prec, name, d)
+        eng.set_debug(False)
+        assert (out - ref).abs().max().item() <= (1e-4 if tol < 0.1 else 0.05) * max(1.0, ref.abs().max().item()), prec
+
+
 def test_sr3_facade_and_reference_config():
     """define_G(which_model_G='ddpm') with the reference's SR3 config (6 levels, attention at 16x16 and in mid),
     strict checkpoint exchange, one forward at 64x64 against the oracle."""
