@@ -62,6 +62,20 @@ struct ConvHCfg {
   static_assert(TH % WM == 0, "TH must be a multiple of WM");
 };
 
+#ifdef CONVH_STAMPS
+// Diagnostic build only (tools/build_obj_variant.sh <tag> fdsr_conv_h.hip -DCONVH_STAMPS -DCONVH_STAMP_CIN=.. -DCONVH_STAMP_COUT=..
+// -DCONVH_STAMP_PREC=..): s_memtime stamps of waves 0 and 7 of the first 256 workgroups of the stride-1 3x3 launches of ONE layer
+// shape at the phase boundaries (the last such launch stays); read back by fdsr_diag_convh_stamps (tools/convh_stamps.py).
+__device__ unsigned long long g_h_stamps[256][2][64];
+#define H_STAMP()                                                                                                  \
+  do {                                                                                                             \
+    if (stamp_on && si < 64) g_h_stamps[blockIdx.x][wave == 0 ? 0 : 1][si] = __builtin_amdgcn_s_memtime();         \
+    ++si;                                                                                                          \
+  } while (0)
+#else
+#define H_STAMP() do {} while (0)
+#endif
+
 template <int KS, int STRIDE, bool UP, int TH, int WN, int PREC, int KSUB, bool RIDER = false>
 __global__ void __launch_bounds__(512, 2) conv_mfma_h_kernel(const ConvParams p) {
   static_assert(!RIDER || (KS == 3 && STRIDE == 1 && !UP && KSUB == 1), "the rider rides the stride-1 3x3 kernels");
@@ -97,6 +111,12 @@ __global__ void __launch_bounds__(512, 2) conv_mfma_h_kernel(const ConvParams p)
   const int oy0 = ty * TH, ox0 = tx * TW, co0 = cot * BN;
 
   const bool gn = p.gn_scale != nullptr;
+#ifdef CONVH_STAMPS
+  int si = 0;
+  const bool stamp_on = KS == 3 && STRIDE == 1 && !UP && !RIDER && PREC == CONVH_STAMP_PREC && lane == 0 && (wave == 0 || wave == 7) &&
+                        blockIdx.x < 256 && Cin == CONVH_STAMP_CIN && p.Cout == CONVH_STAMP_COUT;
+#endif
+  H_STAMP();   // 0: start
 
   // ---- staging indices (chunk invariant): thread -> (halo pixel row0 + i*128, float4 slot q) ----
   const int q = tid % Q4, row0 = tid / Q4;
@@ -212,9 +232,12 @@ __global__ void __launch_bounds__(512, 2) conv_mfma_h_kernel(const ConvParams p)
   for (int tap = 0; tap < T; ++tap)
     if (tap == 0 || !(RIDER && kc0 >= nk)) load_b_tap(kc0, tap);
   prefetch(kc0);
+  H_STAMP();   // 1: weight and input loads issued
   stage(kc0, sBuf0);
+  H_STAMP();   // 2: first chunk staged (its loads have landed)
   if (kc0 + 1 < kc1) prefetch(kc0 + 1);
   __syncthreads();
+  H_STAMP();   // 3: prologue barrier
 
   // A fragments are double-buffered over taps: the reads of tap t+1 are issued before the MFMAs
   // of tap t, so LDS latency hides under 3*MB MFMAs instead of being exposed per read.
@@ -258,11 +281,22 @@ __global__ void __launch_bounds__(512, 2) conv_mfma_h_kernel(const ConvParams p)
       }
       if (more && (tap == 0 || !next_rider)) load_b_tap(kc + 1, tap);   // same registers, next chunk
       if (tap == T / 2 && more) {                    // mid-chunk: fill the other halo buffer
+        H_STAMP();   // per chunk +0: taps 0..T/2 issued
+#ifdef CONVH_KO_STAGE   // perf-only bound (wrong results): no in-loop staging for this precision
+        if (PREC != CONVH_KO_STAGE) {
+          stage(kc + 1, nxt);
+          if (kc + 2 < kc1) prefetch(kc + 2);
+        }
+#else
         stage(kc + 1, nxt);
         if (kc + 2 < kc1) prefetch(kc + 2);
+#endif
+        H_STAMP();   // +1: next chunk staged
       }
     }
+    H_STAMP();       // +2: all taps issued
     __syncthreads();
+    H_STAMP();       // +3: chunk barrier
   }
   if (RIDER && kc1 > nk) {
     // rider chunks: 16 raw channels of the second input each, centre tap only, the 1x1 conv's fragments in slot 0
@@ -405,8 +439,10 @@ __global__ void __launch_bounds__(512, 2) conv_mfma_h_kernel(const ConvParams p)
         }
     }
   };
+  H_STAMP();   // epilogue starts (accumulators final)
   if (PREC == PREC_BF16 && !p.out_f32) epilogue(std::true_type{});
   else epilogue(std::false_type{});
+  H_STAMP();   // stores issued
   if (p.part_out) {
     // the main loop ended with a barrier: the halo buffers are free
     float* sp = reinterpret_cast<float*>(smem_h);   // [WM][BN][2]
@@ -426,7 +462,14 @@ __global__ void __launch_bounds__(512, 2) conv_mfma_h_kernel(const ConvParams p)
       dst[1] = b;
     }
   }
+  H_STAMP();   // end
 }
+
+#ifdef CONVH_STAMPS
+extern "C" int fdsr_diag_convh_stamps(unsigned long long* dst, size_t count) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_h_stamps), count * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 // Split-K second phase: sums the ksplit partial outputs in slice order, applies bias + noise-embedding
 // shift + residual, stores NHWC and emits the per-tile channel statistics.  One workgroup per
