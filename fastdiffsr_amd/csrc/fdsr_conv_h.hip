@@ -539,7 +539,12 @@ static hipError_t launch_h_t(const ConvParams& p, hipStream_t s, int* tiles) {
   const int nwg = p.N * tilesX * tilesY * (p.Cout_pad / Cfg::BN) * sk;
   ConvParams q = p;
   q.out_bf16 = (PREC == PREC_BF16 && !p.out_f32) ? 1 : 0;
-  hipLaunchKernelGGL(kfn, dim3(nwg), dim3(Cfg::NT), lds, s, q);
+  if (KS == 3 && STRIDE == 1 && !UP && KSUB == 1 && (PREC == PREC_F16X3 || PREC == PREC_BF16) && conv_k32_ok(TH, WN, PREC, q)) {
+    const hipError_t e = launch_conv_k32(TH, WN, PREC, q, nwg, s);   // the 16x16x32 form (fdsr_conv_k32.hip): same grid, same outputs
+    if (e != hipSuccess) return e;
+  } else {
+    hipLaunchKernelGGL(kfn, dim3(nwg), dim3(Cfg::NT), lds, s, q);
+  }
   if (sk > 1) {
     const int rt = ((p.Wout + 31) / 32) * ((p.Hout + 1) / 2);
     if (tiles) *tiles = rt;
@@ -655,7 +660,7 @@ hipError_t kernels_h_init() {
   if ((e = init_h_t<3, 1, false, TH_, WN_, PREC_BF16, 1, true>()) != hipSuccess) return e;
   FDSR_CONVH_RIDER_SHAPES(XR)
 #undef XR
-  return hipSuccess;
+  return kernels_k32_init();
 }
 
 }  // namespace fdsr

@@ -1,0 +1,519 @@
+// K=32 form of the stride-1 3x3 convolutions for gfx950: v_mfma_f32_16x16x32_{f16,bf16}, fp32 accumulate.
+//
+// Same arithmetic modes, same ConvParams, same packed weights and the same outputs layout as conv_mfma_h_kernel
+// (fdsr_conv_h.hip): this kernel is a drop-in for its <3, 1, false, TH, WN, PREC, 1, RIDER> instantiations whose wave
+// tile is four rows of 32 pixels (MB = 4) when the input splits into whole 32-channel chunks.  What changes is the matrix
+// instruction: 16x16x32 moves half the accumulator bytes per FLOP through the register file (the
+// sampling loop runs at the package power cap, so throughput follows energy per image; the guide measures 1.12-1.15x for
+// this shape in power-limited loops).
+//
+//   * K chunk = 32 input channels x one tap.  The MFMA's "A" operand is the WEIGHT fragment (rows = 16 output channels),
+//     its "B" operand the ACTIVATION fragment (columns = 16 pixels), so a lane's four accumulator registers are four
+//     consecutive output channels of one pixel: 16-byte stores / residual loads in the NHWC epilogue.
+//   * Weights are read from the arena pack_weights_h() already fills ([cot][kc16][wn][tap][plane][lane] x 16 B, the
+//     32x32x16 B-operand order): the 16x16x32 fragment of (32-channel chunk, tap, cout half ch, plane) is a permutation of
+//     16-byte units of two of those blocks -- lane (g = l >> 4, c = l & 15) takes unit 32 (g & 1) + 16 ch + c of 16-channel
+//     block 2 kc + (g >> 1).  No second weight form, so optimiser re-packs and the transposed (input-gradient) forms serve
+//     this kernel as they are.
+//   * Only a ring of three taps of weight fragments is live in f16x3 (48 VGPRs instead of 144): tap t + 3 is fetched from
+//     L2 while taps t + 1, t + 2 are multiplied (>= 3000 cycles of MFMAs); bf16 keeps all nine taps (72 VGPRs).
+//   * Halo image in LDS: 128-byte pixel rows [4 x 16 B hi | 4 x 16 B lo] (bf16: 64 bytes), no padding -- the 18 x 34 halo
+//     of a 16-row tile, double-buffered, is 153 KB of the CU's 160 -- with the 16-byte slot XOR-swizzled by the pixel
+//     column (f16x3: slot ^ (hx & 7); bf16: slot ^ ((hx >> 1) & 3)): every ds_read_b128 of an activation fragment is
+//     bank-conflict free on the instruction's four 16-lane groups for all three kx shifts.
+#include "fdsr_kernels.h"
+#include "fdsr_act_io.h"
+
+#include <type_traits>
+
+namespace fdsr {
+
+typedef float k_f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 k_h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 k_h4 __attribute__((ext_vector_type(4)));
+typedef __bf16 k_b8 __attribute__((ext_vector_type(8)));
+typedef __bf16 k_b4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float silu_k(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+
+template <int TH, int WN, int PREC>
+struct ConvK32Cfg {
+  static constexpr int TW = 32, NW = 8, KC = 32;
+  static constexpr int NP = PREC == PREC_F16X3 ? 2 : 1;
+  static constexpr int ROWB = 64 * NP;           // LDS bytes per halo pixel (no pad: swizzled)
+  static constexpr int HH = TH + 2, HWD = TW + 2, NPIX = HH * HWD;
+  static constexpr int WM = NW / WN, BN = 32 * WN, MB = TH / WM;
+  static constexpr int NT = 64 * NW;
+  static constexpr int Q4 = KC / 4;              // float4 slots per halo pixel
+  static constexpr int RPP = NT / Q4;            // halo pixels filled per pass
+  static constexpr int NIN = (NPIX + RPP - 1) / RPP;
+  static constexpr int BUF_BYTES = NPIX * ROWB;
+  static constexpr int R = PREC == PREC_F16X3 ? 3 : 9;   // taps of weight fragments in registers
+  static_assert(MB == 4, "wave tile = 4 rows of 32 pixels");
+  static_assert(((TH - WM + 2) * HWD + 16) * ROWB < 65536, "fragment offsets must fit the ds_read immediate");
+};
+
+// 16-byte slot of (k group | plane) within a pixel row, swizzled by the halo column
+template <int PREC>
+__device__ __forceinline__ int k32_slot(int slot, int hx) {
+  return PREC == PREC_F16X3 ? (slot ^ (hx & 7)) : (slot ^ ((hx >> 1) & 3));
+}
+
+template <int TH, int WN, int PREC, bool RIDER>
+__global__ void __launch_bounds__(512, 2) conv_k32_kernel(const ConvParams p) {
+  using Cfg = ConvK32Cfg<TH, WN, PREC>;
+  constexpr int TW = Cfg::TW, KC = Cfg::KC, NP = Cfg::NP, ROWB = Cfg::ROWB, HWD = Cfg::HWD, NPIX = Cfg::NPIX;
+  constexpr int WM = Cfg::WM, BN = Cfg::BN, MB = Cfg::MB, RPP = Cfg::RPP, NIN = Cfg::NIN, R = Cfg::R;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_k[];
+  unsigned char* sBuf0 = smem_k;
+  unsigned char* sBuf1 = smem_k + Cfg::BUF_BYTES;
+  const int Cin = p.C0 + p.C1;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave % WN, wm = wave / WN;
+  const int c15 = lane & 15, g = lane >> 4;
+
+  const int nco = p.Cout_pad / BN;
+  const int tilesX = (p.Wout + TW - 1) / TW, tilesY = (p.Hout + TH - 1) / TH;
+  int bid;
+  {   // consecutive tiles on one XCD (as conv_mfma_h_kernel)
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = b & 7, k = b >> 3;
+    bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
+  }
+  const int SK = p.ksplit > 1 ? p.ksplit : 1;
+  const int ksi = bid % SK;
+  bid /= SK;
+  const int cot = bid % nco;
+  int pt = bid / nco;
+  const int tx = pt % tilesX;
+  pt /= tilesX;
+  const int ty = pt % tilesY;
+  const int n = pt / tilesY;
+  const int oy0 = ty * TH, ox0 = tx * TW, co0 = cot * BN;
+
+  const bool gn = p.gn_scale != nullptr;
+
+  // ---- staging indices (chunk invariant): thread -> (halo pixel row0 + i*64, float4 slot q of the 32 channels) ----
+  const int q = tid & 7, row0 = tid >> 3;
+  int in_pix[NIN];
+  int sdst[NIN];
+#pragma unroll
+  for (int i = 0; i < NIN; ++i) {
+    const int pix = row0 + i * RPP;
+    int v = -2, d = 0;
+    if (pix < NPIX) {
+      const int hy = pix / HWD, hx = pix % HWD;
+      const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+      const bool ok = iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
+      v = ok ? (n * p.Hin + iy) * p.Win + ix : -1;
+      d = pix * ROWB + 16 * k32_slot<PREC>(q >> 1, hx) + 8 * (q & 1);
+    }
+    in_pix[i] = v;
+    sdst[i] = d;
+  }
+
+  using IO = ActIO<PREC>;
+  typedef typename IO::Quad Quad;
+  Quad rin[NIN];
+  Quad rin2[RIDER ? NIN : 1];
+  k_f32x4 rsc = {1.f, 1.f, 1.f, 1.f}, rsh = {0.f, 0.f, 0.f, 0.f};
+  const int nk = p.Cin_pad / KC;               // main chunks; nk .. nk + nkr - 1 are the rider's (raw second input, centre tap)
+  const int nk16 = p.Cin_pad / 16;
+  const int nkr = RIDER ? p.nkr / 2 : 0;
+  auto prefetch_to = [&](int kc, Quad* rin) {
+    int cbase = kc * KC;
+    const float* base;
+    int Cs, cc;
+    bool gg = gn;
+    if (RIDER && kc >= nk) {
+      cbase -= nk * KC;
+      gg = false;
+      if (cbase < p.Cr0) { base = p.xr0; Cs = p.Cr0; cc = cbase + q * 4; }
+      else { base = p.xr1; Cs = p.Cr1; cc = cbase - p.Cr0 + q * 4; }
+    } else if (cbase < p.C0) { base = p.x0; Cs = p.C0; cc = cbase + q * 4; }
+    else { base = p.x1; Cs = p.C1; cc = cbase - p.C0 + q * 4; }
+    if (gg) {
+      rsc = *reinterpret_cast<const k_f32x4*>(p.gn_scale + (size_t)n * Cin + cbase + q * 4);
+      rsh = *reinterpret_cast<const k_f32x4*>(p.gn_shift + (size_t)n * Cin + cbase + q * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < NIN; ++i)
+      rin[i] = IO::load4(base, (size_t)(in_pix[i] < 0 ? 0 : in_pix[i]) * Cs + cc);
+  };
+  auto stage_from = [&](int kc, unsigned char* buf, const Quad* rin) {
+    const k_f32x4 sc = rsc, sh = rsh;
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) {
+      if (NIN * RPP > NPIX && i == NIN - 1 && row0 + i * RPP >= NPIX) continue;   // only the last pass can overrun
+      k_f32x4 v = IO::widen(rin[i]);
+      if (gn && !(RIDER && kc >= nk)) {
+        v = v * sc + sh;
+        if (!p.gn_plain) { v.x = silu_k(v.x); v.y = silu_k(v.y); v.z = silu_k(v.z); v.w = silu_k(v.w); }
+      } else if (PREC == PREC_F16X3 && p.sat_flag) {
+        sat_check(p.sat_flag, v, 65504.f);
+      }
+      unsigned char* dst = buf + sdst[i];
+      if (PREC == PREC_F16X3) {
+        const float lim = in_pix[i] >= 0 ? 65504.f : 0.f;   // f16 range clamp and zero padding in one med3
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], -lim, lim);
+        k_h4 hi = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+        k_h4 lo = {(_Float16)(v.x - (float)hi.x), (_Float16)(v.y - (float)hi.y), (_Float16)(v.z - (float)hi.z),
+                   (_Float16)(v.w - (float)hi.w)};
+        *reinterpret_cast<k_h4*>(dst) = hi;
+        *reinterpret_cast<k_h4*>(buf + (sdst[i] ^ 64)) = lo;   // slot + 4 of the swizzled row
+      } else {
+        const float keep = in_pix[i] >= 0 ? 1.f : 0.f;
+        v = v * keep;
+        k_b4 hb = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+        *reinterpret_cast<k_b4*>(dst) = hb;
+      }
+    }
+  };
+
+  // ---- weight fragments: ring slot s holds tap t with t % R == s; [cout half][plane] ----
+  const uint4* wq = reinterpret_cast<const uint4*>(p.wq);
+  const int nkt = RIDER ? nk + nkr : nk;
+  uint4 Wf[R][2][NP];
+  const int wlane = 32 * (g & 1) + c15;          // + 16 ch: unit within the 32x32x16-order block
+  auto load_w = [&](int kc, int tap, int slot) {
+    const uint4* src = wq + ((((size_t)cot * nk16 + 2 * kc + (g >> 1)) * WN + wn) * 9 + tap) * (NP * 64) + wlane;
+    if (RIDER && kc >= nk)   // the 1x1 conv's own fragments [cot][kc16][wn]
+      src = reinterpret_cast<const uint4*>(p.wq_r) + (((size_t)cot * p.nkr + 2 * (kc - nk) + (g >> 1)) * WN + wn) * (NP * 64) + wlane;
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl) Wf[slot][ch][pl] = src[pl * 64 + 16 * ch];
+  };
+
+  // ---- activation fragment addresses: lane -> pixel column c15 (+ 16 ph) of a 32-pixel row, k group g ----
+  int xoff[3][NP];
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx) {
+    const int hx = c15 + kx;
+    xoff[kx][0] = (wm * HWD + hx) * ROWB + 16 * k32_slot<PREC>(g, hx);
+    if (NP == 2) xoff[kx][NP - 1] = xoff[kx][0] ^ 64;
+  }
+
+  k_f32x4 acc[MB][2][2];   // [row][pixel half][cout half]
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+      for (int ch = 0; ch < 2; ++ch) acc[mb][ph][ch] = k_f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int kc0 = ksi * nkt / SK, kc1 = (ksi + 1) * nkt / SK;   // this slice's chunks
+  if (RIDER && kc0 >= nk) load_w(kc0, 0, 0);
+  else {
+#pragma unroll
+    for (int t = 0; t < R; ++t) load_w(kc0, t, t);
+  }
+  prefetch_to(kc0, rin);
+  stage_from(kc0, sBuf0, rin);
+  if (kc0 + 1 < kc1) prefetch_to(kc0 + 1, rin);
+  __syncthreads();
+
+  uint4 Xf[2][2][NP];   // [slot][pixel half][plane], double-buffered over (tap, row) steps
+  const unsigned char* xptr[3][NP];
+  auto load_x = [&](int slot, int ky, int kx, int mb) {
+#pragma unroll
+    for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl)
+        Xf[slot][ph][pl] = *reinterpret_cast<const uint4*>(xptr[kx][pl] + ((mb * WM + ky) * HWD + 16 * ph) * ROWB);
+  };
+  auto mfma_step = [&](int xs, int ws, int mb) {
+    if (PREC == PREC_F16X3) {
+      // small terms first: lo(x) hi(w), hi(x) lo(w), hi(x) hi(w); four independent accumulators between dependent MFMAs
+#pragma unroll
+      for (int term = 0; term < 3; ++term)
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+          for (int ch = 0; ch < 2; ++ch) {
+            const uint4 xv = Xf[xs][ph][term == 0 ? NP - 1 : 0];
+            const uint4 wv = Wf[ws][ch][term == 1 ? NP - 1 : 0];
+            acc[mb][ph][ch] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(k_h8, wv), __builtin_bit_cast(k_h8, xv),
+                                                                    acc[mb][ph][ch], 0, 0, 0);
+          }
+    } else {
+#pragma unroll
+      for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch)
+          acc[mb][ph][ch] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(k_b8, Wf[ws][ch][0]),
+                                                                   __builtin_bit_cast(k_b8, Xf[xs][ph][0]), acc[mb][ph][ch], 0, 0, 0);
+    }
+  };
+
+  // main chunks: all nine taps of 32 GroupNorm'ed channels
+  const int kcm = RIDER ? (kc1 < nk ? kc1 : nk) : kc1;
+  for (int kc = kc0; kc < kcm; ++kc) {
+    unsigned char* cur = ((kc - kc0) & 1) ? sBuf1 : sBuf0;
+    unsigned char* nxt = ((kc - kc0) & 1) ? sBuf0 : sBuf1;
+    const bool more = kc + 1 < kc1;
+    const bool next_rider = RIDER && kc + 1 >= nk;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl) xptr[kx][pl] = cur + xoff[kx][pl];
+    load_x(0, 0, 0, 0);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        const int s = tap * MB + mb;
+        if (s + 1 < 9 * MB) {
+          const int t2 = (s + 1) / MB, m2 = (s + 1) % MB;
+          load_x((s + 1) & 1, t2 / 3, t2 % 3, m2);
+        }
+        mfma_step(s & 1, tap % R, mb);
+      }
+      // this tap's ring slot is free: fetch the tap that will use it next
+      if (tap + R < 9) load_w(kc, tap + R, tap % R);
+      else if (more && (tap + R - 9 == 0 || !next_rider)) load_w(kc + 1, tap + R - 9, tap % R);
+      if (tap == 4 && more) {   // mid-chunk: fill the other halo buffer
+        stage_from(kc + 1, nxt, rin);
+        if (kc + 2 < kc1) prefetch_to(kc + 2, rin);
+      }
+    }
+    __syncthreads();
+  }
+  if (RIDER && kc1 > nk) {
+    // rider chunks: 32 raw channels of the second input each, centre tap only, the 1x1 conv's fragments in ring slot 0
+    if (kc0 < nk) {   // the accumulators leave the main conv's weight scale for the rider's (a power of two: exact)
+      const float ratio = (p.w_inv_scale_dev ? *p.w_inv_scale_dev : p.w_inv_scale) / (p.w_inv_scale_r_dev ? *p.w_inv_scale_r_dev : p.w_inv_scale_r);
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+          for (int ch = 0; ch < 2; ++ch) acc[mb][ph][ch] *= ratio;
+    }
+    // input fetched TWO chunks ahead into two alternating register sets (on entry `rin` holds chunk k0 + 1)
+    const int k0 = kc0 > nk ? kc0 : nk;
+    if (k0 + 2 < kc1) prefetch_to(k0 + 2, rin2);
+    auto rider_chunk = [&](int kc, Quad* r1) {   // r1 holds chunk kc + 1
+      unsigned char* cur = ((kc - kc0) & 1) ? sBuf1 : sBuf0;
+      unsigned char* nxt = ((kc - kc0) & 1) ? sBuf0 : sBuf1;
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl) xptr[1][pl] = cur + xoff[1][pl];
+      load_x(0, 1, 1, 0);
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        if (mb + 1 < MB) load_x((mb + 1) & 1, 1, 1, mb + 1);
+        mfma_step(mb & 1, 0, mb);
+      }
+      if (kc + 1 < kc1) {
+        load_w(kc + 1, 0, 0);
+        stage_from(kc + 1, nxt, r1);
+        if (kc + 3 < kc1) prefetch_to(kc + 3, r1);
+      }
+      __syncthreads();
+    };
+    for (int kc = k0; kc < kc1; kc += 2) {
+      rider_chunk(kc, rin);
+      if (kc + 1 < kc1) rider_chunk(kc + 1, rin2);
+    }
+  }
+
+  // ---- epilogue: lane = pixel c15 (+ 16 ph) of row wm + mb*WM, output channels cob + 16 ch + 0..3 ----
+  const int cob = co0 + wn * 32 + 4 * g;
+  k_f32x4 add[2];
+  bool cok[2];
+#pragma unroll
+  for (int ch = 0; ch < 2; ++ch) {
+    const int co = cob + 16 * ch;
+    cok[ch] = co < p.Cout;   // Cout % 4 == 0 (launcher)
+    add[ch] = k_f32x4{0.f, 0.f, 0.f, 0.f};
+    if (cok[ch]) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float a = p.bias[co + r];
+        if (RIDER) a += p.bias_r[co + r];
+        if (p.temb) a += p.temb[(size_t)n * p.temb_stride + p.temb_off + co + r];
+        add[ch][r] = a;
+      }
+    }
+  }
+  const float winv_m = p.w_inv_scale_dev ? *p.w_inv_scale_dev : p.w_inv_scale;
+  const float winv = RIDER ? (p.w_inv_scale_r_dev ? *p.w_inv_scale_r_dev : p.w_inv_scale_r) : winv_m;
+  if (RIDER && kc1 <= nk) {   // (split K) a slice that never reached the rider chunks: bring it to the rider's scale too
+    const float ratio = winv_m / winv;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) acc[mb][ph][ch] *= ratio;
+  }
+  const bool interior = (oy0 + TH <= p.Hout) && (ox0 + TW <= p.Wout) && (co0 + BN <= p.Cout);
+  const size_t obase = ((size_t)(n * p.Hout + oy0 + wm) * p.Wout + ox0 + c15) * p.Cout + cob;
+  const size_t rstride = (size_t)WM * p.Wout * p.Cout, pstride = (size_t)16 * p.Cout;
+  if (SK > 1) {   // raw partial accumulators; bias, shift, residual and statistics happen in the reduce
+    float* sb = p.kscratch + (size_t)ksi * p.N * p.Hout * p.Wout * p.Cout;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+          const int oy = oy0 + wm + mb * WM, ox = ox0 + 16 * ph + c15;
+          if (interior || (cok[ch] && oy < p.Hout && ox < p.Wout))
+            *reinterpret_cast<k_f32x4*>(sb + obase + mb * rstride + ph * pstride + 16 * ch) = acc[mb][ph][ch];
+        }
+    return;
+  }
+  k_f32x4 s1[2], s2[2];
+#pragma unroll
+  for (int ch = 0; ch < 2; ++ch) s1[ch] = s2[ch] = k_f32x4{0.f, 0.f, 0.f, 0.f};
+  auto epilogue = [&](auto out16_tag) {
+    constexpr bool OUT16 = decltype(out16_tag)::value;
+    auto put4 = [&](size_t idx, k_f32x4 v) {
+      if (OUT16) {
+        uint2 pk;
+        pk.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
+        pk.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
+        *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p.out) + idx) = pk;
+      } else {
+        *reinterpret_cast<k_f32x4*>(p.out + idx) = v;
+      }
+    };
+    Quad rv[MB][2][2];
+    if (interior) {
+      if (p.res) {
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch) rv[mb][ph][ch] = IO::load4(p.res, obase + mb * rstride + ph * pstride + 16 * ch);
+      }
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+          for (int ch = 0; ch < 2; ++ch) {
+            k_f32x4 v = acc[mb][ph][ch] * winv + add[ch];
+            if (p.res) v += IO::widen(rv[mb][ph][ch]);
+            put4(obase + mb * rstride + ph * pstride + 16 * ch, v);
+            s1[ch] += v;
+            s2[ch] += v * v;
+          }
+    } else {
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+          for (int ch = 0; ch < 2; ++ch) {
+            const int oy = oy0 + wm + mb * WM, ox = ox0 + 16 * ph + c15;
+            if (cok[ch] && oy < p.Hout && ox < p.Wout) {
+              const size_t idx = obase + mb * rstride + ph * pstride + 16 * ch;
+              k_f32x4 v = acc[mb][ph][ch] * winv + add[ch];
+              if (p.res) v += IO::widen(IO::load4(p.res, idx));
+              put4(idx, v);
+              s1[ch] += v;
+              s2[ch] += v * v;
+            }
+          }
+    }
+  };
+  if (PREC == PREC_BF16 && !p.out_f32) epilogue(std::true_type{});
+  else epilogue(std::false_type{});
+  if (p.part_out) {
+    // Per-channel (sum, sumsq) of this wave's 4 x 32 pixels: the 16 lanes of a k group hold 16 values each
+    // (value v = ch*8 + r*2 + stat); a halving butterfly over the pixel lanes leaves lane c15 with the total of value c15.
+    float vals[16];
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { vals[ch * 8 + r * 2] = s1[ch][r]; vals[ch * 8 + r * 2 + 1] = s2[ch][r]; }
+#pragma unroll
+    for (int half = 8; half >= 1; half >>= 1) {
+      const bool up = (c15 & half) != 0;
+#pragma unroll
+      for (int i = 0; i < half; ++i) {
+        const float keep = up ? vals[i + half] : vals[i];
+        const float send = up ? vals[i] : vals[i + half];
+        vals[i] = keep + __shfl_xor(send, half, 64);
+      }
+    }
+    // the main loop ended with a barrier: the halo buffers are free
+    float* sp = reinterpret_cast<float*>(smem_k);   // [WM][BN][2]
+    {
+      const int ch = c15 >> 3, r = (c15 >> 1) & 3, st = c15 & 1;
+      sp[(wm * BN + wn * 32 + 16 * ch + 4 * g + r) * 2 + st] = vals[0];
+    }
+    __syncthreads();
+    if (tid < BN && co0 + tid < p.Cout) {
+      float a = 0.f, b = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) { a += sp[(w * BN + tid) * 2 + 0]; b += sp[(w * BN + tid) * 2 + 1]; }
+      float* dst = p.part_out + (((size_t)n * (tilesX * tilesY) + ty * tilesX + tx) * p.Cout + co0 + tid) * 2;
+      dst[0] = a;
+      dst[1] = b;
+    }
+  }
+}
+
+// (TH, WN) pairs with MB = TH / (8 / WN) = 4
+#define FDSR_K32_SHAPES(X) X(16, 2) X(8, 4) X(4, 8)
+
+bool conv_k32_ok(int TH, int WN, int prec, const ConvParams& p) {
+  if (!g_tun.k32 || (prec == PREC_BF16 && g_tun.k32 < 2)) return false;   // bf16: only on request (measured slower)
+  if (TH * WN != 32) return false;                                   // MB == 4
+  if (WN != 2 && WN != 4 && WN != 8) return false;
+  if (p.Cin_pad % 32 || (p.C0 + p.C1) != p.Cin_pad) return false;    // whole 32-channel chunks
+  if (p.C1 != 0 && p.C0 % 32) return false;                          // the concat seam on a chunk boundary
+  if (p.Cout % 4) return false;                                      // 16-byte stores
+  if (p.xr0) {
+    if (p.nkr % 2 || (p.Cr0 + p.Cr1) != p.nkr * 16) return false;
+    if (p.Cr1 != 0 && p.Cr0 % 32) return false;
+  }
+  return true;
+}
+
+template <int TH, int WN, int PREC, bool RIDER>
+static hipError_t launch_k32_t(const ConvParams& q, int nwg, hipStream_t s) {
+  using Cfg = ConvK32Cfg<TH, WN, PREC>;
+  hipLaunchKernelGGL((conv_k32_kernel<TH, WN, PREC, RIDER>), dim3(nwg), dim3(Cfg::NT), (size_t)2 * Cfg::BUF_BYTES, s, q);
+  return hipGetLastError();
+}
+
+hipError_t launch_conv_k32(int TH, int WN, int prec, const ConvParams& q, int nwg, hipStream_t s) {
+#define X(TH_, WN_)                                                                                             \
+  if (TH == TH_ && WN == WN_) {                                                                                 \
+    if (q.xr0) return prec == PREC_F16X3 ? launch_k32_t<TH_, WN_, PREC_F16X3, true>(q, nwg, s)                  \
+                                         : launch_k32_t<TH_, WN_, PREC_BF16, true>(q, nwg, s);                  \
+    return prec == PREC_F16X3 ? launch_k32_t<TH_, WN_, PREC_F16X3, false>(q, nwg, s)                            \
+                              : launch_k32_t<TH_, WN_, PREC_BF16, false>(q, nwg, s);                            \
+  }
+  FDSR_K32_SHAPES(X)
+#undef X
+  return hipErrorInvalidValue;
+}
+
+template <int TH, int WN, int PREC, bool RIDER>
+static hipError_t init_k32_t() {
+  auto kfn = conv_k32_kernel<TH, WN, PREC, RIDER>;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+hipError_t kernels_k32_init() {
+  hipError_t e;
+#define X(TH_, WN_)                                                                        \
+  if ((e = init_k32_t<TH_, WN_, PREC_F16X3, false>()) != hipSuccess) return e;             \
+  if ((e = init_k32_t<TH_, WN_, PREC_F16X3, true>()) != hipSuccess) return e;              \
+  if ((e = init_k32_t<TH_, WN_, PREC_BF16, false>()) != hipSuccess) return e;              \
+  if ((e = init_k32_t<TH_, WN_, PREC_BF16, true>()) != hipSuccess) return e;
+  FDSR_K32_SHAPES(X)
+#undef X
+  return hipSuccess;
+}
+
+}  // namespace fdsr

@@ -78,6 +78,7 @@ struct Tunables {
                             // (serial-phase) form, 0 direct everywhere
   long wino_min_wgs = 256;  // ... only for launches with at least this many workgroups
   int wino_all = 0;         // ... 0: only the layers where it measured faster (conv_wino_ok); 1: every eligible launch
+  int k32 = 1;              // v_mfma_f32_16x16x32 form (fdsr_conv_k32.hip) of the stride-1 3x3 launches that fit it: 1 f16x3 only, 2 bf16 too, 0 never
   int sat_guard = 1;        // f16x3: sticky device flag when a RAW conv input exceeds the f16 range
   int drop_image_offset = 0;   // tests: the batch is images [offset, offset + N) of a larger one (its dropout masks follow)
   unsigned epoch = 0;
@@ -102,6 +103,11 @@ hipError_t launch_conv_h(ConvKind kind, int prec, const ConvParams& p, hipStream
 // workspace planner and the launcher agree.  Only grids that would leave most of the 256 CUs idle split.
 int conv_h_ksplit(ConvKind kind, int N, int Hout, int Wout, int Cout, int Cout_pad, int Cin_pad, int C0, int C1);
 hipError_t kernels_h_init();
+// K=32 MFMA form of the stride-1 3x3 launches (fdsr_conv_k32.hip): same ConvParams, same packed weights; launch_conv_h
+// dispatches to it when conv_k32_ok() (wave tile of 4 x 32 pixels, whole 32-channel chunks on both sides of a concat seam).
+bool conv_k32_ok(int TH, int WN, int prec, const ConvParams& p);
+hipError_t launch_conv_k32(int TH, int WN, int prec, const ConvParams& q, int nwg, hipStream_t s);
+hipError_t kernels_k32_init();
 // Winograd F(2x2,3x3) form of the stride-1 3x3 convs (fdsr_conv_wino.hip; f16x3 only): transformed weights U = G g G^T packed
 // [cot][kc][role][nu][plane][lane] x 16 B (role = position row xi | cout half << 2).  conv_wino_ok: does this launch take it?
 bool conv_wino_ok(ConvKind kind, int prec, const ConvParams& p, bool has_rider);
