@@ -36,6 +36,25 @@ typedef __bf16 k_b4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float silu_k(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
+#ifndef XS_F16X3
+#define XS_F16X3 2
+#endif
+#ifndef XS_BF16
+#define XS_BF16 4
+#endif
+#ifndef K32_PIN      // pin the fragment reads ahead of the MFMAs (sched_barrier) in the 8- and 4-row tiles
+#define K32_PIN 1
+#endif
+#ifndef K32_RIDER2   // rider chunks fetch their input two chunks ahead (two register sets) instead of one
+#define K32_RIDER2 1
+#endif
+#ifndef K32_SPLIT     // f16x3: the next chunk's input is fetched and staged in two halves (taps 0-3, 3-7): half the prefetch registers
+#define K32_SPLIT 1
+#endif
+#ifndef K32_PIN16    // ... and in the 16-row tile (its ten staging quads leave no registers for it: spills)
+#define K32_PIN16 0
+#endif
+
 template <int TH, int WN, int PREC>
 struct ConvK32Cfg {
   static constexpr int TW = 32, NW = 8, KC = 32;
@@ -48,7 +67,8 @@ struct ConvK32Cfg {
   static constexpr int RPP = NT / Q4;            // halo pixels filled per pass
   static constexpr int NIN = (NPIX + RPP - 1) / RPP;
   static constexpr int BUF_BYTES = NPIX * ROWB;
-  static constexpr int R = PREC == PREC_F16X3 ? 3 : 9;   // taps of weight fragments in registers
+  static constexpr int R = 3;                     // taps of weight fragments in registers (a ring: 9 % R == 0)
+  static constexpr int XS = PREC == PREC_F16X3 ? XS_F16X3 : XS_BF16;   // activation-fragment slots: XS - 1 (tap, row) steps ahead
   static_assert(MB == 4, "wave tile = 4 rows of 32 pixels");
   static_assert(((TH - WM + 2) * HWD + 16) * ROWB < 65536, "fragment offsets must fit the ds_read immediate");
 };
@@ -63,7 +83,8 @@ template <int TH, int WN, int PREC, bool RIDER>
 __global__ void __launch_bounds__(512, 2) conv_k32_kernel(const ConvParams p) {
   using Cfg = ConvK32Cfg<TH, WN, PREC>;
   constexpr int TW = Cfg::TW, KC = Cfg::KC, NP = Cfg::NP, ROWB = Cfg::ROWB, HWD = Cfg::HWD, NPIX = Cfg::NPIX;
-  constexpr int WM = Cfg::WM, BN = Cfg::BN, MB = Cfg::MB, RPP = Cfg::RPP, NIN = Cfg::NIN, R = Cfg::R;
+  constexpr int WM = Cfg::WM, BN = Cfg::BN, MB = Cfg::MB, RPP = Cfg::RPP, NIN = Cfg::NIN, R = Cfg::R, XS = Cfg::XS;
+  constexpr bool PIN = TH == 16 ? K32_PIN16 != 0 : K32_PIN != 0;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_k[];
   unsigned char* sBuf0 = smem_k;
@@ -98,31 +119,39 @@ __global__ void __launch_bounds__(512, 2) conv_k32_kernel(const ConvParams p) {
   // ---- staging indices (chunk invariant): thread -> (halo pixel row0 + i*64, float4 slot q of the 32 channels) ----
   const int q = tid & 7, row0 = tid >> 3;
   int in_pix[NIN];
-  int sdst[NIN];
+  unsigned skeys = 0;   // 3 bits per pass: the swizzle key of this thread's halo column (NIN <= 10)
+  static_assert(NIN <= 10, "swizzle keys are packed into one register");
 #pragma unroll
   for (int i = 0; i < NIN; ++i) {
     const int pix = row0 + i * RPP;
-    int v = -2, d = 0;
+    int v = -2;
     if (pix < NPIX) {
       const int hy = pix / HWD, hx = pix % HWD;
       const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
       const bool ok = iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
       v = ok ? (n * p.Hin + iy) * p.Win + ix : -1;
-      d = pix * ROWB + 16 * k32_slot<PREC>(q >> 1, hx) + 8 * (q & 1);
+      skeys |= (unsigned)k32_slot<PREC>(0, hx) << (3 * i);
     }
     in_pix[i] = v;
-    sdst[i] = d;
   }
+  const int sbase = row0 * ROWB + 8 * (q & 1);   // + i * RPP * ROWB + 16 * ((q >> 1) ^ key_i)
 
   using IO = ActIO<PREC>;
   typedef typename IO::Quad Quad;
-  Quad rin[NIN];
-  Quad rin2[RIDER ? NIN : 1];
+  constexpr bool SPLIT = K32_SPLIT != 0 && PREC == PREC_F16X3 && !RIDER;   // (the rider's whole-chunk sets would stay live across the main loop)
+  constexpr int NA = SPLIT ? (NIN + 1) / 2 : NIN;   // quads in flight in the main loop
+  typedef std::integral_constant<int, 0> I_0;
+  typedef std::integral_constant<int, NA> I_A;
+  typedef std::integral_constant<int, NIN> I_N;
+  Quad rin[NA];
+  Quad rr1[RIDER && SPLIT ? NIN : 1];          // rider chunks are fetched whole: first set (rin itself when not SPLIT)
+  Quad rin2[RIDER && K32_RIDER2 ? NIN : 1];   // second prefetch set of the rider chunks
   k_f32x4 rsc = {1.f, 1.f, 1.f, 1.f}, rsh = {0.f, 0.f, 0.f, 0.f};
   const int nk = p.Cin_pad / KC;               // main chunks; nk .. nk + nkr - 1 are the rider's (raw second input, centre tap)
   const int nk16 = p.Cin_pad / 16;
   const int nkr = RIDER ? p.nkr / 2 : 0;
-  auto prefetch_to = [&](int kc, Quad* rin) {
+  auto prefetch_rng = [&](int kc, Quad* rin, auto i0_tag, auto i1_tag, bool load_gn) {
+    constexpr int I0 = decltype(i0_tag)::value, I1 = decltype(i1_tag)::value;
     int cbase = kc * KC;
     const float* base;
     int Cs, cc;
@@ -134,27 +163,30 @@ __global__ void __launch_bounds__(512, 2) conv_k32_kernel(const ConvParams p) {
       else { base = p.xr1; Cs = p.Cr1; cc = cbase - p.Cr0 + q * 4; }
     } else if (cbase < p.C0) { base = p.x0; Cs = p.C0; cc = cbase + q * 4; }
     else { base = p.x1; Cs = p.C1; cc = cbase - p.C0 + q * 4; }
-    if (gg) {
+    if (gg && load_gn) {
       rsc = *reinterpret_cast<const k_f32x4*>(p.gn_scale + (size_t)n * Cin + cbase + q * 4);
       rsh = *reinterpret_cast<const k_f32x4*>(p.gn_shift + (size_t)n * Cin + cbase + q * 4);
     }
 #pragma unroll
-    for (int i = 0; i < NIN; ++i)
-      rin[i] = IO::load4(base, (size_t)(in_pix[i] < 0 ? 0 : in_pix[i]) * Cs + cc);
+    for (int i = I0; i < I1; ++i)
+      rin[i - I0] = IO::load4(base, (size_t)(in_pix[i] < 0 ? 0 : in_pix[i]) * Cs + cc);
   };
-  auto stage_from = [&](int kc, unsigned char* buf, const Quad* rin) {
+  auto prefetch_to = [&](int kc, Quad* rin) { prefetch_rng(kc, rin, I_0{}, I_N{}, true); };
+  auto stage_rng = [&](int kc, unsigned char* buf, const Quad* rin, auto i0_tag, auto i1_tag) {
+    constexpr int I0 = decltype(i0_tag)::value, I1 = decltype(i1_tag)::value;
     const k_f32x4 sc = rsc, sh = rsh;
 #pragma unroll
-    for (int i = 0; i < NIN; ++i) {
+    for (int i = I0; i < I1; ++i) {
       if (NIN * RPP > NPIX && i == NIN - 1 && row0 + i * RPP >= NPIX) continue;   // only the last pass can overrun
-      k_f32x4 v = IO::widen(rin[i]);
+      k_f32x4 v = IO::widen(rin[i - I0]);
       if (gn && !(RIDER && kc >= nk)) {
         v = v * sc + sh;
         if (!p.gn_plain) { v.x = silu_k(v.x); v.y = silu_k(v.y); v.z = silu_k(v.z); v.w = silu_k(v.w); }
       } else if (PREC == PREC_F16X3 && p.sat_flag) {
         sat_check(p.sat_flag, v, 65504.f);
       }
-      unsigned char* dst = buf + sdst[i];
+      const int sd = sbase + i * (RPP * ROWB) + 16 * ((q >> 1) ^ (int)((skeys >> (3 * i)) & 7u));
+      unsigned char* dst = buf + sd;
       if (PREC == PREC_F16X3) {
         const float lim = in_pix[i] >= 0 ? 65504.f : 0.f;   // f16 range clamp and zero padding in one med3
 #pragma unroll
@@ -163,7 +195,7 @@ __global__ void __launch_bounds__(512, 2) conv_k32_kernel(const ConvParams p) {
         k_h4 lo = {(_Float16)(v.x - (float)hi.x), (_Float16)(v.y - (float)hi.y), (_Float16)(v.z - (float)hi.z),
                    (_Float16)(v.w - (float)hi.w)};
         *reinterpret_cast<k_h4*>(dst) = hi;
-        *reinterpret_cast<k_h4*>(buf + (sdst[i] ^ 64)) = lo;   // slot + 4 of the swizzled row
+        *reinterpret_cast<k_h4*>(buf + (sd ^ 64)) = lo;   // slot + 4 of the swizzled row
       } else {
         const float keep = in_pix[i] >= 0 ? 1.f : 0.f;
         v = v * keep;
@@ -172,6 +204,7 @@ __global__ void __launch_bounds__(512, 2) conv_k32_kernel(const ConvParams p) {
       }
     }
   };
+  auto stage_from = [&](int kc, unsigned char* buf, const Quad* rin) { stage_rng(kc, buf, rin, I_0{}, I_N{}); };
 
   // ---- weight fragments: ring slot s holds tap t with t % R == s; [cout half][plane] ----
   const uint4* wq = reinterpret_cast<const uint4*>(p.wq);
@@ -211,12 +244,21 @@ __global__ void __launch_bounds__(512, 2) conv_k32_kernel(const ConvParams p) {
 #pragma unroll
     for (int t = 0; t < R; ++t) load_w(kc0, t, t);
   }
-  prefetch_to(kc0, rin);
-  stage_from(kc0, sBuf0, rin);
-  if (kc0 + 1 < kc1) prefetch_to(kc0 + 1, rin);
+  if (SPLIT) {
+    {   // the first chunk is fetched whole (the accumulators are not live yet)
+      Quad r0[NIN];
+      prefetch_to(kc0, r0);
+      stage_from(kc0, sBuf0, r0);
+    }
+    if (RIDER && kc0 >= nk && kc0 + 1 < kc1) prefetch_to(kc0 + 1, rr1);   // (a slice that starts among the rider chunks)
+  } else {
+    prefetch_to(kc0, rin);
+    stage_from(kc0, sBuf0, rin);
+    if (kc0 + 1 < kc1) prefetch_to(kc0 + 1, rin);
+  }
   __syncthreads();
 
-  uint4 Xf[2][2][NP];   // [slot][pixel half][plane], double-buffered over (tap, row) steps
+  uint4 Xf[XS][2][NP];   // [slot][pixel half][plane]: a ring over (tap, row) steps, XS - 1 steps ahead of the MFMAs
   const unsigned char* xptr[3][NP];
   auto load_x = [&](int slot, int ky, int kx, int mb) {
 #pragma unroll
@@ -260,22 +302,35 @@ __global__ void __launch_bounds__(512, 2) conv_k32_kernel(const ConvParams p) {
     for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
       for (int pl = 0; pl < NP; ++pl) xptr[kx][pl] = cur + xoff[kx][pl];
-    load_x(0, 0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < XS - 1; ++s) load_x(s, (s / MB) / 3, (s / MB) % 3, s % MB);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) {
-        const int s = tap * MB + mb;
-        if (s + 1 < 9 * MB) {
-          const int t2 = (s + 1) / MB, m2 = (s + 1) % MB;
-          load_x((s + 1) & 1, t2 / 3, t2 % 3, m2);
+        const int s = tap * MB + mb, s2 = s + XS - 1;
+        if (s2 < 9 * MB) {
+          const int t2 = s2 / MB, m2 = s2 % MB;
+          load_x(s2 % XS, t2 / 3, t2 % 3, m2);
         }
-        mfma_step(s & 1, tap % R, mb);
+        if (PIN) __builtin_amdgcn_sched_barrier(0);   // keep the fragment reads AHEAD of the MFMAs (the scheduler otherwise sinks them to their use)
+        mfma_step(s % XS, tap % R, mb);
+        if (PIN) __builtin_amdgcn_sched_barrier(0);
       }
       // this tap's ring slot is free: fetch the tap that will use it next
       if (tap + R < 9) load_w(kc, tap + R, tap % R);
       else if (more && (tap + R - 9 == 0 || !next_rider)) load_w(kc + 1, tap + R - 9, tap % R);
-      if (tap == 4 && more) {   // mid-chunk: fill the other halo buffer
+      if (SPLIT) {   // the other halo buffer is filled in two halves, each fetched four taps before it is staged
+        if (tap == 0 && more) prefetch_rng(kc + 1, rin, I_0{}, I_A{}, true);
+        if (tap == 3 && more) {
+          stage_rng(kc + 1, nxt, rin, I_0{}, I_A{});
+          prefetch_rng(kc + 1, rin, I_A{}, I_N{}, false);
+        }
+        if (tap == 7 && more) {
+          stage_rng(kc + 1, nxt, rin, I_A{}, I_N{});
+          if (next_rider && kc + 2 < kc1) prefetch_to(kc + 2, rr1);   // the rider loop expects its second chunk in flight
+        }
+      } else if (tap == 4 && more) {   // mid-chunk: fill the other halo buffer
         stage_from(kc + 1, nxt, rin);
         if (kc + 2 < kc1) prefetch_to(kc + 2, rin);
       }
@@ -293,30 +348,38 @@ __global__ void __launch_bounds__(512, 2) conv_k32_kernel(const ConvParams p) {
 #pragma unroll
           for (int ch = 0; ch < 2; ++ch) acc[mb][ph][ch] *= ratio;
     }
-    // input fetched TWO chunks ahead into two alternating register sets (on entry `rin` holds chunk k0 + 1)
+    // A rider chunk is short (48 MFMAs per wave): its input is fetched TWO chunks ahead, into two register sets that alternate
+    // (on entry the first set holds chunk k0 + 1, as the main loop leaves it; two of the three weight-ring slots are free by now).
     const int k0 = kc0 > nk ? kc0 : nk;
-    if (k0 + 2 < kc1) prefetch_to(k0 + 2, rin2);
+    constexpr int AH = K32_RIDER2 ? 2 : 1;
+    if (AH == 2 && k0 + 2 < kc1) prefetch_to(k0 + 2, rin2);
     auto rider_chunk = [&](int kc, Quad* r1) {   // r1 holds chunk kc + 1
       unsigned char* cur = ((kc - kc0) & 1) ? sBuf1 : sBuf0;
       unsigned char* nxt = ((kc - kc0) & 1) ? sBuf0 : sBuf1;
 #pragma unroll
       for (int pl = 0; pl < NP; ++pl) xptr[1][pl] = cur + xoff[1][pl];
-      load_x(0, 1, 1, 0);
+#pragma unroll
+      for (int mb = 0; mb < XS - 1 && mb < MB; ++mb) load_x(mb, 1, 1, mb);
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) {
-        if (mb + 1 < MB) load_x((mb + 1) & 1, 1, 1, mb + 1);
-        mfma_step(mb & 1, 0, mb);
+        if (mb + XS - 1 < MB) load_x((mb + XS - 1) % XS, 1, 1, mb + XS - 1);
+        mfma_step(mb % XS, 0, mb);
       }
       if (kc + 1 < kc1) {
         load_w(kc + 1, 0, 0);
         stage_from(kc + 1, nxt, r1);
-        if (kc + 3 < kc1) prefetch_to(kc + 3, r1);
+        if (kc + 1 + AH < kc1) prefetch_to(kc + 1 + AH, r1);
       }
       __syncthreads();
     };
-    for (int kc = k0; kc < kc1; kc += 2) {
-      rider_chunk(kc, rin);
-      if (kc + 1 < kc1) rider_chunk(kc + 1, rin2);
+    Quad* rfirst = SPLIT ? rr1 : rin;
+    if (AH == 2) {
+      for (int kc = k0; kc < kc1; kc += 2) {
+        rider_chunk(kc, rfirst);
+        if (kc + 1 < kc1) rider_chunk(kc + 1, rin2);
+      }
+    } else {
+      for (int kc = k0; kc < kc1; ++kc) rider_chunk(kc, rfirst);
     }
   }
 
@@ -465,7 +528,9 @@ __global__ void __launch_bounds__(512, 2) conv_k32_kernel(const ConvParams p) {
 #define FDSR_K32_SHAPES(X) X(16, 2) X(8, 4) X(4, 8)
 
 bool conv_k32_ok(int TH, int WN, int prec, const ConvParams& p) {
-  if (!g_tun.k32 || (prec == PREC_BF16 && g_tun.k32 < 2)) return false;   // bf16: only on request (measured slower)
+  // g_tun.k32 bits: 1 f16x3, 2 bf16 (measured equal to the 32x32x16 form: off by default), 4 the 16-row tile with a rider (measured slower)
+  if (!(g_tun.k32 & (prec == PREC_BF16 ? 2 : 1))) return false;
+  if (TH == 16 && p.xr0 && !(g_tun.k32 & 4)) return false;
   if (TH * WN != 32) return false;                                   // MB == 4
   if (WN != 2 && WN != 4 && WN != 8) return false;
   if (p.Cin_pad % 32 || (p.C0 + p.C1) != p.Cin_pad) return false;    // whole 32-channel chunks

@@ -78,7 +78,7 @@ struct Tunables {
                             // (serial-phase) form, 0 direct everywhere
   long wino_min_wgs = 256;  // ... only for launches with at least this many workgroups
   int wino_all = 0;         // ... 0: only the layers where it measured faster (conv_wino_ok); 1: every eligible launch
-  int k32 = 1;              // v_mfma_f32_16x16x32 form (fdsr_conv_k32.hip) of the stride-1 3x3 launches that fit it: 1 f16x3 only, 2 bf16 too, 0 never
+  int k32 = 1;              // v_mfma_f32_16x16x32 form (fdsr_conv_k32.hip) of the stride-1 3x3 launches that fit it; bits: 1 f16x3, 2 bf16, 4 the 16-row tile with a rider; 0 never
   int sat_guard = 1;        // f16x3: sticky device flag when a RAW conv input exceeds the f16 range
   int drop_image_offset = 0;   // tests: the batch is images [offset, offset + N) of a larger one (its dropout masks follow)
   unsigned epoch = 0;

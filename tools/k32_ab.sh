@@ -7,5 +7,5 @@ run() {  # precision batch extra option steps
 }
 for rep in $(seq 1 ${1:-2}); do
   for o in k32=1 k32=0; do run f16x3 16 "" $o 5; done
-  for o in k32=1 k32=0; do run bf16 64 --graph $o 3; done
+  for o in k32=3 k32=0; do run bf16 64 --graph $o 3; done
 done
