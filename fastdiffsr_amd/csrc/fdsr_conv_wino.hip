@@ -1078,10 +1078,12 @@ bool conv_wino_ok(ConvKind kind, int prec, const ConvParams& p, bool has_rider) 
   // Where the form pays (same-box per-layer timings at B = 16, profiles/r03_wino_per_layer.txt): the kernel is LDS-bound at about
   // the direct kernel's speed, so it wins only where the direct one is at its worst -- the 32 x 32 maps (-18 %) and the widest
   // concatenated inputs (-3 .. -7 %) -- and never where it would cost a ResnetBlock its res_conv rider (the 1x1 comes back as a
-  // launch of its own).  Debug option wino_all = 1 lifts the rule (tests run every layer through the form).
+  // launch of its own).  Since the 16x16x32 direct form (fdsr_conv_k32.hip) the wide-input launches are faster direct again
+  // (wino_wide_cin, default off); the 32 x 32 maps, whose 2-row tiles that form does not cover, keep the Winograd kernel.
+  // Debug option wino_all = 1 lifts the rule (tests run every layer through the form).
   if (!g_tun.wino_all) {
     const bool small_map = (long)p.Hout * p.Wout <= 1024;
-    if (!(small_map || (!has_rider && p.C0 + p.C1 >= 384))) return false;
+    if (!(small_map || (!has_rider && p.C0 + p.C1 >= g_tun.wino_wide_cin))) return false;
   }
   if (p.xr0 || p.drop_mask || p.ksplit > 1 || p.gn_plain) return false;
   if ((p.Hout & 15) || (p.Wout & 15) || p.Hin != p.Hout || p.Win != p.Wout) return false;
