@@ -51,6 +51,9 @@ __device__ __forceinline__ float silu_k(float v) { return v * __builtin_amdgcn_r
 #ifndef K32_SPLIT     // f16x3: the next chunk's input is fetched and staged in two halves (taps 0-3, 3-7): half the prefetch registers
 #define K32_SPLIT 1
 #endif
+#ifndef K32_MIXSPLIT  // hi/lo split of the staging as v_cvt_pk_f16_f32 + v_fma_mix (fewer VALU instructions, same bits)
+#define K32_MIXSPLIT 1
+#endif
 #ifndef K32_PIN16    // ... and in the 16-row tile (its ten staging quads leave no registers for it: spills)
 #define K32_PIN16 0
 #endif
@@ -191,11 +194,30 @@ __global__ void __launch_bounds__(512, 2) conv_k32_kernel(const ConvParams p) {
         const float lim = in_pix[i] >= 0 ? 65504.f : 0.f;   // f16 range clamp and zero padding in one med3
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], -lim, lim);
+#if K32_MIXSPLIT
+        // one packed convert and two v_fma_mix per pair: lo = f16(fma(hi, -1, v)), rounded once -- bit-identical to the two-step
+        // form below (as in fdsr_conv_wino.hip / fdsr_train.hip).  With 16x16x32 MFMAs holding the issue port half of their time
+        // the staging VALU count matters more than it did beside 32x32x16.
+        typedef _Float16 h2t __attribute__((ext_vector_type(2)));
+        uint2 hi, lo;
+        {
+          const h2t h0 = {(_Float16)v[0], (_Float16)v[1]}, h1 = {(_Float16)v[2], (_Float16)v[3]};
+          hi.x = __builtin_bit_cast(unsigned, h0);
+          hi.y = __builtin_bit_cast(unsigned, h1);
+        }
+        asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo.x) : "v"(hi.x), "v"(v[0]));
+        asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo.x) : "v"(hi.x), "v"(v[1]));
+        asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo.y) : "v"(hi.y), "v"(v[2]));
+        asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo.y) : "v"(hi.y), "v"(v[3]));
+        *reinterpret_cast<uint2*>(dst) = hi;
+        *reinterpret_cast<uint2*>(buf + (sd ^ 64)) = lo;   // slot + 4 of the swizzled row
+#else
         k_h4 hi = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
         k_h4 lo = {(_Float16)(v.x - (float)hi.x), (_Float16)(v.y - (float)hi.y), (_Float16)(v.z - (float)hi.z),
                    (_Float16)(v.w - (float)hi.w)};
         *reinterpret_cast<k_h4*>(dst) = hi;
         *reinterpret_cast<k_h4*>(buf + (sd ^ 64)) = lo;   // slot + 4 of the swizzled row
+#endif
       } else {
         const float keep = in_pix[i] >= 0 ? 1.f : 0.f;
         v = v * keep;
