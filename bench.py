@@ -170,7 +170,7 @@ def kernel_source_hash():
     import hashlib
     d = os.path.join(ROOT, 'fastdiffsr_amd', 'csrc')
     h = hashlib.sha256()
-    for f in ('fdsr_act_io.h', 'fdsr_conv_h.hip', 'fdsr_conv_up2.hip', 'fdsr_conv_wino.hip', 'fdsr_kernels.h', 'fdsr_kernels.hip'):
+    for f in ('fdsr_act_io.h', 'fdsr_conv_h.hip', 'fdsr_conv_k32.hip', 'fdsr_conv_up2.hip', 'fdsr_conv_wino.hip', 'fdsr_kernels.h', 'fdsr_kernels.hip'):
         h.update(f.encode() + b'\0' + open(os.path.join(d, f), 'rb').read() + b'\0')
     return h.hexdigest()
 
@@ -181,7 +181,7 @@ def conv_roofline(prof, precision, B, S, dt_total, round_tag='r03'):
     ach = prof['conv_flops'] / (prof['conv_ms'] * 1e-3) / 1e12
     peak = PEAK_F32_MFMA if precision == 'f32' else PEAK_16BIT_MFMA
     passes = 3 if precision == 'f16x3' else 1     # MFMA products issued per algorithmic product
-    kern = 'conv_mfma_f32_kernel' if precision == 'f32' else ('conv_mfma_h_kernel + conv_wino2_h_kernel' if precision == 'f16x3' else 'conv_mfma_h_kernel')
+    kern = 'conv_mfma_f32_kernel' if precision == 'f32' else ('conv_k32_kernel + conv_mfma_h_kernel + conv_wino2_h_kernel' if precision == 'f16x3' else 'conv_mfma_h_kernel')
     # HBM bytes per launch of the SAME launch set (3x3 family), from rocprofv3 --pmc passes of this command kept
     # under profiles/ (separate FETCH_SIZE / WRITE_SIZE runs, gfx950 x2 read correction: tools/pmc_traffic.py).
     # Quoted only while the file was measured on these very kernel sources; otherwise null.
