@@ -54,6 +54,9 @@ __device__ __forceinline__ float silu_k(float v) { return v * __builtin_amdgcn_r
 #ifndef K32_MIXSPLIT  // hi/lo split of the staging as v_cvt_pk_f16_f32 + v_fma_mix (fewer VALU instructions, same bits)
 #define K32_MIXSPLIT 1
 #endif
+#ifndef K32_PEEL      // rider-less kernels: the last chunk is a code copy of its own that also fetches the residual tile
+#define K32_PEEL 1
+#endif
 #ifndef K32_PIN16    // ... and in the 16-row tile (its ten staging quads leave no registers for it: spills)
 #define K32_PIN16 0
 #endif
@@ -313,12 +316,34 @@ __global__ void __launch_bounds__(512, 2) conv_k32_kernel(const ConvParams p) {
     }
   };
 
+  // epilogue geometry (needed early: the last chunk already fetches the residual tile)
+  const int cob = co0 + wn * 32 + 4 * g;
+  const bool interior = (oy0 + TH <= p.Hout) && (ox0 + TW <= p.Wout) && (co0 + BN <= p.Cout);
+  const size_t obase = ((size_t)(n * p.Hout + oy0 + wm) * p.Wout + ox0 + c15) * p.Cout + cob;
+  const size_t rstride = (size_t)WM * p.Wout * p.Cout, pstride = (size_t)16 * p.Cout;
+  constexpr bool PEEL = K32_PEEL != 0 && !RIDER;
+  Quad rv[MB][2][2];   // residual tile [row][pixel half][cout half]
+  const bool res_early = PEEL && p.res && interior && SK == 1;   // ... fetched during the last chunk, into registers the loop no longer needs
+  auto load_res = [&](auto q0_tag, auto q1_tag) {
+    constexpr int Q0 = decltype(q0_tag)::value, Q1 = decltype(q1_tag)::value;
+#pragma unroll
+    for (int qi = Q0; qi < Q1; ++qi) {
+      const int mb = qi >> 2, ph = (qi >> 1) & 1, ch = qi & 1;
+      rv[mb][ph][ch] = IO::load4(p.res, obase + mb * rstride + ph * pstride + 16 * ch);
+    }
+  };
+  typedef std::integral_constant<int, 7> I_7;
+  typedef std::integral_constant<int, 11> I_11;
+  typedef std::integral_constant<int, 15> I_15;
+  typedef std::integral_constant<int, 16> I_16;
+
   // main chunks: all nine taps of 32 GroupNorm'ed channels
   const int kcm = RIDER ? (kc1 < nk ? kc1 : nk) : kc1;
-  for (int kc = kc0; kc < kcm; ++kc) {
+  auto main_chunk = [&](int kc, auto last_tag) {
+    constexpr bool LAST = decltype(last_tag)::value;   // the peeled final chunk: nothing to fetch or stage for a next one
     unsigned char* cur = ((kc - kc0) & 1) ? sBuf1 : sBuf0;
     unsigned char* nxt = ((kc - kc0) & 1) ? sBuf0 : sBuf1;
-    const bool more = kc + 1 < kc1;
+    const bool more = LAST ? false : (kc + 1 < kc1);
     const bool next_rider = RIDER && kc + 1 >= nk;
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx)
@@ -356,8 +381,20 @@ __global__ void __launch_bounds__(512, 2) conv_k32_kernel(const ConvParams p) {
         stage_from(kc + 1, nxt, rin);
         if (kc + 2 < kc1) prefetch_to(kc + 2, rin);
       }
+      if (LAST && res_early) {   // the staging registers are free from the start, a weight-ring slot after each of taps 6, 7, 8
+        if (tap == 0) load_res(I_0{}, I_7{});
+        if (tap == 6) load_res(I_7{}, I_11{});
+        if (tap == 7) load_res(I_11{}, I_15{});
+        if (tap == 8) load_res(I_15{}, I_16{});
+      }
     }
     __syncthreads();
+  };
+  if (PEEL) {
+    for (int kc = kc0; kc < kcm - 1; ++kc) main_chunk(kc, std::false_type{});
+    if (kcm > kc0) main_chunk(kcm - 1, std::true_type{});
+  } else {
+    for (int kc = kc0; kc < kcm; ++kc) main_chunk(kc, std::false_type{});
   }
   if (RIDER && kc1 > nk) {
     // rider chunks: 32 raw channels of the second input each, centre tap only, the 1x1 conv's fragments in ring slot 0
@@ -406,7 +443,6 @@ __global__ void __launch_bounds__(512, 2) conv_k32_kernel(const ConvParams p) {
   }
 
   // ---- epilogue: lane = pixel c15 (+ 16 ph) of row wm + mb*WM, output channels cob + 16 ch + 0..3 ----
-  const int cob = co0 + wn * 32 + 4 * g;
   k_f32x4 add[2];
   bool cok[2];
 #pragma unroll
@@ -435,9 +471,6 @@ __global__ void __launch_bounds__(512, 2) conv_k32_kernel(const ConvParams p) {
 #pragma unroll
         for (int ch = 0; ch < 2; ++ch) acc[mb][ph][ch] *= ratio;
   }
-  const bool interior = (oy0 + TH <= p.Hout) && (ox0 + TW <= p.Wout) && (co0 + BN <= p.Cout);
-  const size_t obase = ((size_t)(n * p.Hout + oy0 + wm) * p.Wout + ox0 + c15) * p.Cout + cob;
-  const size_t rstride = (size_t)WM * p.Wout * p.Cout, pstride = (size_t)16 * p.Cout;
   if (SK > 1) {   // raw partial accumulators; bias, shift, residual and statistics happen in the reduce
     float* sb = p.kscratch + (size_t)ksi * p.N * p.Hout * p.Wout * p.Cout;
 #pragma unroll
@@ -467,9 +500,8 @@ __global__ void __launch_bounds__(512, 2) conv_k32_kernel(const ConvParams p) {
         *reinterpret_cast<k_f32x4*>(p.out + idx) = v;
       }
     };
-    Quad rv[MB][2][2];
     if (interior) {
-      if (p.res) {
+      if (p.res && !res_early) {
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
