@@ -15,12 +15,17 @@
 //     16-byte units of two of those blocks -- lane (g = l >> 4, c = l & 15) takes unit 32 (g & 1) + 16 ch + c of 16-channel
 //     block 2 kc + (g >> 1).  No second weight form, so optimiser re-packs and the transposed (input-gradient) forms serve
 //     this kernel as they are.
-//   * Only a ring of three taps of weight fragments is live in f16x3 (48 VGPRs instead of 144): tap t + 3 is fetched from
-//     L2 while taps t + 1, t + 2 are multiplied (>= 3000 cycles of MFMAs); bf16 keeps all nine taps (72 VGPRs).
+//   * Only a ring of three taps of weight fragments is live (48 VGPRs in f16x3 instead of 144; 24 in bf16): tap t + 3 is
+//     fetched from L2 right after tap t's last MFMA, while taps t + 1, t + 2 are multiplied (>= 3000 cycles of MFMAs in f16x3).
 //   * Halo image in LDS: 128-byte pixel rows [4 x 16 B hi | 4 x 16 B lo] (bf16: 64 bytes), no padding -- the 18 x 34 halo
 //     of a 16-row tile, double-buffered, is 153 KB of the CU's 160 -- with the 16-byte slot XOR-swizzled by the pixel
 //     column (f16x3: slot ^ (hx & 7); bf16: slot ^ ((hx >> 1) & 3)): every ds_read_b128 of an activation fragment is
-//     bank-conflict free on the instruction's four 16-lane groups for all three kx shifts.
+//     bank-conflict free on the instruction's four 16-lane groups for all three kx shifts (tests/test_k32_maps.py replays
+//     the maps lane by lane in numpy).
+//   * Activation fragments are read one (tap, row) step ahead of their MFMAs and the reads are pinned there (sched_barrier) in
+//     the 8- / 4-row tiles; f16x3 rider-less kernels fetch and stage the next chunk in two halves and run their last chunk
+//     as a code copy that already fetches the residual tile.  The K32_* / XS_* macros below are the A/B switches of those
+//     choices (tools/k32_variant.sh builds a variant library; every measured pair is in profiles/r03_k32_ab.txt).
 #include "fdsr_kernels.h"
 #include "fdsr_act_io.h"
 
