@@ -181,7 +181,7 @@ def conv_roofline(prof, precision, B, S, dt_total, round_tag='r03'):
     ach = prof['conv_flops'] / (prof['conv_ms'] * 1e-3) / 1e12
     peak = PEAK_F32_MFMA if precision == 'f32' else PEAK_16BIT_MFMA
     passes = 3 if precision == 'f16x3' else 1     # MFMA products issued per algorithmic product
-    kern = 'conv_mfma_f32_kernel' if precision == 'f32' else ('conv_k32_kernel + conv_mfma_h_kernel + conv_wino2_h_kernel' if precision == 'f16x3' else 'conv_mfma_h_kernel')
+    kern = 'conv_mfma_f32_kernel' if precision == 'f32' else ('conv_k32_kernel + conv_mfma_h_kernel' if precision == 'f16x3' else 'conv_mfma_h_kernel')
     # HBM bytes per launch of the SAME launch set (3x3 family), from rocprofv3 --pmc passes of this command kept
     # under profiles/ (separate FETCH_SIZE / WRITE_SIZE runs, gfx950 x2 read correction: tools/pmc_traffic.py).
     # Quoted only while the file was measured on these very kernel sources; otherwise null.
@@ -209,12 +209,12 @@ def conv_roofline(prof, precision, B, S, dt_total, round_tag='r03'):
          # events (5 of 20 steps): <1 % overhead in the timed region, measured 2.6 % with all
          'timed_steps_of_20': n_timed}
     if precision == 'f16x3':
-        r['executed_note'] = ('executed_tflops prices every product at 3 MFMA passes of the DIRECT form; launches that take the Winograd '
-                              'F(2x2,3x3) form (stride-1 3x3, grids >= 256 workgroups) issue 16/36 of those MFMAs for the same algorithmic FLOPs')
+        r['executed_note'] = ('executed_tflops prices every product at 3 MFMA passes (hi*hi + hi*lo + lo*hi); with --debug-option wino=2 the '
+                              'launches that take the Winograd F(2x2,3x3) form issue 16/36 of those MFMAs for the same algorithmic FLOPs')
     if precision != 'f32':
         # (until round 2's last change these launches did not contain the 1x1 res_convs: their time sat outside the family)
         r['launch_set'] = ('every 3x3 conv launch; 1x1 res_convs that ride inside a direct block2 launch (ConvParams::xr0) have their '
-                           'FLOPs, bytes and time in these figures; behind a Winograd block2 launch the res_conv is a launch of its own, outside them')
+                           'FLOPs, bytes and time in these figures')
     if dt_total:
         r['conv_time_share'] = prof['conv_ms'] * 1e-3 * (20 / n_timed) / dt_total
     return r

@@ -80,7 +80,7 @@ struct ConvK32Cfg {
   static constexpr int BUF_BYTES = NPIX * ROWB;
   static constexpr int R = 3;                     // taps of weight fragments in registers (a ring: 9 % R == 0)
   static constexpr int XS = PREC == PREC_F16X3 ? XS_F16X3 : XS_BF16;   // activation-fragment slots: XS - 1 (tap, row) steps ahead
-  static_assert(MB == 4, "wave tile = 4 rows of 32 pixels");
+  static_assert(MB == 4 || MB == 2, "wave tile = 4 (or, small grids, 2) rows of 32 pixels");
   static_assert(((TH - WM + 2) * HWD + 16) * ROWB < 65536, "fragment offsets must fit the ds_read immediate");
 };
 
@@ -337,10 +337,11 @@ __global__ void __launch_bounds__(512, 2) conv_k32_kernel(const ConvParams p) {
       rv[mb][ph][ch] = IO::load4(p.res, obase + mb * rstride + ph * pstride + 16 * ch);
     }
   };
-  typedef std::integral_constant<int, 7> I_7;
-  typedef std::integral_constant<int, 11> I_11;
-  typedef std::integral_constant<int, 15> I_15;
-  typedef std::integral_constant<int, 16> I_16;
+  constexpr int NQ = 4 * MB;   // residual quads per lane
+  typedef std::integral_constant<int, (NQ < 7 ? NQ : 7)> I_7;
+  typedef std::integral_constant<int, (NQ < 11 ? NQ : 11)> I_11;
+  typedef std::integral_constant<int, (NQ < 15 ? NQ : 15)> I_15;
+  typedef std::integral_constant<int, NQ> I_16;
 
   // main chunks: all nine taps of 32 GroupNorm'ed channels
   const int kcm = RIDER ? (kc1 < nk ? kc1 : nk) : kc1;
@@ -583,14 +584,14 @@ __global__ void __launch_bounds__(512, 2) conv_k32_kernel(const ConvParams p) {
   }
 }
 
-// (TH, WN) pairs with MB = TH / (8 / WN) = 4
-#define FDSR_K32_SHAPES(X) X(16, 2) X(8, 4) X(4, 8)
+// (TH, WN) pairs with MB = TH / (8 / WN) = 4, and the 2-row-per-wave tiles of small grids (MB = 2)
+#define FDSR_K32_SHAPES(X) X(16, 2) X(8, 4) X(4, 8) X(8, 2) X(4, 4) X(2, 8)
 
 bool conv_k32_ok(int TH, int WN, int prec, const ConvParams& p) {
   // g_tun.k32 bits: 1 f16x3, 2 bf16 (measured equal to the 32x32x16 form: off by default), 4 the 16-row tile with a rider (measured slower)
   if (!(g_tun.k32 & (prec == PREC_BF16 ? 2 : 1))) return false;
   if (TH == 16 && p.xr0 && !(g_tun.k32 & 4)) return false;
-  if (TH * WN != 32) return false;                                   // MB == 4
+  if (TH * WN != 32 && !(TH * WN == 16 && (g_tun.k32 & 8))) return false;   // MB == 4 (bit 8: the 2-row tiles of small grids too)
   if (WN != 2 && WN != 4 && WN != 8) return false;
   if (p.Cin_pad % 32 || (p.C0 + p.C1) != p.Cin_pad) return false;    // whole 32-channel chunks
   if (p.C1 != 0 && p.C0 % 32) return false;                          // the concat seam on a chunk boundary

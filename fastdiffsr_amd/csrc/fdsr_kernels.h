@@ -74,13 +74,14 @@ struct Tunables {
   int wgrad_colsum = 1;     // column sums of dy fused into the in-row weight-gradient kernel
   int wgrad_f32 = 0;        // f16x3 steps keep exact-fp32 weight gradients
   long long wgrad_big_bytes = 1ll << 32;   // tensors from this size on take the 4-wave weight-gradient kernel (64-bit offsets)
-  int wino = 2;             // Winograd F(2x2,3x3) form of the stride-1 3x3 convs in f16x3: 2 half-tile pipeline (default), 1 first
-                            // (serial-phase) form, 0 direct everywhere
+  int wino = 0;             // Winograd F(2x2,3x3) form of the stride-1 3x3 convs in f16x3: 0 direct everywhere (default since the
+                            // 16x16x32 direct form took the 32 x 32 maps' 2-row tiles too: 69.7 vs 69.0 img/s same box), 2 half-tile pipeline, 1 first
+                            // (serial-phase) form, 4 two workgroups per CU
   long wino_min_wgs = 256;  // ... only for launches with at least this many workgroups
   int wino_wide_cin = 1 << 30;   // ... rider-less launches with at least this many input channels take it too (384 until the 16x16x32
-                            // direct form overtook it there: 67.9 vs 66.8 img/s same box); default: only the 32 x 32 maps
+                            // direct form overtook it there: 67.9 vs 66.8 img/s same box); with wino on: only the 32 x 32 maps
   int wino_all = 0;         // ... 0: only the layers where it measured faster (conv_wino_ok); 1: every eligible launch
-  int k32 = 1;              // v_mfma_f32_16x16x32 form (fdsr_conv_k32.hip) of the stride-1 3x3 launches that fit it; bits: 1 f16x3, 2 bf16, 4 the 16-row tile with a rider; 0 never
+  int k32 = 9;              // v_mfma_f32_16x16x32 form (fdsr_conv_k32.hip) of the stride-1 3x3 launches that fit it; bits: 1 f16x3, 2 bf16, 4 the 16-row tile with a rider, 8 the 2-row-per-wave tiles of small grids; 0 never
   int sat_guard = 1;        // f16x3: sticky device flag when a RAW conv input exceeds the f16 range
   int drop_image_offset = 0;   // tests: the batch is images [offset, offset + N) of a larger one (its dropout masks follow)
   unsigned epoch = 0;

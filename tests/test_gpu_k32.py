@@ -1,7 +1,7 @@
 """The 16x16x32-MFMA form of the stride-1 3x3 convolutions (fdsr_conv_k32.hip): on by default for f16x3 launches whose wave tile is
-4 x 32 pixels; here it is FORCED onto every eligible launch of a small forward (largest tile regardless of the grid size, so
+4 x 32 or 2 x 32 pixels (except the 16-row tile with a rider); here it is FORCED onto every eligible launch of a small forward (largest tile regardless of the grid size, so
 the split-K, partial-tile and rider paths of the form all run), layer by layer against the oracle, in every option setting
-(bits of `k32`: 1 f16x3, 2 bf16, 4 the 16-row tile with a rider), against the 32x32x16 kernels on the same input, and through the
+(bits of `k32`: 1 f16x3, 2 bf16, 4 the 16-row tile with a rider, 8 the 2-row tiles of small grids), against the 32x32x16 kernels on the same input, and through the
 20-step loop.  Same bounds as every other conv kernel: layerwise 1e-4 * max(1, |ref|), loop 1e-3 (north_star); bf16 0.25 layerwise
 (judged on PSNR elsewhere).  Reference: fastdiffsr_modules/unet.py:89-120."""
 import pytest
@@ -37,12 +37,12 @@ def forced():
     _lib.debug_option('wino', 0)
     yield
     _lib.debug_option('th_min_wgs', 256)
-    _lib.debug_option('wino', 2)
-    _lib.debug_option('k32', 1)
+    _lib.debug_option('wino', 0)
+    _lib.debug_option('k32', 9)
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize('k32', [1, 5], ids=['default', 'rider-on-16-row-tiles'])
+@pytest.mark.parametrize('k32', [9, 5], ids=['default', 'rider-on-16-row-tiles'])
 def test_layerwise_forced_k32_vs_oracle(full, forced, k32):
     """128x128, B=2: 64-, 128- and 256-channel outputs, concat inputs 128 .. 512 with seams on 32-channel boundaries, riders,
     16-pixel maps under 32-pixel tiles (partial tiles), grids below 256 workgroups (split K)."""
@@ -79,6 +79,47 @@ def test_layerwise_forced_k32_vs_oracle(full, forced, k32):
         assert torch.equal(eng.unet_forward(x.cuda(), nl.cuda()), out)
     finally:
         eng.set_debug(False)
+
+
+@pytest.mark.timeout(900)
+def test_small_grid_two_row_tiles_k32_vs_oracle(full):
+    """Bit 8 of the option: the 2-row-per-wave tiles that small grids pick (B = 2 at 128 x 128 with the default tile rule: 8 x 2-,
+    4 x 4- and 2 x 8-shaped workgroups, most of them with split K) on the form too, riders included (bit 4)."""
+    from fastdiffsr_amd import _lib
+    from oracle import fdsr_oracle as O
+    cfg, eng, sd = full
+    _lib.debug_option('wino', 0)
+    _lib.debug_option('k32', 13)
+    try:
+        gen = torch.Generator().manual_seed(11)
+        x = torch.randn(2, 6, 128, 128, generator=gen)
+        nl = torch.tensor([[0.3], [0.9]])
+        cap = {}
+        with torch.no_grad():
+            ref = O.unet_forward(O.to_torch_sd(sd), cfg, x, nl, capture=cap)
+        eng.set_debug(True)
+        out = eng.unet_forward(x.cuda(), nl.cuda())
+        torch.cuda.synchronize()
+        for L in build_layers(cfg):
+            d = (eng.debug_tensor(L.name).cpu() - cap[L.name]).abs().max().item()
+            scale = max(cap[L.name].abs().max().item(), 1.0)
+            assert d <= TOL_FWD * scale, f'{L.name}: {d:.3e} (scale {scale:.2f})'
+        assert (out.cpu() - ref).abs().max().item() <= TOL_FWD
+        eng.set_debug(False)
+        assert torch.equal(eng.unet_forward(x.cuda(), nl.cuda()), out)
+        _lib.debug_option('k32', 0)      # the 32x32x16 kernels on the same input
+        out_d = eng.unet_forward(x.cuda(), nl.cuda())
+        dd = (out_d - out).abs().max().item()
+        assert 0.0 < dd <= 2e-5, dd
+        # B = 1, 64 x 64 through the loop (every level on 2-row tiles)
+        _lib.debug_option('k32', 13)
+        cond, noise = synth_inputs(1, 64, 64, 20)
+        refl = O.p_sample_loop(O.to_torch_sd(sd), cfg, O.schedule_tables(FASTDIFFSR_SCHEDULE_VAL), cond, noise)
+        assert (eng.sample(cond.cuda(), noise.cuda()).cpu() - refl).abs().max().item() <= TOL_LOOP
+    finally:
+        eng.set_debug(False)
+        _lib.debug_option('wino', 0)
+        _lib.debug_option('k32', 9)
 
 
 @pytest.mark.timeout(900)
