@@ -584,6 +584,323 @@ __global__ void __launch_bounds__(512, 2) conv_k32_kernel(const ConvParams p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The sub-pixel form of Upsample(nearest x2) + Conv3x3 (fdsr_conv_up2.hip: four 2x2 convolutions on the source grid, one per output
+// parity, with pre-summed weights) on the same 16x16x32 machinery: same ConvParams, same grid (source tile x row parity py x cout
+// block), the same packed weights ([cot][kc16][wn][py][slot = px*4 + a*2 + b][plane][lane], read by the same 16-byte permutation).
+// A wave owns 2 source rows x 32 source pixels x 32 couts for both column parities: acc[row][px][pixel half][cout half].  The eight
+// (px, a, b) weight slots of a 32-channel chunk would be 128 VGPRs resident, so the loop runs SLOT-outer / row-inner with a ring of
+// four slots: slot s + 4 is fetched right after slot s's 24 MFMAs.  The activation fragment of (row, a, shift c = px + b) is re-read
+// per slot (8 instead of 6 fragment reads per row: the LDS has the room), one (slot, row) step ahead, pinned.
+template <int TH, int WN, int PREC>
+struct ConvUp2K32Cfg {
+  static constexpr int TW = 32, KC = 32;
+  static constexpr int NP = PREC == PREC_F16X3 ? 2 : 1;
+  static constexpr int ROWB = 64 * NP;
+  static constexpr int HH = TH + 1, HWD = TW + 2, NPIX = HH * HWD;
+  static constexpr int WM = 8 / WN, BN = 32 * WN, MB = TH / WM;
+  static constexpr int RPP = 512 / 8, NIN = (NPIX + RPP - 1) / RPP;
+  static constexpr int BUF_BYTES = NPIX * ROWB;
+  static constexpr int R = 4;   // weight slots in registers (a ring: 8 % R == 0)
+  static_assert(MB == 2, "two source rows per wave");
+};
+
+template <int TH, int WN, int PREC>
+__global__ void __launch_bounds__(512, 2) conv_up2_k32_kernel(const ConvParams p) {
+  using Cfg = ConvUp2K32Cfg<TH, WN, PREC>;
+  constexpr int TW = Cfg::TW, KC = Cfg::KC, NP = Cfg::NP, ROWB = Cfg::ROWB, HWD = Cfg::HWD, NPIX = Cfg::NPIX;
+  constexpr int WM = Cfg::WM, BN = Cfg::BN, MB = Cfg::MB, RPP = Cfg::RPP, NIN = Cfg::NIN, R = Cfg::R;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_uk[];
+  unsigned char* sBuf0 = smem_uk;
+  unsigned char* sBuf1 = smem_uk + Cfg::BUF_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave % WN, wm = wave / WN;
+  const int c15 = lane & 15, g = lane >> 4;
+
+  // source-resolution tiling; p.Hin/Win = source dims, p.Hout/Wout = 2x (as conv_up2_h_kernel)
+  const int nco = p.Cout_pad / BN;
+  const int tilesX = (p.Win + TW - 1) / TW, tilesY = (p.Hin + TH - 1) / TH;
+  int bid;
+  {
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = b & 7, k = b >> 3;
+    bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
+  }
+  const int cot = bid % nco;
+  int pt = bid / nco;
+  const int py = pt & 1;
+  pt >>= 1;
+  const int tx = pt % tilesX;
+  pt /= tilesX;
+  const int ty = pt % tilesY;
+  const int n = pt / tilesY;
+  const int oy0 = ty * TH, ox0 = tx * TW, co0 = cot * BN;
+
+  // ---- staging: halo rows oy0-1+py .. oy0+TH-1+py, cols ox0-1 .. ox0+32 of the SOURCE; raw input (no GroupNorm before an upsample conv)
+  const int q = tid & 7, row0 = tid >> 3;
+  int in_pix[NIN];
+  unsigned skeys = 0;
+#pragma unroll
+  for (int i = 0; i < NIN; ++i) {
+    const int pix = row0 + i * RPP;
+    int v = -2;
+    if (pix < NPIX) {
+      const int hy = pix / HWD, hx = pix % HWD;
+      const int iy = oy0 - 1 + py + hy, ix = ox0 - 1 + hx;
+      const bool ok = iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
+      v = ok ? (n * p.Hin + iy) * p.Win + ix : -1;
+      skeys |= (unsigned)k32_slot<PREC>(0, hx) << (3 * i);
+    }
+    in_pix[i] = v;
+  }
+  const int sbase = row0 * ROWB + 8 * (q & 1);
+  using IO = ActIO<PREC>;
+  typedef typename IO::Quad Quad;
+  Quad rin[NIN];
+  auto prefetch = [&](int kc) {
+    const size_t coff = (size_t)kc * KC + q * 4;
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) rin[i] = IO::load4(p.x0, (size_t)(in_pix[i] < 0 ? 0 : in_pix[i]) * p.C0 + coff);
+  };
+  auto stage = [&](unsigned char* buf) {
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) {
+      if (NIN * RPP > NPIX && i == NIN - 1 && row0 + i * RPP >= NPIX) continue;
+      k_f32x4 v = IO::widen(rin[i]);
+      const int sd = sbase + i * (RPP * ROWB) + 16 * ((q >> 1) ^ (int)((skeys >> (3 * i)) & 7u));
+      if (PREC == PREC_F16X3) {
+        if (p.sat_flag) sat_check(p.sat_flag, v, 65504.f);
+        const float lim = in_pix[i] >= 0 ? 65504.f : 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], -lim, lim);
+        typedef _Float16 h2t __attribute__((ext_vector_type(2)));
+        uint2 hi, lo;
+        {
+          const h2t h0 = {(_Float16)v[0], (_Float16)v[1]}, h1 = {(_Float16)v[2], (_Float16)v[3]};
+          hi.x = __builtin_bit_cast(unsigned, h0);
+          hi.y = __builtin_bit_cast(unsigned, h1);
+        }
+        asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo.x) : "v"(hi.x), "v"(v[0]));
+        asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo.x) : "v"(hi.x), "v"(v[1]));
+        asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo.y) : "v"(hi.y), "v"(v[2]));
+        asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo.y) : "v"(hi.y), "v"(v[3]));
+        *reinterpret_cast<uint2*>(buf + sd) = hi;
+        *reinterpret_cast<uint2*>(buf + (sd ^ 64)) = lo;
+      } else {
+        const float keep = in_pix[i] >= 0 ? 1.f : 0.f;
+        v = v * keep;
+        k_b4 hb = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+        *reinterpret_cast<k_b4*>(buf + sd) = hb;
+      }
+    }
+  };
+
+  // ---- weight fragments: ring slot s % R; [cout half][plane] ----
+  const uint4* wq = reinterpret_cast<const uint4*>(p.wq);
+  const int nk = p.Cin_pad / KC, nk16 = p.Cin_pad / 16;
+  uint4 Wf[R][2][NP];
+  const int wlane = 32 * (g & 1) + c15;
+  auto load_w = [&](int kc, int slot) {
+    const uint4* src = wq + ((((((size_t)cot * nk16 + 2 * kc + (g >> 1)) * WN + wn) * 2 + py) * 8 + slot) * (NP * 64)) + wlane;
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl) Wf[slot % R][ch][pl] = src[pl * 64 + 16 * ch];
+  };
+
+  int xoff[3][NP];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int hx = c15 + c;
+    xoff[c][0] = (wm * HWD + hx) * ROWB + 16 * k32_slot<PREC>(g, hx);
+    if (NP == 2) xoff[c][NP - 1] = xoff[c][0] ^ 64;
+  }
+
+  k_f32x4 acc[MB][2][2][2];   // [row][px][pixel half][cout half]
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int px = 0; px < 2; ++px)
+#pragma unroll
+      for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) acc[mb][px][ph][ch] = k_f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int sl = 0; sl < R; ++sl) load_w(0, sl);
+  prefetch(0);
+  stage(sBuf0);
+  if (nk > 1) prefetch(1);
+  __syncthreads();
+
+  uint4 Xf[2][2][NP];   // [ring slot][pixel half][plane]
+  const unsigned char* xptr[3][NP];
+  auto load_x = [&](int xs, int slot, int mb) {
+    const int a = (slot >> 1) & 1, c = (slot >> 2) + (slot & 1);   // halo row a, column shift px + b
+#pragma unroll
+    for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl)
+        Xf[xs][ph][pl] = *reinterpret_cast<const uint4*>(xptr[c][pl] + ((mb * WM + a) * HWD + 16 * ph) * ROWB);
+  };
+  auto mfma_step = [&](int xs, int slot, int mb) {
+    const int px = slot >> 2, ws = slot % R;
+    if (PREC == PREC_F16X3) {
+#pragma unroll
+      for (int term = 0; term < 3; ++term)
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+          for (int ch = 0; ch < 2; ++ch) {
+            const uint4 xv = Xf[xs][ph][term == 0 ? NP - 1 : 0];
+            const uint4 wv = Wf[ws][ch][term == 1 ? NP - 1 : 0];
+            acc[mb][px][ph][ch] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(k_h8, wv), __builtin_bit_cast(k_h8, xv),
+                                                                        acc[mb][px][ph][ch], 0, 0, 0);
+          }
+    } else {
+#pragma unroll
+      for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch)
+          acc[mb][px][ph][ch] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(k_b8, Wf[ws][ch][0]),
+                                                                       __builtin_bit_cast(k_b8, Xf[xs][ph][0]), acc[mb][px][ph][ch], 0, 0, 0);
+    }
+  };
+
+  for (int kc = 0; kc < nk; ++kc) {
+    unsigned char* cur = (kc & 1) ? sBuf1 : sBuf0;
+    unsigned char* nxt = (kc & 1) ? sBuf0 : sBuf1;
+    const bool more = kc + 1 < nk;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl) xptr[c][pl] = cur + xoff[c][pl];
+    load_x(0, 0, 0);
+#pragma unroll
+    for (int slot = 0; slot < 8; ++slot) {
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        const int s = slot * MB + mb;
+        if (s + 1 < 8 * MB) load_x((s + 1) & 1, (s + 1) / MB, (s + 1) % MB);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_step(s & 1, slot, mb);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (slot + R < 8) load_w(kc, slot + R);
+      else if (more) load_w(kc + 1, slot + R - 8);
+      if (slot == 3 && more) {   // mid-chunk: fill the other halo buffer
+        stage(nxt);
+        if (kc + 2 < nk) prefetch(kc + 2);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: out[2 (oy0 + row) + py][2 (ox0 + col) + px], + bias (+ temb), GroupNorm partials of the output ----
+  const int cob = co0 + wn * 32 + 4 * g;
+  const float winv = p.w_inv_scale_dev ? *p.w_inv_scale_dev : p.w_inv_scale;
+  k_f32x4 add[2];
+  bool cok[2];
+#pragma unroll
+  for (int ch = 0; ch < 2; ++ch) {
+    const int co = cob + 16 * ch;
+    cok[ch] = co < p.Cout;
+    add[ch] = k_f32x4{0.f, 0.f, 0.f, 0.f};
+    if (cok[ch]) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float a = p.bias[co + r];
+        if (p.temb) a += p.temb[(size_t)n * p.temb_stride + p.temb_off + co + r];
+        add[ch][r] = a;
+      }
+    }
+  }
+  k_f32x4 s1[2], s2[2];
+#pragma unroll
+  for (int ch = 0; ch < 2; ++ch) s1[ch] = s2[ch] = k_f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool out16 = PREC == PREC_BF16;   // bf16 mode: the upsample conv's output is a bf16 activation
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int px = 0; px < 2; ++px)
+#pragma unroll
+      for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+          const int sy = oy0 + wm + mb * WM, sx = ox0 + 16 * ph + c15;
+          if (cok[ch] && sy < p.Hin && sx < p.Win) {
+            const size_t idx = ((size_t)(n * p.Hout + 2 * sy + py) * p.Wout + 2 * sx + px) * p.Cout + cob + 16 * ch;
+            const k_f32x4 v = acc[mb][px][ph][ch] * winv + add[ch];
+            if (out16) {
+              uint2 pk;
+              pk.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
+              pk.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
+              *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p.out) + idx) = pk;
+            } else {
+              *reinterpret_cast<k_f32x4*>(p.out + idx) = v;
+            }
+            s1[ch] += v;
+            s2[ch] += v * v;
+          }
+        }
+  if (p.part_out) {
+    float vals[16];
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { vals[ch * 8 + r * 2] = s1[ch][r]; vals[ch * 8 + r * 2 + 1] = s2[ch][r]; }
+#pragma unroll
+    for (int half = 8; half >= 1; half >>= 1) {
+      const bool up = (c15 & half) != 0;
+#pragma unroll
+      for (int i = 0; i < half; ++i) {
+        const float keep = up ? vals[i + half] : vals[i];
+        const float send = up ? vals[i] : vals[i + half];
+        vals[i] = keep + __shfl_xor(send, half, 64);
+      }
+    }
+    float* sp = reinterpret_cast<float*>(smem_uk);   // halo buffers are free after the last barrier
+    {
+      const int ch = c15 >> 3, r = (c15 >> 1) & 3, st = c15 & 1;
+      sp[(wm * BN + wn * 32 + 16 * ch + 4 * g + r) * 2 + st] = vals[0];
+    }
+    __syncthreads();
+    if (tid < BN && co0 + tid < p.Cout) {
+      float a = 0.f, b = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) { a += sp[(w * BN + tid) * 2 + 0]; b += sp[(w * BN + tid) * 2 + 1]; }
+      float* dst = p.part_out + (((size_t)n * (tilesX * tilesY * 2) + (ty * tilesX + tx) * 2 + py) * p.Cout + co0 + tid) * 2;
+      dst[0] = a;
+      dst[1] = b;
+    }
+  }
+}
+
+bool conv_up2_k32_ok(int prec, const ConvParams& p) {
+  if (!(g_tun.k32 & 16) || !(g_tun.k32 & (prec == PREC_BF16 ? 2 : 1))) return false;
+  return p.C1 == 0 && p.C0 % 32 == 0 && p.C0 == p.Cin_pad && p.Cout % 4 == 0 && !p.gn_scale && !p.res;
+}
+
+template <int TH, int WN, int PREC>
+static hipError_t launch_up2_k32_t(const ConvParams& q, int nwg, hipStream_t s) {
+  using Cfg = ConvUp2K32Cfg<TH, WN, PREC>;
+  hipLaunchKernelGGL((conv_up2_k32_kernel<TH, WN, PREC>), dim3(nwg), dim3(512), (size_t)2 * Cfg::BUF_BYTES, s, q);
+  return hipGetLastError();
+}
+
+#define FDSR_UP2_K32_SHAPES(X) X(8, 2) X(4, 4) X(2, 8)
+
+hipError_t launch_conv_up2_k32(int TH, int WN, int prec, const ConvParams& q, int nwg, hipStream_t s) {
+#define X(TH_, WN_)                                                                                    \
+  if (TH == TH_ && WN == WN_)                                                                          \
+    return prec == PREC_F16X3 ? launch_up2_k32_t<TH_, WN_, PREC_F16X3>(q, nwg, s) : launch_up2_k32_t<TH_, WN_, PREC_BF16>(q, nwg, s);
+  FDSR_UP2_K32_SHAPES(X)
+#undef X
+  return hipErrorInvalidValue;
+}
+
 // (TH, WN) pairs with MB = TH / (8 / WN) = 4, and the 2-row-per-wave tiles of small grids (MB = 2)
 #define FDSR_K32_SHAPES(X) X(16, 2) X(8, 4) X(4, 8) X(8, 2) X(4, 4) X(2, 8)
 
@@ -629,8 +946,19 @@ static hipError_t init_k32_t() {
   return hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
+template <int TH, int WN, int PREC>
+static hipError_t init_up2_k32_t() {
+  auto kfn = conv_up2_k32_kernel<TH, WN, PREC>;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
 hipError_t kernels_k32_init() {
   hipError_t e;
+#define X(TH_, WN_)                                                                 \
+  if ((e = init_up2_k32_t<TH_, WN_, PREC_F16X3>()) != hipSuccess) return e;         \
+  if ((e = init_up2_k32_t<TH_, WN_, PREC_BF16>()) != hipSuccess) return e;
+  FDSR_UP2_K32_SHAPES(X)
+#undef X
 #define X(TH_, WN_)                                                                        \
   if ((e = init_k32_t<TH_, WN_, PREC_F16X3, false>()) != hipSuccess) return e;             \
   if ((e = init_k32_t<TH_, WN_, PREC_F16X3, true>()) != hipSuccess) return e;              \

@@ -253,6 +253,7 @@ static hipError_t launch_up2_t(const ConvParams& p, hipStream_t s, int* tiles) {
   const int tilesX = (p.Win + Cfg::TW - 1) / Cfg::TW, tilesY = (p.Hin + TH - 1) / TH;
   if (tiles) *tiles = tilesX * tilesY * 2;
   const int nwg = p.N * tilesX * tilesY * 2 * (p.Cout_pad / Cfg::BN);
+  if (conv_up2_k32_ok(PREC, p)) return launch_conv_up2_k32(TH, WN, PREC, p, nwg, s);   // the 16x16x32 form (fdsr_conv_k32.hip): same grid
   hipLaunchKernelGGL(kfn, dim3(nwg), dim3(512), (size_t)2 * Cfg::BUF_BYTES, s, p);
   return hipGetLastError();
 }

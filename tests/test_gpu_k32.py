@@ -123,6 +123,47 @@ def test_small_grid_two_row_tiles_k32_vs_oracle(full):
 
 
 @pytest.mark.timeout(900)
+@pytest.mark.parametrize('prec', ['f16x3', 'bf16'])
+def test_subpixel_upsample_convs_on_the_form(full, prec):
+    """Bit 16: the sub-pixel Upsample + Conv3x3 launches (ups.3 / ups.7 / ups.11: 256 -> 256, 256 -> 128 ... at 2x the resolution) on
+    the 16x16x32 kernel: layer by layer against the oracle on a ragged map (partial source tiles), against the 32x32x16 up2 kernel."""
+    from fastdiffsr_amd import _lib
+    from oracle import fdsr_oracle as O
+    cfg, eng, sd = full
+    eng.set_precision(prec)
+    tol = TOL_FWD if prec == 'f16x3' else 0.25
+    bits = 25 if prec == 'f16x3' else 27
+    _lib.debug_option('k32', bits)
+    try:
+        gen = torch.Generator().manual_seed(13)
+        x = torch.randn(2, 6, 72, 104, generator=gen)
+        nl = torch.tensor([[0.2], [0.8]])
+        cap = {}
+        with torch.no_grad():
+            ref = O.unet_forward(O.to_torch_sd(sd), cfg, x, nl, capture=cap)
+        eng.set_debug(True)
+        out = eng.unet_forward(x.cuda(), nl.cuda())
+        torch.cuda.synchronize()
+        for L in build_layers(cfg):
+            d = (eng.debug_tensor(L.name).cpu() - cap[L.name]).abs().max().item()
+            scale = max(cap[L.name].abs().max().item(), 1.0)
+            assert d <= tol * scale, f'{L.name}: {d:.3e} (scale {scale:.2f})'
+        eng.set_debug(False)
+        assert torch.equal(eng.unet_forward(x.cuda(), nl.cuda()), out)
+        _lib.debug_option('k32', bits & ~16)
+        out_d = eng.unet_forward(x.cuda(), nl.cuda())
+        dd = (out_d - out).abs().max().item()
+        assert dd > 0.0                   # (0.0 would mean the form was never taken)
+        if prec == 'f16x3':
+            assert dd <= 2e-5, dd
+            assert (out.cpu() - ref).abs().max().item() <= TOL_FWD
+    finally:
+        eng.set_debug(False)
+        eng.set_precision('f16x3')
+        _lib.debug_option('k32', 9)
+
+
+@pytest.mark.timeout(900)
 def test_loop_forced_k32_vs_oracle_and_graph(full, forced):
     """The 20-step loop, 64x64, B=2, every eligible launch on the form; eager == hipGraph replay."""
     from fastdiffsr_amd import _lib
