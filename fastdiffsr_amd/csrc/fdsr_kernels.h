@@ -81,7 +81,7 @@ struct Tunables {
   int wino_wide_cin = 1 << 30;   // ... rider-less launches with at least this many input channels take it too (384 until the 16x16x32
                             // direct form overtook it there: 67.9 vs 66.8 img/s same box); with wino on: only the 32 x 32 maps
   int wino_all = 0;         // ... 0: only the layers where it measured faster (conv_wino_ok); 1: every eligible launch
-  int k32 = 9;              // v_mfma_f32_16x16x32 form (fdsr_conv_k32.hip) of the stride-1 3x3 launches that fit it; bits: 1 f16x3, 2 bf16, 4 the 16-row tile with a rider, 8 the 2-row-per-wave tiles of small grids, 16 the sub-pixel upsample convs; 0 never
+  int k32 = 27;             // v_mfma_f32_16x16x32 form (fdsr_conv_k32.hip) of the stride-1 3x3 launches that fit it; bits: 1 f16x3, 2 bf16, 4 the 16-row tile with a rider, 8 the 2-row-per-wave tiles of small grids, 16 the sub-pixel upsample convs; 0 never
   int sat_guard = 1;        // f16x3: sticky device flag when a RAW conv input exceeds the f16 range
   int drop_image_offset = 0;   // tests: the batch is images [offset, offset + N) of a larger one (its dropout masks follow)
   unsigned epoch = 0;

@@ -189,7 +189,7 @@ int fdsr_check_saturation(fdsr_handle h, void* hip_stream);
 /* Debug / A-B options of the launchers (process-wide; nothing in the library reads the environment).  Names:
  * "rider" (0|1|2), "up2" (0|1), "th_min_wgs", "splitk" (0|1), "sk_target", "wgrad_form" (0 default | 1 four-wave | 2 eight-wave
  * plain), "wgrad_colsum" (0|1), "wgrad_f32" (0|1), "wgrad_big_bytes", "wino" (0 default|1|2|4), "wino_min_wgs", "wino_all" (0|1), "wino_wide_cin",
- * "k32" (bits: 1 f16x3, 2 bf16, 4 16-row tiles with a rider, 8 2-row tiles of small grids; default 9 -- the 16x16x32-MFMA form of the
+ * "k32" (bits: 1 f16x3, 2 bf16, 4 16-row tiles with a rider, 8 2-row tiles of small grids, 16 the sub-pixel upsample convs; default 27 -- the 16x16x32-MFMA form of the
  * stride-1 3x3 launches), "sat_guard" (0|1),
  * "drop_image_offset" (the batch is images [k, k+N) of a larger one: its dropout masks are those images' masks).
  * Every setting computes the same function within the tested bounds; they exist so that tests can force each kernel

@@ -1,7 +1,7 @@
 """The 16x16x32-MFMA form of the stride-1 3x3 convolutions (fdsr_conv_k32.hip): on by default for f16x3 launches whose wave tile is
 4 x 32 or 2 x 32 pixels (except the 16-row tile with a rider); here it is FORCED onto every eligible launch of a small forward (largest tile regardless of the grid size, so
 the split-K, partial-tile and rider paths of the form all run), layer by layer against the oracle, in every option setting
-(bits of `k32`: 1 f16x3, 2 bf16, 4 the 16-row tile with a rider, 8 the 2-row tiles of small grids), against the 32x32x16 kernels on the same input, and through the
+(bits of `k32`: 1 f16x3, 2 bf16, 4 the 16-row tile with a rider, 8 the 2-row tiles of small grids, 16 the sub-pixel upsample convs; default 27), against the 32x32x16 kernels on the same input, and through the
 20-step loop.  Same bounds as every other conv kernel: layerwise 1e-4 * max(1, |ref|), loop 1e-3 (north_star); bf16 0.25 layerwise
 (judged on PSNR elsewhere).  Reference: fastdiffsr_modules/unet.py:89-120."""
 import pytest
@@ -38,11 +38,11 @@ def forced():
     yield
     _lib.debug_option('th_min_wgs', 256)
     _lib.debug_option('wino', 0)
-    _lib.debug_option('k32', 9)
+    _lib.debug_option('k32', 27)
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize('k32', [9, 5], ids=['default', 'rider-on-16-row-tiles'])
+@pytest.mark.parametrize('k32', [27, 5], ids=['default', 'rider-on-16-row-tiles'])
 def test_layerwise_forced_k32_vs_oracle(full, forced, k32):
     """128x128, B=2: 64-, 128- and 256-channel outputs, concat inputs 128 .. 512 with seams on 32-channel boundaries, riders,
     16-pixel maps under 32-pixel tiles (partial tiles), grids below 256 workgroups (split K)."""
@@ -119,7 +119,7 @@ def test_small_grid_two_row_tiles_k32_vs_oracle(full):
     finally:
         eng.set_debug(False)
         _lib.debug_option('wino', 0)
-        _lib.debug_option('k32', 9)
+        _lib.debug_option('k32', 27)
 
 
 @pytest.mark.timeout(900)
@@ -160,7 +160,7 @@ def test_subpixel_upsample_convs_on_the_form(full, prec):
     finally:
         eng.set_debug(False)
         eng.set_precision('f16x3')
-        _lib.debug_option('k32', 9)
+        _lib.debug_option('k32', 27)
 
 
 @pytest.mark.timeout(900)
@@ -185,8 +185,8 @@ def test_loop_forced_k32_vs_oracle_and_graph(full, forced):
 
 @pytest.mark.timeout(900)
 def test_bf16_k32_layerwise(full, forced):
-    """bf16 mode takes the form only on request (bit 2): same layerwise bound as the bf16 32x32x16 kernels, and the two
-    agree to bf16 rounding of the intermediate tensors."""
+    """bf16 mode on the form (bit 2): same layerwise bound as the bf16 32x32x16 kernels, and the two agree to bf16 rounding of the
+    intermediate tensors."""
     from fastdiffsr_amd import _lib
     from oracle import fdsr_oracle as O
     cfg, eng, sd = full
