@@ -56,6 +56,9 @@ __device__ __forceinline__ float silu_k(float v) { return v * __builtin_amdgcn_r
 #ifndef K32_SPLIT     // f16x3: the next chunk's input is fetched and staged in two halves (taps 0-3, 3-7): half the prefetch registers
 #define K32_SPLIT 1
 #endif
+#ifndef K32_SPLIT_BF16   // ... in bf16 mode too
+#define K32_SPLIT_BF16 1
+#endif
 #ifndef K32_MIXSPLIT  // hi/lo split of the staging as v_cvt_pk_f16_f32 + v_fma_mix (fewer VALU instructions, same bits)
 #define K32_MIXSPLIT 1
 #endif
@@ -149,7 +152,7 @@ __global__ void __launch_bounds__(512, 2) conv_k32_kernel(const ConvParams p) {
 
   using IO = ActIO<PREC>;
   typedef typename IO::Quad Quad;
-  constexpr bool SPLIT = K32_SPLIT != 0 && PREC == PREC_F16X3 && !RIDER;   // (the rider's whole-chunk sets would stay live across the main loop)
+  constexpr bool SPLIT = K32_SPLIT != 0 && (PREC == PREC_F16X3 || K32_SPLIT_BF16 != 0) && !RIDER;   // (the rider's whole-chunk sets would stay live across the main loop)
   constexpr int NA = SPLIT ? (NIN + 1) / 2 : NIN;   // quads in flight in the main loop
   typedef std::integral_constant<int, 0> I_0;
   typedef std::integral_constant<int, NA> I_A;
