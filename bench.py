@@ -175,13 +175,33 @@ def kernel_source_hash():
     return h.hexdigest()
 
 
-def conv_roofline(prof, precision, B, S, dt_total, round_tag='r03'):
+K32_BITS = 27      # Tunables::k32 default (include/fdsr.h); --debug-option k32=... overrides it for the labels below
+
+
+def family_label(precision):
+    """Names of the kernels the 3x3 family's launches run on under the active options (what to sum in a rocprofv3 stats file)."""
+    if precision == 'f32':
+        return 'conv_mfma_f32_kernel'
+    bit = 1 if precision == 'f16x3' else 2
+    names = []
+    if K32_BITS & bit:
+        names.append('conv_k32_kernel')
+        if K32_BITS & 16:
+            names.append('conv_up2_k32_kernel')
+    names.append('conv_mfma_h_kernel<3, ...>')
+    if not (K32_BITS & bit and K32_BITS & 16):
+        names.append('conv_up2_h_kernel')
+    names.append('conv_mfma_f32_kernel<3, ...> (the 6-channel input conv)')
+    return ' + '.join(names)
+
+
+def conv_roofline(prof, precision, B, S, dt_total, round_tag='r04'):
     """Roofline of the dominant kernel family = every 3x3 convolution launch (implicit-GEMM MFMA kernels incl. the
     sub-pixel upsample form and the 6-channel input conv): algorithmic FLOPs / HIP-event time around those launches."""
     ach = prof['conv_flops'] / (prof['conv_ms'] * 1e-3) / 1e12
     peak = PEAK_F32_MFMA if precision == 'f32' else PEAK_16BIT_MFMA
     passes = 3 if precision == 'f16x3' else 1     # MFMA products issued per algorithmic product
-    kern = 'conv_mfma_f32_kernel' if precision == 'f32' else ('conv_k32_kernel + conv_mfma_h_kernel' if precision == 'f16x3' else 'conv_mfma_h_kernel')
+    kern = family_label(precision)
     # HBM bytes per launch of the SAME launch set (3x3 family), from rocprofv3 --pmc passes of this command kept
     # under profiles/ (separate FETCH_SIZE / WRITE_SIZE runs, gfx950 x2 read correction: tools/pmc_traffic.py).
     # Quoted only while the file was measured on these very kernel sources; otherwise null.
@@ -228,10 +248,12 @@ def whole_path(ips_per_gpu, precision):
             'ideal_fused_gbytes_per_s': ips_per_gpu * gb, 'frac_hbm_peak': ips_per_gpu * gb / 8000.0}
 
 
-def run_config(eng, dev, precision, B, S, steps, warmup, graph, noise_mode, rank=0, sync=None, want_profile=True):
+def run_config(eng, dev, precision, B, S, steps, warmup, graph, noise_mode, rank=0, sync=None, want_profile=True, per_pass=None):
     """Time `steps` passes of the hot path for one configuration.  Returns (seconds, out tensor, profile or None).
     With graph=True the timed region replays the captured loop; the per-launch roofline then comes from ONE extra
-    eager pass after the timed region (HIP events cannot bracket launches inside a graph replay)."""
+    eager pass after the timed region (HIP events cannot bracket launches inside a graph replay).
+    per_pass: a list that receives every pass's own seconds (a synchronisation after each pass; sub-records only -- the
+    headline times its K steps in one bracket, as the contract says)."""
     from fastdiffsr_amd.synth import synth_inputs
     eng.set_precision(precision)
     if noise_mode == 'tensor':
@@ -253,7 +275,11 @@ def run_config(eng, dev, precision, B, S, steps, warmup, graph, noise_mode, rank
         eng.profile_begin()
     t0 = time.perf_counter()
     for _ in range(steps):
+        tp = time.perf_counter()
         eng.sample(cond, noise, out=out, graph=graph)
+        if per_pass is not None:
+            sync()
+            per_pass.append(time.perf_counter() - tp)
     sync()
     dt = time.perf_counter() - t0
     prof = eng.profile_end() if profile else None
@@ -268,7 +294,7 @@ def run_config(eng, dev, precision, B, S, steps, warmup, graph, noise_mode, rank
     return dt, out, prof, prof_dt
 
 
-def run_train(eng, dev, B, S, steps, warmup, rank=0, sync=None, allreduce=None, precision='f16x3'):
+def run_train(eng, dev, B, S, steps, warmup, rank=0, sync=None, allreduce=None, precision='f16x3', per_pass=None):
     """Time `steps` optimisation steps (BASELINE configs[4], "training step"): noise draw + img2res + q_sample + forward + L1 loss /
     (b*c*h*w) + backward + Adam, all in the engine (no ATen kernel in the timed region), Dropout(0.2) live as in .train() mode.
     Returns seconds.  A "step" = one optimizer step over one batch of B synthetic 256x256 HR/SR pairs per GPU."""
@@ -299,7 +325,11 @@ def run_train(eng, dev, B, S, steps, warmup, rank=0, sync=None, allreduce=None, 
     sync()
     t0 = time.perf_counter()
     for _ in range(steps):
-        loss = one()
+        tp = time.perf_counter()
+        loss = one()           # returns the loss: the step is synchronous (fdsr_train_grads hands the scalar back)
+        if per_pass is not None:
+            sync()
+            per_pass.append(time.perf_counter() - tp)
     sync()
     dt = time.perf_counter() - t0
     eng.set_training(False)
@@ -316,10 +346,16 @@ def train_roofline(ips_per_gpu, precision):
     peak = PEAK_F32_MFMA if precision == 'f32' else PEAK_16BIT_MFMA
     passes = 3 if precision == 'f16x3' else 1
     fam = ('conv_mfma_f32_kernel (forward, input gradients) + wgrad_kernel (weight gradients)' if precision == 'f32' else
-           'conv_mfma_h_kernel (forward, input gradients) + wgrad_h8i_kernel / wgrad_h_kernel (weight gradients)')
+           family_label(precision) + ' (forward, input gradients) + wgrad_h8i_kernel / wgrad_h_kernel (weight gradients)')
     return {'bound': 'mfma', 'kernel': fam, 'achieved': tf, 'peak': peak, 'unit': 'TFLOP/s', 'frac': tf / peak,
             'mfma_passes_per_product': passes, 'executed_tflops': tf * passes, 'frac_executed': tf * passes / peak, 'traffic': None,
             'scope': 'whole optimisation step (algorithmic conv FLOPs of forward + backward / step time)'}
+
+
+def pass_stats(per_pass, units):
+    """min / median / max over the timed passes of a record, as images/s (each pass synchronised on its own)."""
+    v = sorted(units / t for t in per_pass)
+    return {'passes': len(v), 'min': v[0], 'median': float(np.median(v)), 'max': v[-1], 'unit': 'images/s per pass'}
 
 
 def train_record(cfg, sd, dev, B, S, steps, warmup, precision='f16x3'):
@@ -328,14 +364,15 @@ def train_record(cfg, sd, dev, B, S, steps, warmup, precision='f16x3'):
         from fastdiffsr_amd.engine import Engine
         eng = Engine(cfg)
         eng.load_state_dict(sd)
-        dt = run_train(eng, dev, B, S, steps, warmup, precision=precision)
+        pp = []
+        dt = run_train(eng, dev, B, S, steps, warmup, precision=precision, per_pass=pp)
         del eng
         torch.cuda.empty_cache()
         ips = B * steps / dt
         # forward + backward = 3 x the forward's 268.31 GFLOP per image, exact fp32 MFMA
         tf = ips * 3 * FLOPS_PER_IMAGE / 20 / 1e12
         return {'value': ips, 'unit': 'images/s (one optimisation step per batch)', 'ms_per_step': 1e3 * dt / steps, 'steps': steps,
-                'warmup': warmup, 'dtype': precision, 'batch': B,
+                'warmup': warmup, 'dtype': precision, 'batch': B, 'per_pass': pass_stats(pp, B),
                 'workload': 'configs[4] per-GPU slice: batch 32, 256x256, q_sample + L1(sum)/(b*c*h*w) (define_G fixes loss_type l1) + '
                             'backward + Adam, Dropout(0.2) live; ' + ('everything exact fp32' if precision == 'f32' else
                                                                  'every convolution (forward, input and weight gradients) f16x3 = fp32-grade'),
@@ -344,12 +381,149 @@ def train_record(cfg, sd, dev, B, S, steps, warmup, precision='f16x3'):
         return {'error': f'{type(e).__name__}: {e}'}
 
 
+def synth_folder(root, n, hr_size=256, lr_size=64, workers=8):
+    """A dataset folder in the reference's layout (data/prepare_data_mfe_dm.py: hr_{r}/, lr_{l}/, sr_{l}_{r}/ of PNG files): n
+    smooth-plus-noise RGB images, the LR / SR members made with Pillow's bicubic as the reference's preparation script does."""
+    from concurrent.futures import ThreadPoolExecutor
+    from PIL import Image
+    import shutil
+    subs = (f'hr_{hr_size}', f'lr_{lr_size}', f'sr_{lr_size}_{hr_size}')
+    for sub in subs:
+        os.makedirs(os.path.join(root, sub), exist_ok=True)
+    yy, xx = np.mgrid[0:hr_size, 0:hr_size]
+    unique = min(n, 32)        # 32 different images; the rest of the n files are copies of them (every file is still decoded)
+
+    def one(i):
+        rng = np.random.default_rng(1000 + i)
+        hr = np.stack([127 + 90 * np.sin(xx / (5.0 + i % 7) + c) * np.cos(yy / (9.0 + (i // 7) % 5) + c) for c in range(3)], -1)
+        hr = np.clip(hr + rng.normal(0, 6, hr.shape), 0, 255).astype(np.uint8)
+        him = Image.fromarray(hr)
+        lim = him.resize((lr_size, lr_size), Image.BICUBIC)
+        sim = lim.resize((hr_size, hr_size), Image.BICUBIC)
+        name = '%05d.png' % i
+        him.save(os.path.join(root, f'hr_{hr_size}', name))
+        lim.save(os.path.join(root, f'lr_{lr_size}', name))
+        sim.save(os.path.join(root, f'sr_{lr_size}_{hr_size}', name))
+
+    with ThreadPoolExecutor(max_workers=workers) as ex:
+        list(ex.map(one, range(unique)))
+    for i in range(unique, n):
+        for sub in subs:
+            shutil.copyfile(os.path.join(root, sub, '%05d.png' % (i % unique)), os.path.join(root, sub, '%05d.png' % i))
+    return root
+
+
+def facade_opt(root, phase, batch_size=32, workers=8):
+    """The option tree core/logger.py parses from config/sr_fastdiffsr_{train,test}_64_256.json, for a synthetic folder."""
+    from fastdiffsr_amd.arch import FASTDIFFSR_SCHEDULE_VAL
+    from fastdiffsr_amd.config import dict_to_nonedict
+    ds = {'dataroot': root, 'datatype': 'img', 'l_resolution': 64, 'r_resolution': 256, 'data_len': -1}
+    return dict_to_nonedict({
+        'name': 'bench_facade', 'phase': phase, 'gpu_ids': [0], 'distributed': False,
+        'path': {'log': None, 'results': os.path.join(root, 'results'), 'checkpoint': os.path.join(root, 'checkpoint'), 'resume_state': None},
+        'datasets': {'train': dict(ds, name='t', mode='HR', batch_size=batch_size, num_workers=workers, use_shuffle=True),
+                     'val': dict(ds, name='v', mode='LRHR')},
+        'model': {'which_model_G': 'fastdiffsr', 'finetune_norm': False,
+                  'unet': {'in_channel': 6, 'out_channel': 3, 'inner_channel': 64, 'norm_groups': 32, 'channel_multiplier': [1, 2, 4, 4],
+                           'attn_res': [16], 'res_blocks': 2, 'dropout': 0.2},
+                  'beta_schedule': {'train': dict(FASTDIFFSR_SCHEDULE_VAL), 'val': dict(FASTDIFFSR_SCHEDULE_VAL)},
+                  'diffusion': {'image_size': 256, 'channels': 3, 'conditional': True}},
+        'train': {'n_iter': 10 ** 9, 'val_freq': 10 ** 9, 'save_checkpoint_freq': 10 ** 9, 'print_freq': 10 ** 9,
+                  'optimizer': {'type': 'adam', 'lr': 1e-4}}})
+
+
+def facade_records(cfg, sd, dev, S, engine_ips, n_images=256, batch=16):
+    """The path a user of the reference drives, end to end, on files: `val_e2e` = fastdiffsr_amd.val.run over a folder of n_images
+    256x256 pairs (PNG decode in loader threads, uint8 over PCIe, the 20-step loop, device tensor2img + MSE / PSNR / SSIM / ERGAS,
+    uint8 back, .tif files written) -- wall clock of the whole call; `train_facade_b32` = create_model(opt) + the threaded loader +
+    DDPM.feed_data / optimize_parameters (model/model.py:44-57), the loop of fastdiffsr_amd.train.run."""
+    import shutil
+    import tempfile
+    recs = {}
+    if S != 256:
+        return recs
+    root = tempfile.mkdtemp(prefix='fdsr_bench_')
+    try:
+        t0 = time.perf_counter()
+        synth_folder(root, n_images)
+        t_make = time.perf_counter() - t0
+        from fastdiffsr_amd import val as V
+        from fastdiffsr_amd.dataset import ThreadedBatchLoader, create_dataset
+        from fastdiffsr_amd.model import create_model
+        tsd = {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
+        try:
+            opt = facade_opt(root, 'val')
+            model = create_model(opt)
+            model.netG.denoise_fn.load_state_dict(tsd, strict=True)
+            log = []
+            V.run(opt, batch=batch, results=os.path.join(root, 'warm'), max_images=2 * batch, log=log.append, diffusion=model)   # warm-up: uploads, graph capture
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            r = V.run(opt, batch=batch, results=os.path.join(root, 'out'), log=log.append, diffusion=model)
+            torch.cuda.synchronize(dev)
+            dt = time.perf_counter() - t0
+            written = len(os.listdir(os.path.join(root, 'out')))
+            ips = r['images'] / dt
+            recs['val_e2e'] = {
+                'value': ips, 'unit': 'images/s', 'images': r['images'], 'files_written': written, 'batch': batch, 'dtype': 'f16x3', 'seconds': dt,
+                'sampling_seconds': r['sample_seconds_this_rank'], 'sampling_share': r['sample_seconds_this_rank'] / dt,
+                'vs_engine_headline': ips / engine_ips if engine_ips else None,
+                'sr_psnr': r['sr_psnr'], 'sr_ssim': r['sr_ssim'], 'bic_psnr': r['bic_psnr'],
+                'workload': f'fastdiffsr_amd.val.run (= python -m fastdiffsr_amd.val --batch {batch}) over {n_images} synthetic 256x256 PNG pairs (32 distinct images): decode, '
+                            'H2D as uint8, 20-step loop (torch-drawn noise, hipGraph replay from the 2nd batch), device tensor2img + MSE/PSNR/SSIM/ERGAS, '
+                            'D2H as uint8, one .tif per image -- wall clock of the whole call',
+                'dataset_build_seconds': t_make, 'host_cores': host_cores()}
+            del model
+            torch.cuda.empty_cache()
+        except Exception as e:
+            recs['val_e2e'] = {'error': f'{type(e).__name__}: {e}'}
+        try:
+            B, steps, warmup = 32, 6, 2
+            opt = facade_opt(root, 'train', batch_size=B)
+            torch.manual_seed(7)
+            np.random.seed(7)
+            model = create_model(opt)
+            model.netG.denoise_fn.load_state_dict(tsd, strict=True)
+            ops = V.HipOps('cuda')
+            loader = ThreadedBatchLoader(create_dataset(opt['datasets']['train'], 'train'), B, shuffle=True, workers=8)
+            model.set_new_noise_schedule(opt['model']['beta_schedule']['train'], schedule_phase='train')
+            it = iter(loader)
+            pp = []
+            for k in range(warmup + steps):
+                if k == warmup:
+                    torch.cuda.synchronize(dev)
+                    t0 = time.perf_counter()
+                tp = time.perf_counter()
+                data = next(it)
+                data.pop('Index')
+                model.feed_data({key: ops.to_tensor(ops.upload(key, v)) for key, v in data.items()})
+                model.optimize_parameters()
+                if k >= warmup:
+                    pp.append(time.perf_counter() - tp)     # optimize_parameters returns the loss: the step is synchronous
+            torch.cuda.synchronize(dev)
+            dt = time.perf_counter() - t0
+            ips = B * steps / dt
+            recs['train_facade_b32'] = {
+                'value': ips, 'unit': 'images/s (one optimisation step per batch)', 'ms_per_step': 1e3 * dt / steps, 'steps': steps, 'warmup': warmup,
+                'dtype': 'f16x3', 'batch': B, 'per_pass': pass_stats(pp, B), 'l_pix': model.get_current_log().get('l_pix'),
+                'workload': 'create_model(opt) + threaded loader over PNG files + DDPM.feed_data / optimize_parameters (model/model.py:44-57): the loop '
+                            'of fastdiffsr_amd.train.run; numpy-drawn t and gamma, torch-drawn noise, Dropout(0.2) live, every convolution f16x3'}
+            del model
+            torch.cuda.empty_cache()
+        except Exception as e:
+            recs['train_facade_b32'] = {'error': f'{type(e).__name__}: {e}'}
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+    return recs
+
+
 def sub_record(eng, dev, name, precision, B, S, steps, warmup, graph, note):
     try:
-        dt, _, prof, prof_dt = run_config(eng, dev, precision, B, S, steps, warmup, graph, 'engine')
+        pp = []
+        dt, _, prof, prof_dt = run_config(eng, dev, precision, B, S, steps, warmup, graph, 'engine', per_pass=pp)
         ips = B * steps / dt
         r = {'value': ips, 'unit': 'images/s', 'ms_per_step': 1e3 * dt / steps, 'steps': steps, 'warmup': warmup,
-             'dtype': precision, 'batch': B, 'hipgraph': bool(graph), 'workload': note,
+             'dtype': precision, 'batch': B, 'hipgraph': bool(graph), 'workload': note, 'per_pass': pass_stats(pp, B),
              'whole_path': whole_path(ips, precision)}
         if prof and prof['conv_ms'] > 0:
             r['roofline'] = conv_roofline(prof, precision, B, S, prof_dt)
@@ -441,27 +615,94 @@ def rank_env(base, rank, world, port):
     return env
 
 
-def launch_ranks(n, argv, visible=None, popen=None, script=None):
-    """`python bench.py --gpus N` without torchrun: this process -- which has NOT touched the GPU (no torch.cuda call that
-    initialises HIP; device_count() does not) -- starts N fresh child processes, one per GPU, relays rank 0's single JSON
-    line on stdout (every other rank's stdout goes to stderr) and returns the worst child exit code.  Never an exec."""
+def visible_gpus():
+    """How many GPUs this process may use, WITHOUT bringing up HIP in it (the launcher parent must stay GPU-free: its children
+    are the ranks).  HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES when set, else the KFD topology: nodes with SIMDs."""
+    for var in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(',') if x.strip() != ''])
+    n, root = 0, '/sys/class/kfd/kfd/topology/nodes'
+    try:
+        for d in os.listdir(root):
+            try:
+                for line in open(os.path.join(root, d, 'properties')):
+                    if line.startswith('simd_count') and int(line.split()[1]) > 0:
+                        n += 1
+            except OSError:
+                pass
+    except OSError:
+        return None       # no KFD view: let rank k fail on set_device instead of guessing
+    return n
+
+
+def launch_ranks(n, argv, visible=None, popen=None, script=None, poll_s=0.2, grace_s=5.0):
+    """`python bench.py --gpus N` without torchrun: this process -- which never touches the GPU (visible_gpus() reads sysfs) --
+    starts N fresh child processes, one per GPU and each in a session of its own, relays rank 0's single JSON line on stdout
+    (every other rank's stdout goes to stderr) and watches ALL of them: the first rank that exits non-zero, or a SIGTERM / SIGINT
+    to this process, takes the whole job down (terminate, then kill after `grace_s`), so no rank is left waiting in a rendezvous
+    and none outlives the launcher.  Returns the first failing exit code.  Never an exec."""
+    import signal
     import subprocess
     if visible is None:
-        visible = torch.cuda.device_count()
-    if visible < n:
+        visible = visible_gpus()
+    if visible is not None and visible < n:
         print(f'bench.py: --gpus {n} but only {visible} device(s) visible', file=sys.stderr)
         return 2
     popen = popen or subprocess.Popen
     port = free_port()
     procs = []
-    for r in range(n):
-        procs.append(popen([sys.executable, script or os.path.abspath(__file__)] + list(argv), env=rank_env(os.environ, r, n, port),
-                           stdout=(None if r == 0 else sys.stderr)))
+    stop = {'sig': None}
+
+    def on_signal(signum, frame):
+        stop['sig'] = signum
+
+    old = {}
+    for sg in (signal.SIGTERM, signal.SIGINT):
+        try:
+            old[sg] = signal.signal(sg, on_signal)
+        except ValueError:          # not the main thread (tests): no handlers, polling still tears down on failure
+            pass
+
+    def teardown():
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, signal.SIGTERM)        # start_new_session: pid == pgid, the rank and anything it started
+                except (ProcessLookupError, PermissionError, AttributeError):
+                    p.terminate()
+        t_end = time.time() + grace_s
+        for p in procs:
+            while p.poll() is None and time.time() < t_end:
+                time.sleep(0.05)
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)
+                except (ProcessLookupError, PermissionError, AttributeError):
+                    p.kill()
+                p.wait()
+
     rc = 0
-    for p in procs:
-        c = p.wait()
-        if c != 0:
-            rc = c if rc == 0 or abs(c) > abs(rc) else rc
+    try:
+        for r in range(n):
+            procs.append(popen([sys.executable, script or os.path.abspath(__file__)] + list(argv), env=rank_env(os.environ, r, n, port),
+                               stdout=(None if r == 0 else sys.stderr), start_new_session=True))
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [c for c in codes if c not in (None, 0)]
+            if bad:
+                rc = bad[0]
+                break
+            if stop['sig'] is not None:
+                rc = 128 + int(stop['sig'])
+                break
+            if all(c == 0 for c in codes):
+                break
+            time.sleep(poll_s)
+    finally:
+        teardown()
+        for sg, h in old.items():
+            signal.signal(sg, h)
     return rc
 
 
@@ -510,9 +751,12 @@ def main():
 
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
+    global K32_BITS
     for item in args.debug_option:
         k, v = item.split('=')
         _lib.debug_option(k, int(v))
+        if k == 'k32':
+            K32_BITS = int(v)
     cfg = UNetConfig(**FASTDIFFSR_UNET)
     # weights: rank 0 builds the random-init UNet, ONE RCCL broadcast replicates it
     sd = synth_state_dict(cfg, 0) if rank == 0 else None
@@ -602,17 +846,21 @@ def main():
             res['sub_records'] = dist_recs
         if world == 1 and not distributed and not args.no_sub_records:
             # the other arithmetic modes and batch regimes of BASELINE.json, driver-visible in the same line
+            # every record: >= 6 timed passes after >= 2 warm-up passes (more when the driver asks for more: steps/3, warmup/2),
+            # each pass synchronised on its own so that min / median / max ride in the record
+            ks, kw = max(6, args.steps // 3), max(2, args.warmup // 2)
             res['sub_records'] = {
-                'exact_f32': sub_record(eng, dev, 'exact_f32', 'f32', 16, S, 2, 1, False,
+                'exact_f32': sub_record(eng, dev, 'exact_f32', 'f32', 16, S, ks, kw, False,
                                         'configs[1] in exact fp32 MFMA arithmetic (v_mfma_f32_32x32x2_f32), B=16'),
-                'bf16_b64_graph': sub_record(eng, dev, 'bf16_b64_graph', 'bf16', 64, S, 2, 1, True,
+                'bf16_b64_graph': sub_record(eng, dev, 'bf16_b64_graph', 'bf16', 64, S, ks, kw, True,
                                              'configs[2]: B=64, bf16 activations + bf16 MFMA, 20-step loop replayed as a hipGraph'),
-                'b1_graph': sub_record(eng, dev, 'b1_graph', 'f16x3', 1, S, 10, 2, True,
+                'b1_graph': sub_record(eng, dev, 'b1_graph', 'f16x3', 1, S, max(20, args.steps), max(5, args.warmup), True,
                                        'configs[0] regime (the reference val loop is B=1, sr_mfe.py:279-284): latency per image, hipGraph'),
             }
-            res['sub_records']['train_step_b32'] = train_record(cfg, sd, dev, 32, S, 2, 1, 'f16x3')
-            res['sub_records']['train_step_b32_f32'] = train_record(cfg, sd, dev, 32, S, 2, 1, 'f32')
+            res['sub_records']['train_step_b32'] = train_record(cfg, sd, dev, 32, S, ks, kw, 'f16x3')
+            res['sub_records']['train_step_b32_f32'] = train_record(cfg, sd, dev, 32, S, ks, kw, 'f32')
             eng.set_precision(args.precision)
+            res['sub_records'].update(facade_records(cfg, sd, dev, S, ips))
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'], ref = cpu_baseline(cfg, sd)
             eng.set_precision(args.precision)

@@ -7,6 +7,8 @@ from .build import LIB
 
 FDSR_MAX_MULTS = 8
 FDSR_SAMPLE_GRAPH = 1
+FDSR_METRIC_FIELDS = 8
+FDSR_SSIM_UNIFORM7, FDSR_SSIM_GAUSS11 = 1, 2
 PRECISIONS = {'f32': 0, 'f16x3': 1, 'bf16': 2}
 
 
@@ -63,6 +65,11 @@ SYMBOLS = {
                                          C.c_void_p, C.c_void_p]),
     'fdsr_tensor2img_u8': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                      C.c_void_p]),
+    'fdsr_u8_to_tensor': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
+                                    C.c_void_p]),
+    'fdsr_image_metrics_workspace_bytes': (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
+    'fdsr_image_metrics_u8': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                        C.c_void_p, C.c_size_t, C.c_void_p]),
     'fdsr_set_debug': (C.c_int, [C.c_void_p, C.c_int]),
     'fdsr_debug_option': (C.c_int, [C.c_char_p, C.c_longlong]),
     'fdsr_check_saturation': (C.c_int, [C.c_void_p, C.c_void_p]),

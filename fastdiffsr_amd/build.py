@@ -11,7 +11,7 @@ LIB = os.path.join(CSRC, 'libfdsr_hip.so')
 SOURCES = [('fdsr_kernels.hip', ['-O3', '-munsafe-fp-atomics']), ('fdsr_conv_h.hip', ['-O3', '-fno-slp-vectorize']),
            ('fdsr_conv_up2.hip', ['-O3', '-fno-slp-vectorize']), ('fdsr_conv_wino.hip', ['-O3', '-fno-slp-vectorize']),
            ('fdsr_conv_k32.hip', ['-O3', '-fno-slp-vectorize']),
-           ('fdsr_train.hip', ['-O3']), ('fdsr_engine.cpp', ['-O2']), ('fdsr_train.cpp', ['-O2'])]
+           ('fdsr_val.hip', ['-O3']), ('fdsr_train.hip', ['-O3']), ('fdsr_engine.cpp', ['-O2']), ('fdsr_train.cpp', ['-O2'])]
 COMMON = ['--offload-arch=gfx950', '-std=c++17', '-fPIC', '-Wno-unused-result']
 
 
@@ -97,7 +97,7 @@ def build(force=False, verbose=True):
 
     with ThreadPoolExecutor(max_workers=min(6, len(SOURCES))) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', LIB]
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-Wl,-z,defs'] + objs + ['-o', LIB]   # a missing object fails HERE, not at dlopen
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -908,7 +908,7 @@ hipError_t launch_conv_up2_k32(int TH, int WN, int prec, const ConvParams& q, in
 #define FDSR_K32_SHAPES(X) X(16, 2) X(8, 4) X(4, 8) X(8, 2) X(4, 4) X(2, 8)
 
 bool conv_k32_ok(int TH, int WN, int prec, const ConvParams& p) {
-  // g_tun.k32 bits: 1 f16x3, 2 bf16 (measured equal to the 32x32x16 form: off by default), 4 the 16-row tile with a rider (measured slower)
+  // g_tun.k32 bits (default 27 = 1|2|8|16): 1 f16x3, 2 bf16 (+2.7 % at B=64 once the ring / pinning / peeled last chunk were in), 4 the 16-row tile with a rider (measured slower: off)
   if (!(g_tun.k32 & (prec == PREC_BF16 ? 2 : 1))) return false;
   if (TH == 16 && p.xr0 && !(g_tun.k32 & 4)) return false;
   if (TH * WN != 32 && !(TH * WN == 16 && (g_tun.k32 & 8))) return false;   // MB == 4 (bit 8: the 2-row tiles of small grids too)

@@ -1282,6 +1282,8 @@ int sample_body(fdsr_handle h, const float* cond, const float* noise, float* out
   // x_in = cond, img = randn(shape)                                       diffusion.py:204-208
   // packed input: cat([cond, x_t]) (diffusion.py:173); GDP: cat([x_t, cond]) (gdp_modules/diffusion.py:191)
   const int x_off = h->gdp ? 0 : 3, c_off = h->gdp ? 3 : 0;
+  // the f16x3 range flag speaks for THIS call only (a captured loop clears it at every replay)
+  if (h->prec == PREC_F16X3 && g_tun.sat_guard) HIPCHK(h, hipMemsetAsync(h->d_sat, 0, sizeof(int), st));
   HIPCHK(h, launch_nchw_to_nhwc(cond, xin, N, 3, H, W, h->CP, c_off, 1, st));
   if (noise) {
     HIPCHK(h, launch_nchw_to_nhwc(noise, xin, N, 3, H, W, h->CP, x_off, 0, st));
@@ -1352,6 +1354,7 @@ void fdsr_destroy(fdsr_handle h) {
   if (h->d_params) (void)hipFree(h->d_params);
   if (h->d_wq) (void)hipFree(h->d_wq);
   if (h->d_sat) (void)hipFree(h->d_sat);
+  if (h->h_sat) (void)hipHostFree(h->h_sat);
   if (h->d_temb_table) (void)hipFree(h->d_temb_table);
   if (h->d_nl) (void)hipFree(h->d_nl);
   if (h->d_rng) (void)hipFree(h->d_rng);
@@ -1458,6 +1461,7 @@ int fdsr_unet_forward(fdsr_handle h, const float* x_nchw, const float* noise_lev
   hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
   char* ws = reinterpret_cast<char*>(workspace);
   float* xin = reinterpret_cast<float*>(ws + h->plan.tensor_off[h->t_in]);
+  if (h->prec == PREC_F16X3 && g_tun.sat_guard) HIPCHK(h, hipMemsetAsync(h->d_sat, 0, sizeof(int), st));
   HIPCHK(h, launch_nchw_to_nhwc(x_nchw, xin, batch, h->cfg.in_channel, height, width, h->CP, 0, 1, st));
   if ((rc = run_unet(h, batch, height, width, ws, noise_level, 0.f, st))) return rc;
   const float* eps = reinterpret_cast<const float*>(ws + h->plan.tensor_off[h->t_eps]);
@@ -1536,6 +1540,34 @@ int fdsr_tensor2img_u8(fdsr_handle h, const float* src_nchw, uint8_t* dst_nhwc, 
   if (!src_nchw || !dst_nhwc || batch < 1 || channels < 1 || height < 1 || width < 1 || !(hi > lo))
     return fail(h, FDSR_E_INVALID, "bad tensor2img arguments");
   HIPCHK(h, launch_tensor2img_u8(src_nchw, dst_nhwc, batch, channels, height, width, lo, hi, reinterpret_cast<hipStream_t>(hip_stream)));
+  return FDSR_OK;
+}
+
+int fdsr_u8_to_tensor(fdsr_handle h, const uint8_t* src_nhwc, float* dst_nchw, int batch, int channels, int height, int width,
+                      float lo, float hi, void* hip_stream) {
+  if (!src_nhwc || !dst_nchw || batch < 1 || channels < 1 || height < 1 || width < 1 || !(hi > lo))
+    return fail(h, FDSR_E_INVALID, "bad u8_to_tensor arguments");
+  HIPCHK(h, launch_u8_to_tensor(src_nhwc, dst_nchw, batch, channels, height, width, lo, hi, reinterpret_cast<hipStream_t>(hip_stream)));
+  return FDSR_OK;
+}
+
+int fdsr_image_metrics_workspace_bytes(int batch, int height, int width, size_t* bytes) {
+  if (!bytes || batch < 1 || height < 1 || width < 1) return fail(nullptr, FDSR_E_INVALID, "bad image-metrics shape");
+  *bytes = image_metrics_workspace_bytes(batch, height, width);
+  return FDSR_OK;
+}
+
+int fdsr_image_metrics_u8(fdsr_handle h, const uint8_t* test_nhwc, const uint8_t* truth_nhwc, int batch, int height, int width,
+                          int channels, int flags, double* out_dev, void* workspace, size_t workspace_bytes, void* hip_stream) {
+  if (!test_nhwc || !truth_nhwc || !out_dev || !workspace || batch < 1 || channels < 1 || channels > 4 ||
+      !(flags & (FDSR_SSIM_UNIFORM7 | FDSR_SSIM_GAUSS11)) || (flags & ~(FDSR_SSIM_UNIFORM7 | FDSR_SSIM_GAUSS11)))
+    return fail(h, FDSR_E_INVALID, "bad image-metrics arguments (1..4 channels; flags = FDSR_SSIM_UNIFORM7 | FDSR_SSIM_GAUSS11)");
+  const int need = (flags & FDSR_SSIM_GAUSS11) ? 11 : 7;       // skimage raises for images smaller than the window too
+  if (height < need || width < need) return fail(h, FDSR_E_INVALID, "image smaller than the %dx%d SSIM window", need, need);
+  if (workspace_bytes < image_metrics_workspace_bytes(batch, height, width) || (reinterpret_cast<uintptr_t>(workspace) & 7))
+    return fail(h, FDSR_E_WORKSPACE, "image-metrics workspace too small or misaligned");
+  HIPCHK(h, launch_image_metrics_u8(test_nhwc, truth_nhwc, batch, height, width, channels, flags, out_dev, workspace,
+                                    reinterpret_cast<hipStream_t>(hip_stream)));
   return FDSR_OK;
 }
 
@@ -1666,11 +1698,12 @@ int fdsr_check_saturation(fdsr_handle h, void* hip_stream) {
   if (!h) return FDSR_E_INVALID;
   if (!h->d_sat) return FDSR_OK;
   hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
-  int flag = 0;
-  HIPCHK(h, hipMemcpyAsync(&flag, h->d_sat, sizeof flag, hipMemcpyDeviceToHost, st));
+  if (!h->h_sat) HIPCHK(h, hipHostMalloc((void**)&h->h_sat, 64, hipHostMallocDefault));   // pinned: the copy below is truly asynchronous
+  *h->h_sat = 0;
+  HIPCHK(h, hipMemcpyAsync(h->h_sat, h->d_sat, sizeof(int), hipMemcpyDeviceToHost, st));
   HIPCHK(h, hipStreamSynchronize(st));
-  if (!flag) return FDSR_OK;
-  HIPCHK(h, hipMemsetAsync(h->d_sat, 0, sizeof flag, st));
+  if (!*h->h_sat) return FDSR_OK;
+  HIPCHK(h, hipMemsetAsync(h->d_sat, 0, sizeof(int), st));
   return fail(h, FDSR_E_SATURATED, "f16x3: a raw convolution input exceeded the f16 range (+-65504) and was clamped; "
                                    "re-run this call with fdsr_set_precision(FDSR_PREC_F32)");
 }

@@ -126,6 +126,7 @@ struct fdsr_engine {
   // (weights, schedule) and the conv epilogues index it with batch stride 0.
   unsigned long long* d_rng = nullptr;   // {seed, call counter}: noise drawn by the engine (fdsr_sample, noise == NULL)
   unsigned long long rng_seed = 0;
+  int* h_sat = nullptr;            // pinned landing word of fdsr_check_saturation / the training step's own check
   int* d_sat = nullptr;            // f16x3 range guard: sticky flag raised by the raw-input staging paths
   float* d_temb_table = nullptr;
   float* d_nl = nullptr;

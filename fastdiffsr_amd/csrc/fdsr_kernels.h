@@ -208,6 +208,12 @@ hipError_t launch_upsample2(const float* x, float* out, int N, int H, int W, int
 hipError_t launch_tensor2img_u8(const float* src, unsigned char* dst, int N, int C, int H, int W, float lo, float hi,
                                 hipStream_t s);
 
+// the val loop's per-image metric sums on uint8 images and the dataset's tensor transform (fdsr_val.hip)
+size_t image_metrics_workspace_bytes(int N, int H, int W);
+hipError_t launch_image_metrics_u8(const unsigned char* a, const unsigned char* b, int N, int H, int W, int C, int flags, double* out,
+                                   void* ws, hipStream_t s);
+hipError_t launch_u8_to_tensor(const unsigned char* src, float* dst, int N, int C, int H, int W, float lo, float hi, hipStream_t s);
+
 // PIL-exact 8-bit bicubic resize (two passes) + uint8 -> model tensor; tables built on the host
 hipError_t launch_resize_bicubic_u8(const unsigned char* src, unsigned char* tmp, unsigned char* dst_u8, float* dst_f32, int N,
                                     int h, int w, int H, int W, const int* bounds_x, const int* kk_x, int ksize_x,

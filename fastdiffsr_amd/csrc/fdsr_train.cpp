@@ -374,6 +374,8 @@ int train_grads_impl(fdsr_handle h, const float* x_nchw, const float* hr_nchw, c
     HIPCHK(h, launch_qsample_pack(hr_nchw, sr_nchw, noise_level, target_nchw, xin, N, H * W, h->CP, st));
   }
   h->keep_stats = true;
+  const bool sat_armed = h->prec == PREC_F16X3 && g_tun.sat_guard && h->d_sat;
+  if (sat_armed) HIPCHK(h, hipMemsetAsync(h->d_sat, 0, sizeof(int), st));   // the range flag speaks for this step only
   rc = run_unet(h, N, H, W, ws, noise_level, 0.f, st);
   keep_mode.restore();
   if (rc) return rc;
@@ -530,8 +532,18 @@ int train_grads_impl(fdsr_handle h, const float* x_nchw, const float* hr_nchw, c
   }
   if (gscale != 1.0f) HIPCHK(h, launch_scale_inplace(h->d_grad, h->master_floats, 1.0f / gscale, st));
   if (loss_host) {
+    // the step's forward armed the f16x3 range flag (run_unet): it is read in the same synchronisation as the loss, so a
+    // clamped raw input fails THIS call instead of surfacing in an unrelated later fdsr_check_saturation
+    if (sat_armed && !h->h_sat) HIPCHK(h, hipHostMalloc((void**)&h->h_sat, 64, hipHostMallocDefault));
+    if (sat_armed) { *h->h_sat = 0; HIPCHK(h, hipMemcpyAsync(h->h_sat, h->d_sat, sizeof(int), hipMemcpyDeviceToHost, st)); }
     HIPCHK(h, hipMemcpyAsync(loss_host, loss_dev, sizeof(float), hipMemcpyDeviceToHost, st));
     HIPCHK(h, hipStreamSynchronize(st));
+    if (sat_armed && *h->h_sat) {
+      HIPCHK(h, hipMemsetAsync(h->d_sat, 0, sizeof(int), st));
+      return fail(h, FDSR_E_SATURATED, "f16x3 training step: a raw convolution input exceeded the f16 range (+-65504) and was clamped in "
+                                       "the forward pass; the gradients of this call are not fp32-grade: re-run it with "
+                                       "fdsr_set_precision(FDSR_PREC_F32)");
+    }
   }
   return FDSR_OK;
 }

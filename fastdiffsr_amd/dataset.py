@@ -56,6 +56,39 @@ class LRHRDataset(Dataset):
     def __len__(self):
         return self.data_len
 
+    def draw_flips(self):
+        """The train split's two RandomHorizontalFlip decisions of one item (util.py:66-88), drawn from torch's generator in the
+        order __getitem__ draws them; (False, False) elsewhere.  ThreadedBatchLoader draws them on the consumer thread, in item
+        order, so that a run repeats under torch.manual_seed however the decode threads are scheduled."""
+        if self.split != 'train':
+            return False, False
+        flip_hr = bool(torch.rand(1) < 0.5)
+        flip_lr = bool(torch.rand(1) < 0.5) if self.need_LR else False
+        return flip_hr, flip_lr
+
+    def load_u8(self, index, flips=None):
+        """The same item as decoded uint8 HWC arrays ('HR', 'SR', 'LR'), the train-split flips applied: what the pipelined
+        loops (val.py, train.py) ship to the GPU, where metrics.u8_to_tensor finishes the transform (one byte per sample over
+        PCIe, and the decode -- which releases the GIL -- is all a loader thread does).  Same RNG consumption as __getitem__
+        (flips=None), or the decisions handed in (draw_flips)."""
+        from PIL import Image
+        out = {'HR': np.array(Image.open(self.hr_path[index]).convert('RGB'), dtype=np.uint8), 'Index': index}
+        if self.sr_path is not None:
+            out['SR'] = np.array(Image.open(self.sr_path[index]).convert('RGB'), dtype=np.uint8)
+        if self.need_LR:
+            out['LR'] = np.array(Image.open(self.lr_path[index]).convert('RGB'), dtype=np.uint8)
+        if self.split == 'train':
+            flip_hr, flip_lr = self.draw_flips() if flips is None else flips
+            if self.cond_from_lr:
+                flip_lr = flip_hr          # the conditioning image built from LR stands in for SR: it mirrors with HR
+            if flip_hr:
+                for k in ('SR', 'HR'):
+                    if k in out:
+                        out[k] = np.ascontiguousarray(out[k][:, ::-1])
+            if flip_lr:
+                out['LR'] = np.ascontiguousarray(out['LR'][:, ::-1])
+        return out
+
     def __getitem__(self, index):
         from PIL import Image
         out = {'HR': to_tensor(Image.open(self.hr_path[index]).convert('RGB')), 'Index': index}
@@ -90,6 +123,36 @@ def create_dataloader(dataset, dataset_opt, phase):             # data/__init__.
     if phase == 'val':
         return DataLoader(dataset, batch_size=1, shuffle=False, num_workers=1, pin_memory=True)
     raise NotImplementedError('Dataloader [{:s}] is not found.'.format(phase))
+
+
+class ThreadedBatchLoader:
+    """The training loop's loader (the reference: torch DataLoader with `num_workers` worker processes, data/__init__.py:9-15)
+    as worker THREADS of this process: PIL decodes outside the GIL, nothing is forked off a process that holds the GPU, and a
+    batch is handed over as stacked uint8 arrays {'HR','SR','LR': [B,H,W,3], 'Index': [...]} -- the caller ships the bytes and
+    finishes ToTensor()*2-1 on the device (metrics.u8_to_tensor).  Order: torch.randperm(len, generator) per epoch when
+    `shuffle` (RandomSampler's draw), else sequential; the flips are drawn on the consumer thread in item order."""
+
+    def __init__(self, dataset, batch_size, shuffle=False, workers=4, generator=None, depth=3):
+        from concurrent.futures import ThreadPoolExecutor
+        self.ds, self.bs, self.shuffle, self.gen, self.depth = dataset, int(batch_size), bool(shuffle), generator, depth
+        self.pool = ThreadPoolExecutor(max_workers=max(1, int(workers)))
+
+    def __len__(self):
+        return (len(self.ds) + self.bs - 1) // self.bs
+
+    def __iter__(self):
+        n = len(self.ds)
+        order = torch.randperm(n, generator=self.gen).tolist() if self.shuffle else list(range(n))
+        batches = [order[i:i + self.bs] for i in range(0, n, self.bs)]
+        futs, nxt = {}, 0
+        for k in range(len(batches)):
+            while nxt < len(batches) and nxt <= k + self.depth:
+                futs[nxt] = [self.pool.submit(self.ds.load_u8, i, self.ds.draw_flips()) for i in batches[nxt]]
+                nxt += 1
+            items = [f.result() for f in futs.pop(k)]
+            out = {key: np.stack([it[key] for it in items]) for key in ('HR', 'SR', 'LR') if key in items[0]}
+            out['Index'] = [it['Index'] for it in items]
+            yield out
 
 
 def create_dataset(dataset_opt, phase, cond_from_lr=False):     # data/__init__.py:24-40

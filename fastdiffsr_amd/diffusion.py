@@ -14,18 +14,6 @@ from torch import nn
 from .schedule import schedule_buffers, sampling_scalars
 
 
-_warned_saturated = False
-
-
-def _warn_saturated_once():
-    global _warned_saturated
-    if not _warned_saturated:
-        import warnings
-        warnings.warn('fastdiffsr_amd: a raw convolution input exceeded the f16 range in f16x3 mode; this call was re-run on the '
-                      'exact-fp32 kernels (set netG.precision = "f32" to avoid the double work)', RuntimeWarning)
-        _warned_saturated = True
-
-
 class _EngineLoss(torch.autograd.Function):
     """loss = p_losses(...) with the engine's backward pass behind autograd: backward() copies the engine's
     gradients (scaled by the incoming gradient of the loss, e.g. 1 / (b*c*h*w)) into the Parameters' .grad."""
@@ -63,6 +51,12 @@ class GaussianDiffusion(nn.Module):
         # device in the reference's order (reproducible with torch.manual_seed, like the reference);
         # 'engine' = drawn inside the HIP loop (Philox, denoise_fn.engine.set_seed)
         self.rng = 'torch'
+        # the T-step loop as ONE captured hipGraph (north_star; include/fdsr.h FDSR_SAMPLE_GRAPH): 'auto' replays from the second
+        # call of a shape on (capture + instantiation of ~3 600 nodes is not worth it for a one-off shape), 'on' from the first,
+        # 'off' never.  Replays need stable addresses: the facade keeps cond / noise / out / trajectory buffers per shape, copies the
+        # caller's tensors in and hands clones out.
+        self.graph = 'auto'
+        self._gbuf = {}
         # like the reference (:96-98) the schedule is NOT set here; DDPM calls set_new_noise_schedule
 
     def set_loss(self, device):                                   # :101-107
@@ -89,32 +83,55 @@ class GaussianDiffusion(nn.Module):
         device = self.betas.device
         x = x_in.to(device=device, dtype=torch.float32).contiguous()
         T = self.num_timesteps
-        if noise is None and getattr(self, 'rng', 'torch') == 'engine':
-            pass    # the engine draws inside the loop (Philox; Engine.set_seed): the throughput form
-        elif noise is None:
-            # same draws, same order as the reference: randn(shape) then randn_like per step t>0 (:207, :189)
-            noise = torch.empty((T,) + tuple(x.shape), device=device, dtype=torch.float32)
-            noise[0] = torch.randn(x.shape, device=device)
+        unet = self.denoise_fn
+        live_dropout = unet.training and unet.cfg.dropout > 0
+        mode = getattr(self, 'graph', 'auto')
+        key = (tuple(x.shape), bool(continous), str(device))
+        seen = self._gbuf.get(key)
+        use_graph = mode != 'off' and not live_dropout and (mode == 'on' or seen is not None)
+        if mode == 'auto' and seen is None:
+            self._gbuf[key] = {}          # this shape has been sampled once: the next call captures
+        draw_here = noise is None and getattr(self, 'rng', 'torch') != 'engine'
+        if use_graph:
+            buf = self._gbuf.setdefault(key, {})
+            if 'cond' not in buf:
+                if len(self._gbuf) > 4:                       # shapes come and go: keep the buffers of the last few
+                    for old in [k_ for k_ in self._gbuf if k_ != key][:len(self._gbuf) - 4]:
+                        del self._gbuf[old]
+                buf['cond'] = torch.empty_like(x)
+                buf['out'] = torch.empty_like(x)
+                buf['traj'] = torch.empty((T,) + tuple(x.shape), device=device, dtype=torch.float32) if continous else None
+            buf['cond'].copy_(x)
+            if noise is not None or draw_here:
+                if buf.get('noise') is None:
+                    buf['noise'] = torch.empty((T,) + tuple(x.shape), device=device, dtype=torch.float32)
+                nb = buf['noise']
+            if noise is not None:
+                nb.copy_(noise)
+            elif draw_here:
+                # same draws, same order as the reference: randn(shape) then randn_like per step t>0 (:207, :189)
+                for k in range(T):
+                    torch.randn(x.shape, device=device, out=nb[k])
+            noise_arg = nb if (noise is not None or draw_here) else None    # None: the engine draws inside the loop (Philox)
+        elif draw_here:
+            noise_arg = torch.empty((T,) + tuple(x.shape), device=device, dtype=torch.float32)
+            noise_arg[0] = torch.randn(x.shape, device=device)
             for k in range(1, T):
-                noise[k] = torch.randn_like(x)
-        self.denoise_fn.sync_weights()
-        eng = self.denoise_fn.engine
+                noise_arg[k] = torch.randn_like(x)
+        else:
+            noise_arg = noise
+        unet.sync_weights()
+        eng = unet.engine
         eng.set_precision(self.precision)
         # the reference samples after netG.eval() (model.py:60); in .train() mode its Dropout would be live here too,
         # and so it is (the engine then insists on the fp32 kernels)
-        eng.set_training(self.denoise_fn.training and self.denoise_fn.cfg.dropout > 0, seed_from_torch=True)
-        from . import _lib
-        try:
-            res = eng.sample(x, noise, want_traj=bool(continous), graph=False)
-        except _lib.FdsrSaturated:
-            # a raw conv input left the f16 range (checkpoints with very large residual streams): the exact-fp32 kernels
-            # have no such limit.  With engine-drawn noise the re-run draws fresh noise (as a second call would).
-            _warn_saturated_once()
-            eng.set_precision('f32')
-            try:
-                res = eng.sample(x, noise, want_traj=bool(continous), graph=False)
-            finally:
-                eng.set_precision(self.precision)
+        eng.set_training(live_dropout, seed_from_torch=True)
+        # (the f16x3 range guard and its exact-fp32 re-run live in Engine.sample: Engine.on_saturation)
+        if use_graph:
+            res = eng.sample(buf['cond'], noise_arg, want_traj=bool(continous), graph=True, out=buf['out'], traj=buf['traj'])
+            res = (res[0].clone(), res[1]) if continous else res.clone()
+        else:
+            res = eng.sample(x, noise_arg, want_traj=bool(continous), graph=False)
         if not continous:
             return res
         img, traj = res

@@ -41,9 +41,12 @@ class Engine:
         self.trained = False            # at least one optimiser step ran (there is optimiser state to save)
         self.T = 0
         self.precision = 'f32'
-        # f16x3 range guard (include/fdsr.h: fdsr_check_saturation): after every sample / unet_forward in f16x3 the engine
-        # asks whether a raw conv input left the f16 range and raises FdsrSaturated if so (one stream synchronisation per call)
+        # f16x3 range guard (include/fdsr.h: fdsr_check_saturation): after every sample / unet_forward / training step in f16x3
+        # the engine asks whether a raw conv input left the f16 range (one stream synchronisation per call).  What happens then
+        # is decided HERE, for every model family and caller alike: on_saturation = 'f32' (default) re-runs that call on the
+        # exact-fp32 kernels (no range limit), warns once and goes back to f16x3; 'raise' raises FdsrSaturated.
         self.check_saturation = True
+        self.on_saturation = 'f32'
 
     def __del__(self):
         try:
@@ -122,7 +125,31 @@ class Engine:
             raise TypeError(f'{name} must be float32')
         return t.contiguous()
 
+    _warned_saturated = False
+
+    def _with_range_fallback(self, call):
+        """Run `call()`; if the f16x3 range guard trips and the policy says so, run it again in exact fp32."""
+        try:
+            return call()
+        except _lib.FdsrSaturated:
+            if self.on_saturation != 'f32':
+                raise
+        if not Engine._warned_saturated:
+            import warnings
+            warnings.warn('fastdiffsr_amd: a raw convolution input exceeded the f16 range in f16x3 mode; this call was re-run on the '
+                          'exact-fp32 kernels (set the precision to "f32" to avoid the double work)', RuntimeWarning)
+            Engine._warned_saturated = True
+        prec = self.precision
+        self.set_precision('f32')
+        try:
+            return call()       # engine-drawn noise / dropout masks are drawn afresh, as in any second call
+        finally:
+            self.set_precision(prec)
+
     def unet_forward(self, x, noise_level):
+        return self._with_range_fallback(lambda: self._unet_forward(x, noise_level))
+
+    def _unet_forward(self, x, noise_level):
         x = self._check_input(x, 'x')
         B, Cin, H, W = x.shape
         nl = self._check_input(noise_level.to(x.device), 'noise_level').reshape(-1)
@@ -148,6 +175,9 @@ class Engine:
     def sample(self, cond, noise=None, want_traj=False, graph=False, out=None, traj=None):
         """noise: [T,B,3,H,W] (parity runs: the reference's draws), or None: the engine draws
         inside the loop (Philox, see set_seed) like the reference's in-loop randn_like."""
+        return self._with_range_fallback(lambda: self._sample(cond, noise, want_traj, graph, out, traj))
+
+    def _sample(self, cond, noise, want_traj, graph, out, traj):
         cond = self._check_input(cond, 'cond')
         B, _, H, W = cond.shape
         if noise is not None:
@@ -202,9 +232,17 @@ class Engine:
         _lib.check(self.h, self.lib.fdsr_train_workspace_bytes(self.h, B, H, W, C.byref(n)))
         return int(n.value)
 
+    def _check_train(self, rc):
+        if rc == _lib.FDSR_E_SATURATED:
+            raise _lib.FdsrSaturated(rc, self.lib.fdsr_last_error(self.h).decode())
+        _lib.check(self.h, rc)
+
     def train_grads(self, x, noise_level, target, loss_type='l1', loss_scale=1.0):
         """Forward + loss + backward on the device (include/fdsr.h: fdsr_train_grads).  Returns the unscaled
         summed loss (python float); the gradients stay on the device (get_grad / adam_step)."""
+        return self._with_range_fallback(lambda: self._train_grads(x, noise_level, target, loss_type, loss_scale))
+
+    def _train_grads(self, x, noise_level, target, loss_type, loss_scale):
         x = self._check_input(x, 'x')
         target = self._check_input(target, 'target')
         B, _, H, W = x.shape
@@ -218,15 +256,18 @@ class Engine:
         ws = self._ws
         loss = C.c_float()
         st = torch.cuda.current_stream(x.device).cuda_stream
-        _lib.check(self.h, self.lib.fdsr_train_grads(self.h, _ptr(x), _ptr(nl), _ptr(target), {'l1': 0, 'l2': 1}[loss_type],
-                                                     C.c_float(float(loss_scale)), C.byref(loss), B, H, W, _ptr(ws), ws.numel(),
-                                                     C.c_void_p(st)))
+        self._check_train(self.lib.fdsr_train_grads(self.h, _ptr(x), _ptr(nl), _ptr(target), {'l1': 0, 'l2': 1}[loss_type],
+                                                    C.c_float(float(loss_scale)), C.byref(loss), B, H, W, _ptr(ws), ws.numel(),
+                                                    C.c_void_p(st)))
         self._keep = (x, nl, target)
         return float(loss.value)
 
     def train_grads_pairs(self, hr, sr, gamma, noise=None, loss_type='l1', loss_scale=1.0):
         """The same step from the training pair (include/fdsr.h: fdsr_train_grads_pairs): img2res, q_sample and the channel concat
         happen in the engine's input kernel; noise=None: the engine draws the target noise itself (Philox, set_seed)."""
+        return self._with_range_fallback(lambda: self._train_grads_pairs(hr, sr, gamma, noise, loss_type, loss_scale))
+
+    def _train_grads_pairs(self, hr, sr, gamma, noise, loss_type, loss_scale):
         hr, sr = self._check_input(hr, 'hr'), self._check_input(sr, 'sr')
         B, _, H, W = hr.shape
         g = self._check_input(gamma.to(hr.device), 'gamma').reshape(-1)
@@ -242,9 +283,9 @@ class Engine:
             self._ws = torch.empty(need, dtype=torch.uint8, device=hr.device)
         ws, loss = self._ws, C.c_float()
         st = torch.cuda.current_stream(hr.device).cuda_stream
-        _lib.check(self.h, self.lib.fdsr_train_grads_pairs(self.h, _ptr(hr), _ptr(sr), _ptr(g), _ptr(noise), {'l1': 0, 'l2': 1}[loss_type],
-                                                           C.c_float(float(loss_scale)), C.byref(loss), B, H, W, _ptr(ws), ws.numel(),
-                                                           C.c_void_p(st)))
+        self._check_train(self.lib.fdsr_train_grads_pairs(self.h, _ptr(hr), _ptr(sr), _ptr(g), _ptr(noise), {'l1': 0, 'l2': 1}[loss_type],
+                                                          C.c_float(float(loss_scale)), C.byref(loss), B, H, W, _ptr(ws), ws.numel(),
+                                                          C.c_void_p(st)))
         self._keep = (hr, sr, g, noise)
         return float(loss.value)
 

@@ -42,6 +42,77 @@ def tensor2img(tensor, out_type=np.uint8, min_max=(-1, 1)):
     return img.astype(out_type)
 
 
+# --- device-side forms for the evaluation loop (val.py): the batch stays on the GPU as uint8, the per-pixel work of the
+# metrics runs in libfdsr_hip.so (csrc/fdsr_val.hip) and only B x 8 doubles come back ---------------------------------
+def tensor2img_batch(t4, min_max=(-1, 1)):
+    """tensor2img of every image of a [B,C,H,W] CUDA batch in ONE launch -> [B,H,W,C] uint8 CUDA tensor (stays on the device)."""
+    if not t4.is_cuda or t4.dim() != 4:
+        raise ValueError('tensor2img_batch takes a [B,C,H,W] CUDA tensor')
+    t4 = t4.float().contiguous()
+    b, c, h, w = t4.shape
+    dst = torch.empty(b, h, w, c, dtype=torch.uint8, device=t4.device)
+    st = torch.cuda.current_stream(t4.device).cuda_stream
+    _lib.check(None, _lib.load().fdsr_tensor2img_u8(None, C.c_void_p(t4.data_ptr()), C.c_void_p(dst.data_ptr()), b, c, h, w,
+                                                    float(min_max[0]), float(min_max[1]), C.c_void_p(st)))
+    return dst
+
+
+def u8_to_tensor(u8, min_max=(-1, 1)):
+    """The dataset transform (data/util.py:66-75: ToTensor() then * (max - min) + min) of a decoded [B,H,W,C] uint8 CUDA batch
+    -> [B,C,H,W] fp32, bit-identical to dataset.to_tensor on the host."""
+    if not u8.is_cuda or u8.dtype != torch.uint8 or u8.dim() != 4:
+        raise ValueError('u8_to_tensor takes a [B,H,W,C] uint8 CUDA tensor')
+    u8 = u8.contiguous()
+    b, h, w, c = u8.shape
+    dst = torch.empty(b, c, h, w, dtype=torch.float32, device=u8.device)
+    st = torch.cuda.current_stream(u8.device).cuda_stream
+    _lib.check(None, _lib.load().fdsr_u8_to_tensor(None, C.c_void_p(u8.data_ptr()), C.c_void_p(dst.data_ptr()), b, c, h, w,
+                                                   float(min_max[0]), float(min_max[1]), C.c_void_p(st)))
+    return dst
+
+
+_metric_ws = {}
+
+
+def image_metric_sums(test_u8, truth_u8, gauss=False, out=None):
+    """include/fdsr.h: fdsr_image_metrics_u8 -> [B,8] fp64 CUDA tensor of per-image sums (asynchronous on the current stream)."""
+    if (not test_u8.is_cuda or test_u8.dtype != torch.uint8 or test_u8.dim() != 4 or truth_u8.shape != test_u8.shape or
+            truth_u8.dtype != torch.uint8 or truth_u8.device != test_u8.device):
+        raise ValueError('image_metric_sums takes two [B,H,W,C] uint8 CUDA tensors of one shape')
+    test_u8, truth_u8 = test_u8.contiguous(), truth_u8.contiguous()
+    b, h, w, c = test_u8.shape
+    lib = _lib.load()
+    need = C.c_size_t()
+    _lib.check(None, lib.fdsr_image_metrics_workspace_bytes(b, h, w, C.byref(need)))
+    key = (test_u8.device, torch.cuda.current_stream(test_u8.device).cuda_stream)
+    ws = _metric_ws.get(key)
+    if ws is None or ws.numel() < need.value:
+        ws = _metric_ws[key] = torch.empty(int(need.value), dtype=torch.uint8, device=test_u8.device)
+    if out is None:
+        out = torch.empty(b, _lib.FDSR_METRIC_FIELDS, dtype=torch.float64, device=test_u8.device)
+    flags = _lib.FDSR_SSIM_UNIFORM7 | (_lib.FDSR_SSIM_GAUSS11 if gauss else 0)
+    _lib.check(None, lib.fdsr_image_metrics_u8(None, C.c_void_p(test_u8.data_ptr()), C.c_void_p(truth_u8.data_ptr()), b, h, w, c, flags,
+                                               C.c_void_p(out.data_ptr()), C.c_void_p(ws.data_ptr()), ws.numel(), C.c_void_p(key[1])))
+    return out
+
+
+def metrics_from_sums(sums, shape_hwc, scale=4):
+    """Per-image (mse, psnr, ssim, ergas[, ssim_gauss]) from one row of image_metric_sums, with the scalar formulas of
+    compare_mse / compare_psnr / calculate_ergas above (the sums are exact integers, so these three equal the host path
+    bit for bit) and SSIM = map sum / positions."""
+    h, w, c = shape_hwc
+    n = float(h * w * c)
+    sse, s_test, ss7, n7, ss11, n11 = (float(x) for x in sums[:6])
+    mse = sse / n
+    psnr = float('inf') if mse == 0 else 10 * math.log10((255.0 ** 2) / mse)
+    mean2 = (s_test / n) ** 2
+    ergas = float(100.0 * np.sqrt(np.float64(mse) / mean2 / c) / scale)
+    out = {'mse': mse, 'psnr': psnr, 'ssim': ss7 / n7 if n7 else float('nan'), 'ergas': ergas}
+    if n11:
+        out['ssim_gauss'] = ss11 / n11
+    return out
+
+
 def calculate_mse(img1, img2):                       # skimage.measure.compare_mse
     return float(np.mean((img1.astype(np.float64) - img2.astype(np.float64)) ** 2))
 

@@ -12,6 +12,27 @@ import torch.distributed as dist
 from .arch import UNetConfig, param_schema
 
 
+def dist_backend():
+    """'nccl' (= RCCL over xGMI) on a GPU box; 'gloo' where there is no GPU or FDSR_DIST_BACKEND says so (the CPU tests of the
+    sharded drivers)."""
+    import os
+    forced = os.environ.get('FDSR_DIST_BACKEND')
+    if forced:
+        return forced
+    return 'nccl' if torch.cuda.is_available() else 'gloo'
+
+
+def init_process_group():
+    """What `python -m torch.distributed.run ... -m fastdiffsr_amd.val|train` needs at start-up: one process per GPU."""
+    import os
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    backend = dist_backend()
+    if backend == 'nccl':
+        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', 0)))
+    dist.init_process_group(backend)
+    return backend
+
+
 def shard_range(total, rank, world):
     """Contiguous, balanced [lo, hi) slice of `total` images for `rank`."""
     base, rem = divmod(int(total), int(world))

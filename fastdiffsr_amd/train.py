@@ -18,25 +18,30 @@ import torch
 
 from . import val as V
 from .config import load_config
-from .dataset import create_dataloader, create_dataset
+from .dataset import create_dataset
 from .model import create_model
 from .parallel import shard_range
 
 logger = logging.getLogger('base')
 
 
-def run(opt, precision='f16x3', rank=0, world=1, log=print, val_batch=1, max_val_images=None):
+def run(opt, precision='f16x3', rank=0, world=1, log=print, val_batch=1, max_val_images=None, diffusion=None, ops=None):
+    """diffusion / ops: a ready model and the device side of the loaders (val.HipOps) -- injection points of the tests."""
     train_opt = opt['datasets']['train']
     train_set = create_dataset(train_opt, 'train')
     # every rank draws the same batches (same shuffle seed) and keeps its own slice of each
     gen = torch.Generator().manual_seed(int(opt.get('seed', 0) or 0))
-    from torch.utils.data import DataLoader
-    loader = DataLoader(train_set, batch_size=train_opt['batch_size'], shuffle=train_opt['use_shuffle'],
-                        num_workers=train_opt['num_workers'], pin_memory=True, generator=gen) if world > 1 else \
-        create_dataloader(train_set, train_opt, 'train')
-    diffusion = create_model(opt)                                                      # sr_mfe.py:81
+    # the reference's DataLoader(batch_size, shuffle, num_workers, pin_memory) (data/__init__.py:9-15) as loader THREADS that
+    # hand over uint8 batches; the tensor transform runs on the device (val.HipOps)
+    from .dataset import ThreadedBatchLoader
+    loader = ThreadedBatchLoader(train_set, train_opt['batch_size'], shuffle=train_opt['use_shuffle'],
+                                 workers=max(1, int(train_opt['num_workers'] or 0)), generator=gen if world > 1 else None)
+    ops = ops or V.HipOps('cuda')
+    own_model = diffusion is None
+    if own_model:
+        diffusion = create_model(opt)                                                  # sr_mfe.py:81
     diffusion.netG.precision = precision
-    if world > 1:
+    if world > 1 and own_model:
         # every rank ran init_weights / default inits on its OWN torch RNG: start the replicas from rank 0's weights
         # (resumed runs load the same checkpoint everywhere; the broadcast is then a no-op in value)
         from .parallel import broadcast_module_
@@ -59,6 +64,9 @@ def run(opt, precision='f16x3', rank=0, world=1, log=print, val_batch=1, max_val
                 b = train_data['HR'].shape[0]
                 lo, hi = shard_range(b, rank, world)
                 train_data = {k: v[lo:hi] for k, v in train_data.items()}
+            # an empty shard (ragged last batch) still takes part in the step's collectives: zero-sized tensors
+            train_data = {k: (ops.to_tensor(ops.upload(k, v)) if v.shape[0] else
+                              torch.empty((0, v.shape[3], v.shape[1], v.shape[2]), device=ops.device)) for k, v in train_data.items()}
             diffusion.feed_data(train_data)
             diffusion.optimize_parameters()
             if current_step % opt['train']['print_freq'] == 0:
@@ -72,7 +80,7 @@ def run(opt, precision='f16x3', rank=0, world=1, log=print, val_batch=1, max_val
             if current_step % opt['train']['val_freq'] == 0:
                 res = V.run(opt, batch=val_batch, precision=precision, results=(opt.get('path') or {}).get('results'),
                             max_images=max_val_images, rank=rank, world=world, save_images=rank == 0 or world > 1, log=log,
-                            diffusion=diffusion, step=current_step, epoch=current_epoch)
+                            diffusion=diffusion, step=current_step, epoch=current_epoch, ops=ops)
                 history.append((current_step, {'val_psnr': res['sr_psnr']}))
                 diffusion.set_new_noise_schedule(opt['model']['beta_schedule']['train'], schedule_phase='train')   # :233-234
             if current_step % opt['train']['save_checkpoint_freq'] == 0 and rank == 0:
@@ -93,10 +101,8 @@ def main(argv=None):
     a = ap.parse_args(argv)
     rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
     if world > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', 0)))
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl')
+        from .parallel import init_process_group
+        init_process_group()
     opt = load_config(a.config, phase='train', gpu_ids=a.gpu_ids, debug=a.debug)
     log = print
     if rank == 0 and (opt.get('path') or {}).get('log'):

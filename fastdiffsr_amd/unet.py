@@ -132,15 +132,4 @@ class UNet(nn.Module):
         self.engine.set_training(live_dropout, seed_from_torch=True)
         if live_dropout and getattr(self.engine, 'precision', 'f32') == 'bf16':
             self.engine.set_precision('f16x3')       # live dropout needs one of the fp32-grade modes
-        from . import _lib
-        try:
-            return self.engine.unet_forward(x, time)
-        except _lib.FdsrSaturated:          # f16x3 range guard: re-run this call on the exact-fp32 kernels
-            from .diffusion import _warn_saturated_once
-            _warn_saturated_once()
-            prec = self.engine.precision
-            self.engine.set_precision('f32')
-            try:
-                return self.engine.unet_forward(x, time)
-            finally:
-                self.engine.set_precision(prec)
+        return self.engine.unet_forward(x, time)    # the f16x3 range guard and its f32 re-run live in Engine (on_saturation)

@@ -32,16 +32,107 @@ from .parallel import shard_range
 logger = logging.getLogger('base')
 
 
-def _collate(items):
-    out = {k: torch.stack([it[k] for it in items]) for k in items[0] if k != 'Index'}
-    out['Index'] = [it['Index'] for it in items]
-    return out
+class HipOps:
+    """The device side of the loop: uint8 batches in, model tensors / uint8 images / metric sums out, all on the GPU
+    (csrc/fdsr_val.hip, fdsr_kernels.hip) -- there is no host implementation behind it.  run() takes the object as a parameter so
+    that the sharding / reduction logic of the driver can be exercised on a GPU-less box with a stand-in the TESTS provide
+    (tests/test_dist_gloo.py); the product always runs this one."""
+
+    def __init__(self, device):
+        if torch.device(device).type != 'cuda':
+            raise RuntimeError('fastdiffsr_amd.val runs on the GPU only')
+        self.device = torch.device(device)
+        self._up = {}       # (key, shape) -> ring of pinned staging buffers (H2D)
+        self._down = {}     # (tag, shape, dtype) -> ring of pinned landing buffers (D2H)
+
+    def upload(self, key, arr):
+        """Stacked uint8 batch (numpy) -> CUDA tensor through a ring of three pinned buffers: a copy still in flight never sees
+        its source rewritten."""
+        ring = self._up.setdefault((key, arr.shape), [[torch.empty(arr.shape, dtype=torch.uint8).pin_memory() for _ in range(3)], 0, [None] * 3])
+        slot = ring[1] % 3
+        ring[1] += 1
+        if ring[2][slot] is not None:
+            ring[2][slot].synchronize()
+        ring[0][slot].numpy()[...] = arr
+        out = ring[0][slot].to(self.device, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        ring[2][slot] = ev
+        return out
+
+    to_tensor = staticmethod(M.u8_to_tensor)              # data/util.py:66-75 on the device
+    tensor2img_batch = staticmethod(M.tensor2img_batch)   # core/metrics.py:16-42 on the device
+    metric_sums = staticmethod(M.image_metric_sums)       # sr_mfe.py:313-345's per-pixel work on the device
+
+    def lr_to_sr(self, lr_u8, h, w):
+        return lr_to_sr(lr_u8, h, w)
+
+    def new_sums(self, b):
+        return torch.empty(2, b, 8, dtype=torch.float64, device=self.device)
+
+    def land(self, tag, slot, t):
+        """Asynchronous D2H of `t` into pinned buffer `slot` of its ring; valid once the event of mark() has passed."""
+        ring = self._down.setdefault((tag, tuple(t.shape), t.dtype), [torch.empty(t.shape, dtype=t.dtype).pin_memory() for _ in range(3)])
+        ring[slot].copy_(t, non_blocking=True)
+        return ring[slot]
+
+    def mark(self):
+        ev = torch.cuda.Event()
+        ev.record()
+        return ev
+
+    def sync(self):
+        torch.cuda.synchronize()
+
+
+class _Loader:
+    """The reference feeds its loop from a DataLoader (data/__init__.py:7-21: batch 1, one worker).  Here worker THREADS decode
+    the image files of the next `depth` batches (PIL releases the GIL while it decodes) into uint8 arrays; the batch is stacked,
+    crosses PCIe as bytes and becomes the model tensors on the device (ops.to_tensor, bit-identical to the dataset's own host
+    transform)."""
+
+    def __init__(self, dataset, lo, hi, batch, pool, ops, depth=3):
+        self.ds, self.pool, self.depth, self.ops = dataset, pool, depth, ops
+        self.batches = [list(range(b0, min(b0 + batch, hi))) for b0 in range(lo, hi, batch)]
+        self.futs = {}
+        self.next = 0
+
+    def _submit_until(self, k):
+        while self.next < len(self.batches) and self.next <= k:
+            self.futs[self.next] = [self.pool.submit(self.ds.load_u8, i) for i in self.batches[self.next]]
+            self.next += 1
+
+    def __len__(self):
+        return len(self.batches)
+
+    def get(self, k):
+        """Batch k as {'HR','SR','LR': [B,H,W,3] uint8 device tensors (those the dataset has), 'Index': [...]}."""
+        self._submit_until(k + self.depth)
+        items = [f.result() for f in self.futs.pop(k)]
+        out = {'Index': [it['Index'] for it in items]}
+        for key in ('HR', 'SR', 'LR'):
+            if key in items[0]:
+                out[key] = self.ops.upload(key, np.stack([it[key] for it in items]))
+        return out
 
 
 def run(opt, batch=1, cond_from_lr=False, precision='f16x3', results=None, max_images=None, rank=0, world=1,
-        save_images=True, log=print, infer=False, diffusion=None, step=None, epoch=None):
+        save_images=True, log=print, infer=False, diffusion=None, step=None, epoch=None, workers=None, rng=None, graph=None,
+        host_metrics=False, ops=None):
     """infer=True is the reference's infer.py (:62-110): the same loop, `{step}_{idx}_sr.png` outputs, timing, no metrics.
-    diffusion: an existing model (the validation pass inside the training loop, sr_mfe.py:122-244); else one is created."""
+    diffusion: an existing model (the validation pass inside the training loop, sr_mfe.py:122-244); else one is created.
+
+    The loop is a pipeline: loader threads decode the next batches while the GPU samples this one; tensor2img, MSE / PSNR /
+    SSIM / ERGAS run on the device on the uint8 images (csrc/fdsr_val.hip; 2 x B x 8 doubles and the uint8 SR images come back
+    through pinned memory), and a finisher thread turns the sums into the reference's per-image numbers and hands the images
+    to the pool to be written -- none of which the sampling loop waits for.  host_metrics=True scores the landed uint8 images
+    with metrics.compare_* instead (what the tests hold the device kernels against).
+    rng: 'torch' (default; the reference's draws, reproducible under torch.manual_seed) or 'engine' (Philox inside the loop);
+    graph: 'auto' | 'on' | 'off' -- replay the 20-step loop as a captured hipGraph (None: the model's default, 'auto').
+    ops: the device side (HipOps; see there)."""
+    import queue
+    import threading
+    from concurrent.futures import ThreadPoolExecutor
     val_opt = opt['datasets']['val']
     dataset = create_dataset(val_opt, 'val', cond_from_lr=cond_from_lr)
     n_total = len(dataset) if max_images is None else min(len(dataset), max_images)
@@ -50,47 +141,129 @@ def run(opt, batch=1, cond_from_lr=False, precision='f16x3', results=None, max_i
     if diffusion is None:
         diffusion = create_model(opt)                                                 # sr_mfe.py:60
     diffusion.netG.precision = precision
+    if rng is not None:
+        diffusion.netG.rng = rng
+    if graph is not None:
+        diffusion.netG.graph = graph
     diffusion.set_new_noise_schedule(opt['model']['beta_schedule']['val'], schedule_phase='val')   # sr_mfe.py:66-67, :131-132
     current_step = diffusion.begin_step if step is None else step
     current_epoch = diffusion.begin_epoch if epoch is None else epoch
     result_path = results or (opt.get('path') or {}).get('results') or 'results'
     if save_images:
         os.makedirs(result_path, exist_ok=True)
-    sums = np.zeros(9, dtype=np.float64)       # bic mse/psnr/ssim/ergas, sr mse/psnr/ssim/ergas, count
+    if ops is None:
+        ops = HipOps(diffusion.device)
+    rres = int(val_opt['r_resolution'])
+    per_image = {}                     # index -> 8 numbers (bic mse/psnr/ssim/ergas, sr mse/psnr/ssim/ergas); summed in index order
     t_sample = 0.0
-    for b0 in range(lo, hi, batch):
-        items = [dataset[i] for i in range(b0, min(b0 + batch, hi))]
-        data = _collate(items)
-        if cond_from_lr:
-            data['SR'] = lr_to_sr(data.pop('LR_u8').cuda(), int(val_opt['r_resolution']), int(val_opt['r_resolution']))
-        idxs = data.pop('Index')
-        diffusion.feed_data(data)
-        torch.cuda.synchronize()
-        t0 = time.time()
-        diffusion.test(continous=False)
-        torch.cuda.synchronize()
-        t_sample += time.time() - t0
-        logger.info('inference time (s): {:.4f} for {} image(s)'.format(time.time() - t0, len(idxs)))   # sr_mfe.py:279-284
-        sr_batch = diffusion.SR
-        if sr_batch.dim() == 3:       # the ddpm / tesr siblings return ret_img[-1]: one image (their own convention)
-            if len(idxs) != 1:
-                raise ValueError("which_model_G in ('ddpm', 'tesr') returns one image per call: use --batch 1")
-            sr_batch = sr_batch[None]
-        for j, index in enumerate(idxs):
-            idx = index + 1                                                           # sr_mfe.py:274 counts from 1
-            hr_img = M.tensor2img(diffusion.data['HR'][j])
-            fake_img = M.tensor2img(diffusion.data['SR'][j])                          # the bicubic image ('INF')
-            sr_img = M.tensor2img(sr_batch[j])
-            if save_images:
-                from PIL import Image
-                Image.fromarray(sr_img).save('{}/{}_{}_sr.{}'.format(result_path, current_step, idx, 'png' if infer else 'tif'))
-            if infer:
-                sums[8] += 1.0
-                continue
-            sums += np.array([M.compare_mse(fake_img, hr_img), M.compare_psnr(fake_img, hr_img), M.compare_ssim(fake_img, hr_img),
-                              M.calculate_ergas(fake_img, hr_img, scale=scale),
-                              M.compare_mse(sr_img, hr_img), M.compare_psnr(sr_img, hr_img), M.compare_ssim(sr_img, hr_img),
-                              M.calculate_ergas(sr_img, hr_img, scale=scale), 1.0])
+    n_workers = workers if workers else max(2, min(16, (os.cpu_count() or 4)))
+    pool = ThreadPoolExecutor(max_workers=n_workers)
+    jobs = queue.Queue()
+    errors = []
+    saves = []
+
+    def _save(img, path):
+        from PIL import Image
+        Image.fromarray(img).save(path)
+
+    def _finish():
+        while True:
+            job = jobs.get()
+            if job is None:
+                return
+            try:
+                ev, idxs, sr_host, sums_host, hr_host, inf_host, _ = job
+                ev.synchronize()
+                sr_np = sr_host.numpy()
+                for j, index in enumerate(idxs):
+                    idx = index + 1                                                   # sr_mfe.py:274 counts from 1
+                    if save_images:
+                        path = '{}/{}_{}_sr.{}'.format(result_path, current_step, idx, 'png' if infer else 'tif')
+                        saves.append(pool.submit(_save, sr_np[j].copy(), path))
+                    if infer:
+                        per_image[index] = None
+                    elif host_metrics:
+                        h_, f_, s_ = hr_host.numpy()[j], inf_host.numpy()[j], sr_np[j]
+                        per_image[index] = [M.compare_mse(f_, h_), M.compare_psnr(f_, h_), M.compare_ssim(f_, h_),
+                                            M.calculate_ergas(f_, h_, scale=scale),
+                                            M.compare_mse(s_, h_), M.compare_psnr(s_, h_), M.compare_ssim(s_, h_),
+                                            M.calculate_ergas(s_, h_, scale=scale)]
+                    else:
+                        sm = sums_host.numpy()
+                        b_ = M.metrics_from_sums(sm[0, j], sr_np[j].shape, scale)
+                        s_ = M.metrics_from_sums(sm[1, j], sr_np[j].shape, scale)
+                        per_image[index] = [b_['mse'], b_['psnr'], b_['ssim'], b_['ergas'], s_['mse'], s_['psnr'], s_['ssim'], s_['ergas']]
+            except Exception as e:       # surfaced by run() after the loop
+                errors.append(e)
+            finally:
+                job[-1].set()            # this slot's landing buffers may be refilled
+
+    finisher = threading.Thread(target=_finish, daemon=True)
+    finisher.start()
+    loader = _Loader(dataset, lo, hi, batch, pool, ops)
+    slot_free = [None] * 3
+    try:
+        def stage(k):
+            """Batch k on the device as the model tensors: issued BEFORE the previous batch is sampled, so the bytes are
+            there when its loop ends (the copies and the two small kernels sit in front of that loop on the stream)."""
+            if k >= len(loader):
+                return None
+            raw = loader.get(k)
+            idxs = raw.pop('Index')
+            data = {key: ops.to_tensor(v) for key, v in raw.items()}
+            if cond_from_lr:
+                data['SR'] = ops.lr_to_sr(raw['LR'], rres, rres)
+            return idxs, data
+
+        staged = stage(0)
+        for k in range(len(loader)):
+            idxs, data = staged
+            diffusion.feed_data(data)
+            staged = stage(k + 1)
+            ops.sync()
+            t0 = time.time()
+            diffusion.test(continous=False)
+            ops.sync()
+            t_sample += time.time() - t0
+            logger.info('inference time (s): {:.4f} for {} image(s)'.format(time.time() - t0, len(idxs)))   # sr_mfe.py:279-284
+            sr_batch = diffusion.SR
+            if sr_batch.dim() == 3:       # the ddpm / tesr siblings return ret_img[-1]: one image (their own convention)
+                if len(idxs) != 1:
+                    raise ValueError("which_model_G in ('ddpm', 'tesr') returns one image per call: use --batch 1")
+                sr_batch = sr_batch[None]
+            b = len(idxs)
+            sr_u8 = ops.tensor2img_batch(sr_batch)                                    # Metrics.tensor2img, on the device
+            slot = k % 3
+            if slot_free[slot] is not None:
+                slot_free[slot].wait()           # the finisher is done with this slot's previous contents
+            sr_host = ops.land('sr', slot, sr_u8)
+            sums_host = hr_host = inf_host = None
+            if not infer:
+                hr_u8 = ops.tensor2img_batch(diffusion.data['HR'])
+                inf_u8 = ops.tensor2img_batch(diffusion.data['SR'])                   # the bicubic image ('INF')
+                if host_metrics:
+                    hr_host, inf_host = ops.land('hr', slot, hr_u8), ops.land('inf', slot, inf_u8)
+                else:
+                    sums = ops.new_sums(b)
+                    ops.metric_sums(inf_u8, hr_u8, out=sums[0])
+                    ops.metric_sums(sr_u8, hr_u8, out=sums[1])
+                    sums_host = ops.land('sums', slot, sums)
+            done = threading.Event()
+            slot_free[slot] = done
+            jobs.put((ops.mark(), idxs, sr_host, sums_host, hr_host, inf_host, done))
+    finally:
+        jobs.put(None)
+        finisher.join()
+        for f in saves:
+            f.result()
+        pool.shutdown(wait=True)
+    if errors:
+        raise errors[0]
+    sums = np.zeros(9, dtype=np.float64)       # bic mse/psnr/ssim/ergas, sr mse/psnr/ssim/ergas, count
+    for index in sorted(per_image):
+        if per_image[index] is not None:
+            sums[:8] += np.array(per_image[index])
+        sums[8] += 1.0
     if world > 1:
         import torch.distributed as dist
         t = torch.from_numpy(sums).cuda() if dist.get_backend() == 'nccl' else torch.from_numpy(sums)
@@ -111,7 +284,8 @@ def run(opt, batch=1, cond_from_lr=False, precision='f16x3', results=None, max_i
     return res
 
 
-def main(argv=None):
+def main(argv=None, diffusion=None, ops=None):
+    """diffusion / ops: injection points of tests/test_dist_gloo.py (a stand-in model and device side on a GPU-less box)."""
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument('-c', '--config', required=True, help='JSON file for configuration (the reference\'s own)')
     ap.add_argument('-p', '--phase', choices=['val'], default='val')
@@ -124,13 +298,18 @@ def main(argv=None):
     ap.add_argument('--max-images', type=int, default=None)
     ap.add_argument('--no-save', action='store_true')
     ap.add_argument('--infer', action='store_true', help="the reference's infer.py: png outputs and timing, no metrics")
+    ap.add_argument('--workers', type=int, default=None, help='loader / writer threads (default: min(16, cores))')
+    ap.add_argument('--rng', default=None, choices=['torch', 'engine'],
+                    help="sampling noise: 'torch' (default; torch.randn in the reference's order, reproducible under torch.manual_seed) "
+                         "or 'engine' (Philox inside the HIP loop: nothing pre-drawn)")
+    ap.add_argument('--graph', default=None, choices=['auto', 'on', 'off'],
+                    help='replay the T-step loop as a captured hipGraph (default auto: from the second call of a shape on)')
+    ap.add_argument('--host-metrics', action='store_true', help='score on the host (numpy) instead of the device kernels')
     a = ap.parse_args(argv)
     rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
     if world > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', 0)))
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl')
+        from .parallel import init_process_group
+        init_process_group()
     opt = load_config(a.config, phase=a.phase, gpu_ids=a.gpu_ids, debug=a.debug)
     log = print
     if not a.no_save and rank == 0 and (opt.get('path') or {}).get('log'):
@@ -142,7 +321,8 @@ def main(argv=None):
         if a.results is None:
             a.results = opt['path'].get('results')
     res = run(opt, batch=a.batch, cond_from_lr=a.cond_from_lr, precision=a.precision, results=a.results,
-              max_images=a.max_images, rank=rank, world=world, save_images=not a.no_save, infer=a.infer, log=log)
+              max_images=a.max_images, rank=rank, world=world, save_images=not a.no_save, infer=a.infer, log=log,
+              workers=a.workers, rng=a.rng, graph=a.graph, host_metrics=a.host_metrics, diffusion=diffusion, ops=ops)
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()

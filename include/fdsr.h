@@ -168,7 +168,34 @@ int fdsr_set_precision(fdsr_handle h, int mode);
 int fdsr_tensor2img_u8(fdsr_handle h, const float* src_nchw, uint8_t* dst_nhwc, int batch, int channels,
                        int height, int width, float lo, float hi, void* hip_stream);
 
+/* The per-image metric sums of the evaluation loop (sr_mfe.py:313-345: skimage.measure compare_mse / compare_psnr /
+ * compare_ssim(multichannel=True) and Metrics.calculate_ergas, core/metrics.py:147-152; FDSR_SSIM_GAUSS11 adds the 11x11
+ * Gaussian-window SSIM of core/metrics.py:103-145), on uint8 images that are already on the device -- the SR batch never
+ * crosses PCIe as fp32 and the host does no per-pixel work.
+ *   test / truth [B,H,W,C] uint8 device (C = 1..4);  out_dev [B][FDSR_METRIC_FIELDS] fp64 device:
+ *     [0] sum (test - truth)^2      [1] sum test            -- exact integers
+ *     [2] sum of the SSIM map, uniform 7x7 window (skimage defaults: sample covariance, K1 .01, K2 .03, L 255), interior
+ *         positions of every channel                          [3] number of those positions
+ *     [4], [5] the same for the 11x11 Gaussian window (sigma 1.5, "valid" part)      [6], [7] zero
+ * The caller forms MSE = [0]/(H*W*C), PSNR, ERGAS = 100*sqrt(MSE / mean(test)^2 / C) / scale and SSIM = [2]/[3] with the
+ * reference's scalar formulas (fastdiffsr_amd/metrics.py does).  Fixed-order reductions: reruns are bitwise identical.
+ * h may be NULL. */
+#define FDSR_METRIC_FIELDS 8
+#define FDSR_SSIM_UNIFORM7 1
+#define FDSR_SSIM_GAUSS11 2
+int fdsr_image_metrics_workspace_bytes(int batch, int height, int width, size_t* bytes);
+int fdsr_image_metrics_u8(fdsr_handle h, const uint8_t* test_nhwc, const uint8_t* truth_nhwc, int batch, int height,
+                          int width, int channels, int flags, double* out_dev, void* workspace, size_t workspace_bytes,
+                          void* hip_stream);
+
 /* -- input-pipeline helper ------------------------------------ */
+/* The dataset's tensor transform on the device (data/util.py:66-75 transform_augment: ToTensor() = uint8 / 255 as fp32,
+ * HWC -> CHW, then img * (hi - lo) + lo; LRHR_dataset.py:113-119 passes min_max = (-1, 1)): the loader threads hand over
+ * the decoded uint8 batch, one byte per sample crosses PCIe.  src [B,H,W,C] uint8 device, dst [B,C,H,W] fp32 device,
+ * bit-identical to the torch ops of the reference.  h may be NULL. */
+int fdsr_u8_to_tensor(fdsr_handle h, const uint8_t* src_nhwc, float* dst_nchw, int batch, int channels, int height,
+                      int width, float lo, float hi, void* hip_stream);
+
 /* The conditioning image: LR uint8 RGB -> PIL-exact bicubic resize (Image.BICUBIC as used by
  * data/prepare_data_mfe_dm.py:17-40; Pillow's 8-bit fixed-point two-pass resample, bit for bit) ->
  * optionally the val-time tensor transform ToTensor()*2-1 (data/util.py:66-75).

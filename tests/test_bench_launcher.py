@@ -67,3 +67,59 @@ def test_main_takes_the_launcher_when_world_size_is_unset(monkeypatch):
     except SystemExit as e:
         assert e.code == 0
     assert seen == {'n': 8, 'argv': ['--gpus', '8', '--steps', '3', '--warmup', '1']}
+
+
+def test_launcher_tears_the_job_down_when_one_rank_dies_or_the_parent_is_signalled(tmp_path):
+    """A rank that dies at start-up must not leave the others waiting in a rendezvous, and a SIGTERM to the launcher
+    (`timeout 900 python bench.py --gpus 8`) must not orphan the ranks: every child is gone when launch_ranks returns."""
+    import signal
+    import time
+    child = tmp_path / 'child.py'
+    child.write_text(textwrap.dedent('''
+        import os, sys, time
+        open(os.path.join(os.environ['PID_DIR'], 'rank%s.pid' % os.environ['RANK']), 'w').write(str(os.getpid()))
+        if os.environ.get('FAIL_RANK') == os.environ['RANK']:
+            time.sleep(1.5)          # the others are up (and have written their pid files) by then
+            sys.exit(5)
+        time.sleep(600)              # "stuck in the rendezvous"
+    '''))
+    drv = tmp_path / 'drv.py'
+    drv.write_text(textwrap.dedent(f'''
+        import sys
+        sys.path.insert(0, {ROOT!r})
+        import bench
+        sys.exit(bench.launch_ranks(3, [], visible=3, script={str(child)!r}, grace_s=2.0))
+    '''))
+
+    def alive(pid):
+        try:
+            os.kill(pid, 0)
+        except ProcessLookupError:
+            return False
+        # a zombie of an already-reaped session leader does not count
+        try:
+            return open(f'/proc/{pid}/stat').read().split()[2] != 'Z'
+        except OSError:
+            return False
+
+    def pids(d):
+        return [int(open(os.path.join(d, f)).read()) for f in os.listdir(d)]
+
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE')}
+    d1 = tmp_path / 'p1'
+    d1.mkdir()
+    t0 = time.time()
+    r = subprocess.run([sys.executable, str(drv)], capture_output=True, text=True, env=dict(env, PID_DIR=str(d1), FAIL_RANK='1'), timeout=120)
+    assert r.returncode == 5 and time.time() - t0 < 60          # not the 600 s the healthy ranks would have slept
+    assert len(pids(d1)) == 3 and not any(alive(p) for p in pids(d1))
+    d2 = tmp_path / 'p2'
+    d2.mkdir()
+    p = subprocess.Popen([sys.executable, str(drv)], env=dict(env, PID_DIR=str(d2)))
+    for _ in range(200):
+        if len(os.listdir(d2)) == 3:
+            break
+        time.sleep(0.1)
+    assert len(os.listdir(d2)) == 3
+    p.send_signal(signal.SIGTERM)
+    assert p.wait(timeout=60) == 128 + signal.SIGTERM
+    assert not any(alive(q) for q in pids(d2))

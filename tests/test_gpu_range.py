@@ -115,6 +115,24 @@ def test_f16x3_saturation_guard_residual_stream_at_1e5():
     eng = Engine(cfg)
     eng.load_state_dict(sd)
     eng.set_precision('f16x3')
+    # (0) the default policy (Engine.on_saturation == 'f32', shared by every model family and direct caller): the call is
+    # re-run on the exact-fp32 kernels, the answer is right and the engine is back in f16x3 afterwards
+    assert eng.on_saturation == 'f32'
+    with warnings.catch_warnings(record=True):
+        warnings.simplefilter('always')
+        assert (eng.unet_forward(x.cuda(), nl.cuda()).cpu() - ref).abs().max().item() <= TOL * scale
+    assert eng.precision == 'f16x3'
+    # the same for a training step: the step's own forward is checked in the synchronisation that returns the loss
+    tgt = torch.randn(2, 3, 64, 64, generator=torch.Generator().manual_seed(3))
+    eng.on_saturation = 'raise'
+    with pytest.raises(_lib.FdsrSaturated):
+        eng.train_grads(x.cuda(), nl.cuda().reshape(-1), tgt.cuda(), 'l1', 1.0 / tgt.numel())
+    eng.on_saturation = 'f32'
+    with warnings.catch_warnings(record=True):
+        warnings.simplefilter('always')
+        loss = eng.train_grads(x.cuda(), nl.cuda().reshape(-1), tgt.cuda(), 'l1', 1.0 / tgt.numel())
+    assert abs(loss - (ref - tgt).abs().sum().item()) <= 1e-4 * (ref - tgt).abs().sum().item() and eng.precision == 'f16x3'
+    eng.on_saturation = 'raise'
     # (1) the engine reports it
     with pytest.raises(_lib.FdsrSaturated) as ei:
         eng.unet_forward(x.cuda(), nl.cuda())
@@ -130,7 +148,7 @@ def test_f16x3_saturation_guard_residual_stream_at_1e5():
     # (4) the exact-fp32 mode has no such limit
     eng.set_precision('f32')
     assert (eng.unet_forward(x.cuda(), nl.cuda()).cpu() - ref).abs().max().item() <= TOL * scale
-    # (5) the facade: warns once, re-runs the call in f32, stays in f16x3 for the next call
+    # (5) the facade: the same policy through UNet.forward, stays in f16x3 for the next call
     net = UNet(in_channel=6, out_channel=3, norm_groups=32, inner_channel=64, channel_mults=(1, 2, 4, 4), attn_res=(16,),
                res_blocks=2, dropout=0.2, image_size=64)
     net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)

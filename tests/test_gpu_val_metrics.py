@@ -1,0 +1,108 @@
+"""The evaluation loop's device kernels (csrc/fdsr_val.hip) against the host formulas of fastdiffsr_amd/metrics.py (the
+reference's sr_mfe.py:313-345 / core/metrics.py:94-152): MSE / PSNR / ERGAS bit for bit (exact integer sums + the same
+scalar formulas), SSIM (uniform 7x7 = skimage's compare_ssim; Gaussian 11x11 = core/metrics.calculate_ssim) to 1e-9,
+reruns bitwise; the dataset transform and the batched tensor2img bit for bit."""
+import numpy as np
+import pytest
+import torch
+
+from fastdiffsr_amd import metrics as M
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(rng, shape, spread):
+    a = rng.integers(0, 256, shape).astype(np.uint8)
+    b = np.clip(a.astype(np.int32) + rng.integers(-spread, spread + 1, shape), 0, 255).astype(np.uint8)
+    return a, b
+
+
+@pytest.mark.parametrize('shape,spread', [((3, 256, 256, 3), 12), ((2, 40, 300, 3), 40), ((2, 17, 23, 1), 5), ((1, 64, 520, 4), 90),
+                                          ((2, 11, 11, 3), 20), ((1, 33, 262, 3), 255)])
+def test_metric_sums_match_host_formulas(shape, spread):
+    rng = np.random.default_rng(sum(shape))
+    a, b = _pair(rng, shape, spread)
+    if shape[0] > 1:
+        b[1] = a[1]                                   # identical pair: mse 0, psnr inf, ssim 1
+    ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    s1 = M.image_metric_sums(ta, tb, gauss=True).cpu().numpy()
+    s2 = M.image_metric_sums(ta, tb, gauss=True).cpu().numpy()
+    assert np.array_equal(s1, s2)                     # fixed-order reductions
+    for j in range(shape[0]):
+        h, w, c = shape[1:]
+        r = M.metrics_from_sums(s1[j], (h, w, c), scale=4)
+        assert s1[j][0] == float(((a[j].astype(np.int64) - b[j]) ** 2).sum()) and s1[j][1] == float(a[j].astype(np.int64).sum())
+        assert s1[j][3] == (h - 6) * (w - 6) * c and s1[j][5] == (h - 10) * (w - 10) * c
+        img_a, img_b = (a[j], b[j]) if c > 1 else (a[j][..., 0], b[j][..., 0])
+        assert r['mse'] == M.compare_mse(a[j], b[j]) and r['psnr'] == M.compare_psnr(a[j], b[j])          # bit for bit
+        assert r['ergas'] == M.calculate_ergas(a[j], b[j], scale=4)
+        want7 = M.compare_ssim(img_a, img_b, multichannel=(c > 1))
+        assert abs(r['ssim'] - want7) <= 1e-9 * max(1.0, abs(want7)), (r['ssim'], want7)
+        want11 = M.ssim(img_a, img_b)                 # core/metrics.py:103-123 on the whole array (per channel, 'valid' part)
+        assert abs(r['ssim_gauss'] - want11) <= 1e-9 * max(1.0, abs(want11)), (r['ssim_gauss'], want11)
+    # uniform window alone: the Gaussian fields stay zero, the integer sums are unchanged
+    s3 = M.image_metric_sums(ta, tb).cpu().numpy()
+    assert np.array_equal(s3[:, :4], s1[:, :4]) and not s3[:, 4:].any()
+
+
+def test_metric_kernel_refuses_what_skimage_refuses():
+    from fastdiffsr_amd import _lib
+    t = torch.zeros(1, 6, 40, 3, dtype=torch.uint8, device='cuda')
+    with pytest.raises(_lib.FdsrError):
+        M.image_metric_sums(t, t)                     # smaller than the 7x7 window
+    with pytest.raises(ValueError):
+        M.image_metric_sums(t, t[:, :, :20])
+
+
+def test_dataset_transform_and_batched_tensor2img_bit_exact():
+    from PIL import Image
+    from fastdiffsr_amd.dataset import to_tensor
+    rng = np.random.default_rng(3)
+    u8 = rng.integers(0, 256, (5, 48, 40, 3)).astype(np.uint8)
+    u8[0, :16, :16] = np.arange(256, dtype=np.uint8).reshape(16, 16, 1)      # every byte value
+    dev = M.u8_to_tensor(torch.from_numpy(u8).cuda())
+    for j in range(5):
+        assert torch.equal(dev[j].cpu(), to_tensor(Image.fromarray(u8[j])))    # ToTensor() * 2 - 1 (data/util.py:66-75)
+    back = M.tensor2img_batch(dev)
+    assert torch.equal(back.cpu(), torch.from_numpy(u8))                       # tensor2img undoes the transform exactly
+    x = (torch.randn(4, 3, 32, 40, generator=torch.Generator().manual_seed(1)) * 0.7).cuda()
+    got = M.tensor2img_batch(x).cpu().numpy()
+    for j in range(4):
+        assert np.array_equal(got[j], M.tensor2img(x[j].cpu().clone())) and np.array_equal(got[j], M.tensor2img(x[j]))
+
+
+def test_val_loop_device_metrics_equal_host_metrics(tmp_path):
+    """The pipelined loop (loader threads, device tensor2img + metric kernels, finisher thread) against the same loop scoring
+    the landed uint8 images with the host formulas; ragged last batch, engine-drawn and torch-drawn noise, graph replay."""
+    import json
+    from fastdiffsr_amd import val
+    from fastdiffsr_amd.config import load_config
+    from test_gpu_val import _config_plain
+    from test_val_host import make_dataset
+    root = make_dataset(str(tmp_path / 'data'), n=7, l=16, r=64, seed=4)
+    cfg = _config_plain(root)
+    for ph in ('train', 'val'):
+        cfg['datasets'][ph].update(l_resolution=16, r_resolution=64)
+    cfg['model']['diffusion']['image_size'] = 64
+    cpath = tmp_path / 'cfg.json'
+    cpath.write_text(json.dumps(cfg))
+    lines = []
+    res = {}
+    for name, kw in (('dev', {}), ('host', {'host_metrics': True})):
+        torch.manual_seed(5)
+        res[name] = val.run(load_config(str(cpath), phase='val'), batch=3, results=str(tmp_path / name), log=lines.append, workers=3, **kw)
+    assert res['dev']['images'] == 7
+    for k in ('bic_mse', 'bic_psnr', 'bic_ergas', 'sr_mse', 'sr_psnr', 'sr_ergas'):
+        assert res['dev'][k] == res['host'][k], k                                # exact sums + the same scalar formulas
+    for k in ('bic_ssim', 'sr_ssim'):
+        assert abs(res['dev'][k] - res['host'][k]) <= 1e-9
+    from PIL import Image
+    for f in sorted((tmp_path / 'dev').iterdir()):
+        assert np.array_equal(np.asarray(Image.open(f)), np.asarray(Image.open(tmp_path / 'host' / f.name)))
+    # batches 1 and 2 share a shape: the second was a graph replay ('auto'); forcing the graph off gives the same images
+    torch.manual_seed(5)
+    off = val.run(load_config(str(cpath), phase='val'), batch=3, results=str(tmp_path / 'off'), log=lines.append, graph='off')
+    assert off['sr_psnr'] == res['dev']['sr_psnr'] and off['sr_ssim'] == res['dev']['sr_ssim']
+    # engine-drawn noise: other draws, a valid run
+    eng = val.run(load_config(str(cpath), phase='val'), batch=4, results=str(tmp_path / 'eng'), log=lines.append, rng='engine', graph='on')
+    assert eng['images'] == 7 and np.isfinite(eng['sr_psnr']) and eng['bic_psnr'] == res['dev']['bic_psnr']

@@ -1,0 +1,169 @@
+"""`python -m fastdiffsr_amd.val` under two ranks on a GPU-less box (gloo): the images are sharded by parallel.shard_range,
+every rank writes its own results, the metric sums are all-reduced -- union of the shards == all images, reduced averages ==
+the single-rank run's.  The model is an oracle-backed stand-in and the device side of the loop (val.HipOps: HIP kernels, GPU
+only) is replaced by a numpy stand-in defined HERE; the driver code under test (val.main / val.run, the loader threads, the
+finisher, the sharding and the reduction) is the product's."""
+import json
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from fastdiffsr_amd import metrics as M
+from fastdiffsr_amd.arch import UNetConfig, FASTDIFFSR_SCHEDULE_VAL
+from fastdiffsr_amd.synth import synth_state_dict
+
+CFG = dict(in_channel=6, out_channel=3, inner_channel=32, norm_groups=32, channel_mults=(1, 2), attn_res=(16,),
+           res_blocks=1, dropout=0.0, image_size=32)
+
+
+class _Done:
+    def synchronize(self):
+        pass
+
+
+class HostOps:
+    """numpy stand-in of val.HipOps (test infrastructure): same methods, host arithmetic of fastdiffsr_amd.metrics."""
+    device = torch.device('cpu')
+
+    def upload(self, key, arr):
+        return torch.from_numpy(np.ascontiguousarray(arr))
+
+    def to_tensor(self, u8):
+        return u8.permute(0, 3, 1, 2).to(torch.float32).div(255) * 2 + (-1)
+
+    def tensor2img_batch(self, t4):
+        return torch.from_numpy(np.stack([M.tensor2img(t.clone()) for t in t4]))
+
+    def metric_sums(self, test, truth, out=None):
+        a, b = test.numpy(), truth.numpy()
+        for j in range(a.shape[0]):
+            h, w, c = a[j].shape
+            n7 = (h - 6) * (w - 6) * c
+            out[j] = torch.tensor([float(((a[j].astype(np.int64) - b[j]) ** 2).sum()), float(a[j].astype(np.int64).sum()),
+                                   M.compare_ssim(a[j], b[j]) * n7, n7, 0, 0, 0, 0], dtype=torch.float64)
+        return out
+
+    def new_sums(self, b):
+        return torch.empty(2, b, 8, dtype=torch.float64)
+
+    def land(self, tag, slot, t):
+        return t.clone()
+
+    def mark(self):
+        return _Done()
+
+    def sync(self):
+        pass
+
+
+class _NetG:
+    precision, rng, graph = 'f16x3', 'torch', 'auto'
+
+
+class OracleDDPM:
+    """What val.run asks of the DDPM wrapper (model/model.py), on the CPU restatement: every image is its own chain whose noise
+    is keyed by the image content, so a sharded run and a single-rank run sample the same thing."""
+
+    def __init__(self):
+        from oracle import fdsr_oracle as O
+        self.O = O
+        self.cfg = UNetConfig(**CFG)
+        self.sd = O.to_torch_sd(synth_state_dict(self.cfg, 5))
+        self.tab = None
+        self.netG = _NetG()
+        self.device = torch.device('cpu')
+        self.begin_step = self.begin_epoch = 0
+
+    def set_new_noise_schedule(self, schedule_opt, schedule_phase='train'):
+        self.tab = self.O.schedule_tables(schedule_opt)
+
+    def feed_data(self, data):
+        self.data = data
+
+    def test(self, continous=False):
+        cond = self.data['SR']
+        outs = []
+        for j in range(cond.shape[0]):
+            g = torch.Generator().manual_seed(int(cond[j].abs().sum().item() * 1000) % (2 ** 31))
+            noise = torch.randn(20, 1, 3, cond.shape[2], cond.shape[3], generator=g)
+            outs.append(self.O.p_sample_loop(self.sd, self.cfg, self.tab, cond[j:j + 1], noise))
+        self.SR = torch.cat(outs)
+
+
+def _config(root, l, r):
+    return {"name": "sr_fastdiffsr_gloo", "phase": "val", "gpu_ids": [0],
+            "path": {"log": "logs", "tb_logger": "tb_logger", "results": "results", "checkpoint": "checkpoint", "resume_state": None},
+            "datasets": {"train": {"name": "t", "mode": "HR", "dataroot": root, "datatype": "img", "l_resolution": l, "r_resolution": r,
+                                   "batch_size": 2, "num_workers": 1, "use_shuffle": True, "data_len": -1},
+                         "val": {"name": "v", "mode": "LRHR", "dataroot": root, "datatype": "img", "l_resolution": l, "r_resolution": r,
+                                 "data_len": -1}},
+            "model": {"which_model_G": "fastdiffsr", "finetune_norm": False,
+                      "unet": {"in_channel": 6, "out_channel": 3, "inner_channel": 32, "channel_multiplier": [1, 2], "attn_res": [16],
+                               "res_blocks": 1, "dropout": 0.0},
+                      "beta_schedule": {"train": dict(FASTDIFFSR_SCHEDULE_VAL), "val": dict(FASTDIFFSR_SCHEDULE_VAL)},
+                      "diffusion": {"image_size": r, "channels": 3, "conditional": True}},
+            "train": {"n_iter": 1, "val_freq": 1, "save_checkpoint_freq": 1, "print_freq": 1, "optimizer": {"type": "adam", "lr": 1e-4}},
+            "wandb": {"project": "x"}}
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rank(rank, world, port, cpath, out_dir, cwd, q):
+    from fastdiffsr_amd import val
+    os.chdir(cwd)
+    torch.set_num_threads(2)
+    os.environ.update({'RANK': str(rank), 'LOCAL_RANK': str(rank), 'WORLD_SIZE': str(world), 'MASTER_ADDR': '127.0.0.1',
+                       'MASTER_PORT': str(port)})
+    os.environ.pop('FDSR_DIST_BACKEND', None)        # no GPU here: parallel.dist_backend() picks gloo by itself
+    res = val.main(['-c', cpath, '--batch', '2', '--results', out_dir, '--workers', '2'], diffusion=OracleDDPM(), ops=HostOps())
+    q.put((rank, {k: v for k, v in res.items() if k != 'result_path'}))
+
+
+@pytest.mark.timeout(600)
+def test_val_cli_two_ranks_gloo(tmp_path):
+    from test_val_host import make_dataset
+    from fastdiffsr_amd import val
+    from fastdiffsr_amd.config import load_config
+    root = make_dataset(str(tmp_path / 'data'), n=5, l=8, r=32, seed=9)
+    cpath = str(tmp_path / 'cfg.json')
+    with open(cpath, 'w') as f:
+        json.dump(_config(root, 8, 32), f)
+    # single rank, in this process
+    lines = []
+    one = val.run(load_config(cpath, phase='val'), batch=2, results=str(tmp_path / 'one'), log=lines.append, diffusion=OracleDDPM(),
+                  ops=HostOps(), workers=2)
+    assert one['images'] == 5 and len(lines) == 2 and sorted(os.listdir(tmp_path / 'one')) == ['0_%d_sr.tif' % i for i in range(1, 6)]
+    # the loop's own numbers against the metrics recomputed from the files it wrote
+    from PIL import Image
+    hr = [np.asarray(Image.open(os.path.join(root, 'hr_32', '%05d.png' % (i + 1)))) for i in range(5)]
+    sr = [np.asarray(Image.open(tmp_path / 'one' / ('0_%d_sr.tif' % (i + 1)))) for i in range(5)]
+    assert abs(one['sr_psnr'] - np.mean([M.compare_psnr(s, h) for s, h in zip(sr, hr)])) < 1e-9
+    assert abs(one['sr_ssim'] - np.mean([M.compare_ssim(s, h) for s, h in zip(sr, hr)])) < 1e-9
+    # two ranks through the CLI entry point
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank, args=(r, 2, port, cpath, str(tmp_path / 'two'), str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=500) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert sorted(os.listdir(tmp_path / 'two')) == ['0_%d_sr.tif' % i for i in range(1, 6)]      # shard union == all images
+    for i in range(1, 6):       # and every image is the one the single-rank run produced
+        assert np.array_equal(np.asarray(Image.open(tmp_path / 'two' / ('0_%d_sr.tif' % i))), sr[i - 1])
+    for r in (0, 1):            # the all-reduced averages are the single-rank averages on EVERY rank
+        assert got[r]['images'] == 5
+        for k in ('bic_mse', 'bic_psnr', 'bic_ssim', 'bic_ergas', 'sr_mse', 'sr_psnr', 'sr_ssim', 'sr_ergas'):
+            assert abs(got[r][k] - one[k]) <= 1e-12 * max(1.0, abs(one[k])), (k, got[r][k], one[k])

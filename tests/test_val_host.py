@@ -50,6 +50,19 @@ def test_dataset_matches_reference_conventions(tmp_path):
                           'mode': 'HR'}, 'val', cond_from_lr=True)
     it2 = ds2[1]
     assert 'SR' not in it2 and it2['LR_u8'].dtype == torch.uint8 and it2['LR_u8'].shape == (16, 16, 3)
+    # the pipelined loops ship the decoded bytes and finish the transform on the device: same pixels
+    raw_item = ds.load_u8(0)
+    assert set(raw_item) == {'HR', 'SR', 'LR', 'Index'} and raw_item['HR'].dtype == np.uint8 and raw_item['HR'].shape == (64, 64, 3)
+    for k in ('HR', 'SR', 'LR'):
+        assert torch.equal(to_tensor(Image.fromarray(raw_item[k])), it[k])
+    tr = LRHRDataset(root, 'img', l_resolution=16, r_resolution=64, split='train', data_len=-1, need_LR=True)
+    torch.manual_seed(4)
+    a = [tr[i] for i in range(3)]
+    torch.manual_seed(4)
+    b = [tr.load_u8(i) for i in range(3)]                    # same RNG consumption, same flips
+    for x, y in zip(a, b):
+        for k in ('HR', 'SR', 'LR'):
+            assert torch.equal(to_tensor(Image.fromarray(y[k])), x[k])
     g = to_tensor(Image.fromarray(np.full((4, 4), 255, np.uint8)))
     assert g.shape == (1, 4, 4) and float(g.max()) == 1.0
 
