@@ -175,7 +175,7 @@ def kernel_source_hash():
     return h.hexdigest()
 
 
-K32_BITS = 27      # Tunables::k32 default (include/fdsr.h); --debug-option k32=... overrides it for the labels below
+K32_BITS = 59      # Tunables::k32 default (include/fdsr.h); --debug-option k32=... overrides it for the labels below
 
 
 def family_label(precision):
@@ -468,7 +468,7 @@ def facade_records(cfg, sd, dev, S, engine_ips, n_images=256, batch=16):
                 'value': ips, 'unit': 'images/s', 'images': r['images'], 'files_written': written, 'batch': batch, 'dtype': 'f16x3', 'seconds': dt,
                 'sampling_seconds': r['sample_seconds_this_rank'], 'sampling_share': r['sample_seconds_this_rank'] / dt,
                 'vs_engine_headline': ips / engine_ips if engine_ips else None,
-                'sr_psnr': r['sr_psnr'], 'sr_ssim': r['sr_ssim'], 'bic_psnr': r['bic_psnr'],
+                'sr_psnr': r['sr_psnr'], 'sr_ssim': r['sr_ssim'], 'bic_psnr': r['bic_psnr'], 'host_seconds': r['host_seconds'],
                 'workload': f'fastdiffsr_amd.val.run (= python -m fastdiffsr_amd.val --batch {batch}) over {n_images} synthetic 256x256 PNG pairs (32 distinct images): decode, '
                             'H2D as uint8, 20-step loop (torch-drawn noise, hipGraph replay from the 2nd batch), device tensor2img + MSE/PSNR/SSIM/ERGAS, '
                             'D2H as uint8, one .tif per image -- wall clock of the whole call',
@@ -478,7 +478,7 @@ def facade_records(cfg, sd, dev, S, engine_ips, n_images=256, batch=16):
         except Exception as e:
             recs['val_e2e'] = {'error': f'{type(e).__name__}: {e}'}
         try:
-            B, steps, warmup = 32, 6, 2
+            B, steps, warmup = 32, 6, 3
             opt = facade_opt(root, 'train', batch_size=B)
             torch.manual_seed(7)
             np.random.seed(7)

@@ -69,9 +69,15 @@ __device__ __forceinline__ float silu_k(float v) { return v * __builtin_amdgcn_r
 #define K32_PIN16 0
 #endif
 
-template <int TH, int WN, int PREC>
+// NW_ = 8: one 512-thread workgroup per CU (two waves per SIMD in ONE barrier domain).
+// NW_ = 4 ("small workgroups", round 4): 256-thread workgroups, TWO per CU -- the same two waves per SIMD, but in two barrier
+// domains, so that one workgroup's prologue / epilogue can run beside the other's main loop.  Built for the 64-channel level, whose
+// tiles have 2 - 6 chunks: there prologue + epilogue of a one-workgroup-per-CU tile are ~40 % of its time.  Two
+// double-buffered halo images must fit 80 KB: 6-row tiles (f16x3: 2 x 8 x 34 pixels x 128 B = 69.6 KB; bf16 half of that -- its 8-row
+// tile fits too but spills 24 - 42 VGPRs around its eleven staging quads).
+template <int TH, int WN, int PREC, int NW_ = 8>
 struct ConvK32Cfg {
-  static constexpr int TW = 32, NW = 8, KC = 32;
+  static constexpr int TW = 32, NW = NW_, KC = 32;
   static constexpr int NP = PREC == PREC_F16X3 ? 2 : 1;
   static constexpr int ROWB = 64 * NP;           // LDS bytes per halo pixel (no pad: swizzled)
   static constexpr int HH = TH + 2, HWD = TW + 2, NPIX = HH * HWD;
@@ -81,9 +87,10 @@ struct ConvK32Cfg {
   static constexpr int RPP = NT / Q4;            // halo pixels filled per pass
   static constexpr int NIN = (NPIX + RPP - 1) / RPP;
   static constexpr int BUF_BYTES = NPIX * ROWB;
+  static constexpr int LDS_BYTES = 2 * BUF_BYTES;
   static constexpr int R = 3;                     // taps of weight fragments in registers (a ring: 9 % R == 0)
   static constexpr int XS = PREC == PREC_F16X3 ? XS_F16X3 : XS_BF16;   // activation-fragment slots: XS - 1 (tap, row) steps ahead
-  static_assert(MB == 4 || MB == 2, "wave tile = 4 (or, small grids, 2) rows of 32 pixels");
+  static_assert(MB == 4 || MB == 3 || MB == 2, "wave tile = 4 (small grids: 2; small workgroups in f16x3: 3) rows of 32 pixels");
   static_assert(((TH - WM + 2) * HWD + 16) * ROWB < 65536, "fragment offsets must fit the ds_read immediate");
 };
 
@@ -93,9 +100,9 @@ __device__ __forceinline__ int k32_slot(int slot, int hx) {
   return PREC == PREC_F16X3 ? (slot ^ (hx & 7)) : (slot ^ ((hx >> 1) & 3));
 }
 
-template <int TH, int WN, int PREC, bool RIDER>
-__global__ void __launch_bounds__(512, 2) conv_k32_kernel(const ConvParams p) {
-  using Cfg = ConvK32Cfg<TH, WN, PREC>;
+template <int TH, int WN, int PREC, bool RIDER, int NW = 8>
+__global__ void __launch_bounds__(64 * NW, 2) conv_k32_kernel(const ConvParams p) {
+  using Cfg = ConvK32Cfg<TH, WN, PREC, NW>;
   constexpr int TW = Cfg::TW, KC = Cfg::KC, NP = Cfg::NP, ROWB = Cfg::ROWB, HWD = Cfg::HWD, NPIX = Cfg::NPIX;
   constexpr int WM = Cfg::WM, BN = Cfg::BN, MB = Cfg::MB, RPP = Cfg::RPP, NIN = Cfg::NIN, R = Cfg::R, XS = Cfg::XS;
   constexpr bool PIN = TH == 16 ? K32_PIN16 != 0 : K32_PIN != 0;
@@ -130,11 +137,24 @@ __global__ void __launch_bounds__(512, 2) conv_k32_kernel(const ConvParams p) {
 
   const bool gn = p.gn_scale != nullptr;
 
+  if (NW == 4 && p.stagger > 0) {
+    // Two of these workgroups share a CU.  Dispatched together and running the same program they would stay in phase: both in
+    // their prologue, both in their MFMAs, both in their epilogue.  The one in an odd workgroup slot of its CU (HW_ID.TG_ID) starts
+    // late by a share of a tile's time, so that its prologue / epilogue fall beside the other's main loop.  Timing only: nothing
+    // is computed from it.
+    unsigned hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    if ((hwid >> 16) & 1u) {
+      const int n64 = p.stagger * (p.Cin_pad / KC + (RIDER ? p.nkr / 2 : 0));
+      for (int i = 0; i < n64; i += 8) __builtin_amdgcn_s_sleep(8);     // s_sleep 8 = 8 x 64 cycles
+    }
+  }
+
   // ---- staging indices (chunk invariant): thread -> (halo pixel row0 + i*64, float4 slot q of the 32 channels) ----
   const int q = tid & 7, row0 = tid >> 3;
   int in_pix[NIN];
-  unsigned skeys = 0;   // 3 bits per pass: the swizzle key of this thread's halo column (NIN <= 10)
-  static_assert(NIN <= 10, "swizzle keys are packed into one register");
+  unsigned long long skeys = 0;   // 3 bits per pass: the swizzle key of this thread's halo column (the shifts are compile-time)
+  static_assert(NIN <= 21, "swizzle keys are packed into one register pair");
 #pragma unroll
   for (int i = 0; i < NIN; ++i) {
     const int pix = row0 + i * RPP;
@@ -144,7 +164,7 @@ __global__ void __launch_bounds__(512, 2) conv_k32_kernel(const ConvParams p) {
       const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
       const bool ok = iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
       v = ok ? (n * p.Hin + iy) * p.Win + ix : -1;
-      skeys |= (unsigned)k32_slot<PREC>(0, hx) << (3 * i);
+      skeys |= (unsigned long long)k32_slot<PREC>(0, hx) << (3 * i);
     }
     in_pix[i] = v;
   }
@@ -159,12 +179,12 @@ __global__ void __launch_bounds__(512, 2) conv_k32_kernel(const ConvParams p) {
   typedef std::integral_constant<int, NIN> I_N;
   Quad rin[NA];
   Quad rr1[RIDER && SPLIT ? NIN : 1];          // rider chunks are fetched whole: first set (rin itself when not SPLIT)
-  Quad rin2[RIDER && K32_RIDER2 ? NIN : 1];   // second prefetch set of the rider chunks
+  Quad rin2[RIDER && K32_RIDER2 && NW == 8 ? NIN : 1];   // (small workgroups: one set -- the CU's other workgroup covers the latency)   // second prefetch set of the rider chunks
   k_f32x4 rsc = {1.f, 1.f, 1.f, 1.f}, rsh = {0.f, 0.f, 0.f, 0.f};
   const int nk = p.Cin_pad / KC;               // main chunks; nk .. nk + nkr - 1 are the rider's (raw second input, centre tap)
   const int nk16 = p.Cin_pad / 16;
   const int nkr = RIDER ? p.nkr / 2 : 0;
-  auto prefetch_rng = [&](int kc, Quad* rin, auto i0_tag, auto i1_tag, bool load_gn) {
+  auto prefetch_rng = [&](int kc, Quad* rin, auto i0_tag, auto i1_tag, bool load_gn) __attribute__((always_inline)) {
     constexpr int I0 = decltype(i0_tag)::value, I1 = decltype(i1_tag)::value;
     int cbase = kc * KC;
     const float* base;
@@ -185,8 +205,8 @@ __global__ void __launch_bounds__(512, 2) conv_k32_kernel(const ConvParams p) {
     for (int i = I0; i < I1; ++i)
       rin[i - I0] = IO::load4(base, (size_t)(in_pix[i] < 0 ? 0 : in_pix[i]) * Cs + cc);
   };
-  auto prefetch_to = [&](int kc, Quad* rin) { prefetch_rng(kc, rin, I_0{}, I_N{}, true); };
-  auto stage_rng = [&](int kc, unsigned char* buf, const Quad* rin, auto i0_tag, auto i1_tag) {
+  auto prefetch_to = [&](int kc, Quad* rin) __attribute__((always_inline)) { prefetch_rng(kc, rin, I_0{}, I_N{}, true); };
+  auto stage_rng = [&](int kc, unsigned char* buf, const Quad* rin, auto i0_tag, auto i1_tag) __attribute__((always_inline)) {
     constexpr int I0 = decltype(i0_tag)::value, I1 = decltype(i1_tag)::value;
     const k_f32x4 sc = rsc, sh = rsh;
 #pragma unroll
@@ -237,14 +257,14 @@ __global__ void __launch_bounds__(512, 2) conv_k32_kernel(const ConvParams p) {
       }
     }
   };
-  auto stage_from = [&](int kc, unsigned char* buf, const Quad* rin) { stage_rng(kc, buf, rin, I_0{}, I_N{}); };
+  auto stage_from = [&](int kc, unsigned char* buf, const Quad* rin) __attribute__((always_inline)) { stage_rng(kc, buf, rin, I_0{}, I_N{}); };
 
   // ---- weight fragments: ring slot s holds tap t with t % R == s; [cout half][plane] ----
   const uint4* wq = reinterpret_cast<const uint4*>(p.wq);
   const int nkt = RIDER ? nk + nkr : nk;
   uint4 Wf[R][2][NP];
   const int wlane = 32 * (g & 1) + c15;          // + 16 ch: unit within the 32x32x16-order block
-  auto load_w = [&](int kc, int tap, int slot) {
+  auto load_w = [&](int kc, int tap, int slot) __attribute__((always_inline)) {
     const uint4* src = wq + ((((size_t)cot * nk16 + 2 * kc + (g >> 1)) * WN + wn) * 9 + tap) * (NP * 64) + wlane;
     if (RIDER && kc >= nk)   // the 1x1 conv's own fragments [cot][kc16][wn]
       src = reinterpret_cast<const uint4*>(p.wq_r) + (((size_t)cot * p.nkr + 2 * (kc - nk) + (g >> 1)) * WN + wn) * (NP * 64) + wlane;
@@ -293,14 +313,14 @@ __global__ void __launch_bounds__(512, 2) conv_k32_kernel(const ConvParams p) {
 
   uint4 Xf[XS][2][NP];   // [slot][pixel half][plane]: a ring over (tap, row) steps, XS - 1 steps ahead of the MFMAs
   const unsigned char* xptr[3][NP];
-  auto load_x = [&](int slot, int ky, int kx, int mb) {
+  auto load_x = [&](int slot, int ky, int kx, int mb) __attribute__((always_inline)) {
 #pragma unroll
     for (int ph = 0; ph < 2; ++ph)
 #pragma unroll
       for (int pl = 0; pl < NP; ++pl)
         Xf[slot][ph][pl] = *reinterpret_cast<const uint4*>(xptr[kx][pl] + ((mb * WM + ky) * HWD + 16 * ph) * ROWB);
   };
-  auto mfma_step = [&](int xs, int ws, int mb) {
+  auto mfma_step = [&](int xs, int ws, int mb) __attribute__((always_inline)) {
     if (PREC == PREC_F16X3) {
       // small terms first: lo(x) hi(w), hi(x) lo(w), hi(x) hi(w); four independent accumulators between dependent MFMAs
 #pragma unroll
@@ -332,7 +352,7 @@ __global__ void __launch_bounds__(512, 2) conv_k32_kernel(const ConvParams p) {
   constexpr bool PEEL = K32_PEEL != 0 && !RIDER;
   Quad rv[MB][2][2];   // residual tile [row][pixel half][cout half]
   const bool res_early = PEEL && p.res && interior && SK == 1;   // ... fetched during the last chunk, into registers the loop no longer needs
-  auto load_res = [&](auto q0_tag, auto q1_tag) {
+  auto load_res = [&](auto q0_tag, auto q1_tag) __attribute__((always_inline)) {
     constexpr int Q0 = decltype(q0_tag)::value, Q1 = decltype(q1_tag)::value;
 #pragma unroll
     for (int qi = Q0; qi < Q1; ++qi) {
@@ -348,7 +368,7 @@ __global__ void __launch_bounds__(512, 2) conv_k32_kernel(const ConvParams p) {
 
   // main chunks: all nine taps of 32 GroupNorm'ed channels
   const int kcm = RIDER ? (kc1 < nk ? kc1 : nk) : kc1;
-  auto main_chunk = [&](int kc, auto last_tag) {
+  auto main_chunk = [&](int kc, auto last_tag) __attribute__((always_inline)) {
     constexpr bool LAST = decltype(last_tag)::value;   // the peeled final chunk: nothing to fetch or stage for a next one
     unsigned char* cur = ((kc - kc0) & 1) ? sBuf1 : sBuf0;
     unsigned char* nxt = ((kc - kc0) & 1) ? sBuf0 : sBuf1;
@@ -419,9 +439,9 @@ __global__ void __launch_bounds__(512, 2) conv_k32_kernel(const ConvParams p) {
     // A rider chunk is short (48 MFMAs per wave): its input is fetched TWO chunks ahead, into two register sets that alternate
     // (on entry the first set holds chunk k0 + 1, as the main loop leaves it; two of the three weight-ring slots are free by now).
     const int k0 = kc0 > nk ? kc0 : nk;
-    constexpr int AH = K32_RIDER2 ? 2 : 1;
+    constexpr int AH = K32_RIDER2 && NW == 8 ? 2 : 1;
     if (AH == 2 && k0 + 2 < kc1) prefetch_to(k0 + 2, rin2);
-    auto rider_chunk = [&](int kc, Quad* r1) {   // r1 holds chunk kc + 1
+    auto rider_chunk = [&](int kc, Quad* r1) __attribute__((always_inline)) {   // r1 holds chunk kc + 1
       unsigned char* cur = ((kc - kc0) & 1) ? sBuf1 : sBuf0;
       unsigned char* nxt = ((kc - kc0) & 1) ? sBuf0 : sBuf1;
 #pragma unroll
@@ -497,7 +517,7 @@ __global__ void __launch_bounds__(512, 2) conv_k32_kernel(const ConvParams p) {
   k_f32x4 s1[2], s2[2];
 #pragma unroll
   for (int ch = 0; ch < 2; ++ch) s1[ch] = s2[ch] = k_f32x4{0.f, 0.f, 0.f, 0.f};
-  auto epilogue = [&](auto out16_tag) {
+  auto epilogue = [&](auto out16_tag) __attribute__((always_inline)) {
     constexpr bool OUT16 = decltype(out16_tag)::value;
     auto put4 = [&](size_t idx, k_f32x4 v) {
       if (OUT16) {
@@ -923,11 +943,39 @@ bool conv_k32_ok(int TH, int WN, int prec, const ConvParams& p) {
   return true;
 }
 
-template <int TH, int WN, int PREC, bool RIDER>
+template <int TH, int WN, int PREC, bool RIDER, int NW = 8>
 static hipError_t launch_k32_t(const ConvParams& q, int nwg, hipStream_t s) {
-  using Cfg = ConvK32Cfg<TH, WN, PREC>;
-  hipLaunchKernelGGL((conv_k32_kernel<TH, WN, PREC, RIDER>), dim3(nwg), dim3(Cfg::NT), (size_t)2 * Cfg::BUF_BYTES, s, q);
+  using Cfg = ConvK32Cfg<TH, WN, PREC, NW>;
+  hipLaunchKernelGGL((conv_k32_kernel<TH, WN, PREC, RIDER, NW>), dim3(nwg), dim3(Cfg::NT), (size_t)Cfg::LDS_BYTES, s, q);
   return hipGetLastError();
+}
+
+// The small-workgroup form (NW = 4, two workgroups per CU) of the 64-cout launches: 6-row tiles (what two double-buffered f16x3 halo
+// images per CU leave room for).  Large grids only: a small grid wants all eight waves of a CU on its one
+// tile.  launch_conv_h asks before it picks a tile of its own; tiles / nwg are computed here.
+static int k32_small_rows(int) { return 6; }
+
+bool conv_k32_small_ok(ConvKind kind, int prec, const ConvParams& p) {
+  if (!(g_tun.k32 & 32) || kind != CONV3_S1 || p.ksplit > 1 || p.Cout_pad != 64) return false;
+  if (prec == PREC_BF16 && !(g_tun.k32 & 128)) return false;   // bf16: measured equal per kernel, -0.4 % end to end (more GroupNorm partials): bit 128
+  if (p.xr0 && !(g_tun.k32 & 64)) return false;   // launches with a rider keep the 32x32x16 rider kernel (bit 64: measured 7 % slower on this form)
+  if (!conv_k32_ok(8, 4, prec, p)) return false;          // the form's own conditions (an MB = 4 shape: no tile-size bits involved)
+  const int th = k32_small_rows(prec);
+  const long wgs = (long)p.N * ((p.Wout + 31) / 32) * ((p.Hout + th - 1) / th);
+  return wgs >= g_tun.k32_sb_min_wgs;
+}
+
+hipError_t launch_conv_k32_small(int prec, const ConvParams& p, hipStream_t s, int* tiles) {
+  const int th = k32_small_rows(prec);
+  const int tilesX = (p.Wout + 31) / 32, tilesY = (p.Hout + th - 1) / th;
+  if (tiles) *tiles = tilesX * tilesY;
+  const int nwg = p.N * tilesX * tilesY;
+  ConvParams q = p;
+  q.out_bf16 = (prec == PREC_BF16 && !p.out_f32) ? 1 : 0;
+  q.stagger = g_tun.k32_stagger;
+  if (prec == PREC_F16X3)
+    return q.xr0 ? launch_k32_t<6, 2, PREC_F16X3, true, 4>(q, nwg, s) : launch_k32_t<6, 2, PREC_F16X3, false, 4>(q, nwg, s);
+  return q.xr0 ? launch_k32_t<6, 2, PREC_BF16, true, 4>(q, nwg, s) : launch_k32_t<6, 2, PREC_BF16, false, 4>(q, nwg, s);
 }
 
 hipError_t launch_conv_k32(int TH, int WN, int prec, const ConvParams& q, int nwg, hipStream_t s) {
@@ -943,9 +991,9 @@ hipError_t launch_conv_k32(int TH, int WN, int prec, const ConvParams& q, int nw
   return hipErrorInvalidValue;
 }
 
-template <int TH, int WN, int PREC, bool RIDER>
+template <int TH, int WN, int PREC, bool RIDER, int NW = 8>
 static hipError_t init_k32_t() {
-  auto kfn = conv_k32_kernel<TH, WN, PREC, RIDER>;
+  auto kfn = conv_k32_kernel<TH, WN, PREC, RIDER, NW>;
   return hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
@@ -969,6 +1017,10 @@ hipError_t kernels_k32_init() {
   if ((e = init_k32_t<TH_, WN_, PREC_BF16, true>()) != hipSuccess) return e;
   FDSR_K32_SHAPES(X)
 #undef X
+  if ((e = init_k32_t<6, 2, PREC_F16X3, false, 4>()) != hipSuccess) return e;
+  if ((e = init_k32_t<6, 2, PREC_F16X3, true, 4>()) != hipSuccess) return e;
+  if ((e = init_k32_t<6, 2, PREC_BF16, false, 4>()) != hipSuccess) return e;
+  if ((e = init_k32_t<6, 2, PREC_BF16, true, 4>()) != hipSuccess) return e;
   return hipSuccess;
 }
 

@@ -9,6 +9,9 @@
 // The input transform runs in fp32 on the ACTIVATED tensor (GroupNorm-apply + Swish fused into the staging as in the
 // direct kernel) BEFORE the hi/lo split, so operands keep 22 mantissa bits: x = hi + lo, product = hi*hi + hi*lo + lo*hi.
 //
+// OFF by default (fdsr_debug_option("wino", 2) turns it on): the 16x16x32 direct kernel (fdsr_conv_k32.hip) overtook it on every
+// layer set in round 3; what stays is the half-tile pipeline form, as the documented option and A/B partner.
+//
 // Workgroup = 8 wave64 = one 16x16-pixel output block (8x8 tiles) x 64 output channels, all 16 Winograd positions:
 //   * accumulators: 16 positions x 64 tiles x 64 couts fp32 = 256 KB = half the CU's register file.  Wave w owns
 //     position row xi = w & 3 (4 positions), cout half w >> 2 and all 64 tiles: 8 accumulator tiles (128 VGPRs).
@@ -48,268 +51,17 @@ constexpr int W_V_BYTES = 16 * W_TT * W_ROWB;  // 81920
 constexpr int W_RAW_BYTES = W_NPIX * W_RAWB;   // 25920
 constexpr int W_ZROWB = 272;                   // exchange row: 64 couts fp32 + 16 B pad
 constexpr int W_Z_BYTES = 8 * W_TT * W_ZROWB;  // 139264: Z[xi][j][tile][cout]
-constexpr int W_LDS = W_Z_BYTES > W_V_BYTES + 2 * W_RAW_BYTES ? W_Z_BYTES : W_V_BYTES + 2 * W_RAW_BYTES;
 constexpr int W_NIN = 3;                       // halo (pixel, quad) items per thread: 324 * 4 / 512 -> 3 passes
 
 __device__ __forceinline__ float silu_w(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
-
-// split 4 fp32 into hi = rn_f16(v), lo = rn_f16(v - hi) and store them at dst (hi) and dst + 32 (lo)
-__device__ __forceinline__ void split_store(unsigned char* dst, f32x4 v) {
-  h4 hi = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
-  h4 lo = {(_Float16)(v.x - (float)hi.x), (_Float16)(v.y - (float)hi.y), (_Float16)(v.z - (float)hi.z), (_Float16)(v.w - (float)hi.w)};
-  *reinterpret_cast<h4*>(dst) = hi;
-  *reinterpret_cast<h4*>(dst + 32) = lo;
-}
 
 }  // namespace
 
 // Perf-only knock-out builds (tools/build_wino_variant.sh -DWINO_KO_...): remove one part of the kernel to price it; results are garbage.
 #define WINO_SINK4(u) asm volatile("" ::"v"((u).x), "v"((u).y), "v"((u).z), "v"((u).w))
 
-__global__ void __launch_bounds__(512, 2) conv_wino_h_kernel(const ConvParams p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_w[];
-  unsigned char* sV = smem_w;
-  unsigned char* sRaw0 = smem_w + W_V_BYTES;
-  unsigned char* sRaw1 = sRaw0 + W_RAW_BYTES;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int Cin = p.C0 + p.C1;
-  const int nk = p.Cin_pad >> 4;
-  const int nco = p.Cout_pad >> 6;
-  const int tilesX = p.Wout >> 4, ntile = tilesX * (p.Hout >> 4);
-  int cot, sp;
-  {
-    const int b = blockIdx.x;
-    if (nco <= 8 && (8 % nco) == 0 && (gridDim.x & 7) == 0) {   // one cout block per XCD (round-robin dispatch: XCD = b & 7)
-      const int xcd = b & 7, k = b >> 3, per = 8 / nco;
-      cot = xcd % nco;
-      sp = k * per + xcd / nco;
-    } else {
-      cot = b % nco;
-      sp = b / nco;
-    }
-  }
-  const int n = sp / ntile, tl = sp % ntile;
-  const int oy0 = (tl / tilesX) * 16, ox0 = (tl % tilesX) * 16, co0 = cot * 64;
-  const bool gn = p.gn_scale != nullptr;
-
-  // ---- halo staging: thread -> (pixel row0 + 128 i, channel quad q) ----
-  const int q = tid & 3, row0 = tid >> 2;
-  int in_pix[W_NIN];
-#pragma unroll
-  for (int i = 0; i < W_NIN; ++i) {
-    const int pix = row0 + i * 128;
-    int v = -2;
-    if (pix < W_NPIX) {
-      const int hy = pix / W_HW, hx = pix % W_HW;
-      const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
-      const bool ok = iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
-      v = ok ? (n * p.Hin + iy) * p.Win + ix : -1;
-    }
-    in_pix[i] = v;
-  }
-  f32x4 rin[W_NIN];
-  f32x4 rsc = {1.f, 1.f, 1.f, 1.f}, rsh = {0.f, 0.f, 0.f, 0.f};
-  auto prefetch = [&](int kc) {
-    const int cbase = kc * 16;
-    const float* base;
-    int Cs, cc;
-    if (cbase < p.C0) { base = p.x0; Cs = p.C0; cc = cbase + q * 4; }
-    else { base = p.x1; Cs = p.C1; cc = cbase - p.C0 + q * 4; }
-    if (gn) {
-      rsc = *reinterpret_cast<const f32x4*>(p.gn_scale + (size_t)n * Cin + cbase + q * 4);
-      rsh = *reinterpret_cast<const f32x4*>(p.gn_shift + (size_t)n * Cin + cbase + q * 4);
-    }
-#pragma unroll
-    for (int i = 0; i < W_NIN; ++i)   // branch-free: padding / unused items read pixel 0 and are zeroed in stage()
-      rin[i] = *reinterpret_cast<const f32x4*>(base + (size_t)(in_pix[i] < 0 ? 0 : in_pix[i]) * Cs + cc);
-  };
-  auto stage = [&](unsigned char* buf) {
-    const f32x4 sc = rsc, sh = rsh;
-#pragma unroll
-    for (int i = 0; i < W_NIN; ++i) {
-      if (i == W_NIN - 1 && row0 + i * 128 >= W_NPIX) continue;
-      f32x4 v = rin[i];
-      if (gn) {
-        v = v * sc + sh;
-        if (!p.gn_plain) { v.x = silu_w(v.x); v.y = silu_w(v.y); v.z = silu_w(v.z); v.w = silu_w(v.w); }
-      }
-      // the conv zero-pads the ACTIVATED tensor (lim = 0); |V| <= 4 max|a| must stay inside the f16 range after the transform
-      const float lim = in_pix[i] >= 0 ? 16376.f : 0.f;
-      if (p.sat_flag) sat_check(p.sat_flag, v, 16376.f);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], -lim, lim);
-      *reinterpret_cast<f32x4*>(buf + (row0 + i * 128) * W_RAWB + q * 16) = v;
-    }
-  };
-
-  // ---- transformed-weight fragments: [cot][kc][wave][nu][plane][lane] x 16 B, straight to VGPRs, one chunk ahead ----
-  const uint4* wq = reinterpret_cast<const uint4*>(p.wq) + ((size_t)cot * nk * 8 + wave) * (4 * 2 * 64) + lane;
-  uint4 Bf[4][2];
-  auto load_b = [&](int kc, int nu) {
-    const uint4* src = wq + (size_t)kc * (8 * 4 * 2 * 64) + nu * (2 * 64);
-    Bf[nu][0] = src[0];
-    Bf[nu][1] = src[64];
-  };
-
-  // ---- input transform roles: lane bits chosen so that the 16-lane groups of ds_read_b128 / ds_write_b64 hit 64 / 32
-  // distinct banks: tx = lane[2:0], channel quad = {lane[5], lane[3]}, tile row = {lane[4], wave[1:0]}, position-row pair = wave[2]
-  const int t_tx = lane & 7, t_cq = ((lane >> 3) & 1) | (((lane >> 5) & 1) << 1);
-  const int t_ty = (((lane >> 4) & 1) << 2) | (wave & 3), t_xh = wave >> 2;
-  const int t_rd = ((2 * t_ty + t_xh) * W_HW + 2 * t_tx) * W_RAWB + t_cq * 16;        // rows xh .. xh + 2 of the 4 x 4 patch
-  const int t_wr = ((t_xh * 8) * W_TT + t_ty * 8 + t_tx) * W_ROWB + t_cq * 8;         // positions (2 xh) * 4 .. + 7
-  auto transform = [&](const unsigned char* raw) {
-    f32x4 R0[4], R1[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(raw + t_rd + (0 * W_HW + c) * W_RAWB);
-      const f32x4 b = *reinterpret_cast<const f32x4*>(raw + t_rd + (1 * W_HW + c) * W_RAWB);
-      const f32x4 d = *reinterpret_cast<const f32x4*>(raw + t_rd + (2 * W_HW + c) * W_RAWB);
-      if (t_xh == 0) { R0[c] = a - d; R1[c] = b + d; }      // xi = 0: d0 - d2 ; xi = 1: d1 + d2   (rows 0, 1, 2)
-      else           { R0[c] = b - a; R1[c] = a - d; }      // xi = 2: d2 - d1 ; xi = 3: d1 - d3   (rows 1, 2, 3)
-    }
-    unsigned char* dst = sV + t_wr;
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const f32x4* R = r ? R1 : R0;
-      split_store(dst + (r * 4 + 0) * (W_TT * W_ROWB), R[0] - R[2]);
-      split_store(dst + (r * 4 + 1) * (W_TT * W_ROWB), R[1] + R[2]);
-      split_store(dst + (r * 4 + 2) * (W_TT * W_ROWB), R[2] - R[1]);
-      split_store(dst + (r * 4 + 3) * (W_TT * W_ROWB), R[1] - R[3]);
-    }
-  };
-
-  // ---- MFMA roles: position row xi = wave & 3, cout half = wave >> 2; lane -> tile l & 31 of a 32-tile block, k half l >> 5 ----
-  const int xi = wave & 3, chalf = wave >> 2;
-  const int r31 = lane & 31, kh = lane >> 5;
-  const unsigned char* abase = sV + ((xi * 4) * W_TT + r31) * W_ROWB + 16 * kh;
-
-  f32x16 acc[4][2];
-#pragma unroll
-  for (int nu = 0; nu < 4; ++nu)
-#pragma unroll
-    for (int tb = 0; tb < 2; ++tb)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[nu][tb][i] = 0.f;
-
-#pragma unroll
-  for (int nu = 0; nu < 4; ++nu) load_b(0, nu);
-  prefetch(0);
-  stage(sRaw0);
-  if (nk > 1) prefetch(1);
-  __syncthreads();
-
-  uint4 Af[2][2][2];   // [slot][tile block][plane]
-  auto load_a = [&](int slot, int nu) {
-#pragma unroll
-    for (int tb = 0; tb < 2; ++tb)
-#pragma unroll
-      for (int pl = 0; pl < 2; ++pl)
-        Af[slot][tb][pl] = *reinterpret_cast<const uint4*>(abase + (nu * W_TT + tb * 32) * W_ROWB + 32 * pl);
-  };
-
-  for (int kc = 0; kc < nk; ++kc) {
-    unsigned char* cur = (kc & 1) ? sRaw1 : sRaw0;
-    unsigned char* nxt = (kc & 1) ? sRaw0 : sRaw1;
-    const bool more = kc + 1 < nk;
-#ifndef WINO_KO_T
-    transform(cur);
-#endif
-    __syncthreads();          // V complete
-#ifndef WINO_KO_A
-    load_a(0, 0);
-#endif
-#pragma unroll
-    for (int nu = 0; nu < 4; ++nu) {
-#ifndef WINO_KO_A
-      if (nu + 1 < 4) load_a((nu + 1) & 1, nu + 1);
-#endif
-#pragma unroll
-      for (int tb = 0; tb < 2; ++tb) {
-        const uint4 ahi = Af[nu & 1][tb][0], alo = Af[nu & 1][tb][1];
-#ifndef WINO_KO_M
-        acc[nu][tb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, alo), __builtin_bit_cast(h8, Bf[nu][0]), acc[nu][tb], 0, 0, 0);
-        acc[nu][tb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, ahi), __builtin_bit_cast(h8, Bf[nu][1]), acc[nu][tb], 0, 0, 0);
-        acc[nu][tb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, ahi), __builtin_bit_cast(h8, Bf[nu][0]), acc[nu][tb], 0, 0, 0);
-#else
-        WINO_SINK4(ahi); WINO_SINK4(alo); WINO_SINK4(Bf[nu][0]); WINO_SINK4(Bf[nu][1]);
-#endif
-      }
-#ifndef WINO_KO_B
-      if (more) load_b(kc + 1, nu);   // same registers, next chunk
-#endif
-#ifndef WINO_KO_STAGE
-      if (nu == 1 && more) {          // mid-phase: activate and store the next chunk's halo, fetch the one after
-        stage(nxt);
-        if (kc + 2 < nk) prefetch(kc + 2);
-      }
-#endif
-    }
-    __syncthreads();          // V free again; next halo complete
-  }
-
-  // ---- epilogue.  Fold the position row over nu: Z[xi][0] = M0 + M1 + M2, Z[xi][1] = M1 - M2 - M3; rows meet in LDS ----
-  {
-    float* z = reinterpret_cast<float*>(smem_w);
-    const int cz = chalf * 32 + r31;
-#pragma unroll
-    for (int tb = 0; tb < 2; ++tb)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int tile = tb * 32 + (i & 3) + 8 * (i >> 2) + 4 * kh;
-        const float m0 = acc[0][tb][i], m1 = acc[1][tb][i], m2 = acc[2][tb][i], m3 = acc[3][tb][i];
-        z[(((xi * 2 + 0) * W_TT + tile) * W_ZROWB >> 2) + cz] = m0 + m1 + m2;
-        z[(((xi * 2 + 1) * W_TT + tile) * W_ZROWB >> 2) + cz] = m1 - m2 - m3;
-      }
-  }
-  __syncthreads();
-  const float winv = p.w_inv_scale_dev ? *p.w_inv_scale_dev : p.w_inv_scale;
-  const int cqo = tid & 15, pp0 = tid >> 4;    // cout quad, first pixel (then + 32 per pass)
-  const int co = co0 + cqo * 4;
-  f32x4 add = *reinterpret_cast<const f32x4*>(p.bias + co);
-  if (p.temb) add += *reinterpret_cast<const f32x4*>(p.temb + (size_t)n * p.temb_stride + p.temb_off + co);
-  f32x4 rv[8], yv[8];
-#pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    const int pp = pp0 + it * 32, py = pp >> 4, px = pp & 15;
-    const size_t o = ((size_t)(n * p.Hout + oy0 + py) * p.Wout + ox0 + px) * p.Cout + co;
-    rv[it] = p.res ? *reinterpret_cast<const f32x4*>(p.res + o) : f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-#pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    const int pp = pp0 + it * 32, py = pp >> 4, px = pp & 15;
-    const int tile = (py >> 1) * 8 + (px >> 1), i = py & 1, j = px & 1;
-    const unsigned char* zb = smem_w + ((size_t)j * W_TT + tile) * W_ZROWB + cqo * 16;
-    const f32x4 z0 = *reinterpret_cast<const f32x4*>(zb + (size_t)(0 + i) * 2 * W_TT * W_ZROWB);   // i = 0: xi 0, 1, 2 ; i = 1: xi 1, 2, 3
-    const f32x4 z1 = *reinterpret_cast<const f32x4*>(zb + (size_t)(1 + i) * 2 * W_TT * W_ZROWB);
-    const f32x4 z2 = *reinterpret_cast<const f32x4*>(zb + (size_t)(2 + i) * 2 * W_TT * W_ZROWB);
-    const f32x4 y = i == 0 ? (z0 + z1) + z2 : (z0 - z1) - z2;
-    yv[it] = y * winv + add + rv[it];
-  }
-  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    const int pp = pp0 + it * 32, py = pp >> 4, px = pp & 15;
-    const size_t o = ((size_t)(n * p.Hout + oy0 + py) * p.Wout + ox0 + px) * p.Cout + co;
-    *reinterpret_cast<f32x4*>(p.out + o) = yv[it];
-    s1 += yv[it];
-    s2 += yv[it] * yv[it];
-  }
-  if (p.part_out) {
-    __syncthreads();                                   // every Z read is done: the arena is free
-    f32x4* sred = reinterpret_cast<f32x4*>(smem_w);    // [32 pixel groups][16 quads][2]
-    sred[(pp0 * 16 + cqo) * 2 + 0] = s1;
-    sred[(pp0 * 16 + cqo) * 2 + 1] = s2;
-    __syncthreads();
-    if (tid < 16) {
-      f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
-      for (int g = 0; g < 32; ++g) { a += sred[(g * 16 + tid) * 2 + 0]; b += sred[(g * 16 + tid) * 2 + 1]; }
-      float* dst = p.part_out + (((size_t)n * ntile + tl) * p.Cout + co0 + tid * 4) * 2;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { dst[2 * e] = a[e]; dst[2 * e + 1] = b[e]; }
-    }
-  }
-}
+// (The first, serial-phase form of this kernel and a 256-thread two-workgroups-per-CU form were built, measured and removed in
+// round 4: they never beat the half-tile pipeline below -- DESIGN / EXPERIMENTS, "Winograd".)
 
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -816,260 +568,6 @@ __global__ void __launch_bounds__(512, 2) conv_wino2_h_kernel(const ConvParams p
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Fourth form: 256-thread workgroups, TWO per CU.  The eight waves of the forms above march in lockstep between two barriers per
-// chunk, and the chunk time is the SUM of the LDS, VALU and MFMA work (profiles/r03_wino_knockouts.txt).  Two independent
-// workgroups on a CU share nothing but the hardware: while one transforms (VALU + LDS) the other multiplies.  A workgroup = 4 waves
-// (one per SIMD) = 32 tiles (8 x 16 pixels) x 64 couts; wave xi owns its position row for BOTH cout halves (8 accumulator tiles);
-// weight fragments in a ring of three positions (48 VGPRs) fetched two positions ahead; serial phases inside the workgroup
-// (transform | barrier | MFMAs with the next halo's staging in the middle | barrier).  LDS 78 KB per workgroup.
-namespace {
-constexpr int W4_TT = 32;                               // tiles per workgroup: 4 rows x 8 columns of 2 x 2 outputs
-constexpr int W4_HH = 10, W4_NPIX = W4_HH * W_HW;       // halo 10 x 18 pixels = 180
-constexpr int W4_V_BYTES = 16 * W4_TT * W_ROWB;         // 40960
-constexpr int W4_RAW_BYTES = W4_HH * W2_RAWROW;         // 15360
-constexpr int W4_SS_OFF = W4_V_BYTES + 2 * W4_RAW_BYTES;   // 71680
-constexpr int W4_LDS = W4_SS_OFF + W2_MAXCIN * 8;       // 79872 (the epilogue's exchange image: 8 x 32 x 272 = 69632)
-}  // namespace
-
-__global__ void __launch_bounds__(256, 2) conv_wino4_h_kernel(const ConvParams p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_w[];
-  unsigned char* sV = smem_w;
-  unsigned char* sRaw0 = smem_w + W4_V_BYTES;
-  unsigned char* sRaw1 = sRaw0 + W4_RAW_BYTES;
-  float* sSS = reinterpret_cast<float*>(smem_w + W4_SS_OFF);
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // = position row xi of the MFMA part
-  const int Cin = p.C0 + p.C1;
-  const int nk = p.Cin_pad >> 4;
-  const int nco = p.Cout_pad >> 6;
-  const int tilesX = p.Wout >> 4, ntile = tilesX * (p.Hout >> 3);
-  int cot, sp;
-  {
-    const int b = blockIdx.x;
-    if (nco <= 8 && (8 % nco) == 0 && (gridDim.x & 7) == 0) {   // one cout block per XCD
-      const int xcd = b & 7, k = b >> 3, per = 8 / nco;
-      cot = xcd % nco;
-      sp = k * per + xcd / nco;
-    } else {
-      cot = b % nco;
-      sp = b / nco;
-    }
-  }
-  const int n = sp / ntile, tl = sp % ntile;
-  const int oy0 = (tl / tilesX) * 8, ox0 = (tl % tilesX) * 16, co0 = cot * 64;
-
-  // ---- halo staging: thread -> (pixel row0 + 64 i, channel quad q), i = 0..2 (180 pixels x 4 quads over 256 threads) ----
-  const int q = tid & 3, row0 = tid >> 2;
-  int in_pix[3], raw_off[3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const int pix = row0 + i * 64;
-    int v = -2, ro = 18 * W_RAWB + q * 16;        // no third item on this lane: a dummy slot in the padding of halo row 0
-    if (pix < W4_NPIX) {
-      const int hy = pix / W_HW, hx = pix % W_HW;
-      const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
-      const bool ok = iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
-      v = ok ? (n * p.Hin + iy) * p.Win + ix : -1;
-      ro = hy * W2_RAWROW + hx * W_RAWB + q * 16;
-    }
-    in_pix[i] = v;
-    raw_off[i] = ro;
-  }
-  f32x4 rin[3];
-  for (int c4 = tid; c4 < (Cin >> 2); c4 += 256) {
-    *reinterpret_cast<f32x4*>(sSS + c4 * 4) = *reinterpret_cast<const f32x4*>(p.gn_scale + (size_t)n * Cin + c4 * 4);
-    *reinterpret_cast<f32x4*>(sSS + Cin + c4 * 4) = *reinterpret_cast<const f32x4*>(p.gn_shift + (size_t)n * Cin + c4 * 4);
-  }
-  auto prefetch = [&](int kc) {
-    const int cbase = kc * 16;
-    const float* base;
-    int Cs, cc;
-    if (cbase < p.C0) { base = p.x0; Cs = p.C0; cc = cbase + q * 4; }
-    else { base = p.x1; Cs = p.C1; cc = cbase - p.C0 + q * 4; }
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-      rin[i] = *reinterpret_cast<const f32x4*>(base + (size_t)(in_pix[i] < 0 ? 0 : in_pix[i]) * Cs + cc);
-  };
-  auto stage = [&](int kc, unsigned char* buf) {
-    const f32x4 sc = *reinterpret_cast<const f32x4*>(sSS + kc * 16 + q * 4), sh = *reinterpret_cast<const f32x4*>(sSS + Cin + kc * 16 + q * 4);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      f32x4 v = rin[i] * sc + sh;
-      v.x = silu_w(v.x); v.y = silu_w(v.y); v.z = silu_w(v.z); v.w = silu_w(v.w);
-      const float lim = in_pix[i] >= 0 ? 16376.f : 0.f;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], -lim, lim);
-      *reinterpret_cast<f32x4*>(buf + raw_off[i]) = v;
-    }
-  };
-
-  // ---- transform: item = (tile of the 32, 4 channels, position row): lane = {ty[1:0], cq[0], tx[2:0]}, wave = {xi pair, cq[1]}; two items per
-  // thread (position rows 2 (wave >> 1) + j) ----
-  const int t_tx = lane & 7, t_ty = lane >> 4, t_cq = ((lane >> 3) & 1) | ((wave & 1) << 1);
-  const int t_rd = (2 * t_ty) * W2_RAWROW + (2 * t_tx) * W_RAWB + t_cq * 16;
-  auto transform = [&](const unsigned char* raw) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int xi_t = (wave >> 1) * 2 + j;
-      const int ra_off = (xi_t == 0 ? 0 : (xi_t == 2 ? 2 : 1)) * W2_RAWROW, rb_off = (xi_t == 3 ? 3 : (xi_t == 2 ? 1 : 2)) * W2_RAWROW;
-      const float t_s = xi_t == 1 ? 1.f : -1.f;
-      const unsigned char* ra = raw + t_rd + ra_off;
-      const unsigned char* rb = raw + t_rd + rb_off;
-      f32x4 a[4], b[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        a[c] = *reinterpret_cast<const f32x4*>(ra + c * W_RAWB);
-        b[c] = *reinterpret_cast<const f32x4*>(rb + c * W_RAWB);
-      }
-      unsigned char* dst = sV + ((xi_t * 4) * W4_TT + t_ty * 8 + t_tx) * W_ROWB + t_cq * 8;
-      const f32x4 R0 = b[0] * t_s + a[0], R2 = b[2] * t_s + a[2];
-      split_store2(dst + 0 * (W4_TT * W_ROWB), R0 - R2);
-      const f32x4 R1 = b[1] * t_s + a[1];
-      split_store2(dst + 1 * (W4_TT * W_ROWB), R1 + R2);
-      split_store2(dst + 2 * (W4_TT * W_ROWB), R2 - R1);
-      const f32x4 R3 = b[3] * t_s + a[3];
-      split_store2(dst + 3 * (W4_TT * W_ROWB), R1 - R3);
-    }
-  };
-
-  // ---- MFMA part: wave = position row xi; both cout halves; weight fragments [cot][kc][role = xi | half << 2][nu][plane][lane] ----
-  const int xi = wave;
-  const int r31 = lane & 31, kh = lane >> 5;
-  const unsigned char* abase = sV + ((xi * 4) * W4_TT + r31) * W_ROWB + 16 * kh;
-  const u32x4* wq = reinterpret_cast<const u32x4*>(p.wq) + ((size_t)cot * nk * 8 + xi) * (4 * 2 * 64) + lane;
-  u32x4 Bf[3][2][2];   // ring over positions: [slot][cout half][plane]
-  auto load_b = [&](int slot, int kc, int nu) {
-    const u32x4* src = wq + (size_t)kc * (8 * 4 * 2 * 64) + nu * (2 * 64);
-#pragma unroll
-    for (int ch = 0; ch < 2; ++ch) {
-      Bf[slot][ch][0] = src[ch * (4 * 4 * 2 * 64)];
-      Bf[slot][ch][1] = src[ch * (4 * 4 * 2 * 64) + 64];
-    }
-  };
-
-  f32x16 acc[4][2];
-#pragma unroll
-  for (int nu = 0; nu < 4; ++nu)
-#pragma unroll
-    for (int ch = 0; ch < 2; ++ch)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[nu][ch][i] = 0.f;
-
-  // ---- prologue ----
-  prefetch(0);
-  load_b(0, 0, 0);
-  load_b(1, 0, 1);
-  load_b(2, 0, 2);
-  __syncthreads();          // scale / shift in LDS
-  stage(0, sRaw0);
-  prefetch(nk > 1 ? 1 : 0);
-  __syncthreads();
-
-  for (int kc = 0; kc < nk; ++kc) {
-    unsigned char* cur = (kc & 1) ? sRaw1 : sRaw0;
-    unsigned char* nxt = (kc & 1) ? sRaw0 : sRaw1;
-    const int kc1 = kc + 1 < nk ? kc + 1 : nk - 1, kc2 = kc + 2 < nk ? kc + 2 : nk - 1;
-    transform(cur);
-    __syncthreads();          // V complete
-    // positions in order; slot of position nu of chunk kc: (4 kc + nu) % 3 -- written out for the four residues of kc mod 3 would
-    // need a rotating index; instead the ring is re-based every chunk: slots hold (nu0, nu1, nu2) at the start of every chunk
-#pragma unroll
-    for (int nu = 0; nu < 4; ++nu) {
-      const int slot = nu == 3 ? 0 : nu;
-      u32x4 ahi = *reinterpret_cast<const u32x4*>(abase + (nu * W4_TT) * W_ROWB);
-      u32x4 alo = *reinterpret_cast<const u32x4*>(abase + (nu * W4_TT) * W_ROWB + 32);
-#pragma unroll
-      for (int ch = 0; ch < 2; ++ch) {
-        acc[nu][ch] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, alo), __builtin_bit_cast(h8, Bf[slot][ch][0]), acc[nu][ch], 0, 0, 0);
-        acc[nu][ch] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, ahi), __builtin_bit_cast(h8, Bf[slot][ch][1]), acc[nu][ch], 0, 0, 0);
-        acc[nu][ch] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, ahi), __builtin_bit_cast(h8, Bf[slot][ch][0]), acc[nu][ch], 0, 0, 0);
-      }
-      // ring: slot 0 takes position 3 of this chunk after position 0, then the next chunk's 0, 1, 2 follow their last uses
-      if (nu == 0) load_b(0, kc, 3);
-      else if (nu == 1) load_b(1, kc1, 1);
-      else if (nu == 2) load_b(2, kc1, 2);
-      else load_b(0, kc1, 0);
-      if (nu == 1) {          // mid-phase: activate and store the next chunk's halo, fetch the one after
-        stage(kc1, nxt);
-        prefetch(kc2);
-      }
-    }
-    __syncthreads();          // V free again; next halo complete
-  }
-
-  // ---- epilogue: fold over nu, rows meet in LDS (Z[xi][j][tile][cout]) ----
-  {
-    float* z = reinterpret_cast<float*>(smem_w);
-#pragma unroll
-    for (int ch = 0; ch < 2; ++ch) {
-      const int cz = ch * 32 + r31;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int tile = (i & 3) + 8 * (i >> 2) + 4 * kh;
-        const float m0 = acc[0][ch][i], m1 = acc[1][ch][i], m2 = acc[2][ch][i], m3 = acc[3][ch][i];
-        z[(((xi * 2 + 0) * W4_TT + tile) * W_ZROWB >> 2) + cz] = m0 + m1 + m2;
-        z[(((xi * 2 + 1) * W4_TT + tile) * W_ZROWB >> 2) + cz] = m1 - m2 - m3;
-      }
-    }
-  }
-  __syncthreads();
-  const float winv = p.w_inv_scale_dev ? *p.w_inv_scale_dev : p.w_inv_scale;
-  const int cqo = tid & 15, pp0 = tid >> 4;    // cout quad, first pixel (then + 16 per pass): 128 pixels x 16 quads over 256 threads
-  const int co = co0 + cqo * 4;
-  f32x4 add = *reinterpret_cast<const f32x4*>(p.bias + co);
-  if (p.temb) add += *reinterpret_cast<const f32x4*>(p.temb + (size_t)n * p.temb_stride + p.temb_off + co);
-  f32x4 rv[8], yv[8];
-#pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    const int pp = pp0 + it * 16, py = pp >> 4, px = pp & 15;
-    const size_t o = ((size_t)(n * p.Hout + oy0 + py) * p.Wout + ox0 + px) * p.Cout + co;
-    rv[it] = p.res ? *reinterpret_cast<const f32x4*>(p.res + o) : f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-#pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    const int pp = pp0 + it * 16, py = pp >> 4, px = pp & 15;
-    const int tile = (py >> 1) * 8 + (px >> 1), i = py & 1, j = px & 1;
-    const unsigned char* zb = smem_w + ((size_t)j * W4_TT + tile) * W_ZROWB + cqo * 16;
-    const f32x4 z0 = *reinterpret_cast<const f32x4*>(zb + (size_t)(0 + i) * 2 * W4_TT * W_ZROWB);
-    const f32x4 z1 = *reinterpret_cast<const f32x4*>(zb + (size_t)(1 + i) * 2 * W4_TT * W_ZROWB);
-    const f32x4 z2 = *reinterpret_cast<const f32x4*>(zb + (size_t)(2 + i) * 2 * W4_TT * W_ZROWB);
-    const f32x4 y = i == 0 ? (z0 + z1) + z2 : (z0 - z1) - z2;
-    yv[it] = y * winv + add + rv[it];
-  }
-  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    const int pp = pp0 + it * 16, py = pp >> 4, px = pp & 15;
-    const size_t o = ((size_t)(n * p.Hout + oy0 + py) * p.Wout + ox0 + px) * p.Cout + co;
-    *reinterpret_cast<f32x4*>(p.out + o) = yv[it];
-    s1 += yv[it];
-    s2 += yv[it] * yv[it];
-  }
-  if (p.part_out) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      s1[e] += __shfl_xor(s1[e], 16, 64); s2[e] += __shfl_xor(s2[e], 16, 64);
-      s1[e] += __shfl_xor(s1[e], 32, 64); s2[e] += __shfl_xor(s2[e], 32, 64);
-    }
-    __syncthreads();
-    f32x4* sred = reinterpret_cast<f32x4*>(smem_w);    // [4 waves][16 quads][2]
-    if (lane < 16) {
-      sred[(wave * 16 + lane) * 2 + 0] = s1;
-      sred[(wave * 16 + lane) * 2 + 1] = s2;
-    }
-    __syncthreads();
-    if (tid < 16) {
-      f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) { a += sred[(g * 16 + tid) * 2 + 0]; b += sred[(g * 16 + tid) * 2 + 1]; }
-      float* dst = p.part_out + (((size_t)n * ntile + tl) * p.Cout + co0 + tid * 4) * 2;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { dst[2 * e] = a[e]; dst[2 * e + 1] = b[e]; }
-    }
-  }
-}
 
 // Which launches take the Winograd form: stride-1 3x3, f16x3, 16-pixel-aligned maps, whole 64-cout blocks, 16-aligned concat
 // halves, and a grid that fills the chip (small grids keep the direct kernel with its K split).
@@ -1085,7 +583,7 @@ bool conv_wino_ok(ConvKind kind, int prec, const ConvParams& p, bool has_rider) 
     const bool small_map = (long)p.Hout * p.Wout <= 1024;
     if (!(small_map || (!has_rider && p.C0 + p.C1 >= g_tun.wino_wide_cin))) return false;
   }
-  if (p.xr0 || p.drop_mask || p.ksplit > 1 || p.gn_plain) return false;
+  if (p.xr0 || p.drop_mask || p.ksplit > 1 || p.gn_plain || !p.gn_scale) return false;   // (raw inputs: the kernel has no range check)
   if ((p.Hout & 15) || (p.Wout & 15) || p.Hin != p.Hout || p.Win != p.Wout) return false;
   if ((p.Cout & 63) || (p.C0 & 15) || (p.C1 & 15) || p.C0 + p.C1 < 16 || p.C0 + p.C1 > 1024) return false;
   const long wgs = (long)p.N * (p.Hout >> 4) * (p.Wout >> 4) * (p.Cout >> 6);
@@ -1093,19 +591,13 @@ bool conv_wino_ok(ConvKind kind, int prec, const ConvParams& p, bool has_rider) 
 }
 
 hipError_t launch_conv_wino_h(const ConvParams& p, hipStream_t s, int* tiles) {
-  const bool v4 = g_tun.wino == 4 && p.gn_scale;          // 8 x 16-pixel blocks, two 256-thread workgroups per CU
-  const int ntile = v4 ? (p.Hout >> 3) * (p.Wout >> 4) : (p.Hout >> 4) * (p.Wout >> 4);
+  const int ntile = (p.Hout >> 4) * (p.Wout >> 4);
   if (tiles) *tiles = ntile;
   ConvParams q = p;
   q.Cin_pad = p.C0 + p.C1;     // 16-aligned halves: no channel padding in this form
   q.Cout_pad = p.Cout;
   const int nwg = p.N * ntile * (p.Cout >> 6);
-  if (v4)
-    hipLaunchKernelGGL(conv_wino4_h_kernel, dim3(nwg), dim3(256), (size_t)W4_LDS, s, q);
-  else if (g_tun.wino == 1 || !p.gn_scale)   // debug option wino = 1: the first (serial-phase) form, kept for A/B; it also takes raw inputs
-    hipLaunchKernelGGL(conv_wino_h_kernel, dim3(nwg), dim3(512), (size_t)W_LDS, s, q);
-  else
-    hipLaunchKernelGGL(conv_wino2_h_kernel, dim3(nwg), dim3(512), (size_t)W2_LDS, s, q);
+  hipLaunchKernelGGL(conv_wino2_h_kernel, dim3(nwg), dim3(512), (size_t)W2_LDS, s, q);
   return hipGetLastError();
 }
 
@@ -1115,20 +607,8 @@ extern "C" int fdsr_diag_wino_stamps(unsigned long long* dst, size_t count) {
 }
 #endif
 
-// diagnostic (not in the header): workgroups per CU the runtime grants each form
-extern "C" int fdsr_diag_wino_occupancy(int* v1, int* v2, int* v4) {
-  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(v1, conv_wino_h_kernel, 512, (size_t)W_LDS);
-  if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(v2, conv_wino2_h_kernel, 512, (size_t)W2_LDS);
-  if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(v4, conv_wino4_h_kernel, 256, (size_t)W4_LDS);
-  return (int)e;
-}
-
 hipError_t kernels_wino_init() {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino2_h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e != hipSuccess) return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino4_h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino2_h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
 }  // namespace fdsr

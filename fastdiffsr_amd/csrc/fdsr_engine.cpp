@@ -1461,6 +1461,7 @@ int fdsr_unet_forward(fdsr_handle h, const float* x_nchw, const float* noise_lev
   hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
   char* ws = reinterpret_cast<char*>(workspace);
   float* xin = reinterpret_cast<float*>(ws + h->plan.tensor_off[h->t_in]);
+  if (h->prec != PREC_F32 && h->h_forms_stale && !h->training && (rc = fdsr_sync_weight_forms(h))) return rc;
   if (h->prec == PREC_F16X3 && g_tun.sat_guard) HIPCHK(h, hipMemsetAsync(h->d_sat, 0, sizeof(int), st));
   HIPCHK(h, launch_nchw_to_nhwc(x_nchw, xin, batch, h->cfg.in_channel, height, width, h->CP, 0, 1, st));
   if ((rc = run_unet(h, batch, height, width, ws, noise_level, 0.f, st))) return rc;
@@ -1482,6 +1483,7 @@ int fdsr_sample(fdsr_handle h, const float* cond_nchw, const float* noise, float
   char* ws = reinterpret_cast<char*>(workspace);
   if ((rc = ensure_temb_table(h, st))) return rc;
   if (!noise && (rc = ensure_rng(h))) return rc;
+  if (h->prec != PREC_F32 && h->h_forms_stale && (rc = fdsr_sync_weight_forms(h))) return rc;   // optimiser steps moved the master copy
   if ((flags & FDSR_SAMPLE_GRAPH) && st == nullptr)
     return fail(h, FDSR_E_INVALID, "FDSR_SAMPLE_GRAPH needs a non-default stream (stream capture cannot run on the NULL stream)");
   const bool use_graph = (flags & FDSR_SAMPLE_GRAPH) && !h->profiling;
@@ -1650,10 +1652,8 @@ int fdsr_set_precision(fdsr_handle h, int mode) {
     if (rc) return rc;
     HIPCHK(h, hipDeviceSynchronize());
   }
-  if (mode != PREC_F32 && h->h_forms_stale) {   // optimiser steps moved the master copy: refresh the 16-bit forms
-    int rc = fdsr_sync_weight_forms(h);
-    if (rc) return rc;
-  }
+  // (the 16-bit forms that lag behind optimiser steps are refreshed by the calls that READ them -- fdsr_sample and the eval-mode
+  // fdsr_unet_forward -- not here: a training loop that re-states its precision every step must not pay a host re-pack per step)
   if (h->prec != mode) {
     for (auto& g : h->graphs) (void)hipGraphExecDestroy(g.exec);
     h->graphs.clear();

@@ -57,6 +57,7 @@ struct ConvParams {
   float w_inv_scale_r;               // the rider's accumulator un-scaling; the accumulator is brought to THIS scale when the
   const float* w_inv_scale_r_dev;    // K loop passes from the main chunks to the rider chunks (powers of two: exact)
   int* sat_flag;                     // f16x3: set to 1 when a RAW input value exceeds the f16 range (null: no check)
+  int stagger;                       // small-workgroup k32 form: workgroups in an odd slot of their CU start this many 64-cycle sleeps per K chunk late
 };
 
 enum Precision { PREC_F32 = 0, PREC_F16X3 = 1, PREC_BF16 = 2 };
@@ -74,14 +75,15 @@ struct Tunables {
   int wgrad_colsum = 1;     // column sums of dy fused into the in-row weight-gradient kernel
   int wgrad_f32 = 0;        // f16x3 steps keep exact-fp32 weight gradients
   long long wgrad_big_bytes = 1ll << 32;   // tensors from this size on take the 4-wave weight-gradient kernel (64-bit offsets)
-  int wino = 0;             // Winograd F(2x2,3x3) form of the stride-1 3x3 convs in f16x3: 0 direct everywhere (default since the
-                            // 16x16x32 direct form took the 32 x 32 maps' 2-row tiles too: 69.7 vs 69.0 img/s same box), 2 half-tile pipeline, 1 first
-                            // (serial-phase) form, 4 two workgroups per CU
+  int wino = 0;             // Winograd F(2x2,3x3) form (half-tile pipeline, fdsr_conv_wino.hip) of the stride-1 3x3 convs in f16x3: 0 direct everywhere
+                            // (default since the 16x16x32 direct form took the 32 x 32 maps' 2-row tiles too: 69.7 vs 69.0 img/s same box), non-zero: on
   long wino_min_wgs = 256;  // ... only for launches with at least this many workgroups
   int wino_wide_cin = 1 << 30;   // ... rider-less launches with at least this many input channels take it too (384 until the 16x16x32
                             // direct form overtook it there: 67.9 vs 66.8 img/s same box); with wino on: only the 32 x 32 maps
   int wino_all = 0;         // ... 0: only the layers where it measured faster (conv_wino_ok); 1: every eligible launch
-  int k32 = 27;             // v_mfma_f32_16x16x32 form (fdsr_conv_k32.hip) of the stride-1 3x3 launches that fit it; bits: 1 f16x3, 2 bf16, 4 the 16-row tile with a rider, 8 the 2-row-per-wave tiles of small grids, 16 the sub-pixel upsample convs; 0 never
+  int k32 = 59;             // v_mfma_f32_16x16x32 form (fdsr_conv_k32.hip) of the stride-1 3x3 launches that fit it; bits: 1 f16x3, 2 bf16, 4 the 16-row tile with a rider, 8 the 2-row-per-wave tiles of small grids, 16 the sub-pixel upsample convs, 32 the small-workgroup form (4 waves, two workgroups per CU; 6-row tiles in f16x3, 8-row tiles in bf16) of the rider-less f16x3 64-cout launches of large grids, 64 of those with a rider too, 128 in bf16 too; 0 never
+  int k32_stagger = 0;      // ... start delay of the CU's odd workgroup slot, in 64-cycle units per K chunk (0: none)
+  long k32_sb_min_wgs = 1024;   // ... from this many workgroups on (a small grid wants all eight waves of a CU on its one tile)
   int sat_guard = 1;        // f16x3: sticky device flag when a RAW conv input exceeds the f16 range
   int drop_image_offset = 0;   // tests: the batch is images [offset, offset + N) of a larger one (its dropout masks follow)
   unsigned epoch = 0;
@@ -110,6 +112,9 @@ hipError_t kernels_h_init();
 // dispatches to it when conv_k32_ok() (wave tile of 4 x 32 pixels, whole 32-channel chunks on both sides of a concat seam).
 bool conv_k32_ok(int TH, int WN, int prec, const ConvParams& p);
 hipError_t launch_conv_k32(int TH, int WN, int prec, const ConvParams& q, int nwg, hipStream_t s);
+// ... as 256-thread workgroups, two per CU, for the 64-cout launches of large grids (k32 bit 32): asked before a tile is picked
+bool conv_k32_small_ok(ConvKind kind, int prec, const ConvParams& p);
+hipError_t launch_conv_k32_small(int prec, const ConvParams& p, hipStream_t s, int* tiles);
 hipError_t kernels_k32_init();
 // ... and of the sub-pixel upsample kernel (fdsr_conv_up2.hip): k32 bit 16
 bool conv_up2_k32_ok(int prec, const ConvParams& p);

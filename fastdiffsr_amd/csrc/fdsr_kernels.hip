@@ -463,6 +463,8 @@ int set_tunable(const char* name, long long v) {
   else if (n == "wino_wide_cin") g_tun.wino_wide_cin = (int)v;
   else if (n == "wino_all") g_tun.wino_all = (int)v;
   else if (n == "k32") g_tun.k32 = (int)v;
+  else if (n == "k32_sb_min_wgs") g_tun.k32_sb_min_wgs = (long)v;
+  else if (n == "k32_stagger") g_tun.k32_stagger = (int)v;
   else if (n == "sat_guard") g_tun.sat_guard = (int)v;
   else if (n == "drop_image_offset") g_tun.drop_image_offset = (int)v;
   else return -1;

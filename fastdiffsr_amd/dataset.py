@@ -145,13 +145,34 @@ class ThreadedBatchLoader:
         order = torch.randperm(n, generator=self.gen).tolist() if self.shuffle else list(range(n))
         batches = [order[i:i + self.bs] for i in range(0, n, self.bs)]
         futs, nxt = {}, 0
-        for k in range(len(batches)):
-            while nxt < len(batches) and nxt <= k + self.depth:
+
+        def submit_until(k):
+            nonlocal nxt
+            while nxt < len(batches) and nxt <= k:
                 futs[nxt] = [self.pool.submit(self.ds.load_u8, i, self.ds.draw_flips()) for i in batches[nxt]]
                 nxt += 1
+
+        # The consumer hands the GIL over around every launch / synchronisation; with Python's default 5 ms switch interval every
+        # hand-back can cost it up to 5 ms while a decode thread is in a Python section (measured on the training loop: 16 ms per
+        # step): 0.2 ms while this loader is being iterated.
+        import sys
+        old_switch = sys.getswitchinterval()
+        sys.setswitchinterval(2e-4)
+        try:
+            yield from self._batches(batches, futs, submit_until)
+        finally:
+            sys.setswitchinterval(old_switch)
+
+    def _batches(self, batches, futs, submit_until):
+        submit_until(self.depth - 1)
+        for k in range(len(batches)):
+            submit_until(k)                    # (only if depth == 0)
             items = [f.result() for f in futs.pop(k)]
             out = {key: np.stack([it[key] for it in items]) for key in ('HR', 'SR', 'LR') if key in items[0]}
             out['Index'] = [it['Index'] for it in items]
+            # the next decode jobs go to the pool right before the consumer takes this batch into its GPU call: the workers' Python
+            # sections then run while the consumer sits in C without the GIL, not against this thread's own stacking code
+            submit_until(k + self.depth)
             yield out
 
 

@@ -215,9 +215,11 @@ int fdsr_check_saturation(fdsr_handle h, void* hip_stream);
 /* -- introspection for parity tests and bench.py -------------------------- */
 /* Debug / A-B options of the launchers (process-wide; nothing in the library reads the environment).  Names:
  * "rider" (0|1|2), "up2" (0|1), "th_min_wgs", "splitk" (0|1), "sk_target", "wgrad_form" (0 default | 1 four-wave | 2 eight-wave
- * plain), "wgrad_colsum" (0|1), "wgrad_f32" (0|1), "wgrad_big_bytes", "wino" (0 default|1|2|4), "wino_min_wgs", "wino_all" (0|1), "wino_wide_cin",
- * "k32" (bits: 1 f16x3, 2 bf16, 4 16-row tiles with a rider, 8 2-row tiles of small grids, 16 the sub-pixel upsample convs; default 27 -- the 16x16x32-MFMA form of the
- * stride-1 3x3 launches), "sat_guard" (0|1),
+ * plain), "wgrad_colsum" (0|1), "wgrad_f32" (0|1), "wgrad_big_bytes", "wino" (0 default | 2: the Winograd F(2x2,3x3) form), "wino_min_wgs", "wino_all" (0|1), "wino_wide_cin",
+ * "k32" (bits: 1 f16x3, 2 bf16, 4 16-row tiles with a rider, 8 2-row tiles of small grids, 16 the sub-pixel upsample convs, 32 the rider-less f16x3 64-cout
+ * launches of large grids on 4-wave workgroups, two per CU, 64 those with a rider too, 128 in bf16 too; default 59 -- the 16x16x32-MFMA form of the
+ * stride-1 3x3 launches), "k32_sb_min_wgs" (bit 32 from this many workgroups on; default 1024), "k32_stagger" (start delay of a CU's odd
+ * workgroup slot in that form, 64-cycle units per K chunk; default 0), "sat_guard" (0|1),
  * "drop_image_offset" (the batch is images [k, k+N) of a larger one: its dropout masks are those images' masks).
  * Every setting computes the same function within the tested bounds; they exist so that tests can force each kernel
  * form and same-box A/B runs can price them.  Returns FDSR_E_INVALID for an unknown name.  Not for production use. */
@@ -303,7 +305,8 @@ int fdsr_set_optimizer_state(fdsr_handle h, const char* key, const float* exp_av
 int fdsr_grad_arena(fdsr_handle h, float** dev_ptr, size_t* count);
 
 /* After optimiser steps: rebuild the 16-bit weight forms (f16x3 / bf16 sampling) from the master copy.
- * fdsr_set_precision does this by itself when needed. */
+ * fdsr_sample and the eval-mode fdsr_unet_forward do this by themselves when needed (one host re-pack after the last optimiser
+ * step, not one per step). */
 int fdsr_sync_weight_forms(fdsr_handle h);
 
 #ifdef __cplusplus

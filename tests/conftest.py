@@ -29,3 +29,43 @@ def _debug_options_from_env():
             k, v = item.split('=')
             _lib.debug_option(k.strip(), int(v))
     yield
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# One CPU oracle image of a 256x256 20-step loop costs 10-25 s; several GPU test modules compare an engine image with it.
+# They share this session-wide cache (keyed by the weights and the exact cond / noise bytes), and wherever a test is free to
+# choose its inputs it plants `standard_pair()` at the batch index it checks, so that ONE oracle image serves them all.
+# ---------------------------------------------------------------------------------------------------------------------
+_ORACLE_IMAGES = {}
+
+
+def standard_pair():
+    """The B=1 256x256 inputs of the parity tests: (cond [1,3,256,256], noise [20,1,3,256,256])."""
+    from fastdiffsr_amd.synth import synth_inputs
+    return synth_inputs(1, 256, 256, 20)
+
+
+def plant_standard_pair(cond, noise, index):
+    """Overwrite image `index` of a batch's inputs with the standard pair (in place); returns (cond, noise)."""
+    c1, n1 = standard_pair()
+    cond[index] = c1[0]
+    noise[:, index] = n1[:, 0]
+    return cond, noise
+
+
+def oracle_loop_image(sd, cfg, cond, noise):
+    """oracle p_sample_loop(cond, noise) for ONE image under the val schedule, cached for the session."""
+    import hashlib
+    import numpy as np
+    from fastdiffsr_amd.arch import FASTDIFFSR_SCHEDULE_VAL
+    from fastdiffsr_amd.synth import state_dict_sha256
+    from oracle import fdsr_oracle as O
+    h = hashlib.sha256()
+    h.update(state_dict_sha256(sd).encode())
+    h.update(repr(cfg).encode())
+    h.update(np.ascontiguousarray(cond.numpy()).tobytes())
+    h.update(np.ascontiguousarray(noise.numpy()).tobytes())
+    key = h.hexdigest()
+    if key not in _ORACLE_IMAGES:
+        _ORACLE_IMAGES[key] = O.p_sample_loop(O.to_torch_sd(sd), cfg, O.schedule_tables(FASTDIFFSR_SCHEDULE_VAL), cond, noise)
+    return _ORACLE_IMAGES[key].clone()          # tensor2img clamps its argument in place, like the reference's

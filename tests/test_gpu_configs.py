@@ -51,8 +51,8 @@ def _psnr_delta(out, ref, cond):
 
 
 def _oracle_image(sd, cfg, cond1, noise1):
-    from oracle import fdsr_oracle as O
-    return O.p_sample_loop(O.to_torch_sd(sd), cfg, O.schedule_tables(FASTDIFFSR_SCHEDULE_VAL), cond1, noise1)
+    from conftest import oracle_loop_image      # session-wide cache, shared with the other GPU test modules
+    return oracle_loop_image(sd, cfg, cond1, noise1)
 
 
 def _batch_properties(eng, c, n, graph):
@@ -75,7 +75,9 @@ def _batch_properties(eng, c, n, graph):
 def test_config2_bf16_b64_hipgraph_256(full):
     """configs[2]: batch 64, 256x256, bf16 activations + bf16 MFMA, the 20-step loop replayed as a hipGraph."""
     cfg, eng, sd = full
+    from conftest import plant_standard_pair
     cond, noise = synth_inputs(64, 256, 256, 20)
+    plant_standard_pair(cond, noise, 41)       # the image compared with the oracle: the session's shared oracle image
     c, n = cond.cuda(), noise.cuda()
     eng.set_precision('bf16')
     try:
@@ -104,7 +106,9 @@ def test_config3_per_gpu_slice_bf16_b64(full):
     lo, hi = parallel.shard_range(512, 5, 8)
     assert hi - lo == 64
     # rank r draws its own shard (bench.py seeds per rank); the global batch is never materialised on one GPU
+    from conftest import plant_standard_pair
     cond, noise = synth_inputs(hi - lo, 256, 256, 20, cond_seed=1234 + 5, noise_seed=4321 + 5)
+    plant_standard_pair(cond, noise, 63)       # the image compared with the oracle: the session's shared oracle image
     c, n = cond.cuda(), noise.cuda()
     eng.set_precision('bf16')
     try:

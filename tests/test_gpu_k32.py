@@ -1,7 +1,7 @@
 """The 16x16x32-MFMA form of the stride-1 3x3 convolutions (fdsr_conv_k32.hip): on by default for f16x3 launches whose wave tile is
 4 x 32 or 2 x 32 pixels (except the 16-row tile with a rider); here it is FORCED onto every eligible launch of a small forward (largest tile regardless of the grid size, so
 the split-K, partial-tile and rider paths of the form all run), layer by layer against the oracle, in every option setting
-(bits of `k32`: 1 f16x3, 2 bf16, 4 the 16-row tile with a rider, 8 the 2-row tiles of small grids, 16 the sub-pixel upsample convs; default 27), against the 32x32x16 kernels on the same input, and through the
+(bits of `k32`: 1 f16x3, 2 bf16, 4 the 16-row tile with a rider, 8 the 2-row tiles of small grids, 16 the sub-pixel upsample convs, 32 the small-workgroup form of the 8-row x 64-cout tiles; default 59), against the 32x32x16 kernels on the same input, and through the
 20-step loop.  Same bounds as every other conv kernel: layerwise 1e-4 * max(1, |ref|), loop 1e-3 (north_star); bf16 0.25 layerwise
 (judged on PSNR elsewhere).  Reference: fastdiffsr_modules/unet.py:89-120."""
 import pytest
@@ -38,7 +38,7 @@ def forced():
     yield
     _lib.debug_option('th_min_wgs', 256)
     _lib.debug_option('wino', 0)
-    _lib.debug_option('k32', 27)
+    _lib.debug_option('k32', 59)
 
 
 @pytest.mark.timeout(900)
@@ -119,7 +119,7 @@ def test_small_grid_two_row_tiles_k32_vs_oracle(full):
     finally:
         eng.set_debug(False)
         _lib.debug_option('wino', 0)
-        _lib.debug_option('k32', 27)
+        _lib.debug_option('k32', 59)
 
 
 @pytest.mark.timeout(900)
@@ -160,7 +160,67 @@ def test_subpixel_upsample_convs_on_the_form(full, prec):
     finally:
         eng.set_debug(False)
         eng.set_precision('f16x3')
-        _lib.debug_option('k32', 27)
+        _lib.debug_option('k32', 59)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize('prec', ['f16x3', 'bf16'])
+def test_small_workgroup_form_vs_oracle(full, prec):
+    """Bit 32: the 64-cout launches on 4-wave workgroups, two per CU (6-row tiles in f16x3, 8-row tiles in bf16), which large
+    grids take by default; here forced onto every grid size (k32_sb_min_wgs = 1, no split K: riders, partial tiles in both directions
+    on 128 x 128 and a ragged 72 x 104 map, the start stagger on), layer by layer against the oracle, against the 8-wave forms on the
+    same input, bitwise reruns, loop + hipGraph."""
+    from fastdiffsr_amd import _lib
+    from oracle import fdsr_oracle as O
+    cfg, eng, sd = full
+    eng.set_precision(prec)
+    tol = TOL_FWD if prec == 'f16x3' else 0.25
+    _lib.debug_option('wino', 0)
+    _lib.debug_option('k32', 59 | 64 | 128)       # with the riders and in bf16 (bits 64, 128: off by default)
+    _lib.debug_option('k32_sb_min_wgs', 1)
+    _lib.debug_option('splitk', 0)          # (a launch with a K split keeps the 8-wave forms)
+    _lib.debug_option('k32_stagger', 3)
+    try:
+        for shape, seed in (((2, 6, 128, 128), 21), ((3, 6, 72, 104), 22)):
+            gen = torch.Generator().manual_seed(seed)
+            x = torch.randn(*shape, generator=gen)
+            nl = torch.rand(shape[0], 1, generator=gen) * 0.9 + 0.05
+            cap = {}
+            with torch.no_grad():
+                ref = O.unet_forward(O.to_torch_sd(sd), cfg, x, nl, capture=cap)
+            eng.set_debug(True)
+            out = eng.unet_forward(x.cuda(), nl.cuda())
+            torch.cuda.synchronize()
+            for L in build_layers(cfg):
+                d = (eng.debug_tensor(L.name).cpu() - cap[L.name]).abs().max().item()
+                scale = max(cap[L.name].abs().max().item(), 1.0)
+                assert d <= tol * scale, f'{shape} {L.name}: {d:.3e} (scale {scale:.2f})'
+            eng.set_debug(False)
+            assert torch.equal(eng.unet_forward(x.cuda(), nl.cuda()), out)              # ordered reductions only
+            _lib.debug_option('k32', 27)                                                # the same launches on the 8-wave forms
+            out_d = eng.unet_forward(x.cuda(), nl.cuda())
+            _lib.debug_option('k32', 59 | 64 | 128)
+            dd = (out_d - out).abs().max().item()
+            assert dd > 0.0                                                             # (0.0: the form was never taken)
+            if prec == 'f16x3':
+                assert dd <= 2e-5 and (out.cpu() - ref).abs().max().item() <= TOL_FWD
+        if prec == 'f16x3':
+            cond, noise = synth_inputs(2, 64, 64, 20)
+            refl = O.p_sample_loop(O.to_torch_sd(sd), cfg, O.schedule_tables(FASTDIFFSR_SCHEDULE_VAL), cond, noise)
+            outl = eng.sample(cond.cuda(), noise.cuda()).cpu()
+            assert (outl - refl).abs().max().item() <= TOL_LOOP
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                g1 = eng.sample(cond.cuda(), noise.cuda(), graph=True)
+            s.synchronize()
+            assert torch.equal(g1.cpu(), outl)
+    finally:
+        eng.set_debug(False)
+        eng.set_precision('f16x3')
+        _lib.debug_option('k32_sb_min_wgs', 1024)
+        _lib.debug_option('k32_stagger', 0)
+        _lib.debug_option('splitk', 1)
+        _lib.debug_option('k32', 59)
 
 
 @pytest.mark.timeout(900)

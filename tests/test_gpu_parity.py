@@ -166,16 +166,11 @@ def test_graph_replay_matches_eager(full):
     assert d <= TOL_LOOP / 4
 
 
-_ORACLE_256 = {}
-
-
 def _oracle_256(sd, cfg, idx, cond, noise):
-    """Oracle image for image `idx` of the standard 256x256 inputs (~7-25 s of CPU each): computed once per module."""
-    from oracle import fdsr_oracle as O
-    if idx not in _ORACLE_256:
-        tab = O.schedule_tables(FASTDIFFSR_SCHEDULE_VAL)
-        _ORACLE_256[idx] = O.p_sample_loop(O.to_torch_sd(sd), cfg, tab, cond, noise)
-    return _ORACLE_256[idx].clone()          # tensor2img clamps its argument in place, like the reference's
+    """Oracle image of one 256x256 loop (~7-25 s of CPU): cached for the whole session and shared with the other GPU test
+    modules (tests/conftest.py: oracle_loop_image)."""
+    from conftest import oracle_loop_image
+    return oracle_loop_image(sd, cfg, cond, noise)
 
 
 @pytest.mark.parametrize('prec', ['f32', 'f16x3'])
@@ -204,7 +199,9 @@ def test_batch16_properties(full, prec):
     """BASELINE configs[1] workload (B=16, 256x256) in both fp32-grade modes: batch independence, run-to-run
     stability (size-independent properties) and one image of the batch against the oracle."""
     cfg, eng, sd = full
+    from conftest import plant_standard_pair
     cond, noise = synth_inputs(16, 256, 256, 20)
+    plant_standard_pair(cond, noise, 15)       # image 15 is the one compared with the oracle: the session's shared image
     c, n = cond.cuda(), noise.cuda()
     eng.set_precision(prec)
     try:

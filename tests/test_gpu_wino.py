@@ -28,10 +28,10 @@ def full():
     return cfg, eng, sd
 
 
-@pytest.fixture(params=[2, 1, 4], ids=['half-tile-pipeline', 'serial-phases', 'two-workgroups-per-cu'])
+@pytest.fixture(params=[2], ids=['half-tile-pipeline'])
 def forced(request):
-    """Winograd for every eligible launch regardless of the grid size, in both forms of the kernel (2: the half-tile
-    pipeline, 1: the first, serial-phase form, 4: 256-thread workgroups, two per CU); restored afterwards."""
+    """Winograd (the half-tile pipeline kernel; the two other forms of round 3 were removed) for every eligible launch
+    regardless of the grid size; restored afterwards."""
     from fastdiffsr_amd import _lib
     _lib.debug_option('wino_min_wgs', 1)
     _lib.debug_option('wino_all', 1)
