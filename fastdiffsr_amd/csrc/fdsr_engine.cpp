@@ -704,6 +704,7 @@ int ensure_device(fdsr_handle h) {
   if (!h->kernels_ready) {
     HIPCHK(h, kernels_init());
     HIPCHK(h, kernels_h_init());
+    HIPCHK(h, kernels_tail_init());
     HIPCHK(h, kernels_wino_init());
     h->kernels_ready = true;
   }
@@ -976,7 +977,17 @@ int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, 
           }
           HIPCHK(h, hipEventRecord(h->ev_pool[h->ev_used++], st));
         }
-        if (h->prec != PREC_F32 && w.h_ok) {
+        // the two ends of the UNet in the 16-bit modes: bandwidth-shaped kernels of their own (fdsr_conv_tail.hip), weights read
+        // from the fp32 master copy (always current, also right after optimiser steps)
+        const float* wmaster = h->master_off[op.w] != SIZE_MAX ? h->d_master + h->master_off[op.w] : nullptr;
+        const int* satf = (h->prec == PREC_F16X3 && g_tun.sat_guard) ? h->d_sat : nullptr;
+        if (h->prec != PREC_F32 && wmaster && op.src0 == h->t_in && h->CP == 8 &&
+            conv_in8_ok(op.ck, h->prec, p, (int)w.shape[1])) {
+          p.sat_flag = const_cast<int*>(satf);
+          HIPCHK(h, launch_conv_in8(h->prec, p, wmaster, (int)w.shape[1], st, &nt));
+        } else if (h->prec != PREC_F32 && wmaster && w.h_ok && conv_out3_ok(op.ck, h->prec, p)) {
+          HIPCHK(h, launch_conv_out3(h->prec, p, wmaster, (int)w.shape[1], st, &nt));
+        } else if (h->prec != PREC_F32 && w.h_ok) {
           p.sat_flag = (h->prec == PREC_F16X3 && g_tun.sat_guard) ? h->d_sat : nullptr;
           p.wq = h->d_wq + w.hq_off[h->prec];
           p.w_inv_scale = w.h_inv_scale[h->prec];

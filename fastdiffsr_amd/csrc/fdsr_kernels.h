@@ -84,6 +84,7 @@ struct Tunables {
   int k32 = 59;             // v_mfma_f32_16x16x32 form (fdsr_conv_k32.hip) of the stride-1 3x3 launches that fit it; bits: 1 f16x3, 2 bf16, 4 the 16-row tile with a rider, 8 the 2-row-per-wave tiles of small grids, 16 the sub-pixel upsample convs, 32 the small-workgroup form (4 waves, two workgroups per CU; 6-row tiles in f16x3, 8-row tiles in bf16) of the rider-less f16x3 64-cout launches of large grids, 64 of those with a rider too, 128 in bf16 too; 0 never
   int k32_stagger = 0;      // ... start delay of the CU's odd workgroup slot, in 64-cycle units per K chunk (0: none)
   long k32_sb_min_wgs = 1024;   // ... from this many workgroups on (a small grid wants all eight waves of a CU on its one tile)
+  int tail = 1;             // the input / output convs of the 16-bit modes on their own kernels (fdsr_conv_tail.hip); 0: the general ones
   int sat_guard = 1;        // f16x3: sticky device flag when a RAW conv input exceeds the f16 range
   int drop_image_offset = 0;   // tests: the batch is images [offset, offset + N) of a larger one (its dropout masks follow)
   unsigned epoch = 0;
@@ -108,6 +109,13 @@ hipError_t launch_conv_h(ConvKind kind, int prec, const ConvParams& p, hipStream
 // workspace planner and the launcher agree.  Only grids that would leave most of the 256 CUs idle split.
 int conv_h_ksplit(ConvKind kind, int N, int Hout, int Wout, int Cout, int Cout_pad, int Cin_pad, int C0, int C1);
 hipError_t kernels_h_init();
+// the two ends of the UNet in the 16-bit modes (fdsr_conv_tail.hip): the 6(8)-channel input conv as a gather + 16x16x32 MFMA kernel
+// without LDS, the <= 3-channel output conv as fp32 FMAs in scatter form; weights from the fp32 master copy [Cout][Cin][3][3]
+bool conv_in8_ok(ConvKind kind, int prec, const ConvParams& p, int cin_real);
+hipError_t launch_conv_in8(int prec, const ConvParams& p, const float* wmaster, int cin_real, hipStream_t s, int* tiles);
+bool conv_out3_ok(ConvKind kind, int prec, const ConvParams& p);
+hipError_t launch_conv_out3(int prec, const ConvParams& p, const float* wmaster, int cin_real, hipStream_t s, int* tiles);
+hipError_t kernels_tail_init();
 // K=32 MFMA form of the stride-1 3x3 launches (fdsr_conv_k32.hip): same ConvParams, same packed weights; launch_conv_h
 // dispatches to it when conv_k32_ok() (wave tile of 4 x 32 pixels, whole 32-channel chunks on both sides of a concat seam).
 bool conv_k32_ok(int TH, int WN, int prec, const ConvParams& p);
