@@ -494,7 +494,11 @@ def facade_records(cfg, sd, dev, S, engine_ips, n_images=256, batch=16):
                     torch.cuda.synchronize(dev)
                     t0 = time.perf_counter()
                 tp = time.perf_counter()
-                data = next(it)
+                try:
+                    data = next(it)
+                except StopIteration:        # the next epoch of the folder
+                    it = iter(loader)
+                    data = next(it)
                 data.pop('Index')
                 model.feed_data({key: ops.to_tensor(ops.upload(key, v)) for key, v in data.items()})
                 model.optimize_parameters()

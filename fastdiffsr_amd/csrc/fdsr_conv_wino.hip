@@ -583,7 +583,7 @@ bool conv_wino_ok(ConvKind kind, int prec, const ConvParams& p, bool has_rider) 
     const bool small_map = (long)p.Hout * p.Wout <= 1024;
     if (!(small_map || (!has_rider && p.C0 + p.C1 >= g_tun.wino_wide_cin))) return false;
   }
-  if (p.xr0 || p.drop_mask || p.ksplit > 1 || p.gn_plain || !p.gn_scale) return false;   // (raw inputs: the kernel has no range check)
+  if (p.xr0 || p.drop_mask || p.ksplit > 1 || p.gn_plain) return false;   // (raw inputs -- no GroupNorm in front -- are turned away by the engine: the kernel has no range check)
   if ((p.Hout & 15) || (p.Wout & 15) || p.Hin != p.Hout || p.Win != p.Wout) return false;
   if ((p.Cout & 63) || (p.C0 & 15) || (p.C1 & 15) || p.C0 + p.C1 < 16 || p.C0 + p.C1 > 1024) return false;
   const long wgs = (long)p.N * (p.Hout >> 4) * (p.Wout >> 4) * (p.Cout >> 6);

@@ -1663,8 +1663,13 @@ int fdsr_set_precision(fdsr_handle h, int mode) {
     if (rc) return rc;
     HIPCHK(h, hipDeviceSynchronize());
   }
-  // (the 16-bit forms that lag behind optimiser steps are refreshed by the calls that READ them -- fdsr_sample and the eval-mode
-  // fdsr_unet_forward -- not here: a training loop that re-states its precision every step must not pay a host re-pack per step)
+  // The 16-bit forms that lag behind optimiser steps are refreshed when the mode is SWITCHED to (here) and by the calls that read them
+  // in eval mode (fdsr_sample, fdsr_unet_forward) -- not when a training loop merely re-states its precision before every step: that
+  // used to cost a host re-pack of every weight per step.
+  if (mode != PREC_F32 && mode != h->prec && h->h_forms_stale) {
+    int rc = fdsr_sync_weight_forms(h);
+    if (rc) return rc;
+  }
   if (h->prec != mode) {
     for (auto& g : h->graphs) (void)hipGraphExecDestroy(g.exec);
     h->graphs.clear();

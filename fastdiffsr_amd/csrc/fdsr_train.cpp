@@ -235,7 +235,11 @@ int repack_from_master(fdsr_handle h, hipStream_t st, bool forward_forms, bool a
                                          w.h_WN, w.h_cout_pad, w.h_cin_pad, st));
     }
   }
-  if (forward_forms) h->up2_dev_fresh = true;
+  if (forward_forms) {
+    h->up2_dev_fresh = true;
+    h->h_forms_stale = true;   // the sampling forms (bf16, the host-packed sub-pixel forms) now differ from what this pass wrote: the next
+                               // eval-mode sample / forward, or a switch of the precision, re-packs them on the host
+  }
   for (const Op& op : h->ops) {
     if (op.kind != Op::CONV || op.src0 == h->t_in || h->wtq_off0[op.w] == SIZE_MAX) continue;
     const WeightEntry& w = h->weights[op.w];
@@ -355,7 +359,9 @@ int train_grads_impl(fdsr_handle h, const float* x_nchw, const float* hr_nchw, c
   // the transposed forms follow the master copy
   if (h->prec == PREC_F32 && (rc = ensure_f32_forms(h, st))) return rc;
   if (!h->wt_valid) {
-    if ((rc = repack_from_master(h, st, false, false))) return rc;
+    // f16x3: the forward forms are re-packed on the device here too, as every optimiser step will: a run resumed from a checkpoint
+    // (host-packed at load) then steps on the same bits as the uninterrupted run (the two packers round the sub-pixel forms differently)
+    if ((rc = repack_from_master(h, st, h->prec == PREC_F16X3, false))) return rc;
     h->wt_valid = true;
   }
 

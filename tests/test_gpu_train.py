@@ -117,7 +117,8 @@ def test_adam_update_and_weights_in_use(stepped, golden_dir):
     for prec in ('f32', 'f16x3'):
         eng.set_precision(prec)
         e2.set_precision(prec)
-        assert torch.equal(eng.unet_forward(x, nl), e2.unet_forward(x, nl)), prec
+        ya, yb = eng.unet_forward(x, nl), e2.unet_forward(x, nl)
+        assert torch.equal(ya, yb), (prec, (ya - yb).abs().max().item())
     eng.set_precision('f32')
 
 
