@@ -170,11 +170,12 @@ def kernel_source_hash():
     import hashlib
     d = os.path.join(ROOT, 'fastdiffsr_amd', 'csrc')
     h = hashlib.sha256()
-    for f in ('fdsr_act_io.h', 'fdsr_conv_h.hip', 'fdsr_conv_k32.hip', 'fdsr_conv_up2.hip', 'fdsr_conv_wino.hip', 'fdsr_kernels.h', 'fdsr_kernels.hip'):
+    for f in ('fdsr_act_io.h', 'fdsr_conv_h.hip', 'fdsr_conv_k32.hip', 'fdsr_conv_tail.hip', 'fdsr_conv_up2.hip', 'fdsr_conv_wino.hip', 'fdsr_kernels.h', 'fdsr_kernels.hip'):
         h.update(f.encode() + b'\0' + open(os.path.join(d, f), 'rb').read() + b'\0')
     return h.hexdigest()
 
 
+KNOCKOUT = False   # --debug-option knockout=...: timing-only probes whose results are garbage
 K32_BITS = 59      # Tunables::k32 default (include/fdsr.h); --debug-option k32=... overrides it for the labels below
 
 
@@ -191,7 +192,7 @@ def family_label(precision):
     names.append('conv_mfma_h_kernel<3, ...>')
     if not (K32_BITS & bit and K32_BITS & 16):
         names.append('conv_up2_h_kernel')
-    names.append('conv_mfma_f32_kernel<3, ...> (the 6-channel input conv)')
+    names.append('conv_in8_kernel + conv_out3_kernel (the two ends of the UNet)')
     return ' + '.join(names)
 
 
@@ -290,7 +291,7 @@ def run_config(eng, dev, precision, B, S, steps, warmup, graph, noise_mode, rank
         torch.cuda.synchronize(dev)
         prof = eng.profile_end()
         prof_dt = None
-    assert torch.isfinite(out).all()
+    assert KNOCKOUT or torch.isfinite(out).all()
     return dt, out, prof, prof_dt
 
 
@@ -755,12 +756,14 @@ def main():
 
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    global K32_BITS
+    global K32_BITS, KNOCKOUT
     for item in args.debug_option:
         k, v = item.split('=')
         _lib.debug_option(k, int(v))
         if k == 'k32':
             K32_BITS = int(v)
+        if k == 'knockout' and int(v):
+            KNOCKOUT = True
     cfg = UNetConfig(**FASTDIFFSR_UNET)
     # weights: rank 0 builds the random-init UNet, ONE RCCL broadcast replicates it
     sd = synth_state_dict(cfg, 0) if rank == 0 else None

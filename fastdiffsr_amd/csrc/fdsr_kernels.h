@@ -85,6 +85,8 @@ struct Tunables {
   int k32_stagger = 0;      // ... start delay of the CU's odd workgroup slot, in 64-cycle units per K chunk (0: none)
   long k32_sb_min_wgs = 1024;   // ... from this many workgroups on (a small grid wants all eight waves of a CU on its one tile)
   int tail = 1;             // the input / output convs of the 16-bit modes on their own kernels (fdsr_conv_tail.hip); 0: the general ones
+  int knockout = 0;         // TIMING-ONLY probes, results are garbage: bit 1 leaves the gn_finalize launches out, bit 2 the splitk_reduce launches
+                            // (the upper bound of what fusing them into their producers could save; EXPERIMENTS round 4)
   int sat_guard = 1;        // f16x3: sticky device flag when a RAW conv input exceeds the f16 range
   int drop_image_offset = 0;   // tests: the batch is images [offset, offset + N) of a larger one (its dropout masks follow)
   unsigned epoch = 0;

@@ -467,6 +467,7 @@ int set_tunable(const char* name, long long v) {
   else if (n == "k32_stagger") g_tun.k32_stagger = (int)v;
   else if (n == "sat_guard") g_tun.sat_guard = (int)v;
   else if (n == "tail") g_tun.tail = (int)v;
+  else if (n == "knockout") g_tun.knockout = (int)v;
   else if (n == "drop_image_offset") g_tun.drop_image_offset = (int)v;
   else return -1;
   ++g_tun.epoch;

@@ -16,7 +16,7 @@ def short(name):
 
 def is_3x3(name):
     k = short(name)
-    if k in ('conv_up2_h_kernel', 'conv_wino_h_kernel', 'conv_wino2_h_kernel', 'conv_k32_kernel'):
+    if k in ('conv_up2_h_kernel', 'conv_up2_k32_kernel', 'conv_wino_h_kernel', 'conv_wino2_h_kernel', 'conv_k32_kernel', 'conv_in8_kernel', 'conv_out3_kernel'):
         return True
     if k in ('conv_mfma_h_kernel', 'conv_mfma_f32_kernel'):
         m = re.search(r'<\s*(\d+)\s*,', name)
