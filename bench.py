@@ -486,7 +486,7 @@ def facade_records(cfg, sd, dev, S, engine_ips, n_images=256, batch=16):
             model = create_model(opt)
             model.netG.denoise_fn.load_state_dict(tsd, strict=True)
             ops = V.HipOps('cuda')
-            loader = ThreadedBatchLoader(create_dataset(opt['datasets']['train'], 'train'), B, shuffle=True, workers=8)
+            loader = ThreadedBatchLoader(create_dataset(opt['datasets']['train'], 'train'), B, shuffle=True, workers=8, stage=ops.stage_host)
             model.set_new_noise_schedule(opt['model']['beta_schedule']['train'], schedule_phase='train')
             it = iter(loader)
             pp = []
@@ -501,7 +501,7 @@ def facade_records(cfg, sd, dev, S, engine_ips, n_images=256, batch=16):
                     it = iter(loader)
                     data = next(it)
                 data.pop('Index')
-                model.feed_data({key: ops.to_tensor(ops.upload(key, v)) for key, v in data.items()})
+                model.feed_data({key: ops.to_tensor(ops.to_device(v)) for key, v in data.items()})
                 model.optimize_parameters()
                 if k >= warmup:
                     pp.append(time.perf_counter() - tp)     # optimize_parameters returns the loss: the step is synchronous

@@ -6,7 +6,7 @@
 //                     of output; 578 us at B = 64 in bf16).  Here: K = 9 taps x 8 channels = 72 (padded to 96 = three 16x16x32
 //                     steps), the im2col row of a pixel gathered straight from L1 / L2 by the MFMA's own operand lanes (lane (pixel,
 //                     k group g) reads the 32 bytes of tap 4 i + g) -- no LDS on the data path; the 64 x 72 weights live in
-//                     registers, split / scaled once per workgroup of a persistent grid; f16x3 = three MFMAs per product like every
+//                     registers, split / scaled once per workgroup of a persistent grid (two workgroups per CU); f16x3 = three MFMAs per product like every
 //                     other conv of that mode, bf16 = one.  Epilogue: bias, 16-byte stores, the GroupNorm partials of the next Block.
 //   conv_out3_kernel  final_conv (unet.py:293: Block(pre_channel, out_channel = 3): GroupNorm -> Swish -> Conv3x3) -- it padded its
 //                     3 output channels to a 32-wide MFMA tile (201 us at B = 16 to read 268 MB = 1.3 TB/s, 12.6 % MFMA busy).
@@ -61,11 +61,10 @@ constexpr int IN_TH = 8, IN_TW = 32;     // workgroup tile of the input conv: 4 
 template <int PREC, int NCB>
 __global__ void __launch_bounds__(256, 2) conv_in8_kernel(const ConvParams p, const float* __restrict__ wm, int Cin, int ntiles) {
   constexpr int NP = PREC == PREC_F16X3 ? 2 : 1;
-  // LDS: the weight fragments [cb][k step][plane][lane] x 16 B (24 KB in f16x3 at 64 couts) -- in registers they cost 96 VGPRs and two
-  // of the four waves per SIMD that hide this kernel's load and store latency -- and, after the loop, the statistics exchange
-  __shared__ __attribute__((aligned(16))) unsigned char sraw[(NCB * 3 * NP * 64 * 16 > 4 * 64 * 8 * NCB * 4) ? NCB * 3 * NP * 64 * 16 : 4 * 64 * 8 * NCB * 4];
+  // (the weight fragments live in registers: 96 VGPRs in f16x3 at 64 couts.  A form with them in LDS and three / four workgroups per CU
+  // was tried: the compiler hoists the fragment reads of a whole pixel group and spills 79 - 148 VGPRs under the smaller caps)
+  __shared__ __attribute__((aligned(16))) unsigned char sraw[4 * 16 * NCB * 2 * 4];     // the statistics exchange [4 waves][Cout][2]
   __shared__ float samax[4];
-  uint4* sW = reinterpret_cast<uint4*>(sraw);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c15 = lane & 15, g = lane >> 4;
   const int Cout = 16 * NCB;
@@ -86,17 +85,17 @@ __global__ void __launch_bounds__(256, 2) conv_in8_kernel(const ConvParams p, co
     wscale = ldexpf(1.0f, e);
     winv = ldexpf(1.0f, -e);
   }
-  for (int f = wave; f < NCB * 3; f += 4) {         // fragment (cb, i) built by one wave
-    const int cb = f / 3, i = f % 3;
-    const int tap = 4 * i + g, co = 16 * cb + c15;
-    float v[8];
+  uint4 Wf[NCB][3][NP];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = (tap < 9 && j < Cin) ? wm[((size_t)co * Cin + j) * 9 + tap] * wscale : 0.f;
-    uint4 pl[NP];
-    to_planes<PREC>(v, pl);
+  for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
-    for (int q = 0; q < NP; ++q) sW[(f * NP + q) * 64 + lane] = pl[q];
-  }
+    for (int i = 0; i < 3; ++i) {
+      const int tap = 4 * i + g, co = 16 * cb + c15;
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (tap < 9 && j < Cin) ? wm[((size_t)co * Cin + j) * 9 + tap] * wscale : 0.f;
+      to_planes<PREC>(v, Wf[cb][i]);
+    }
   t_f32x4 bias4[NCB];
 #pragma unroll
   for (int cb = 0; cb < NCB; ++cb)
@@ -106,8 +105,6 @@ __global__ void __launch_bounds__(256, 2) conv_in8_kernel(const ConvParams p, co
 
   const int tilesX = (p.Wout + IN_TW - 1) / IN_TW, tilesY = (p.Hout + IN_TH - 1) / IN_TH;
   const int per_img = tilesX * tilesY;
-  // statistics of a tile leave through a region of their own behind the weights?  No: the weights stay for the whole persistent loop,
-  // so the exchange uses registers -> global partials per WAVE ROW PAIR instead (tile = 2 rows x 32 pixels of one wave).
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int n = tile / per_img, tt = tile % per_img;
     const int ty = tt / tilesX, tx = tt % tilesX;
@@ -153,9 +150,9 @@ __global__ void __launch_bounds__(256, 2) conv_in8_kernel(const ConvParams p, co
       for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) {
-          const uint4 w0 = sW[((cb * 3 + i) * NP) * 64 + lane];
+          const uint4 w0 = Wf[cb][i][0];
           if (PREC == PREC_F16X3) {
-            const uint4 w1 = sW[((cb * 3 + i) * NP + NP - 1) * 64 + lane];
+            const uint4 w1 = Wf[cb][i][NP - 1];
             // small terms first: lo(x) hi(w), hi(x) lo(w), hi(x) hi(w)
             acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(t_h8, w0), __builtin_bit_cast(t_h8, Xf[i][NP - 1]), acc[cb], 0, 0, 0);
             acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(t_h8, w1), __builtin_bit_cast(t_h8, Xf[i][0]), acc[cb], 0, 0, 0);
@@ -185,8 +182,10 @@ __global__ void __launch_bounds__(256, 2) conv_in8_kernel(const ConvParams p, co
     }
     }   // half
     if (p.part_out) {
-      // per-"tile" (sum, sumsq) per channel, the GroupNorm statistics of the next Block: a statistics tile is ONE wave's 2 rows x 32
-      // pixels (4 per workgroup tile), folded over the 16 pixel lanes by a fixed xor butterfly -- no LDS, no barrier in the loop
+      // per-tile (sum, sumsq) per channel, the GroupNorm statistics of the next Block: each wave folds its 2 rows x 32 pixels over the 16
+      // pixel lanes by a fixed xor butterfly, the four waves meet in LDS and are added in order (one partial tile per workgroup tile:
+      // a partial per WAVE made gn_finalize read 1 024 tiles per image)
+      float* sst = reinterpret_cast<float*>(sraw);             // [4 waves][Cout][2]; the weight fragments live in registers by now
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
@@ -195,11 +194,16 @@ __global__ void __launch_bounds__(256, 2) conv_in8_kernel(const ConvParams p, co
 #pragma unroll
           for (int off = 8; off >= 1; off >>= 1) { a += __shfl_xor(a, off, 64); b += __shfl_xor(b, off, 64); }
           if (c15 == 0) {
-            float* dst = p.part_out + (((size_t)n * (per_img * 4) + tt * 4 + wave) * Cout + 16 * cb + 4 * g + r) * 2;
-            dst[0] = a;
-            dst[1] = b;
+            sst[(wave * Cout + 16 * cb + 4 * g + r) * 2] = a;
+            sst[(wave * Cout + 16 * cb + 4 * g + r) * 2 + 1] = b;
           }
         }
+      __syncthreads();
+      if (tid < 2 * Cout) {
+        const float v = ((sst[tid] + sst[2 * Cout + tid]) + sst[4 * Cout + tid]) + sst[6 * Cout + tid];
+        p.part_out[((size_t)n * per_img + tt) * Cout * 2 + tid] = v;
+      }
+      __syncthreads();                                         // (before the next tile's waves write their sums)
     }
   }
 }
@@ -212,7 +216,7 @@ bool conv_in8_ok(ConvKind kind, int prec, const ConvParams& p, int cin_real) {
 
 hipError_t launch_conv_in8(int prec, const ConvParams& p, const float* wmaster, int cin_real, hipStream_t s, int* tiles) {
   const int per_img = ((p.Wout + IN_TW - 1) / IN_TW) * ((p.Hout + IN_TH - 1) / IN_TH);
-  if (tiles) *tiles = per_img * 4;                   // statistics tiles: one per wave (2 rows x 32 pixels)
+  if (tiles) *tiles = per_img;
   const int ntiles = p.N * per_img;
   const int grid = ntiles < 1024 ? ntiles : 1024;    // persistent: four 256-thread workgroups per CU set the weights up once
   ConvParams q = p;

@@ -132,9 +132,12 @@ class ThreadedBatchLoader:
     finishes ToTensor()*2-1 on the device (metrics.u8_to_tensor).  Order: torch.randperm(len, generator) per epoch when
     `shuffle` (RandomSampler's draw), else sequential; the flips are drawn on the consumer thread in item order."""
 
-    def __init__(self, dataset, batch_size, shuffle=False, workers=4, generator=None, depth=3):
+    def __init__(self, dataset, batch_size, shuffle=False, workers=4, generator=None, depth=3, stage=None):
         from concurrent.futures import ThreadPoolExecutor
         self.ds, self.bs, self.shuffle, self.gen, self.depth = dataset, int(batch_size), bool(shuffle), generator, depth
+        # stage(key, [arrays]) -> what the batch carries for that key: default the stacked array; the GPU loops pass val.HipOps.stage_host,
+        # which stacks straight into pinned memory ON THE LOADER THREAD (the consumer then only issues the asynchronous copy)
+        self.stage = stage or (lambda key, arrays: np.stack(arrays))
         self.pool = ThreadPoolExecutor(max_workers=max(1, int(workers)))
 
     def __len__(self):
@@ -146,10 +149,17 @@ class ThreadedBatchLoader:
         batches = [order[i:i + self.bs] for i in range(0, n, self.bs)]
         futs, nxt = {}, 0
 
+        def collate(item_futs):          # loader thread; its item jobs were queued first, so they are running or done
+            items = [f.result() for f in item_futs]
+            out = {key: self.stage(key, [it[key] for it in items]) for key in ('HR', 'SR', 'LR') if key in items[0]}
+            out['Index'] = [it['Index'] for it in items]
+            return out
+
         def submit_until(k):
             nonlocal nxt
             while nxt < len(batches) and nxt <= k:
-                futs[nxt] = [self.pool.submit(self.ds.load_u8, i, self.ds.draw_flips()) for i in batches[nxt]]
+                item_futs = [self.pool.submit(self.ds.load_u8, i, self.ds.draw_flips()) for i in batches[nxt]]
+                futs[nxt] = self.pool.submit(collate, item_futs)
                 nxt += 1
 
         # The consumer hands the GIL over around every launch / synchronisation; with Python's default 5 ms switch interval every
@@ -167,11 +177,9 @@ class ThreadedBatchLoader:
         submit_until(self.depth - 1)
         for k in range(len(batches)):
             submit_until(k)                    # (only if depth == 0)
-            items = [f.result() for f in futs.pop(k)]
-            out = {key: np.stack([it[key] for it in items]) for key in ('HR', 'SR', 'LR') if key in items[0]}
-            out['Index'] = [it['Index'] for it in items]
+            out = futs.pop(k).result()
             # the next decode jobs go to the pool right before the consumer takes this batch into its GPU call: the workers' Python
-            # sections then run while the consumer sits in C without the GIL, not against this thread's own stacking code
+            # sections then run while the consumer sits in C without the GIL, not against this thread's own code
             submit_until(k + self.depth)
             yield out
 

@@ -34,9 +34,12 @@ def run(opt, precision='f16x3', rank=0, world=1, log=print, val_batch=1, max_val
     # the reference's DataLoader(batch_size, shuffle, num_workers, pin_memory) (data/__init__.py:9-15) as loader THREADS that
     # hand over uint8 batches; the tensor transform runs on the device (val.HipOps)
     from .dataset import ThreadedBatchLoader
-    loader = ThreadedBatchLoader(train_set, train_opt['batch_size'], shuffle=train_opt['use_shuffle'],
-                                 workers=max(1, int(train_opt['num_workers'] or 0)), generator=gen if world > 1 else None)
     ops = ops or V.HipOps('cuda')
+    # one rank: the loader threads stack every batch straight into pinned memory (ops.stage_host); several ranks: every rank decodes the
+    # whole batch (same shuffle seed), keeps its slice and stages that
+    loader = ThreadedBatchLoader(train_set, train_opt['batch_size'], shuffle=train_opt['use_shuffle'],
+                                 workers=max(2, int(train_opt['num_workers'] or 0)), generator=gen if world > 1 else None,
+                                 stage=ops.stage_host if world == 1 else None)
     own_model = diffusion is None
     if own_model:
         diffusion = create_model(opt)                                                  # sr_mfe.py:81
@@ -65,8 +68,11 @@ def run(opt, precision='f16x3', rank=0, world=1, log=print, val_batch=1, max_val
                 lo, hi = shard_range(b, rank, world)
                 train_data = {k: v[lo:hi] for k, v in train_data.items()}
             # an empty shard (ragged last batch) still takes part in the step's collectives: zero-sized tensors
-            train_data = {k: (ops.to_tensor(ops.upload(k, v)) if v.shape[0] else
-                              torch.empty((0, v.shape[3], v.shape[1], v.shape[2]), device=ops.device)) for k, v in train_data.items()}
+            if world == 1:
+                train_data = {k: ops.to_tensor(ops.to_device(v)) for k, v in train_data.items()}
+            else:
+                train_data = {k: (ops.to_tensor(ops.upload(k, v)) if v.shape[0] else
+                                  torch.empty((0, v.shape[3], v.shape[1], v.shape[2]), device=ops.device)) for k, v in train_data.items()}
             diffusion.feed_data(train_data)
             diffusion.optimize_parameters()
             if current_step % opt['train']['print_freq'] == 0:

@@ -29,8 +29,14 @@ class HostOps:
     """numpy stand-in of val.HipOps (test infrastructure): same methods, host arithmetic of fastdiffsr_amd.metrics."""
     device = torch.device('cpu')
 
+    def stage_host(self, key, arrays):
+        return torch.from_numpy(np.stack(arrays) if not isinstance(arrays, np.ndarray) else np.ascontiguousarray(arrays))
+
+    def to_device(self, staged):
+        return staged
+
     def upload(self, key, arr):
-        return torch.from_numpy(np.ascontiguousarray(arr))
+        return self.to_device(self.stage_host(key, arr))
 
     def to_tensor(self, u8):
         return u8.permute(0, 3, 1, 2).to(torch.float32).div(255) * 2 + (-1)
