@@ -491,9 +491,14 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const ConvParams p, 
       const int oy = ty * 2 + (px >> 5), ox = tx * 32 + (px & 31);
       if (oy >= p.Hout || ox >= p.Wout) continue;
       const size_t o = ((size_t)(n * p.Hout + oy) * p.Wout + ox) * p.Cout + cbase + c4 * 4;
-      f32x4 a = *reinterpret_cast<const f32x4*>(p.kscratch + o);
-#pragma unroll 4
-      for (int s = 1; s < p.ksplit; ++s) a += *reinterpret_cast<const f32x4*>(p.kscratch + s * slice + o);
+      // all slices of this quad in flight at once (ksplit <= 16), added in slice order: the kernel is one memory round trip long
+      f32x4 sl[16];
+#pragma unroll
+      for (int s = 0; s < 16; ++s) sl[s] = s < p.ksplit ? *reinterpret_cast<const f32x4*>(p.kscratch + s * slice + o) : f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 a = sl[0];
+#pragma unroll
+      for (int s = 1; s < 16; ++s)
+        if (s < p.ksplit) a += sl[s];
       a = a * (p.xr0 ? (p.w_inv_scale_r_dev ? *p.w_inv_scale_r_dev : p.w_inv_scale_r) : (p.w_inv_scale_dev ? *p.w_inv_scale_dev : p.w_inv_scale)) + add;
       if (p.out_bf16) {   // bf16 mode: residual and output are bf16 tensors
         if (p.res) a += ActIO<PREC_BF16>::widen(ActIO<PREC_BF16>::load4(p.res, o));

@@ -387,6 +387,19 @@ __global__ void __launch_bounds__(256) gn_finalize_kernel(const GnFinalizeParams
   const int S = 256 / cpg;                  // tile slices per channel
   const int ch = tid % cpg, slice = tid / cpg;
   const int c = g * cpg + ch;
+  // the affine parameters of this thread's channel are fetched NOW, beside the partials: issued after the fold they were one more
+  // exposed memory round trip in a kernel that is nothing but latency (45 of these launches per forward)
+  float gam = 0.f, bet = 0.f, f_s = 0.f, f_t = 0.f;
+  if (tid < cpg) {
+    const int cc = g * cpg + tid;
+    gam = p.gamma[cc];
+    bet = p.beta[cc];
+    if (p.film) {
+      const float* f = p.film + (size_t)n * p.film_stride + p.film_off;
+      f_s = f[cc];
+      f_t = f[C + cc];
+    }
+  }
   double a = 0.0, b = 0.0;
   if (slice < S) {
     const float* part;
@@ -425,13 +438,12 @@ __global__ void __launch_bounds__(256) gn_finalize_kernel(const GnFinalizeParams
   __syncthreads();
   if (tid < cpg) {
     const int cc = g * cpg + tid;
-    float sc = (float)gs[1] * p.gamma[cc];
-    float sh = p.beta[cc] - (float)gs[0] * sc;
+    float sc = (float)gs[1] * gam;
+    float sh = bet - (float)gs[0] * sc;
     if (p.film) {   // (x_hat*gamma + beta) * (1 + s) + t
-      const float* f = p.film + (size_t)n * p.film_stride + p.film_off;
-      const float one_s = 1.0f + f[cc];
+      const float one_s = 1.0f + f_s;
       sc *= one_s;
-      sh = sh * one_s + f[C + cc];
+      sh = sh * one_s + f_t;
     }
     p.scale[(size_t)n * C + cc] = sc;
     p.shift[(size_t)n * C + cc] = sh;

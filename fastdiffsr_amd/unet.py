@@ -76,6 +76,12 @@ class UNet(nn.Module):
         bound = 1.0 / math.sqrt(fan_in)
         return t.uniform_(-bound, bound)
 
+    def train(self, mode=True):
+        """nn.Module.train() without the walk over ~330 parameter-holder children (they have no forward and no mode of their own):
+        DDPM.test() flips eval() / train() around every sampling call (model/model.py:60-68), 0.5 ms per call at batch 1."""
+        self.training = bool(mode)
+        return self
+
     # -- engine plumbing ---------------------------------------------------------
     @property
     def engine(self) -> Engine:
