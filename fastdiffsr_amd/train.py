@@ -97,7 +97,8 @@ def run(opt, precision='f16x3', rank=0, world=1, log=print, val_batch=1, max_val
     return diffusion, history
 
 
-def main(argv=None):
+def main(argv=None, diffusion=None, ops=None):
+    """diffusion / ops: injection points of tests/test_val_cli_gloo.py (a stand-in model and device side on a GPU-less box)."""
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument('-c', '--config', required=True)
     ap.add_argument('-p', '--phase', choices=['train'], default='train')
@@ -116,10 +117,11 @@ def main(argv=None):
         tl = setup_logger(None, opt['path']['log'], 'train', screen=True)
         setup_logger('val', opt['path']['log'], 'val')
         log = logging.getLogger('base').info if tl is None else tl.info
-    run(opt, precision=a.precision, rank=rank, world=world, log=log)
+    out = run(opt, precision=a.precision, rank=rank, world=world, log=log, diffusion=diffusion, ops=ops)
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
+    return out
 
 
 if __name__ == '__main__':

@@ -173,3 +173,73 @@ def test_val_cli_two_ranks_gloo(tmp_path):
         assert got[r]['images'] == 5
         for k in ('bic_mse', 'bic_psnr', 'bic_ssim', 'bic_ergas', 'sr_mse', 'sr_psnr', 'sr_ssim', 'sr_ergas'):
             assert abs(got[r][k] - one[k]) <= 1e-12 * max(1.0, abs(one[k])), (k, got[r][k], one[k])
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# `python -m fastdiffsr_amd.train` under two ranks (gloo): same shuffle on every rank, each keeps its slice of every batch, the
+# gradient arena is all-reduced with the GLOBAL divisor -- replicas end bitwise equal and log the same l_pix.
+# ---------------------------------------------------------------------------------------------------------------------------
+def _train_rank(rank, world, port, cpath, cwd, q):
+    from test_dist_gloo import _OracleEngine
+    from fastdiffsr_amd import train
+    from fastdiffsr_amd.diffusion import GaussianDiffusion
+    from fastdiffsr_amd.model import DDPM
+    from fastdiffsr_amd.unet import UNet
+    from fastdiffsr_amd.schedule import schedule_buffers
+    os.chdir(cwd)
+    torch.set_num_threads(2)
+    os.environ.update({'RANK': str(rank), 'LOCAL_RANK': str(rank), 'WORLD_SIZE': str(world), 'MASTER_ADDR': '127.0.0.1',
+                       'MASTER_PORT': str(port)})
+    cfg = UNetConfig(**CFG)
+    torch.manual_seed(0)                                # (resumed-from-the-same-checkpoint situation: equal replicas at the start)
+    unet = UNet(**CFG)
+    netG = GaussianDiffusion(unet, image_size=32)
+    sd = {k: v.detach().numpy().copy() for k, v in super(UNet, unet).state_dict().items()}
+    eng = _OracleEngine(cfg, sd)
+    probe = _OracleEngine(cfg, sd)
+    g0 = torch.Generator().manual_seed(1)
+    probe.train_grads(torch.rand(1, 6, 32, 32, generator=g0), torch.tensor([0.5]), torch.rand(1, 3, 32, 32, generator=g0), 'l1', 1.0)
+    _OracleEngine._live_keys = probe.keys
+    bufs, sqrt_prev = schedule_buffers(FASTDIFFSR_SCHEDULE_VAL)
+    netG.sqrt_alphas_cumprod_prev, netG.num_timesteps = sqrt_prev, 20
+    netG._engine_for_training = lambda: eng
+    ddpm = object.__new__(DDPM)
+    ddpm.netG, ddpm.lr, ddpm.betas, ddpm.adam_eps, ddpm.log_dict = netG, 1e-3, (0.9, 0.999), 1e-8, {}
+    ddpm.device, ddpm.begin_step, ddpm.begin_epoch, ddpm.schedule_phase = torch.device('cpu'), 0, 0, 'train'
+    ddpm.set_new_noise_schedule = lambda *a, **k: None          # (the stand-in engine has no device-side schedule)
+    np.random.seed(11)                                  # t and gamma come from numpy's global RNG, the noise from torch's: same on both ranks
+    torch.manual_seed(12)
+    _, hist = train.main(['-c', cpath], diffusion=ddpm, ops=HostOps())
+    end = torch.cat([eng.leaves[k].detach().reshape(-1) for k in eng.keys])
+    logs = []
+    for d, _, files in os.walk(os.path.join(cwd, 'experiments')):       # rank 0 writes experiments/<name>_<stamp>/logs/train.log
+        if 'train.log' in files:
+            logs += [ln for ln in open(os.path.join(d, 'train.log')) if '<epoch' in ln]
+    q.put((rank, [v['l_pix'] for s, v in hist if 'l_pix' in v], end.numpy().tobytes(), logs if rank == 0 else []))
+
+
+@pytest.mark.timeout(600)
+def test_train_cli_two_ranks_gloo(tmp_path):
+    from test_val_host import make_dataset
+    root = make_dataset(str(tmp_path / 'data'), n=5, l=8, r=32, seed=9)
+    cfg = _config(root, 8, 32)
+    cfg['phase'] = 'train'
+    cfg['datasets']['train'].update(batch_size=3, use_shuffle=True, num_workers=2)      # 5 images: batches of 3 and 2 -> ragged shards
+    cfg['train'].update(n_iter=3, val_freq=100, save_checkpoint_freq=100, print_freq=1)
+    cpath = str(tmp_path / 'train.json')
+    with open(cpath, 'w') as f:
+        json.dump(cfg, f)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_train_rank, args=(r, 2, port, cpath, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (r0, l0, end0, lines0), (r1, l1, end1, lines1) = res
+    assert len(l0) == 3 and l0 == l1 and all(np.isfinite(l0))       # the logged l_pix is the GLOBAL one on every rank
+    assert end0 == end1                                             # replicas bitwise equal after three data-parallel steps
+    assert len(lines0) == 3 and not lines1                          # rank 0 alone writes the iteration lines (logs/train.log)

@@ -91,3 +91,33 @@ def test_skimage_style_metrics():
     assert abs(M.compare_ssim(a[..., 0], b[..., 0], multichannel=False) - np.mean(vals)) < 1e-9
     s = M.compare_ssim(a, b)
     assert 0 < s < 1 and abs(s - np.mean([M.compare_ssim(a[..., c], b[..., c], multichannel=False) for c in range(3)])) < 1e-12
+
+
+def test_prepare_folder_tool_matches_pillow_and_feeds_the_dataset(tmp_path):
+    """data/prepare_data_mfe_dm.py: lr = crop(resize(img, l)), hr = crop(resize(img, r)), sr = crop(resize(lr, r)) with torchvision's
+    shorter-edge resize; square and non-square sources; the folders are what LRHRDataset reads."""
+    from PIL import Image
+    from fastdiffsr_amd import prepare as P
+    rng = np.random.default_rng(2)
+    src = tmp_path / 'src'
+    src.mkdir()
+    for name, (h, w) in (('7', (96, 96)), ('12', (80, 120)), ('3', (130, 72))):
+        Image.fromarray(rng.integers(0, 256, (h, w, 3)).astype(np.uint8)).save(src / f'{name}.png')
+    n = P.main(['-p', str(src), '-o', str(tmp_path / 'set'), '--size', '16,64', '--n_worker', '2'])
+    out = tmp_path / 'set_16_64'
+    assert n == 3 and sorted(os.listdir(out)) == ['hr_64', 'lr_16', 'sr_16_64']
+    assert sorted(os.listdir(out / 'hr_64')) == ['00003.tif', '00007.tif', '00012.tif']
+    # square source: plain Pillow resizes
+    img = Image.open(src / '7.png').convert('RGB')
+    lr = img.resize((16, 16), Image.BICUBIC)
+    assert np.array_equal(np.asarray(Image.open(out / 'lr_16' / '00007.tif')), np.asarray(lr))
+    assert np.array_equal(np.asarray(Image.open(out / 'hr_64' / '00007.tif')), np.asarray(img.resize((64, 64), Image.BICUBIC)))
+    assert np.array_equal(np.asarray(Image.open(out / 'sr_16_64' / '00007.tif')), np.asarray(lr.resize((64, 64), Image.BICUBIC)))
+    # 80 x 120 (h x w): shorter edge 80 -> 64, long edge int(64 * 120 / 80) = 96, centre crop of 64 columns
+    img = Image.open(src / '12.png').convert('RGB')
+    hr = img.resize((96, 64), Image.BICUBIC).crop((16, 0, 80, 64))
+    assert np.array_equal(np.asarray(Image.open(out / 'hr_64' / '00012.tif')), np.asarray(hr))
+    ds = LRHRDataset(str(out), 'img', l_resolution=16, r_resolution=64, split='val', data_len=-1, need_LR=True)
+    assert len(ds) == 3 and ds[0]['HR'].shape == (3, 64, 64) and ds[0]['LR'].shape == (3, 16, 16)
+    with pytest.raises(NotImplementedError):
+        P.main(['-p', str(src), '-o', str(tmp_path / 'x'), '--lmdb'])
