@@ -1,5 +1,5 @@
 #!/bin/bash
-# Same-box A/B of launcher options: tools/ab_k32.sh "<opts A>" "<opts B>" [bench args]   (opts like "k32=27" or "k32=59 k32_sb_min_wgs=512")
+# Same-box A/B of launcher options: tools/ab_options.sh "<opts A>" "<opts B>" [bench args]   (opts like "k32=27" or "k32=59 k32_sb_min_wgs=512")
 # Alternates A B A B (two passes each) so that box-to-box and thermal drift cancel; prints images/s per run.
 A="$1"; B="$2"; shift 2
 for rep in 1 2; do
