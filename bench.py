@@ -561,7 +561,7 @@ def dist_sub_records(cfg, sd, eng, dev, rank, world, S):
         return float(t.item()), err
 
     recs = {}
-    steps, warmup = 2, 1
+    steps, warmup = 6, 2      # as the single-GPU sub-records: >= 6 timed passes after >= 2 warm-up passes
     dt, err = measure(lambda: run_config(eng, dev, 'bf16', 64, S, steps, warmup, True, 'engine', rank=rank, want_profile=False)[0])
     if dt != float('inf'):
         ips = world * 64 * steps / dt
