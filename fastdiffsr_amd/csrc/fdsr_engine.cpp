@@ -915,6 +915,7 @@ int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, 
           const Op& kr = h->ops[k2.rider];
           const WeightEntry &w2 = h->weights[k2.w], &wr = h->weights[kr.w];
           if (!w2.h_ok || !wr.h_ok || wr.h_WN != w2.h_WN || wr.h_cout_pad != w2.h_cout_pad) return false;
+          if (mode == 3) return k2.lvl_out != 0;   // everywhere but the full-resolution level (whose 16-row rider tile is the slowest kernel of the loop)
           return mode == 2 || k2.lvl_out == 0 || kr.C0 + kr.C1 <= k2.Cout;
         };
         if (op.rider_of >= 0 && rides(h->ops[op.rider_of])) break;
