@@ -2,7 +2,9 @@
 `{dataroot}/hr_{r}`, `sr_{l}_{r}` (the bicubic conditioning image), `lr_{l}`, files paired by sorted order.
 Tensors are what `transform_augment(split, min_max=(-1, 1))` gives: ToTensor (uint8 / 255, CHW), in the train split
 ONE RandomHorizontalFlip(p=0.5) decision for the stacked [SR, HR] (and one of its own for LR, util.py:66-88), then
-* 2 - 1.  The lmdb container raises, like the reference does for unknown datatypes.
+* 2 - 1.  `datatype='lmdb'` reads the container the reference's prepare tool writes (LRHR_dataset.py:18-27,61-92: keys
+`hr_{r}_{NNNNN}`, `sr_{l}_{r}_{NNNNN}`, `lr_{l}_{NNNNN}` holding encoded image files, `length`; an index whose HR or SR entry is
+missing is replaced by `random.randint` draws until one is found); the `lmdb` module is imported when such a dataset is opened.
 
 `cond_from_lr=True` builds SR on the GPU from the LR image instead of reading `sr_*` (bit-identical to the
 reference's offline PIL bicubic, see data.lr_to_sr): the val loop then needs only LR + HR folders."""
@@ -42,16 +44,57 @@ def to_tensor(pil_img, min_max=(-1, 1)):
 class LRHRDataset(Dataset):
     def __init__(self, dataroot, datatype='img', l_resolution=64, r_resolution=256, split='val', data_len=-1,
                  need_LR=False, img_mask='no', cond_from_lr=False):
-        if datatype != 'img':
+        if datatype not in ('img', 'lmdb'):
             raise NotImplementedError('data_type [{:s}] is not recognized.'.format(str(datatype)))
+        self.datatype = datatype
         self.l_res, self.r_res, self.split = l_resolution, r_resolution, split
         self.need_LR = need_LR or cond_from_lr
         self.cond_from_lr = cond_from_lr
-        self.hr_path = get_paths_from_images('{}/hr_{}'.format(dataroot, r_resolution))
-        self.sr_path = None if cond_from_lr else get_paths_from_images('{}/sr_{}_{}'.format(dataroot, l_resolution, r_resolution))
-        self.lr_path = get_paths_from_images('{}/lr_{}'.format(dataroot, l_resolution)) if self.need_LR else None
-        self.dataset_len = len(self.hr_path)
+        self.env = None
+        if datatype == 'lmdb':                                     # LRHR_dataset.py:18-27
+            import lmdb
+            self.env = lmdb.open(dataroot, readonly=True, lock=False, readahead=False, meminit=False)
+            with self.env.begin(write=False) as txn:
+                self.dataset_len = int(txn.get('length'.encode('utf-8')))
+            self.hr_path = self.sr_path = self.lr_path = None
+        else:
+            self.hr_path = get_paths_from_images('{}/hr_{}'.format(dataroot, r_resolution))
+            self.sr_path = None if cond_from_lr else get_paths_from_images('{}/sr_{}_{}'.format(dataroot, l_resolution, r_resolution))
+            self.lr_path = get_paths_from_images('{}/lr_{}'.format(dataroot, l_resolution)) if self.need_LR else None
+            self.dataset_len = len(self.hr_path)
         self.data_len = self.dataset_len if data_len is None or data_len <= 0 else min(data_len, self.dataset_len)
+
+    def _open(self, index):
+        """The item's PIL images {'HR', 'SR'?, 'LR'?} from the folders or from the lmdb container."""
+        from PIL import Image
+        want_sr = not self.cond_from_lr
+        if self.env is None:
+            out = {'HR': Image.open(self.hr_path[index]).convert('RGB')}
+            if want_sr:
+                out['SR'] = Image.open(self.sr_path[index]).convert('RGB')
+            if self.need_LR:
+                out['LR'] = Image.open(self.lr_path[index]).convert('RGB')
+            return out
+        import random
+        from io import BytesIO
+        with self.env.begin(write=False) as txn:                   # LRHR_dataset.py:61-92
+
+            def entries(i):
+                n = str(i).zfill(5)
+                hr = txn.get('hr_{}_{}'.format(self.r_res, n).encode('utf-8'))
+                sr = txn.get('sr_{}_{}_{}'.format(self.l_res, self.r_res, n).encode('utf-8'))
+                lr = txn.get('lr_{}_{}'.format(self.l_res, n).encode('utf-8')) if self.need_LR else None
+                return hr, sr, lr
+
+            hr, sr, lr = entries(index)
+            while hr is None or sr is None:                        # "skip the invalid index"
+                hr, sr, lr = entries(random.randint(0, self.data_len - 1))
+            out = {'HR': Image.open(BytesIO(hr)).convert('RGB')}
+            if want_sr:
+                out['SR'] = Image.open(BytesIO(sr)).convert('RGB')
+            if self.need_LR:
+                out['LR'] = Image.open(BytesIO(lr)).convert('RGB')
+        return out
 
     def __len__(self):
         return self.data_len
@@ -71,12 +114,8 @@ class LRHRDataset(Dataset):
         loops (val.py, train.py) ship to the GPU, where metrics.u8_to_tensor finishes the transform (one byte per sample over
         PCIe, and the decode -- which releases the GIL -- is all a loader thread does).  Same RNG consumption as __getitem__
         (flips=None), or the decisions handed in (draw_flips)."""
-        from PIL import Image
-        out = {'HR': np.array(Image.open(self.hr_path[index]).convert('RGB'), dtype=np.uint8), 'Index': index}
-        if self.sr_path is not None:
-            out['SR'] = np.array(Image.open(self.sr_path[index]).convert('RGB'), dtype=np.uint8)
-        if self.need_LR:
-            out['LR'] = np.array(Image.open(self.lr_path[index]).convert('RGB'), dtype=np.uint8)
+        out = {k: np.array(v, dtype=np.uint8) for k, v in self._open(index).items()}
+        out['Index'] = index
         if self.split == 'train':
             flip_hr, flip_lr = self.draw_flips() if flips is None else flips
             if self.cond_from_lr:
@@ -90,15 +129,14 @@ class LRHRDataset(Dataset):
         return out
 
     def __getitem__(self, index):
-        from PIL import Image
-        out = {'HR': to_tensor(Image.open(self.hr_path[index]).convert('RGB')), 'Index': index}
-        if self.sr_path is not None:
-            out['SR'] = to_tensor(Image.open(self.sr_path[index]).convert('RGB'))
+        imgs = self._open(index)
+        out = {'HR': to_tensor(imgs['HR']), 'Index': index}
+        if 'SR' in imgs:
+            out['SR'] = to_tensor(imgs['SR'])
         if self.need_LR:
-            lr = Image.open(self.lr_path[index]).convert('RGB')
-            out['LR'] = to_tensor(lr)
+            out['LR'] = to_tensor(imgs['LR'])
             if self.cond_from_lr:
-                out['LR_u8'] = torch.from_numpy(np.array(lr, dtype=np.uint8))
+                out['LR_u8'] = torch.from_numpy(np.array(imgs['LR'], dtype=np.uint8))
         if self.split == 'train':
             # util.py:66-75: hflip(torch.stack([SR, HR])) -- torchvision's RandomHorizontalFlip draws torch.rand(1) once
             # for the whole stack; util.py:77-88 does the same, separately, for [LR]

@@ -6,8 +6,9 @@ FastDiffSR/data/prepare_data_mfe_dm.py:17-40,100-187).  Every image under `--pat
 
 `resize(img, size)` is torchvision's: the SHORTER edge becomes `size`, aspect kept (long edge = int(size * long / short)), with Pillow's
 resampler (bicubic by default) -- the same Pillow calls as the reference, so the files are the reference's files.  Decoding, resizing
-and writing run on worker threads (Pillow releases the GIL); the lmdb container of the reference (`--lmdb`) is not offered (lmdb is not
-in this image).  On-line, `val.py --cond-from-lr` / `data.lr_to_sr` build the `sr_*` member on the GPU instead, bit-identical to this."""
+and writing run on worker threads (Pillow releases the GIL).  `--lmdb` writes the reference's container instead (:24-27,82-92: the three
+images as encoded tif files under `lr_<l>_<NNNNN>`, `hr_<r>_<NNNNN>`, `sr_<l>_<r>_<NNNNN>`, the running count under `length`; the
+`lmdb` module is imported only then -- `LRHRDataset(datatype='lmdb')` reads it back).  On-line, `val.py --cond-from-lr` / `data.lr_to_sr` build the `sr_*` member on the GPU instead, bit-identical to this."""
 import argparse
 import os
 from concurrent.futures import ThreadPoolExecutor
@@ -48,23 +49,50 @@ def resize_multiple(img, sizes=(64, 256), resample=None):         # :30-40
     return lr_img, hr_img, sr_img
 
 
-def prepare(img_path, out_path, n_worker=4, sizes=(64, 256), resample=None, ext='tif'):
-    """:100-160 without the lmdb branch.  Returns the number of images written."""
+def image_convert_bytes(img):                                      # :24-27
+    from io import BytesIO
+    buffer = BytesIO()
+    img.save(buffer, format='tiff')
+    return buffer.getvalue()
+
+
+def prepare(img_path, out_path, n_worker=4, sizes=(64, 256), resample=None, ext='tif', lmdb_save=False):
+    """:100-160.  Returns the number of images written."""
     from PIL import Image
     files = sorted(p for p in Path(str(img_path)).glob('**/*') if p.is_file())
     dirs = ['{}/lr_{}'.format(out_path, sizes[0]), '{}/hr_{}'.format(out_path, sizes[1]), '{}/sr_{}_{}'.format(out_path, sizes[0], sizes[1])]
-    for d in dirs:
-        os.makedirs(d, exist_ok=True)
+    keys = ['lr_{}_{{}}'.format(sizes[0]), 'hr_{}_{{}}'.format(sizes[1]), 'sr_{}_{}_{{}}'.format(sizes[0], sizes[1])]
+    env = None
+    if lmdb_save:
+        import lmdb
+        env = lmdb.open(str(out_path), map_size=1024 ** 4, readahead=False)     # :113
+    else:
+        for d in dirs:
+            os.makedirs(d, exist_ok=True)
 
     def one(f):
         img = Image.open(f).convert('RGB')                         # :43-44
         name = f.name.split('.')[0].zfill(5)                       # :49, :146
-        for im, d in zip(resize_multiple(img, sizes, resample), dirs):
-            im.save('{}/{}.{}'.format(d, name, ext))
-        return 1
+        imgs = resize_multiple(img, sizes, resample)
+        if env is None:
+            for im, d in zip(imgs, dirs):
+                im.save('{}/{}.{}'.format(d, name, ext))
+            return None
+        return name, [image_convert_bytes(im) for im in imgs]      # encoded on the worker thread, written by the caller
 
+    total = 0
     with ThreadPoolExecutor(max_workers=max(1, int(n_worker))) as ex:
-        return sum(ex.map(one, files))
+        for res in ex.map(one, files):
+            total += 1
+            if env is not None:
+                name, blobs = res
+                with env.begin(write=True) as txn:                 # :82-92
+                    for k, b in zip(keys, blobs):
+                        txn.put(k.format(name).encode('utf-8'), b)
+                    txn.put('length'.encode('utf-8'), str(total).encode('utf-8'))
+    if env is not None and hasattr(env, 'close'):
+        env.close()
+    return total
 
 
 def main(argv=None):
@@ -77,11 +105,10 @@ def main(argv=None):
     ap.add_argument('--resample', type=str, default='bicubic', choices=['bilinear', 'bicubic'])
     ap.add_argument('--lmdb', '-l', action='store_true')
     a = ap.parse_args(argv)
-    if a.lmdb:
-        raise NotImplementedError('the lmdb container is not offered (lmdb is not available here): use the image folders')
     sizes = [int(s.strip()) for s in a.size.split(',')]
     out = '{}_{}_{}'.format(a.out, sizes[0], sizes[1])              # :182
-    n = prepare(a.path, out, a.n_worker, sizes=sizes, resample={'bilinear': Image.BILINEAR, 'bicubic': Image.BICUBIC}[a.resample])
+    n = prepare(a.path, out, a.n_worker, sizes=sizes, resample={'bilinear': Image.BILINEAR, 'bicubic': Image.BICUBIC}[a.resample],
+                lmdb_save=a.lmdb)
     print('{} images -> {}'.format(n, out))
     return n
 

@@ -43,7 +43,7 @@ def test_dataset_matches_reference_conventions(tmp_path):
     assert len(LRHRDataset(root, 'img', 16, 64, data_len=2)) == 2
     assert len(LRHRDataset(root, 'img', 16, 64, data_len=99)) == 3
     with pytest.raises(NotImplementedError):
-        LRHRDataset(root, 'lmdb', 16, 64)
+        LRHRDataset(root, 'zip', 16, 64)
     with pytest.raises(AssertionError):
         LRHRDataset(os.path.join(root, 'nope'), 'img', 16, 64)
     ds2 = create_dataset({'dataroot': root, 'datatype': 'img', 'l_resolution': 16, 'r_resolution': 64, 'data_len': -1,
@@ -119,5 +119,82 @@ def test_prepare_folder_tool_matches_pillow_and_feeds_the_dataset(tmp_path):
     assert np.array_equal(np.asarray(Image.open(out / 'hr_64' / '00012.tif')), np.asarray(hr))
     ds = LRHRDataset(str(out), 'img', l_resolution=16, r_resolution=64, split='val', data_len=-1, need_LR=True)
     assert len(ds) == 3 and ds[0]['HR'].shape == (3, 64, 64) and ds[0]['LR'].shape == (3, 16, 16)
+
+
+class _DictLmdb:
+    """A dict-backed stand-in for the `lmdb` module (absent from this image), with the calls the reference makes:
+    lmdb.open(path, ...) -> env; env.begin(write=) as txn; txn.get / txn.put (prepare_data_mfe_dm.py:82-92,113; LRHR_dataset.py:19-23,61-92)."""
+    stores = {}
+
+    class _Txn:
+        def __init__(self, d, write):
+            self.d, self.write = d, write
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+        def get(self, k):
+            assert isinstance(k, bytes)
+            return self.d.get(k)
+
+        def put(self, k, v):
+            assert self.write and isinstance(k, bytes) and isinstance(v, bytes)
+            self.d[k] = v
+
+    class _Env:
+        def __init__(self, d, readonly):
+            self.d, self.readonly = d, readonly
+
+        def begin(self, write=False):
+            assert not (write and self.readonly)
+            return _DictLmdb._Txn(self.d, write)
+
+        def close(self):
+            pass
+
+    @classmethod
+    def open(cls, path, readonly=False, **kw):
+        return cls._Env(cls.stores.setdefault(str(path), {}), readonly)
+
+
+def test_lmdb_container_written_by_the_tool_and_read_by_the_dataset(tmp_path, monkeypatch):
+    """`--lmdb` (prepare_data_mfe_dm.py:24-27,82-92) and LRHRDataset(datatype='lmdb') (LRHR_dataset.py:18-27,61-92) over a stand-in
+    lmdb module: same keys, encoded tif entries, `length`; items equal the image-folder dataset's; a missing index is re-drawn."""
+    import sys
+    import random
+    from PIL import Image
+    from fastdiffsr_amd import prepare as P
+    monkeypatch.setitem(sys.modules, 'lmdb', _DictLmdb)
+    _DictLmdb.stores.clear()
+    rng = np.random.default_rng(5)
+    src = tmp_path / 'src'
+    src.mkdir()
+    for name in ('0', '1', '2'):
+        Image.fromarray(rng.integers(0, 256, (40, 40, 3)).astype(np.uint8)).save(src / f'{name}.png')
+    assert P.main(['-p', str(src), '-o', str(tmp_path / 'db'), '--size', '8,32', '--lmdb']) == 3
+    assert P.main(['-p', str(src), '-o', str(tmp_path / 'dir'), '--size', '8,32']) == 3
+    store = _DictLmdb.stores[str(tmp_path / 'db_8_32')]
+    assert store[b'length'] == b'3'
+    assert sorted(store) == sorted([b'length'] + [f'{k}_{i:05d}'.encode() for k in ('lr_8', 'hr_32', 'sr_8_32') for i in range(3)])
+    a = LRHRDataset(str(tmp_path / 'db_8_32'), 'lmdb', l_resolution=8, r_resolution=32, split='val', need_LR=True)
+    b = LRHRDataset(str(tmp_path / 'dir_8_32'), 'img', l_resolution=8, r_resolution=32, split='val', need_LR=True)
+    assert len(a) == len(b) == 3
+    for i in range(3):
+        x, y = a[i], b[i]
+        assert sorted(x) == sorted(y) == ['HR', 'Index', 'LR', 'SR']
+        for k in ('HR', 'SR', 'LR'):
+            assert torch.equal(x[k], y[k])
+        u, v = a.load_u8(i), b.load_u8(i)
+        for k in ('HR', 'SR', 'LR'):
+            assert np.array_equal(u[k], v[k])
+    # an index without an HR entry: the reference draws random indices until one is valid (LRHR_dataset.py:77-91)
+    del store[b'hr_32_00001']
+    random.seed(0)
+    got = a[1]['HR']
+    assert any(torch.equal(got, b[i]['HR']) for i in (0, 2))
+    assert len(LRHRDataset(str(tmp_path / 'db_8_32'), 'lmdb', l_resolution=8, r_resolution=32, data_len=2)) == 2
     with pytest.raises(NotImplementedError):
-        P.main(['-p', str(src), '-o', str(tmp_path / 'x'), '--lmdb'])
+        LRHRDataset(str(tmp_path / 'dir_8_32'), 'zip')
