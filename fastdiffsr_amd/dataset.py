@@ -56,11 +56,13 @@ class LRHRDataset(Dataset):
             self.env = lmdb.open(dataroot, readonly=True, lock=False, readahead=False, meminit=False)
             with self.env.begin(write=False) as txn:
                 self.dataset_len = int(txn.get('length'.encode('utf-8')))
-            self.hr_path = self.sr_path = self.lr_path = None
+            self.hr_path = self.sr_path = self.lr_path = self.hr_mask_path = None
         else:
             self.hr_path = get_paths_from_images('{}/hr_{}'.format(dataroot, r_resolution))
             self.sr_path = None if cond_from_lr else get_paths_from_images('{}/sr_{}_{}'.format(dataroot, l_resolution, r_resolution))
             self.lr_path = get_paths_from_images('{}/lr_{}'.format(dataroot, l_resolution)) if self.need_LR else None
+            # LRHR_dataset.py:33-40: any img_mask but 'no' adds the folder hr_mask_{r}; its image rides the [SR, HR] stack ('HR_Mask')
+            self.hr_mask_path = get_paths_from_images('{}/hr_mask_{}'.format(dataroot, r_resolution)) if img_mask != 'no' else None
             self.dataset_len = len(self.hr_path)
         self.data_len = self.dataset_len if data_len is None or data_len <= 0 else min(data_len, self.dataset_len)
 
@@ -72,6 +74,8 @@ class LRHRDataset(Dataset):
             out = {'HR': Image.open(self.hr_path[index]).convert('RGB')}
             if want_sr:
                 out['SR'] = Image.open(self.sr_path[index]).convert('RGB')
+            if self.hr_mask_path:
+                out['HR_Mask'] = Image.open(self.hr_mask_path[index]).convert('RGB')
             if self.need_LR:
                 out['LR'] = Image.open(self.lr_path[index]).convert('RGB')
             return out
@@ -121,7 +125,7 @@ class LRHRDataset(Dataset):
             if self.cond_from_lr:
                 flip_lr = flip_hr          # the conditioning image built from LR stands in for SR: it mirrors with HR
             if flip_hr:
-                for k in ('SR', 'HR'):
+                for k in ('SR', 'HR', 'HR_Mask'):
                     if k in out:
                         out[k] = np.ascontiguousarray(out[k][:, ::-1])
             if flip_lr:
@@ -133,6 +137,8 @@ class LRHRDataset(Dataset):
         out = {'HR': to_tensor(imgs['HR']), 'Index': index}
         if 'SR' in imgs:
             out['SR'] = to_tensor(imgs['SR'])
+        if 'HR_Mask' in imgs:
+            out['HR_Mask'] = to_tensor(imgs['HR_Mask'])
         if self.need_LR:
             out['LR'] = to_tensor(imgs['LR'])
             if self.cond_from_lr:
@@ -142,7 +148,7 @@ class LRHRDataset(Dataset):
             # for the whole stack; util.py:77-88 does the same, separately, for [LR]
             flip_hr = bool(torch.rand(1) < 0.5)
             if flip_hr:
-                for k in ('SR', 'HR'):
+                for k in ('SR', 'HR', 'HR_Mask'):
                     if k in out:
                         out[k] = out[k].flip(-1)
             if 'LR' in out and torch.rand(1) < 0.5:

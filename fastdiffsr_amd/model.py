@@ -101,6 +101,8 @@ class DDPM:
             out['SR'] = self.SR.detach().float().cpu()
             out['INF'] = self.data['SR'].detach().float().cpu()
             out['HR'] = self.data['HR'].detach().float().cpu()
+            if 'HR_Mask' in self.data:
+                out['HR_Mask'] = self.data['HR_Mask'].detach().float().cpu()
             if need_LR and 'LR' in self.data:
                 out['LR'] = self.data['LR'].detach().float().cpu()
             else:

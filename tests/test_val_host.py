@@ -121,6 +121,29 @@ def test_prepare_folder_tool_matches_pillow_and_feeds_the_dataset(tmp_path):
     assert len(ds) == 3 and ds[0]['HR'].shape == (3, 64, 64) and ds[0]['LR'].shape == (3, 16, 16)
 
 
+def test_hr_mask_folder_rides_the_sr_hr_stack(tmp_path):
+    """LRHR_dataset.py:33-40,100-121: any `img_mask` but 'no' adds `hr_mask_{r}`; 'HR_Mask' shares the [SR, HR] flip decision in the
+    train split, and DDPM.get_current_visuals hands it through (model.py:105-106)."""
+    from PIL import Image
+    import shutil
+    root = make_dataset(str(tmp_path))
+    shutil.copytree(os.path.join(root, 'hr_64'), os.path.join(root, 'hr_mask_64'))
+    ds = LRHRDataset(root, 'img', 16, 64, split='val', img_mask='yes')
+    it = ds[1]
+    assert sorted(it) == ['HR', 'HR_Mask', 'Index', 'SR'] and torch.equal(it['HR_Mask'], it['HR'])
+    tr = LRHRDataset(root, 'img', 16, 64, split='train', need_LR=True, img_mask='yes')
+    torch.manual_seed(3)
+    seen = set()
+    for _ in range(8):
+        a = tr[0]
+        assert torch.equal(a['HR_Mask'], a['HR'])                      # mirrored together, whatever the draw
+        seen.add(bool(torch.equal(a['HR'], ds[0]['HR'])))
+        u = tr.load_u8(0)
+        assert np.array_equal(u['HR_Mask'], u['HR'])
+    assert seen == {True, False}
+    assert 'HR_Mask' not in LRHRDataset(root, 'img', 16, 64, split='val')[0]
+
+
 class _DictLmdb:
     """A dict-backed stand-in for the `lmdb` module (absent from this image), with the calls the reference makes:
     lmdb.open(path, ...) -> env; env.begin(write=) as txn; txn.get / txn.put (prepare_data_mfe_dm.py:82-92,113; LRHR_dataset.py:19-23,61-92)."""
