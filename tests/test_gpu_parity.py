@@ -228,6 +228,12 @@ def test_batch16_properties(full, prec):
     d_o = (out[15:16].cpu() - ref).abs().max().item()
     report(f'B=16 256x256 [{prec}]: image 15 of the batch vs oracle max|d|={d_o:.3e}')
     assert d_o <= TOL_LOOP
+    # ... and a second one, with the batch's OWN cond and noise (not the session's shared pair): one more oracle loop, cached for
+    # the other precision of this test
+    ref3 = _oracle_256(sd, cfg, 'b16_3', cond[3:4], noise[:, 3:4])
+    d_3 = (out[3:4].cpu() - ref3).abs().max().item()
+    report(f'B=16 256x256 [{prec}]: image 3 of the batch vs oracle max|d|={d_3:.3e}')
+    assert d_3 <= TOL_LOOP
 
 
 @pytest.mark.parametrize('prec,tol_fwd,tol_loop', [('f16x3', 1e-4, 1e-3), ('bf16', 0.25, None)])
