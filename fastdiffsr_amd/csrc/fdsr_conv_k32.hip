@@ -73,8 +73,8 @@ __device__ __forceinline__ float silu_k(float v) { return v * __builtin_amdgcn_r
 // NW_ = 4 ("small workgroups", round 4): 256-thread workgroups, TWO per CU -- the same two waves per SIMD, but in two barrier
 // domains, so that one workgroup's prologue / epilogue can run beside the other's main loop.  Built for the 64-channel level, whose
 // tiles have 2 - 6 chunks: there prologue + epilogue of a one-workgroup-per-CU tile are ~40 % of its time.  Two
-// double-buffered halo images must fit 80 KB: 6-row tiles (f16x3: 2 x 8 x 34 pixels x 128 B = 69.6 KB; bf16 half of that -- its 8-row
-// tile fits too but spills 24 - 42 VGPRs around its eleven staging quads).
+// double-buffered halo images must fit 80 KB: 6-row tiles in f16x3 (2 x 8 x 34 pixels x 128 B = 69.6 KB), 8-row tiles in bf16 (43.5 KB;
+// three activation-fragment slots instead of four keep that form clear of spills: 256 VGPRs).
 template <int TH, int WN, int PREC, int NW_ = 8>
 struct ConvK32Cfg {
   static constexpr int TW = 32, NW = NW_, KC = 32;
@@ -89,7 +89,7 @@ struct ConvK32Cfg {
   static constexpr int BUF_BYTES = NPIX * ROWB;
   static constexpr int LDS_BYTES = 2 * BUF_BYTES;
   static constexpr int R = 3;                     // taps of weight fragments in registers (a ring: 9 % R == 0)
-  static constexpr int XS = PREC == PREC_F16X3 ? XS_F16X3 : XS_BF16;   // activation-fragment slots: XS - 1 (tap, row) steps ahead
+  static constexpr int XS = PREC == PREC_F16X3 ? XS_F16X3 : (NW_ == 4 && TH == 8 ? 3 : XS_BF16);   // activation-fragment slots: XS - 1 (tap, row) steps ahead (the bf16 8-row small-workgroup tile spills 24 VGPRs with four)
   static_assert(MB == 4 || MB == 3 || MB == 2, "wave tile = 4 (small grids: 2; small workgroups in f16x3: 3) rows of 32 pixels");
   static_assert(((TH - WM + 2) * HWD + 16) * ROWB < 65536, "fragment offsets must fit the ds_read immediate");
 };
@@ -953,20 +953,20 @@ static hipError_t launch_k32_t(const ConvParams& q, int nwg, hipStream_t s) {
 // The small-workgroup form (NW = 4, two workgroups per CU) of the 64-cout launches: 6-row tiles (what two double-buffered f16x3 halo
 // images per CU leave room for).  Large grids only: a small grid wants all eight waves of a CU on its one
 // tile.  launch_conv_h asks before it picks a tile of its own; tiles / nwg are computed here.
-static int k32_small_rows(int) { return 6; }
+static int k32_small_rows(int prec, bool rider) { return prec == PREC_BF16 && !rider ? 8 : 6; }   // (the bf16 8-row tile with a rider spills 27 VGPRs)
 
 bool conv_k32_small_ok(ConvKind kind, int prec, const ConvParams& p) {
   if (!(g_tun.k32 & 32) || kind != CONV3_S1 || p.ksplit > 1 || p.Cout_pad != 64) return false;
-  if (prec == PREC_BF16 && !(g_tun.k32 & 128)) return false;   // bf16: measured equal per kernel, -0.4 % end to end (more GroupNorm partials): bit 128
+  if (prec == PREC_BF16 && !(g_tun.k32 & 128)) return false;   // bf16: bit 128 (its 6-row tile measured -0.4 % end to end, its 8-row tile +1.0 %: on)
   if (p.xr0 && !(g_tun.k32 & 64)) return false;   // launches with a rider keep the 32x32x16 rider kernel (bit 64: measured 7 % slower on this form)
   if (!conv_k32_ok(8, 4, prec, p)) return false;          // the form's own conditions (an MB = 4 shape: no tile-size bits involved)
-  const int th = k32_small_rows(prec);
+  const int th = k32_small_rows(prec, p.xr0 != nullptr);
   const long wgs = (long)p.N * ((p.Wout + 31) / 32) * ((p.Hout + th - 1) / th);
   return wgs >= g_tun.k32_sb_min_wgs;
 }
 
 hipError_t launch_conv_k32_small(int prec, const ConvParams& p, hipStream_t s, int* tiles) {
-  const int th = k32_small_rows(prec);
+  const int th = k32_small_rows(prec, p.xr0 != nullptr);
   const int tilesX = (p.Wout + 31) / 32, tilesY = (p.Hout + th - 1) / th;
   if (tiles) *tiles = tilesX * tilesY;
   const int nwg = p.N * tilesX * tilesY;
@@ -975,7 +975,7 @@ hipError_t launch_conv_k32_small(int prec, const ConvParams& p, hipStream_t s, i
   q.stagger = g_tun.k32_stagger;
   if (prec == PREC_F16X3)
     return q.xr0 ? launch_k32_t<6, 2, PREC_F16X3, true, 4>(q, nwg, s) : launch_k32_t<6, 2, PREC_F16X3, false, 4>(q, nwg, s);
-  return q.xr0 ? launch_k32_t<6, 2, PREC_BF16, true, 4>(q, nwg, s) : launch_k32_t<6, 2, PREC_BF16, false, 4>(q, nwg, s);
+  return q.xr0 ? launch_k32_t<6, 2, PREC_BF16, true, 4>(q, nwg, s) : launch_k32_t<8, 2, PREC_BF16, false, 4>(q, nwg, s);
 }
 
 hipError_t launch_conv_k32(int TH, int WN, int prec, const ConvParams& q, int nwg, hipStream_t s) {
