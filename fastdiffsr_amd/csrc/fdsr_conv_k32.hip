@@ -1019,7 +1019,6 @@ hipError_t kernels_k32_init() {
 #undef X
   if ((e = init_k32_t<6, 2, PREC_F16X3, false, 4>()) != hipSuccess) return e;
   if ((e = init_k32_t<6, 2, PREC_F16X3, true, 4>()) != hipSuccess) return e;
-  if ((e = init_k32_t<6, 2, PREC_BF16, false, 4>()) != hipSuccess) return e;
   if ((e = init_k32_t<6, 2, PREC_BF16, true, 4>()) != hipSuccess) return e;
   return hipSuccess;
 }
