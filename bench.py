@@ -479,7 +479,7 @@ def facade_records(cfg, sd, dev, S, engine_ips, n_images=256, batch=16):
         except Exception as e:
             recs['val_e2e'] = {'error': f'{type(e).__name__}: {e}'}
         try:
-            B, steps, warmup = 32, 6, 3
+            B, steps, warmup = 32, 6, 2       # 8 batches = the folder's 256 images once: no epoch turn (a pipeline refill of ~35 ms, tools/train_facade_probe.py) inside the timed steps
             opt = facade_opt(root, 'train', batch_size=B)
             torch.manual_seed(7)
             np.random.seed(7)
