@@ -65,6 +65,9 @@ __device__ __forceinline__ float silu_k(float v) { return v * __builtin_amdgcn_r
 #ifndef K32_PEEL      // rider-less kernels: the last chunk is a code copy of its own that also fetches the residual tile
 #define K32_PEEL 1
 #endif
+#ifndef K32_RFIRST   // small-workgroup rider kernels: rider chunks first
+#define K32_RFIRST 1
+#endif
 #ifndef K32_PIN16    // ... and in the 16-row tile (its ten staging quads leave no registers for it: spills)
 #define K32_PIN16 0
 #endif
@@ -172,7 +175,10 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_k32_kernel(const ConvParams p
 
   using IO = ActIO<PREC>;
   typedef typename IO::Quad Quad;
-  constexpr bool SPLIT = K32_SPLIT != 0 && (PREC == PREC_F16X3 || K32_SPLIT_BF16 != 0) && !RIDER;   // (the rider's whole-chunk sets would stay live across the main loop)
+  // RFIRST (the small-workgroup rider kernels): the rider's chunks run BEFORE the main chunks, so that their whole-chunk prefetch set is
+  // dead when the main loop starts and that loop is the rider-less one (two-half staging, peeled last chunk) -- the round-3 plan.
+  constexpr bool RFIRST = RIDER && NW == 4 && K32_RFIRST != 0;
+  constexpr bool SPLIT = K32_SPLIT != 0 && (PREC == PREC_F16X3 || K32_SPLIT_BF16 != 0) && (!RIDER || RFIRST);   // (main chunks first: the rider's whole-chunk sets would stay live across the main loop)
   constexpr int NA = SPLIT ? (NIN + 1) / 2 : NIN;   // quads in flight in the main loop
   typedef std::integral_constant<int, 0> I_0;
   typedef std::integral_constant<int, NA> I_A;
@@ -292,12 +298,19 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_k32_kernel(const ConvParams p
       for (int ch = 0; ch < 2; ++ch) acc[mb][ph][ch] = k_f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int kc0 = ksi * nkt / SK, kc1 = (ksi + 1) * nkt / SK;   // this slice's chunks
-  if (RIDER && kc0 >= nk) load_w(kc0, 0, 0);
+  if (RFIRST || (RIDER && kc0 >= nk)) load_w(RFIRST ? nk : kc0, 0, 0);
   else {
 #pragma unroll
     for (int t = 0; t < R; ++t) load_w(kc0, t, t);
   }
-  if (SPLIT) {
+  if (RFIRST) {   // (never split in K: kc0 = 0, kc1 = nk + nkr)
+    {
+      Quad r0[NIN];
+      prefetch_to(nk, r0);
+      stage_from(nk, sBuf0, r0);
+    }
+    prefetch_to(nkr > 1 ? nk + 1 : 0, rr1);   // the second rider chunk -- or, after a single one, the first main chunk (fetched whole)
+  } else if (SPLIT) {
     {   // the first chunk is fetched whole (the accumulators are not live yet)
       Quad r0[NIN];
       prefetch_to(kc0, r0);
@@ -349,7 +362,7 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_k32_kernel(const ConvParams p
   const bool interior = (oy0 + TH <= p.Hout) && (ox0 + TW <= p.Wout) && (co0 + BN <= p.Cout);
   const size_t obase = ((size_t)(n * p.Hout + oy0 + wm) * p.Wout + ox0 + c15) * p.Cout + cob;
   const size_t rstride = (size_t)WM * p.Wout * p.Cout, pstride = (size_t)16 * p.Cout;
-  constexpr bool PEEL = K32_PEEL != 0 && !RIDER;
+  constexpr bool PEEL = K32_PEEL != 0 && (!RIDER || RFIRST);
   Quad rv[MB][2][2];   // residual tile [row][pixel half][cout half]
   const bool res_early = PEEL && p.res && interior && SK == 1;   // ... fetched during the last chunk, into registers the loop no longer needs
   auto load_res = [&](auto q0_tag, auto q1_tag) __attribute__((always_inline)) {
@@ -368,12 +381,13 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_k32_kernel(const ConvParams p
 
   // main chunks: all nine taps of 32 GroupNorm'ed channels
   const int kcm = RIDER ? (kc1 < nk ? kc1 : nk) : kc1;
+  const int par0 = RFIRST ? nkr : 0;          // rider-first: the main chunks take the halo buffers in turn after nkr rider chunks
   auto main_chunk = [&](int kc, auto last_tag) __attribute__((always_inline)) {
     constexpr bool LAST = decltype(last_tag)::value;   // the peeled final chunk: nothing to fetch or stage for a next one
-    unsigned char* cur = ((kc - kc0) & 1) ? sBuf1 : sBuf0;
-    unsigned char* nxt = ((kc - kc0) & 1) ? sBuf0 : sBuf1;
-    const bool more = LAST ? false : (kc + 1 < kc1);
-    const bool next_rider = RIDER && kc + 1 >= nk;
+    unsigned char* cur = ((kc - kc0 + par0) & 1) ? sBuf1 : sBuf0;
+    unsigned char* nxt = ((kc - kc0 + par0) & 1) ? sBuf0 : sBuf1;
+    const bool more = LAST ? false : (kc + 1 < (RFIRST ? nk : kc1));
+    const bool next_rider = RIDER && !RFIRST && kc + 1 >= nk;
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
@@ -419,13 +433,49 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_k32_kernel(const ConvParams p
     }
     __syncthreads();
   };
+  if (RFIRST) {
+    // rider chunks first: centre tap only, the 1x1 conv's fragments in ring slot 0, the next chunk fetched whole into rr1 one chunk
+    // ahead (the CU's other workgroup covers the latency); the last one stages the first MAIN chunk and primes the weight ring
+    for (int v = 0; v < nkr; ++v) {
+      unsigned char* cur = (v & 1) ? sBuf1 : sBuf0;
+      unsigned char* nxt = (v & 1) ? sBuf0 : sBuf1;
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl) xptr[1][pl] = cur + xoff[1][pl];
+#pragma unroll
+      for (int mb = 0; mb < XS - 1 && mb < MB; ++mb) load_x(mb, 1, 1, mb);
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        if (mb + XS - 1 < MB) load_x((mb + XS - 1) % XS, 1, 1, mb + XS - 1);
+        mfma_step(mb % XS, 0, mb);
+      }
+      if (v + 1 < nkr) {
+        load_w(nk + v + 1, 0, 0);
+        stage_from(nk + v + 1, nxt, rr1);
+        prefetch_to(v + 2 < nkr ? nk + v + 2 : 0, rr1);
+      } else {
+#pragma unroll
+        for (int t = 0; t < R; ++t) load_w(0, t, t);
+        stage_from(0, nxt, rr1);
+      }
+      __syncthreads();
+    }
+    {   // the accumulators leave the rider's weight scale for the main conv's (a power of two: exact)
+      const float ratio = (p.w_inv_scale_r_dev ? *p.w_inv_scale_r_dev : p.w_inv_scale_r) / (p.w_inv_scale_dev ? *p.w_inv_scale_dev : p.w_inv_scale);
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+          for (int ch = 0; ch < 2; ++ch) acc[mb][ph][ch] *= ratio;
+    }
+  }
   if (PEEL) {
     for (int kc = kc0; kc < kcm - 1; ++kc) main_chunk(kc, std::false_type{});
     if (kcm > kc0) main_chunk(kcm - 1, std::true_type{});
   } else {
     for (int kc = kc0; kc < kcm; ++kc) main_chunk(kc, std::false_type{});
   }
-  if (RIDER && kc1 > nk) {
+  if (RIDER && !RFIRST && kc1 > nk) {
     // rider chunks: 32 raw channels of the second input each, centre tap only, the 1x1 conv's fragments in ring slot 0
     if (kc0 < nk) {   // the accumulators leave the main conv's weight scale for the rider's (a power of two: exact)
       const float ratio = (p.w_inv_scale_dev ? *p.w_inv_scale_dev : p.w_inv_scale) / (p.w_inv_scale_r_dev ? *p.w_inv_scale_r_dev : p.w_inv_scale_r);
@@ -490,8 +540,8 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_k32_kernel(const ConvParams p
     }
   }
   const float winv_m = p.w_inv_scale_dev ? *p.w_inv_scale_dev : p.w_inv_scale;
-  const float winv = RIDER ? (p.w_inv_scale_r_dev ? *p.w_inv_scale_r_dev : p.w_inv_scale_r) : winv_m;
-  if (RIDER && kc1 <= nk) {   // (split K) a slice that never reached the rider chunks: bring it to the rider's scale too
+  const float winv = RIDER && !RFIRST ? (p.w_inv_scale_r_dev ? *p.w_inv_scale_r_dev : p.w_inv_scale_r) : winv_m;
+  if (RIDER && !RFIRST && kc1 <= nk) {   // (split K) a slice that never reached the rider chunks: bring it to the rider's scale too
     const float ratio = winv_m / winv;
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
@@ -958,7 +1008,9 @@ static int k32_small_rows(int prec, bool rider) { return prec == PREC_BF16 && !r
 bool conv_k32_small_ok(ConvKind kind, int prec, const ConvParams& p) {
   if (!(g_tun.k32 & 32) || kind != CONV3_S1 || p.ksplit > 1 || p.Cout_pad != 64) return false;
   if (prec == PREC_BF16 && !(g_tun.k32 & 128)) return false;   // bf16: bit 128 (its 6-row tile measured -0.4 % end to end, its 8-row tile +1.0 %: on)
-  if (p.xr0 && !(g_tun.k32 & 64)) return false;   // launches with a rider keep the 32x32x16 rider kernel (bit 64: measured 7 % slower on this form)
+  // launches with a rider: bit 64 in f16x3 (on since the rider chunks run FIRST on this form: +0.7 % end to end over the 32x32x16 rider
+  // kernel; main chunks first it measured 4 - 7 % slower on those launches), bit 512 in bf16 (off: -0.4 %)
+  if (p.xr0 && !(g_tun.k32 & (prec == PREC_BF16 ? 512 : 64))) return false;
   if (!conv_k32_ok(8, 4, prec, p)) return false;          // the form's own conditions (an MB = 4 shape: no tile-size bits involved)
   const int th = k32_small_rows(prec, p.xr0 != nullptr);
   const long wgs = (long)p.N * ((p.Wout + 31) / 32) * ((p.Hout + th - 1) / th);
