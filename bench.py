@@ -176,7 +176,7 @@ def kernel_source_hash():
 
 
 KNOCKOUT = False   # --debug-option knockout=...: timing-only probes whose results are garbage
-K32_BITS = 251     # Tunables::k32 default (include/fdsr.h); --debug-option k32=... overrides it for the labels below
+K32_BITS = 1275     # Tunables::k32 default (include/fdsr.h); --debug-option k32=... overrides it for the labels below
 
 
 def family_label(precision):

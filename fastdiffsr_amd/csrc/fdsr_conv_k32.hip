@@ -103,7 +103,7 @@ __device__ __forceinline__ int k32_slot(int slot, int hx) {
   return PREC == PREC_F16X3 ? (slot ^ (hx & 7)) : (slot ^ ((hx >> 1) & 3));
 }
 
-template <int TH, int WN, int PREC, bool RIDER, int NW = 8>
+template <int TH, int WN, int PREC, bool RIDER, int NW = 8, bool RF = (NW == 4)>   // RF: rider chunks first (launches without a K split)
 __global__ void __launch_bounds__(64 * NW, 2) conv_k32_kernel(const ConvParams p) {
   using Cfg = ConvK32Cfg<TH, WN, PREC, NW>;
   constexpr int TW = Cfg::TW, KC = Cfg::KC, NP = Cfg::NP, ROWB = Cfg::ROWB, HWD = Cfg::HWD, NPIX = Cfg::NPIX;
@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_k32_kernel(const ConvParams p
   typedef typename IO::Quad Quad;
   // RFIRST (the small-workgroup rider kernels): the rider's chunks run BEFORE the main chunks, so that their whole-chunk prefetch set is
   // dead when the main loop starts and that loop is the rider-less one (two-half staging, peeled last chunk) -- the round-3 plan.
-  constexpr bool RFIRST = RIDER && NW == 4 && K32_RFIRST != 0;
+  constexpr bool RFIRST = RIDER && RF && K32_RFIRST != 0;
   constexpr bool SPLIT = K32_SPLIT != 0 && (PREC == PREC_F16X3 || K32_SPLIT_BF16 != 0) && (!RIDER || RFIRST);   // (main chunks first: the rider's whole-chunk sets would stay live across the main loop)
   constexpr int NA = SPLIT ? (NIN + 1) / 2 : NIN;   // quads in flight in the main loop
   typedef std::integral_constant<int, 0> I_0;
@@ -993,10 +993,10 @@ bool conv_k32_ok(int TH, int WN, int prec, const ConvParams& p) {
   return true;
 }
 
-template <int TH, int WN, int PREC, bool RIDER, int NW = 8>
+template <int TH, int WN, int PREC, bool RIDER, int NW = 8, bool RF = (NW == 4)>
 static hipError_t launch_k32_t(const ConvParams& q, int nwg, hipStream_t s) {
   using Cfg = ConvK32Cfg<TH, WN, PREC, NW>;
-  hipLaunchKernelGGL((conv_k32_kernel<TH, WN, PREC, RIDER, NW>), dim3(nwg), dim3(Cfg::NT), (size_t)Cfg::LDS_BYTES, s, q);
+  hipLaunchKernelGGL((conv_k32_kernel<TH, WN, PREC, RIDER, NW, RF>), dim3(nwg), dim3(Cfg::NT), (size_t)Cfg::LDS_BYTES, s, q);
   return hipGetLastError();
 }
 
@@ -1033,6 +1033,9 @@ hipError_t launch_conv_k32_small(int prec, const ConvParams& p, hipStream_t s, i
 hipError_t launch_conv_k32(int TH, int WN, int prec, const ConvParams& q, int nwg, hipStream_t s) {
 #define X(TH_, WN_)                                                                                             \
   if (TH == TH_ && WN == WN_) {                                                                                 \
+    if (q.xr0 && q.ksplit <= 1 && (g_tun.k32 & 1024))                                                           \
+      return prec == PREC_F16X3 ? launch_k32_t<TH_, WN_, PREC_F16X3, true, 8, true>(q, nwg, s)                  \
+                                : launch_k32_t<TH_, WN_, PREC_BF16, true, 8, true>(q, nwg, s);                  \
     if (q.xr0) return prec == PREC_F16X3 ? launch_k32_t<TH_, WN_, PREC_F16X3, true>(q, nwg, s)                  \
                                          : launch_k32_t<TH_, WN_, PREC_BF16, true>(q, nwg, s);                  \
     return prec == PREC_F16X3 ? launch_k32_t<TH_, WN_, PREC_F16X3, false>(q, nwg, s)                            \
@@ -1043,9 +1046,9 @@ hipError_t launch_conv_k32(int TH, int WN, int prec, const ConvParams& q, int nw
   return hipErrorInvalidValue;
 }
 
-template <int TH, int WN, int PREC, bool RIDER, int NW = 8>
+template <int TH, int WN, int PREC, bool RIDER, int NW = 8, bool RF = (NW == 4)>
 static hipError_t init_k32_t() {
-  auto kfn = conv_k32_kernel<TH, WN, PREC, RIDER, NW>;
+  auto kfn = conv_k32_kernel<TH, WN, PREC, RIDER, NW, RF>;
   return hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
@@ -1066,7 +1069,9 @@ hipError_t kernels_k32_init() {
   if ((e = init_k32_t<TH_, WN_, PREC_F16X3, false>()) != hipSuccess) return e;             \
   if ((e = init_k32_t<TH_, WN_, PREC_F16X3, true>()) != hipSuccess) return e;              \
   if ((e = init_k32_t<TH_, WN_, PREC_BF16, false>()) != hipSuccess) return e;              \
-  if ((e = init_k32_t<TH_, WN_, PREC_BF16, true>()) != hipSuccess) return e;
+  if ((e = init_k32_t<TH_, WN_, PREC_BF16, true>()) != hipSuccess) return e;                \
+  if ((e = init_k32_t<TH_, WN_, PREC_F16X3, true, 8, true>()) != hipSuccess) return e;     \
+  if ((e = init_k32_t<TH_, WN_, PREC_BF16, true, 8, true>()) != hipSuccess) return e;
   FDSR_K32_SHAPES(X)
 #undef X
   if ((e = init_k32_t<6, 2, PREC_F16X3, false, 4>()) != hipSuccess) return e;

@@ -1,7 +1,7 @@
 """The 16x16x32-MFMA form of the stride-1 3x3 convolutions (fdsr_conv_k32.hip): on by default for f16x3 launches whose wave tile is
 4 x 32 or 2 x 32 pixels (except the 16-row tile with a rider); here it is FORCED onto every eligible launch of a small forward (largest tile regardless of the grid size, so
 the split-K, partial-tile and rider paths of the form all run), layer by layer against the oracle, in every option setting
-(bits of `k32`: 1 f16x3, 2 bf16, 4 the 16-row tile with a rider, 8 the 2-row tiles of small grids, 16 the sub-pixel upsample convs, 32 / 128 the small-workgroup form of the 64-cout tiles in f16x3 / bf16, 64 / 512 with a rider (rider chunks first); default 251), against the 32x32x16 kernels on the same input, and through the
+(bits of `k32`: 1 f16x3, 2 bf16, 4 the 16-row tile with a rider, 8 the 2-row tiles of small grids, 16 the sub-pixel upsample convs, 32 / 128 the small-workgroup form of the 64-cout tiles in f16x3 / bf16, 64 / 512 with a rider (rider chunks first), 1024 the 8-wave rider kernels rider-first too; default 1275), against the 32x32x16 kernels on the same input, and through the
 20-step loop.  Same bounds as every other conv kernel: layerwise 1e-4 * max(1, |ref|), loop 1e-3 (north_star); bf16 0.25 layerwise
 (judged on PSNR elsewhere).  Reference: fastdiffsr_modules/unet.py:89-120."""
 import pytest
@@ -38,7 +38,7 @@ def forced():
     yield
     _lib.debug_option('th_min_wgs', 256)
     _lib.debug_option('wino', 0)
-    _lib.debug_option('k32', 251)
+    _lib.debug_option('k32', 1275)
 
 
 @pytest.mark.timeout(900)
@@ -119,7 +119,7 @@ def test_small_grid_two_row_tiles_k32_vs_oracle(full):
     finally:
         eng.set_debug(False)
         _lib.debug_option('wino', 0)
-        _lib.debug_option('k32', 251)
+        _lib.debug_option('k32', 1275)
 
 
 @pytest.mark.timeout(900)
@@ -160,7 +160,7 @@ def test_subpixel_upsample_convs_on_the_form(full, prec):
     finally:
         eng.set_debug(False)
         eng.set_precision('f16x3')
-        _lib.debug_option('k32', 251)
+        _lib.debug_option('k32', 1275)
 
 
 @pytest.mark.timeout(900)
@@ -176,7 +176,7 @@ def test_small_workgroup_form_vs_oracle(full, prec):
     eng.set_precision(prec)
     tol = TOL_FWD if prec == 'f16x3' else 0.25
     _lib.debug_option('wino', 0)
-    _lib.debug_option('k32', 251 | 512)           # with the bf16 riders too (bit 512: off by default)
+    _lib.debug_option('k32', 1275 | 512)           # with the bf16 riders too (bit 512: off by default)
     _lib.debug_option('k32_sb_min_wgs', 1)
     _lib.debug_option('splitk', 0)          # (a launch with a K split keeps the 8-wave forms)
     _lib.debug_option('k32_stagger', 3)
@@ -199,7 +199,7 @@ def test_small_workgroup_form_vs_oracle(full, prec):
             assert torch.equal(eng.unet_forward(x.cuda(), nl.cuda()), out)              # ordered reductions only
             _lib.debug_option('k32', 27)                                                # the same launches on the 8-wave forms
             out_d = eng.unet_forward(x.cuda(), nl.cuda())
-            _lib.debug_option('k32', 251 | 512)
+            _lib.debug_option('k32', 1275 | 512)
             dd = (out_d - out).abs().max().item()
             assert dd > 0.0                                                             # (0.0: the form was never taken)
             if prec == 'f16x3':
@@ -220,7 +220,7 @@ def test_small_workgroup_form_vs_oracle(full, prec):
         _lib.debug_option('k32_sb_min_wgs', 1024)
         _lib.debug_option('k32_stagger', 0)
         _lib.debug_option('splitk', 1)
-        _lib.debug_option('k32', 251)
+        _lib.debug_option('k32', 1275)
 
 
 @pytest.mark.timeout(900)
