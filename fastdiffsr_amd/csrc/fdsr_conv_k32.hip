@@ -980,9 +980,7 @@ hipError_t launch_conv_up2_k32(int TH, int WN, int prec, const ConvParams& q, in
 bool conv_k32_ok(int TH, int WN, int prec, const ConvParams& p) {
   // g_tun.k32 bits (default 27 = 1|2|8|16): 1 f16x3, 2 bf16 (+2.7 % at B=64 once the ring / pinning / peeled last chunk were in), 4 the 16-row tile with a rider (measured slower: off)
   if (!(g_tun.k32 & (prec == PREC_BF16 ? 2 : 1))) return false;
-  // the 16-row tile with a rider: bit 4 -- or, in bf16, the rider-first instantiation (bit 1024; launches without a K split): 238 VGPRs
-  // and no spills there, +0.4 % at B=64 over the 32x32x16 rider tile (its f16x3 twin spills 26 and stays behind bit 4)
-  if (TH == 16 && p.xr0 && !(g_tun.k32 & 4) && !(prec == PREC_BF16 && (g_tun.k32 & 1024) && p.ksplit <= 1)) return false;
+  if (TH == 16 && p.xr0 && !(g_tun.k32 & 4)) return false;
   if (TH * WN != 32 && !(TH * WN == 16 && (g_tun.k32 & 8))) return false;   // MB == 4 (bit 8: the 2-row tiles of small grids too)
   if (WN != 2 && WN != 4 && WN != 8) return false;
   if (p.Cin_pad % 32 || (p.C0 + p.C1) != p.Cin_pad) return false;    // whole 32-channel chunks
