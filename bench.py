@@ -170,7 +170,7 @@ def kernel_source_hash():
     import hashlib
     d = os.path.join(ROOT, 'fastdiffsr_amd', 'csrc')
     h = hashlib.sha256()
-    for f in ('fdsr_act_io.h', 'fdsr_conv_h.hip', 'fdsr_conv_k32.hip', 'fdsr_conv_tail.hip', 'fdsr_conv_up2.hip', 'fdsr_conv_wino.hip', 'fdsr_kernels.h', 'fdsr_kernels.hip'):
+    for f in ('fdsr_act_io.h', 'fdsr_conv_h.hip', 'fdsr_conv_k32.hip', 'fdsr_conv_tail.hip', 'fdsr_conv_strip.hip', 'fdsr_conv_up2.hip', 'fdsr_kernels.h', 'fdsr_kernels.hip'):
         h.update(f.encode() + b'\0' + open(os.path.join(d, f), 'rb').read() + b'\0')
     return h.hexdigest()
 
@@ -230,8 +230,7 @@ def conv_roofline(prof, precision, B, S, dt_total, round_tag='r04'):
          # events (5 of 20 steps): <1 % overhead in the timed region, measured 2.6 % with all
          'timed_steps_of_20': n_timed}
     if precision == 'f16x3':
-        r['executed_note'] = ('executed_tflops prices every product at 3 MFMA passes (hi*hi + hi*lo + lo*hi); with --debug-option wino=2 the '
-                              'launches that take the Winograd F(2x2,3x3) form issue 16/36 of those MFMAs for the same algorithmic FLOPs')
+        r['executed_note'] = 'executed_tflops prices every product at 3 MFMA passes (hi*hi + hi*lo + lo*hi)'
     if precision != 'f32':
         # (until round 2's last change these launches did not contain the 1x1 res_convs: their time sat outside the family)
         r['launch_set'] = ('every 3x3 conv launch; 1x1 res_convs that ride inside a direct block2 launch (ConvParams::xr0) have their '
@@ -241,11 +240,14 @@ def conv_roofline(prof, precision, B, S, dt_total, round_tag='r04'):
     return r
 
 
-def whole_path(ips_per_gpu, precision):
-    """the whole path against both roofs, per GPU (ideal-fused traffic 32.85 GB / image fp32, 16.4 bf16)."""
-    gb = 16.4 if precision == 'bf16' else 32.85
-    return {'tflops': ips_per_gpu * FLOPS_PER_IMAGE / 1e12,
-            'frac_mfma_peak': ips_per_gpu * FLOPS_PER_IMAGE / 1e12 / (PEAK_F32_MFMA if precision == 'f32' else PEAK_16BIT_MFMA),
+def whole_path(ips_per_gpu, precision, S=256):
+    """SURVEY 8d: the whole path against both roofs, per GPU (ideal-fused traffic 32.85 GB / image fp32, 16.4 bf16, at 256 x 256;
+    FLOPs and bytes scale with the pixel count)."""
+    px = (S / 256.0) ** 2
+    gb = (16.4 if precision == 'bf16' else 32.85) * px
+    flops = FLOPS_PER_IMAGE * px
+    return {'tflops': ips_per_gpu * flops / 1e12,
+            'frac_mfma_peak': ips_per_gpu * flops / 1e12 / (PEAK_F32_MFMA if precision == 'f32' else PEAK_16BIT_MFMA),
             'ideal_fused_gbytes_per_s': ips_per_gpu * gb, 'frac_hbm_peak': ips_per_gpu * gb / 8000.0}
 
 
@@ -529,7 +531,7 @@ def sub_record(eng, dev, name, precision, B, S, steps, warmup, graph, note):
         ips = B * steps / dt
         r = {'value': ips, 'unit': 'images/s', 'ms_per_step': 1e3 * dt / steps, 'steps': steps, 'warmup': warmup,
              'dtype': precision, 'batch': B, 'hipgraph': bool(graph), 'workload': note, 'per_pass': pass_stats(pp, B),
-             'whole_path': whole_path(ips, precision)}
+             'whole_path': whole_path(ips, precision, S)}
         if prof and prof['conv_ms'] > 0:
             r['roofline'] = conv_roofline(prof, precision, B, S, prof_dt)
             if prof_dt is None:
@@ -722,6 +724,7 @@ def main():
     ap.add_argument('--no-sub-records', action='store_true',
                     help='skip the exact_f32 / bf16_b64_graph / b1_graph legs that ride in the same JSON line at N=1')
     ap.add_argument('--no-profile', action='store_true', help='skip the per-conv HIP-event timing')
+    ap.add_argument('--no-facade', action='store_true', help='skip the file-based val_e2e / train_facade_b32 records (768 PNG writes + a 256-image val pass)')
     ap.add_argument('--precision', default='f16x3', choices=['f32', 'f16x3', 'bf16'],
                     help='conv arithmetic: exact fp32 MFMA, fp32-grade split-f16 MFMA, or bf16')
     ap.add_argument('--graph', action='store_true', help='replay the 20-step loop as a hipGraph')
@@ -729,7 +732,7 @@ def main():
                     help='time optimisation steps (forward + loss + backward + Adam, BASELINE configs[4]) instead of sampling; '
                          'the metric is then images/s through one training step')
     ap.add_argument('--debug-option', action='append', default=[], metavar='NAME=VALUE',
-                    help='launcher A/B option (include/fdsr.h: fdsr_debug_option), e.g. wino=0; repeatable; recorded in the line')
+                    help='launcher A/B option (include/fdsr.h: fdsr_debug_option), e.g. strip=0; repeatable; recorded in the line')
     ap.add_argument('--noise', default='engine', choices=['engine', 'tensor'],
                     help="engine: N(0,1) drawn inside the timed loop by the engine (Philox), as the reference draws "
                          "randn_like per step; tensor: a pre-drawn [T,B,3,H,W] tensor resident in HBM (the parity-run form)")
@@ -864,10 +867,18 @@ def main():
                 'b1_graph': sub_record(eng, dev, 'b1_graph', 'f16x3', 1, S, max(20, args.steps), max(5, args.warmup), True,
                                        'configs[0] regime (the reference val loop is B=1, sr_mfe.py:279-284): latency per image, hipGraph'),
             }
+            # the reference's second driver: infer.py runs B=1 at 512 x 512 (infer.py:59-79, :112-113; config/sr_fastdiffsr_infer_x4.json)
+            res['sub_records']['infer_512_b1'] = sub_record(eng, dev, 'infer_512_b1', 'f16x3', 1, 512, max(10, args.steps // 2), max(3, args.warmup // 2), True,
+                                                            "infer.py's regime: B=1 at 512 x 512 (128 -> 512), f16x3, hipGraph; ms_per_step = latency per image")
             res['sub_records']['train_step_b32'] = train_record(cfg, sd, dev, 32, S, ks, kw, 'f16x3')
             res['sub_records']['train_step_b32_f32'] = train_record(cfg, sd, dev, 32, S, ks, kw, 'f32')
             eng.set_precision(args.precision)
-            res['sub_records'].update(facade_records(cfg, sd, dev, S, ips))
+            if not args.no_facade:
+                try:        # optional records must never take the measured line down (no Pillow, /tmp full ...)
+                    res['sub_records'].update(facade_records(cfg, sd, dev, S, ips))
+                except Exception as e:
+                    err = {'error': f'{type(e).__name__}: {e}'}
+                    res['sub_records'].update({'val_e2e': err, 'train_facade_b32': err})
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'], ref = cpu_baseline(cfg, sd)
             eng.set_precision(args.precision)

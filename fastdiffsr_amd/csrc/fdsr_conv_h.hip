@@ -633,6 +633,7 @@ hipError_t launch_conv_h(ConvKind kind, int prec, const ConvParams& p, hipStream
   // 1x1: stage 64 input channels per barrier when the (concatenated) input allows it
   const int ksub = (kind == CONV1 && p.Cin_pad % 64 == 0 && (p.C1 == 0 || p.C0 % 64 == 0)) ? 4 : 1;
   // 64-cout launches of large grids: the small-workgroup form of the 16x16x32 kernel (two workgroups per CU) with tile rows of its own
+  if (WN == 2 && ksub == 1 && conv_strip_ok(kind, prec, p)) return launch_conv_strip(prec, p, WN, s, tiles);
   if (WN == 2 && ksub == 1 && conv_k32_small_ok(kind, prec, p)) return launch_conv_k32_small(prec, p, s, tiles);
   TH = pick_th(kind, WN, ksub, p);
   const int ks = kind == CONV1 ? 1 : 3, stride = kind == CONV3_S2 ? 2 : 1;
@@ -669,7 +670,8 @@ hipError_t kernels_h_init() {
   if ((e = init_h_t<3, 1, false, TH_, WN_, PREC_BF16, 1, true>()) != hipSuccess) return e;
   FDSR_CONVH_RIDER_SHAPES(XR)
 #undef XR
-  return kernels_k32_init();
+  if ((e = kernels_k32_init()) != hipSuccess) return e;
+  return kernels_strip_init();
 }
 
 }  // namespace fdsr

@@ -233,7 +233,7 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_k32_kernel(const ConvParams p
         for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], -lim, lim);
 #if K32_MIXSPLIT
         // one packed convert and two v_fma_mix per pair: lo = f16(fma(hi, -1, v)), rounded once -- bit-identical to the two-step
-        // form below (as in fdsr_conv_wino.hip / fdsr_train.hip).  With 16x16x32 MFMAs holding the issue port half of their time
+        // form below (as in fdsr_train.hip).  With 16x16x32 MFMAs holding the issue port half of their time
         // the staging VALU count matters more than it did beside 32x32x16.
         typedef _Float16 h2t __attribute__((ext_vector_type(2)));
         uint2 hi, lo;

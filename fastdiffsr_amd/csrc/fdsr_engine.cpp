@@ -75,7 +75,6 @@ void mark_conv_pack(fdsr_handle h, int widx, ConvKind ck, int cin_store, int C0,
     w.h_WN = WN;
     w.h_cin_pad = round_up(cin_store, 16);
     w.h_cout_pad = round_up(cout, 32 * WN);
-    w.wino_ok = ck == CONV3_S1 && cout % 64 == 0 && cin_store >= 16;   // (16-aligned concat halves: h_ok)
   }
 }
 
@@ -143,10 +142,6 @@ int finish_plan(fdsr_handle h, const std::string mlp_keys[4], int row_len) {
         const size_t f2 = (size_t)(w.h_cout_pad / 32) * (w.h_cin_pad / 16) * 16 * 64 * 16;
         w.up2_off[PREC_F16X3] = qoff; qoff += align_up(f2 * 2, 256);
         w.up2_off[PREC_BF16] = qoff;  qoff += align_up(f2, 256);
-      }
-      if (w.wino_ok) {          // 16 positions x hi/lo: Cout x Cin x 64 bytes
-        w.wino_off = qoff;
-        qoff += align_up((size_t)w.shape[0] * (size_t)w.h_cin_pad * 64, 256);
       }
     }
     h->wq_bytes = qoff;
@@ -705,7 +700,6 @@ int ensure_device(fdsr_handle h) {
     HIPCHK(h, kernels_init());
     HIPCHK(h, kernels_h_init());
     HIPCHK(h, kernels_tail_init());
-    HIPCHK(h, kernels_wino_init());
     h->kernels_ready = true;
   }
   return FDSR_OK;
@@ -900,18 +894,9 @@ int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, 
         // through HBM.  Measured same-box: every res_conv fused is as good as or better than fusing only the bandwidth-bound
         // ones (FDSR_RIDER=1: full-resolution level + input widths up to the output width), at every batch size;
         // FDSR_RIDER=0 turns it off.  Training forwards ride too (the backward never reads the res_conv output).
-        // stride-1 3x3 launches that take the Winograd F(2x2,3x3) form (f16x3 sampling forwards on host-packed weights)
-        auto will_wino = [&](const Op& k) -> bool {
-          if (h->prec != PREC_F16X3 || !h->weights[k.w].wino_ok || h->h_forms_stale || h->training || h->keep_stats) return false;
-          ConvParams t{};
-          t.N = N; t.Hin = H >> k.lvl_in; t.Win = W >> k.lvl_in; t.Hout = H >> k.lvl_out; t.Wout = W >> k.lvl_out;
-          t.C0 = k.C0; t.C1 = k.C1; t.Cout = k.Cout;
-          return conv_wino_ok(k.ck, h->prec, t, k.rider >= 0 && g_tun.rider != 0);
-        };
         auto rides = [&](const Op& k2) -> bool {
           const int mode = g_tun.rider;
           if (mode == 0 || k2.rider < 0 || h->prec == PREC_F32) return false;
-          if (will_wino(k2)) return false;   // (the Winograd kernel has no rider phase: the res_conv keeps its own launch)
           const Op& kr = h->ops[k2.rider];
           const WeightEntry &w2 = h->weights[k2.w], &wr = h->weights[kr.w];
           if (!w2.h_ok || !wr.h_ok || wr.h_WN != w2.h_WN || wr.h_cout_pad != w2.h_cout_pad) return false;
@@ -998,12 +983,7 @@ int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, 
           const bool no_up2 = !g_tun.up2;
           // (after optimiser steps the sub-pixel forms lag until fdsr_sync_weight_forms: training forwards use the generic kernel)
           const bool up2_dev = h->prec == PREC_F16X3 && h->up2_dev_fresh;   // re-packed on the device by the last optimiser step
-          if (will_wino(op) && !p.drop_mask && p.gn_scale) {
-            p.wq = h->d_wq + w.wino_off;
-            p.w_inv_scale = w.wino_inv_scale;
-            p.w_inv_scale_dev = nullptr;
-            HIPCHK(h, launch_conv_wino_h(p, st, &nt));
-          } else if (op.ck == CONV3_UP && !no_up2 && !op.force_generic && (!h->h_forms_stale || up2_dev)) {
+          if (op.ck == CONV3_UP && !no_up2 && !op.force_generic && (!h->h_forms_stale || up2_dev)) {
             p.w_inv_scale_dev = up2_dev ? h->d_up2_inv + op.w : nullptr;
             p.wq = h->d_wq + w.up2_off[h->prec];
             p.w_inv_scale = w.up2_inv_scale[h->prec];
@@ -1118,53 +1098,6 @@ int pack_weights_h(fdsr_handle h, WeightEntry& w, const float* host) {
   }
   HIPCHK(h, hipMemcpy(h->d_wq + w.hq_off[PREC_F16X3], q3.data(), q3.size() * 2, hipMemcpyHostToDevice));
   HIPCHK(h, hipMemcpy(h->d_wq + w.hq_off[PREC_BF16], qb.data(), qb.size() * 2, hipMemcpyHostToDevice));
-  if (w.wino_ok) {
-    // Winograd F(2x2,3x3): U[xi][nu] = (G g G^T)[xi][nu], G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1], formed in fp64 and split
-    // hi/lo like the direct form (own power-of-two scale: |U| <= 2.25 max|g|).  Fragment order of fdsr_conv_wino.hip:
-    // [cot (64 couts)][kc][role = xi | cout half << 2][nu][plane][lane] x 8 halves, lane -> cout l & 31, k = 8 (l >> 5) + j.
-    static const double Gm[4][3] = {{1, 0, 0}, {.5, .5, .5}, {.5, -.5, .5}, {0, 0, 1}};
-    const int nkw = w.h_cin_pad / 16, ncw = Cout / 64;
-    std::vector<double> U((size_t)Cout * Cin * 16);
-    double umax = 0.0;
-    for (int co = 0; co < Cout; ++co)
-      for (int ci = 0; ci < Cin; ++ci) {
-        const float* g = host + ((size_t)co * Cin + ci) * 9;
-        double t[4][3];
-        for (int a = 0; a < 4; ++a)
-          for (int kx = 0; kx < 3; ++kx) t[a][kx] = Gm[a][0] * g[kx] + Gm[a][1] * g[3 + kx] + Gm[a][2] * g[6 + kx];
-        for (int a = 0; a < 4; ++a)
-          for (int b = 0; b < 4; ++b) {
-            const double u = t[a][0] * Gm[b][0] + t[a][1] * Gm[b][1] + t[a][2] * Gm[b][2];
-            U[((size_t)co * Cin + ci) * 16 + a * 4 + b] = u;
-            umax = std::max(umax, std::fabs(u));
-          }
-      }
-    int ew = 12;
-    if (umax > 0.0) ew = std::min(12, (int)std::floor(std::log2(32768.0 / umax)));
-    w.wino_inv_scale = std::ldexp(1.0f, -ew);
-    const double sw = std::ldexp(1.0, ew);
-    std::vector<uint16_t> qw((size_t)Cout * w.h_cin_pad * 32, 0);
-    for (int cot = 0; cot < ncw; ++cot)
-      for (int kc = 0; kc < nkw; ++kc)
-        for (int role = 0; role < 8; ++role)
-          for (int nu = 0; nu < 4; ++nu)
-            for (int l = 0; l < 64; ++l) {
-              const int xi = role & 3, co = cot * 64 + (role >> 2) * 32 + (l & 31);
-              const size_t f = (((((size_t)cot * nkw + kc) * 8 + role) * 4 + nu) * 2) * 64 + l;
-              for (int j = 0; j < 8; ++j) {
-                const int k = kc * 16 + 8 * (l >> 5) + j;
-                const float vs = k < Cin ? (float)(U[((size_t)co * Cin + k) * 16 + xi * 4 + nu] * sw) : 0.f;
-                const uint16_t hi = f32_to_f16_rn(vs);
-                _Float16 hif;
-                memcpy(&hif, &hi, 2);
-                // the lo part takes the fp64 remainder (U is not an fp32 number in general)
-                const double rem = (k < Cin ? U[((size_t)co * Cin + k) * 16 + xi * 4 + nu] * sw : 0.0) - (double)(float)hif;
-                qw[f * 8 + j] = hi;
-                qw[(f + 64) * 8 + j] = f32_to_f16_rn((float)rem);
-              }
-            }
-    HIPCHK(h, hipMemcpy(h->d_wq + w.wino_off, qw.data(), qw.size() * 2, hipMemcpyHostToDevice));
-  }
   if (w.ck != CONV3_UP) return FDSR_OK;
 
   // Sub-pixel form of Upsample(nearest x2)+Conv3x3 (unet.py:66-74): W2[py][px][a][b] = sum of the 3x3 taps

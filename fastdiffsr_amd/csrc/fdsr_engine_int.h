@@ -31,9 +31,6 @@ struct WeightEntry {
   int h_WN = 0, h_cin_pad = 0, h_cout_pad = 0;
   size_t hq_off[3] = {0, 0, 0};             // byte offsets into the 16-bit weight arena, per Precision
   float h_inv_scale[3] = {1.f, 1.f, 1.f};
-  bool wino_ok = false;                     // stride-1 3x3 with whole 64-cout blocks: also kept in Winograd F(2x2,3x3) form (f16x3)
-  size_t wino_off = 0;                      // byte offset of that form in the 16-bit weight arena
-  float wino_inv_scale = 1.f;
   size_t up2_off[3] = {0, 0, 0};            // CONV3_UP only: sub-pixel (4 x 2x2) form
   float up2_inv_scale[3] = {1.f, 1.f, 1.f};
 };

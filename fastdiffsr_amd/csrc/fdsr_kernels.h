@@ -75,15 +75,11 @@ struct Tunables {
   int wgrad_colsum = 1;     // column sums of dy fused into the in-row weight-gradient kernel
   int wgrad_f32 = 0;        // f16x3 steps keep exact-fp32 weight gradients
   long long wgrad_big_bytes = 1ll << 32;   // tensors from this size on take the 4-wave weight-gradient kernel (64-bit offsets)
-  int wino = 0;             // Winograd F(2x2,3x3) form (half-tile pipeline, fdsr_conv_wino.hip) of the stride-1 3x3 convs in f16x3: 0 direct everywhere
-                            // (default since the 16x16x32 direct form took the 32 x 32 maps' 2-row tiles too: 69.7 vs 69.0 img/s same box), non-zero: on
-  long wino_min_wgs = 256;  // ... only for launches with at least this many workgroups
-  int wino_wide_cin = 1 << 30;   // ... rider-less launches with at least this many input channels take it too (384 until the 16x16x32
-                            // direct form overtook it there: 67.9 vs 66.8 img/s same box); with wino on: only the 32 x 32 maps
-  int wino_all = 0;         // ... 0: only the layers where it measured faster (conv_wino_ok); 1: every eligible launch
   int k32 = 1275;           // v_mfma_f32_16x16x32 form (fdsr_conv_k32.hip) of the stride-1 3x3 launches that fit it; bits: 1 f16x3, 2 bf16, 4 the 16-row tile with a rider, 8 the 2-row-per-wave tiles of small grids, 16 the sub-pixel upsample convs, 32 the small-workgroup form (4 waves, two workgroups per CU; 6-row tiles in f16x3, 8-row tiles in bf16) of the rider-less 64-cout launches of large grids in f16x3, 128 in bf16 too, 64 the f16x3 launches with a rider too (rider chunks first), 512 the bf16 ones with a rider (off: slower), 1024 the 8-wave rider kernels with the rider chunks first (launches without a K split); 0 never
   int k32_stagger = 0;      // ... start delay of the CU's odd workgroup slot, in 64-cycle units per K chunk (0: none)
   long k32_sb_min_wgs = 1024;   // ... from this many workgroups on (a small grid wants all eight waves of a CU on its one tile)
+  int strip = 1;            // column-strip form (fdsr_conv_strip.hip: weights in registers, one input row per step) of the 64 -> 64 launches: bit 1 bf16, bit 2 f16x3
+  long strip_min_wgs = 512; // ... from this many strip segments of >= 16 rows on (two workgroups per CU)
   int tail = 1;             // the input / output convs of the 16-bit modes on their own kernels (fdsr_conv_tail.hip); 0: the general ones
   int knockout = 0;         // TIMING-ONLY probes, results are garbage: bit 1 leaves the gn_finalize launches out, bit 2 the splitk_reduce launches
                             // (the upper bound of what fusing them into their producers could save; EXPERIMENTS round 4)
@@ -126,14 +122,14 @@ hipError_t launch_conv_k32(int TH, int WN, int prec, const ConvParams& q, int nw
 bool conv_k32_small_ok(ConvKind kind, int prec, const ConvParams& p);
 hipError_t launch_conv_k32_small(int prec, const ConvParams& p, hipStream_t s, int* tiles);
 hipError_t kernels_k32_init();
+// Column-strip form of the 64-cout launches (fdsr_conv_strip.hip): same ConvParams, the same packed weights (wn_a: the WN they
+// were packed for); asked before the small-workgroup form
+bool conv_strip_ok(ConvKind kind, int prec, const ConvParams& p);
+hipError_t launch_conv_strip(int prec, const ConvParams& p, int wn_a, hipStream_t s, int* tiles);
+hipError_t kernels_strip_init();
 // ... and of the sub-pixel upsample kernel (fdsr_conv_up2.hip): k32 bit 16
 bool conv_up2_k32_ok(int prec, const ConvParams& p);
 hipError_t launch_conv_up2_k32(int TH, int WN, int prec, const ConvParams& q, int nwg, hipStream_t s);
-// Winograd F(2x2,3x3) form of the stride-1 3x3 convs (fdsr_conv_wino.hip; f16x3 only): transformed weights U = G g G^T packed
-// [cot][kc][role][nu][plane][lane] x 16 B (role = position row xi | cout half << 2).  conv_wino_ok: does this launch take it?
-bool conv_wino_ok(ConvKind kind, int prec, const ConvParams& p, bool has_rider);
-hipError_t launch_conv_wino_h(const ConvParams& p, hipStream_t s, int* tiles_per_image);
-hipError_t kernels_wino_init();
 // Upsample(nearest x2)+Conv3x3 in sub-pixel form (fdsr_conv_up2.hip): four 2x2 convs on the source grid
 // with pre-summed weights packed [cot][kc][wn][py][px*4+a*2+b][plane][lane] x 16 B.
 hipError_t launch_conv_up2_h(int prec, const ConvParams& p, hipStream_t s, int* tiles_per_image);

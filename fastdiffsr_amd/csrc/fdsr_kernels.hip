@@ -470,13 +470,11 @@ int set_tunable(const char* name, long long v) {
   else if (n == "wgrad_colsum") g_tun.wgrad_colsum = (int)v;
   else if (n == "wgrad_f32") g_tun.wgrad_f32 = (int)v;
   else if (n == "wgrad_big_bytes") g_tun.wgrad_big_bytes = v;
-  else if (n == "wino") g_tun.wino = (int)v;
-  else if (n == "wino_min_wgs") g_tun.wino_min_wgs = (long)v;
-  else if (n == "wino_wide_cin") g_tun.wino_wide_cin = (int)v;
-  else if (n == "wino_all") g_tun.wino_all = (int)v;
   else if (n == "k32") g_tun.k32 = (int)v;
   else if (n == "k32_sb_min_wgs") g_tun.k32_sb_min_wgs = (long)v;
   else if (n == "k32_stagger") g_tun.k32_stagger = (int)v;
+  else if (n == "strip") g_tun.strip = (int)v;
+  else if (n == "strip_min_wgs") g_tun.strip_min_wgs = (long)v;
   else if (n == "sat_guard") g_tun.sat_guard = (int)v;
   else if (n == "tail") g_tun.tail = (int)v;
   else if (n == "knockout") g_tun.knockout = (int)v;

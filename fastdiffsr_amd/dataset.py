@@ -91,7 +91,7 @@ class LRHRDataset(Dataset):
                 return hr, sr, lr
 
             hr, sr, lr = entries(index)
-            while hr is None or sr is None:                        # "skip the invalid index"
+            while hr is None or (want_sr and sr is None):          # "skip the invalid index" (cond_from_lr: no sr_* entry needed)
                 hr, sr, lr = entries(random.randint(0, self.data_len - 1))
             out = {'HR': Image.open(BytesIO(hr)).convert('RGB')}
             if want_sr:
@@ -179,9 +179,9 @@ class ThreadedBatchLoader:
     def __init__(self, dataset, batch_size, shuffle=False, workers=4, generator=None, depth=3, stage=None):
         from concurrent.futures import ThreadPoolExecutor
         self.ds, self.bs, self.shuffle, self.gen, self.depth = dataset, int(batch_size), bool(shuffle), generator, depth
-        # stage(key, [arrays]) -> what the batch carries for that key: default the stacked array; the GPU loops pass val.HipOps.stage_host,
+        # stage(key, [arrays], owner=) -> what the batch carries for that key: default the stacked array; the GPU loops pass val.HipOps.stage_host,
         # which stacks straight into pinned memory ON THE LOADER THREAD (the consumer then only issues the asynchronous copy)
-        self.stage = stage or (lambda key, arrays: np.stack(arrays))
+        self.stage = (lambda key, arrays: stage(key, arrays, owner=id(self))) if stage else (lambda key, arrays: np.stack(arrays))
         self.pool = ThreadPoolExecutor(max_workers=max(1, int(workers)))
 
     def __len__(self):

@@ -43,22 +43,34 @@ class HipOps:
             raise RuntimeError('fastdiffsr_amd.val runs on the GPU only')
         import threading
         self.device = torch.device(device)
-        self._lock = threading.Lock()
+        self._cond = threading.Condition()
         self._up = {}       # (key, shape) -> ring of pinned staging buffers (H2D)
         self._down = {}     # (tag, shape, dtype) -> ring of pinned landing buffers (D2H)
 
-    def stage_host(self, key, arrays):
+    RING = 6            # pinned staging buffers per (owner, key, shape): more than any loader keeps staged ahead of its consumer (depth + 1 <= 4)
+
+    def stage_host(self, key, arrays, owner=None):
         """Stack a batch's uint8 images (list of numpy arrays, or one stacked array) into a pinned staging buffer -- called on a
-        LOADER thread, so that the sampling thread's share of the staging is one asynchronous copy.  Ring of four buffers per
-        (key, shape): a buffer is rewritten only after the H2D copy that last read it has completed."""
-        import threading
+        LOADER thread, so that the sampling thread's share of the staging is one asynchronous copy.  A ring of RING buffers per
+        (owner, key, shape); a buffer is OWNED by the batch staged into it until to_device() has issued its copy (batches may be
+        staged out of order and stay staged for a while: a slot is never handed out again on call order alone), and rewritten only
+        after that copy has completed.  `owner` names the loader: two loaders with the same batch shape never share a ring."""
         arr0 = arrays if isinstance(arrays, np.ndarray) else arrays[0]
         shape = tuple(arrays.shape) if isinstance(arrays, np.ndarray) else (len(arrays),) + tuple(arr0.shape)
-        with self._lock:
-            ring = self._up.setdefault((key, shape), {'buf': [torch.empty(shape, dtype=torch.uint8).pin_memory() for _ in range(4)],
-                                                      'ev': [None] * 4, 'next': 0})
-            slot = ring['next'] % 4
-            ring['next'] += 1
+        rkey = (owner, key, shape)
+        with self._cond:
+            ring = self._up.get(rkey)
+            if ring is None:
+                ring = self._up[rkey] = {'buf': [torch.empty(shape, dtype=torch.uint8).pin_memory() for _ in range(self.RING)],
+                                         'ev': [None] * self.RING, 'held': [False] * self.RING, 'next': 0}
+            while True:
+                free = [(ring['next'] + i) % self.RING for i in range(self.RING) if not ring['held'][(ring['next'] + i) % self.RING]]
+                if free:
+                    break
+                self._cond.wait()        # every buffer holds a staged batch that has not been uploaded yet
+            slot = free[0]
+            ring['held'][slot] = True
+            ring['next'] = (slot + 1) % self.RING
             ev = ring['ev'][slot]
         if ev is not None:
             ev.synchronize()
@@ -68,16 +80,19 @@ class HipOps:
         else:
             for j, a in enumerate(arrays):
                 dst[j] = a
-        return (key, shape, slot)
+        return (rkey, slot)
 
     def to_device(self, staged):
-        """The asynchronous H2D copy of a staged batch (sampling thread, current stream)."""
-        key, shape, slot = staged
-        ring = self._up[(key, shape)]
+        """The asynchronous H2D copy of a staged batch (sampling thread, current stream); releases the batch's hold on its buffer."""
+        rkey, slot = staged
+        ring = self._up[rkey]
         out = ring['buf'][slot].to(self.device, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        ring['ev'][slot] = ev
+        with self._cond:
+            ring['ev'][slot] = ev
+            ring['held'][slot] = False
+            self._cond.notify_all()
         return out
 
     def upload(self, key, arr):
@@ -127,7 +142,7 @@ class _Loader:
         out = {'Index': [it['Index'] for it in items]}
         for key in ('HR', 'SR', 'LR'):
             if key in items[0]:
-                out[key] = self.ops.stage_host(key, [it[key] for it in items])
+                out[key] = self.ops.stage_host(key, [it[key] for it in items], owner=id(self))
         return out
 
     def _submit_until(self, k):
@@ -352,7 +367,7 @@ def main(argv=None, diffusion=None, ops=None):
     ap.add_argument('--max-images', type=int, default=None)
     ap.add_argument('--no-save', action='store_true')
     ap.add_argument('--infer', action='store_true', help="the reference's infer.py: png outputs and timing, no metrics")
-    ap.add_argument('--workers', type=int, default=None, help='loader / writer threads (default: min(16, cores))')
+    ap.add_argument('--workers', type=int, default=None, help='loader / writer threads (default: max(2, min(8, cores)))')
     ap.add_argument('--rng', default=None, choices=['torch', 'engine'],
                     help="sampling noise: 'torch' (default; torch.randn in the reference's order, reproducible under torch.manual_seed) "
                          "or 'engine' (Philox inside the HIP loop: nothing pre-drawn)")

@@ -31,13 +31,11 @@ def full():
 @pytest.fixture
 def forced():
     """Every stride-1 3x3 launch on its largest tile (4 x 32 pixels per wave: the form's shape) whatever the grid size -- small
-    grids then split K --, no Winograd; restored afterwards."""
+    grids then split K --; restored afterwards."""
     from fastdiffsr_amd import _lib
     _lib.debug_option('th_min_wgs', 1)
-    _lib.debug_option('wino', 0)
     yield
     _lib.debug_option('th_min_wgs', 256)
-    _lib.debug_option('wino', 0)
     _lib.debug_option('k32', 1275)
 
 
@@ -88,7 +86,6 @@ def test_small_grid_two_row_tiles_k32_vs_oracle(full):
     from fastdiffsr_amd import _lib
     from oracle import fdsr_oracle as O
     cfg, eng, sd = full
-    _lib.debug_option('wino', 0)
     _lib.debug_option('k32', 13)
     try:
         gen = torch.Generator().manual_seed(11)
@@ -118,7 +115,6 @@ def test_small_grid_two_row_tiles_k32_vs_oracle(full):
         assert (eng.sample(cond.cuda(), noise.cuda()).cpu() - refl).abs().max().item() <= TOL_LOOP
     finally:
         eng.set_debug(False)
-        _lib.debug_option('wino', 0)
         _lib.debug_option('k32', 1275)
 
 
@@ -175,7 +171,6 @@ def test_small_workgroup_form_vs_oracle(full, prec):
     cfg, eng, sd = full
     eng.set_precision(prec)
     tol = TOL_FWD if prec == 'f16x3' else 0.25
-    _lib.debug_option('wino', 0)
     _lib.debug_option('k32', 1275 | 512)           # with the bf16 riders too (bit 512: off by default)
     _lib.debug_option('k32_sb_min_wgs', 1)
     _lib.debug_option('splitk', 0)          # (a launch with a K split keeps the 8-wave forms)

@@ -107,3 +107,27 @@ def test_val_cli_with_tesr_sibling(tmp_path):
     assert np.isfinite(r['sr_psnr']) and len(lines) == 2
     with pytest.raises(ValueError, match='--batch 1'):
         val.run(_load(cpath), batch=2, results=str(tmp_path / 'o2'), log=lines.append)
+
+
+def test_staging_ring_slots_are_owned_until_uploaded():
+    """HipOps.stage_host: a pinned buffer belongs to the batch staged into it until to_device() has issued the copy -- batches that are
+    staged out of order and uploaded late keep their bytes, two loaders with one batch shape never share a ring, and a loader that
+    holds every buffer waits instead of overwriting one."""
+    import threading
+    import numpy as np
+    from fastdiffsr_amd import val
+    ops = val.HipOps('cuda')
+    arrs = [np.full((2, 4, 4, 3), i, np.uint8) for i in range(ops.RING)]
+    staged = [ops.stage_host('HR', a, owner=1) for a in arrs]                  # every buffer of the ring staged, none uploaded
+    other = ops.stage_host('HR', np.full((2, 4, 4, 3), 99, np.uint8), owner=2)   # another loader, same key and shape
+    got = {}
+    t = threading.Thread(target=lambda: got.setdefault('late', ops.stage_host('HR', np.full((2, 4, 4, 3), 77, np.uint8), owner=1)))
+    t.start()
+    t.join(0.3)
+    assert t.is_alive()                                                         # no free buffer: it waits
+    for i in reversed(range(ops.RING)):                                         # uploaded in the reverse order
+        assert (ops.to_device(staged[i]).cpu().numpy() == i).all()
+    t.join(10)
+    assert not t.is_alive()
+    assert (ops.to_device(got['late']).cpu().numpy() == 77).all()
+    assert (ops.to_device(other).cpu().numpy() == 99).all()

@@ -1,12 +1,14 @@
-"""The evaluation loop's device kernels (csrc/fdsr_val.hip) against the host formulas of fastdiffsr_amd/metrics.py (the
-reference's sr_mfe.py:313-345 / core/metrics.py:94-152): MSE / PSNR / ERGAS bit for bit (exact integer sums + the same
-scalar formulas), SSIM (uniform 7x7 = skimage's compare_ssim; Gaussian 11x11 = core/metrics.calculate_ssim) to 1e-9,
-reruns bitwise; the dataset transform and the batched tensor2img bit for bit."""
+"""The evaluation loop's device kernels (csrc/fdsr_val.hip) against the ORACLE's restatement of the metrics the reference computes
+(oracle/metrics_oracle.py: skimage.measure.compare_mse / compare_psnr / compare_ssim as sr_mfe.py:165-173, :313-333 calls them, and
+core/metrics.py:94-152): MSE / PSNR / ERGAS bit for bit (exact integer sums + the same scalar formulas), SSIM (uniform 7x7 =
+skimage's compare_ssim; Gaussian 11x11 = core/metrics.ssim) to 1e-9, reruns bitwise; the dataset transform and the batched
+tensor2img bit for bit.  The product's own host formulas (fastdiffsr_amd/metrics.py, the --host-metrics path) are NOT the judge here."""
 import numpy as np
 import pytest
 import torch
 
 from fastdiffsr_amd import metrics as M
+from oracle import metrics_oracle as MO
 
 pytestmark = pytest.mark.gpu
 
@@ -34,11 +36,11 @@ def test_metric_sums_match_host_formulas(shape, spread):
         assert s1[j][0] == float(((a[j].astype(np.int64) - b[j]) ** 2).sum()) and s1[j][1] == float(a[j].astype(np.int64).sum())
         assert s1[j][3] == (h - 6) * (w - 6) * c and s1[j][5] == (h - 10) * (w - 10) * c
         img_a, img_b = (a[j], b[j]) if c > 1 else (a[j][..., 0], b[j][..., 0])
-        assert r['mse'] == M.compare_mse(a[j], b[j]) and r['psnr'] == M.compare_psnr(a[j], b[j])          # bit for bit
-        assert r['ergas'] == M.calculate_ergas(a[j], b[j], scale=4)
-        want7 = M.compare_ssim(img_a, img_b, multichannel=(c > 1))
+        assert r['mse'] == MO.compare_mse(a[j], b[j]) and r['psnr'] == MO.compare_psnr(a[j], b[j])          # bit for bit
+        assert r['ergas'] == MO.calculate_ergas(a[j], b[j], scale=4)
+        want7 = MO.compare_ssim(img_a, img_b, multichannel=(c > 1))
         assert abs(r['ssim'] - want7) <= 1e-9 * max(1.0, abs(want7)), (r['ssim'], want7)
-        want11 = M.ssim(img_a, img_b)                 # core/metrics.py:103-123 on the whole array (per channel, 'valid' part)
+        want11 = MO.ssim(img_a, img_b)                # core/metrics.py:103-123 on the whole array (per channel, 'valid' part)
         assert abs(r['ssim_gauss'] - want11) <= 1e-9 * max(1.0, abs(want11)), (r['ssim_gauss'], want11)
     # uniform window alone: the Gaussian fields stay zero, the integer sums are unchanged
     s3 = M.image_metric_sums(ta, tb).cpu().numpy()
@@ -97,6 +99,19 @@ def test_val_loop_device_metrics_equal_host_metrics(tmp_path):
     for k in ('bic_ssim', 'sr_ssim'):
         assert abs(res['dev'][k] - res['host'][k]) <= 1e-9
     from PIL import Image
+    # the judge: the oracle's metrics on the images the device path WROTE, against the averages it reported
+    import glob, os, re
+    hr_dir = os.path.join(root, 'hr_64')
+    rows = []
+    for i, name in enumerate(sorted(os.listdir(hr_dir))):
+        hr = np.asarray(Image.open(os.path.join(hr_dir, name)).convert('RGB'))
+        (path,) = [q for q in glob.glob(str(tmp_path / 'dev' / '*_sr.tif')) if re.search(r'_%d_sr\.tif$' % (i + 1), q)]
+        sr = np.asarray(Image.open(path))
+        rows.append([MO.compare_mse(sr, hr), MO.compare_psnr(sr, hr), MO.compare_ssim(sr, hr, multichannel=True),
+                     MO.calculate_ergas(sr, hr, scale=4)])
+    want = np.mean(np.array(rows), axis=0)
+    for k, v in zip(('sr_mse', 'sr_psnr', 'sr_ssim', 'sr_ergas'), want):
+        assert abs(res['dev'][k] - v) <= 1e-9 * max(1.0, abs(v)), (k, res['dev'][k], v)
     for f in sorted((tmp_path / 'dev').iterdir()):
         assert np.array_equal(np.asarray(Image.open(f)), np.asarray(Image.open(tmp_path / 'host' / f.name)))
     # batches 1 and 2 share a shape: the second was a graph replay ('auto'); forcing the graph off gives the same images

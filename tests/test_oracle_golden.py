@@ -198,6 +198,51 @@ def test_ssim_ergas_vs_the_references_own_functions(golden_dir):
         assert abs(M.calculate_ergas(a, b, scale=8) - float(g[f'{case}/ergas8'])) < 1e-10, case
 
 
+def test_metrics_oracle_pinned(golden_dir):
+    """oracle/metrics_oracle.py -- the checker of the HIP metric kernels -- against (a) the reference's own core/metrics.py functions
+    run in the build container (tests/golden/metrics_ssim.npz, metrics.npz), (b) brute-force window loops of the published
+    definitions: skimage's compare_ssim (uniform 7 x 7, sample covariance, interior mean), cv2.filter2D's BORDER_REFLECT_101."""
+    from oracle import metrics_oracle as MO
+    g = _load(golden_dir, 'metrics_ssim.npz')
+    for case in ('noisy', 'blur', 'dark', 'same'):
+        a, b = g[f'{case}/a'], g[f'{case}/b']
+        assert abs(MO.calculate_ssim(a, b) - float(g[f'{case}/ssim_rgb'])) < 1e-12, case
+        assert abs(MO.calculate_ssim(a[..., 0], b[..., 0]) - float(g[f'{case}/ssim_gray'])) < 1e-12, case
+        assert abs(MO.calculate_ssim(a[..., :1], b[..., :1]) - float(g[f'{case}/ssim_1ch'])) < 1e-12, case
+        assert abs(MO.calculate_ergas(a, b, scale=4) - float(g[f'{case}/ergas4'])) < 1e-10, case
+        assert abs(MO.calculate_ergas(a, b, scale=8) - float(g[f'{case}/ergas8'])) < 1e-10, case
+    m = _load(golden_dir, 'metrics.npz')
+    assert abs(MO.calculate_psnr(m['img'], m['img2']) - float(m['psnr'])) < 1e-12
+    assert MO.calculate_psnr(m['img'], m['img']) == float('inf') == MO.compare_psnr(m['img'], m['img'])
+    rng = np.random.default_rng(9)
+    a = rng.integers(0, 256, (20, 26, 3)).astype(np.uint8)
+    b = np.clip(a.astype(np.int32) + rng.integers(-30, 31, a.shape), 0, 255).astype(np.uint8)
+    mse = np.mean((a.astype(np.float64) - b) ** 2)
+    assert MO.compare_mse(a, b) == mse and abs(MO.compare_psnr(a, b) - MO.calculate_psnr(a, b)) < 1e-12
+    X, Y = a[..., 1].astype(np.float64), b[..., 1].astype(np.float64)
+    C1, C2 = (0.01 * 255) ** 2, (0.03 * 255) ** 2
+    vals = []
+    for y in range(3, X.shape[0] - 3):
+        for x in range(3, X.shape[1] - 3):
+            wx, wy = X[y - 3:y + 4, x - 3:x + 4].ravel(), Y[y - 3:y + 4, x - 3:x + 4].ravel()
+            ux, uy = wx.mean(), wy.mean()
+            vxy = ((wx - ux) * (wy - uy)).sum() / 48
+            vals.append((2 * ux * uy + C1) * (2 * vxy + C2) / ((ux * ux + uy * uy + C1) * (wx.var(ddof=1) + wy.var(ddof=1) + C2)))
+    assert abs(MO.compare_ssim(a[..., 1], b[..., 1]) - np.mean(vals)) < 1e-9
+    assert abs(MO.compare_ssim(a, b, multichannel=True) - np.mean([MO.compare_ssim(a[..., c], b[..., c]) for c in range(3)])) < 1e-12
+    assert abs(MO.compare_ssim(a, a, multichannel=True) - 1.0) < 1e-12
+    with pytest.raises(ValueError):
+        MO.compare_ssim(a[:6], b[:6], multichannel=True)
+    # cv2.filter2D: correlation (no kernel flip), anchor at the centre, BORDER_REFLECT_101 (gfedcb|abcdefgh|gfedcba)
+    img = rng.random((9, 8))
+    k = rng.random((5, 5))
+    pad = np.pad(img, 2, mode='reflect')
+    brute = np.array([[np.sum(pad[y:y + 5, x:x + 5] * k) for x in range(8)] for y in range(9)])
+    assert np.abs(MO.filter2d(img, k) - brute).max() < 1e-12
+    kk = MO.gaussian_kernel(11, 1.5)
+    assert abs(kk.sum() - 1.0) < 1e-15 and np.argmax(kk) == 5 and np.allclose(kk, kk[::-1]) and abs(kk[5] / kk[4] - np.exp(1 / 4.5)) < 1e-12
+
+
 def test_pil_bicubic_restatement(golden_dir):
     """oracle/pil_bicubic.py == Pillow's Image.resize(BICUBIC), bit for bit (goldens made by PIL itself)."""
     from oracle import pil_bicubic as PB

@@ -29,7 +29,7 @@ class HostOps:
     """numpy stand-in of val.HipOps (test infrastructure): same methods, host arithmetic of fastdiffsr_amd.metrics."""
     device = torch.device('cpu')
 
-    def stage_host(self, key, arrays):
+    def stage_host(self, key, arrays, owner=None):
         return torch.from_numpy(np.stack(arrays) if not isinstance(arrays, np.ndarray) else np.ascontiguousarray(arrays))
 
     def to_device(self, staged):

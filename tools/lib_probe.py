@@ -9,7 +9,7 @@ from fastdiffsr_amd.schedule import schedule_buffers, sampling_scalars
 from fastdiffsr_amd.synth import synth_state_dict, synth_inputs
 
 from fastdiffsr_amd import _lib
-for item in os.environ.get('PROBE_OPTS', '').split(','):      # launcher options (fdsr_debug_option), e.g. PROBE_OPTS=rider=0,wino=0
+for item in os.environ.get('PROBE_OPTS', '').split(','):      # launcher options (fdsr_debug_option), e.g. PROBE_OPTS=rider=0,strip=0
     if item:
         _lib.debug_option(item.split('=')[0], int(item.split('=')[1]))
 prec = sys.argv[1] if len(sys.argv) > 1 else 'f16x3'

@@ -1,5 +1,5 @@
 """HBM traffic per kernel from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE), and for the launch set
-bench.py's roofline brackets with HIP events: every 3x3 convolution op (conv_mfma_h_kernel<3,...>, conv_k32_kernel, conv_wino_h_kernel,
+bench.py's roofline brackets with HIP events: every 3x3 convolution op (conv_mfma_h_kernel<3,...>, conv_k32_kernel, conv_strip_kernel,
 conv_up2_h_kernel, conv_mfma_f32_kernel<3,...> and the split-K reduce that finishes such an op).
 gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reports 1/2 of the bytes of wide coalesced
 reads -> doubled; WRITE_SIZE is exact for 16-B streaming stores.  Units: KiB.
@@ -16,7 +16,7 @@ def short(name):
 
 def is_3x3(name):
     k = short(name)
-    if k in ('conv_up2_h_kernel', 'conv_up2_k32_kernel', 'conv_wino_h_kernel', 'conv_wino2_h_kernel', 'conv_k32_kernel', 'conv_in8_kernel', 'conv_out3_kernel'):
+    if k in ('conv_up2_h_kernel', 'conv_up2_k32_kernel', 'conv_k32_kernel', 'conv_strip_kernel', 'conv_in8_kernel', 'conv_out3_kernel'):
         return True
     if k in ('conv_mfma_h_kernel', 'conv_mfma_f32_kernel'):
         m = re.search(r'<\s*(\d+)\s*,', name)
