@@ -34,6 +34,9 @@ __device__ __forceinline__ float silu_s(float v) { return v * __builtin_amdgcn_r
 #ifndef STRIP_XS      // activation-fragment slots in registers: XS - 1 fragments ahead of their MFMAs
 #define STRIP_XS 4
 #endif
+#ifndef STRIP_DIAG    // timing-only diagnostic builds (results are garbage): 1 no residual loads, 2 no output stores, 4 no activation math
+#define STRIP_DIAG 0
+#endif
 #ifndef STRIP_PIN     // keep the fragment reads ahead of the MFMAs (sched_barrier that VALU / SALU may cross)
 #define STRIP_PIN 1
 #endif
@@ -45,7 +48,14 @@ struct StripCfg {
   static constexpr int OPP = CIN / 8;              // 8-channel units ("octs") per pixel and plane
   static constexpr int RB = 16 * OPP * NP;         // LDS bytes per staged pixel: [plane][oct] x 16 B, swizzled
   static constexpr int SLOT_BYTES = HWD * RB;
-  static constexpr int LDS_BYTES = 2 * SLOT_BYTES;     // (+ 64 OPP bytes behind them: the GroupNorm table)
+  static constexpr int GTAB_OFF = 2 * SLOT_BYTES;      // GroupNorm table: 64 OPP bytes
+  static constexpr int OSZ = PREC == PREC_BF16 ? 2 : 4;   // bytes per output / residual element
+  static constexpr int TILE_BYTES = SW * 64 * OSZ;     // one output (or residual) row of the strip, [pixel][64 couts], 16-byte units swizzled
+  static constexpr int OUT_OFF = GTAB_OFF + 64 * OPP;  // two output-row tiles, then two residual-row tiles
+  static constexpr int RES_OFF = OUT_OFF + 2 * TILE_BYTES;
+  static constexpr int LDS_BYTES = RES_OFF + 2 * TILE_BYTES;
+  static constexpr int NIT = SW * 64 * OSZ / 16 / 256; // 16-byte units of a row tile per thread
+  static_assert(OSZ == 2, "the epilogue tiles below are laid out for bf16 rows (128 bytes per pixel)");
   static constexpr int PPP = 256 / OPP;            // pixels staged per pass
   static constexpr int NPASS = SW / PPP;
   static constexpr int NF = 3 * KCH * NPH;         // activation fragments per step
@@ -146,7 +156,7 @@ __global__ void __launch_bounds__(256, 2) conv_strip_kernel(const ConvParams p, 
   }
   // GroupNorm scale / shift of image n as an LDS table [oct][slice] x (sc0, sc1, sh0, sh1): an activation slice reads its four values
   // when it runs instead of holding sixteen registers for the whole strip
-  float* gtab = reinterpret_cast<float*>(smem_s + Cfg::LDS_BYTES);
+  float* gtab = reinterpret_cast<float*>(smem_s + Cfg::GTAB_OFF);
   if (tid < 4 * OPP) {
     const int c = 8 * (tid >> 2) + 2 * (tid & 3);
     const float* ps = p.gn_scale + (size_t)n * Cin + c;
@@ -183,8 +193,13 @@ __global__ void __launch_bounds__(256, 2) conv_strip_kernel(const ConvParams p, 
   struct Staged { unsigned hi[4]; unsigned lo[PREC == PREC_F16X3 ? 4 : 1]; };
   auto act_pair = [&](float a, float b, int k, unsigned& hi, unsigned& lo) __attribute__((always_inline)) {
     const s_f32x4 gt = *reinterpret_cast<const s_f32x4*>(gmine + 4 * k);
-    a = silu_s(a * gt[0] + gt[2]);
-    b = silu_s(b * gt[1] + gt[3]);
+    if (STRIP_DIAG & 4) {
+      a = a * gt[0] + gt[2];
+      b = b * gt[1] + gt[3];
+    } else {
+      a = silu_s(a * gt[0] + gt[2]);
+      b = silu_s(b * gt[1] + gt[3]);
+    }
     if (PREC == PREC_F16X3) {
       const float ca = __builtin_amdgcn_fmed3f(a, -65504.f, 65504.f), cb = __builtin_amdgcn_fmed3f(b, -65504.f, 65504.f);
       typedef _Float16 h2t __attribute__((ext_vector_type(2)));
@@ -270,35 +285,57 @@ __global__ void __launch_bounds__(256, 2) conv_strip_kernel(const ConvParams p, 
     add[r] = a;
   }
   const float winv = p.w_inv_scale_dev ? *p.w_inv_scale_dev : p.w_inv_scale;
-  constexpr int OSZ = PREC == PREC_BF16 ? 2 : 4;      // bytes per output / residual element (bf16 mode: out_f32 launches stay elsewhere)
+  constexpr int OSZ = Cfg::OSZ, NIT = Cfg::NIT, TILE = Cfg::TILE_BYTES;
   s_f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
-  Quad rq[NPH];
+  // The finished row leaves through LDS: a wave owns 16 of the 64 output channels, so its accumulator layout reaches memory in
+  // 32-byte pieces (bf16) -- and the residual arrives in the same pieces.  Measured at B = 64: the residual launches took 400 us
+  // against 300 us with EITHER their residual loads OR their stores left out, at exactly the algorithmic HBM traffic: the load /
+  // store path was bound by the number of requests, not by bytes.  So: the accumulator lanes write their quads (8 bytes) into a
+  // [pixel][64 couts] row tile, and after the step's barrier every thread moves NIT whole 16-byte units of it (a pixel's 128 bytes =
+  // 8 consecutive threads); the residual row comes the same way in reverse, two steps ahead.  16-byte unit u of pixel px sits at
+  // unit u ^ ((px >> 1) & 7): conflict free for the 8-byte accumulator-side accesses and the 16-byte row-side ones.
+  unsigned char* otile = smem_s + Cfg::OUT_OFF;
+  unsigned char* rtile = smem_s + Cfg::RES_OFF;
+  const int a64 = c15 * 128 + 16 * (((4 * w + g) >> 1) ^ ((c15 >> 1) & 7)) + 8 * (g & 1);   // + 2048 ph: quad ph of this lane
+  int a128[NIT];
+  unsigned gofs[NIT];            // byte offset of this thread's unit i inside an output row of the strip
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int px = tid / 8 + 32 * i, u = tid % 8;
+    a128[i] = px * 128 + 16 * (u ^ ((px >> 1) & 7));
+    gofs[i] = (unsigned)((ox0 + px) * 64 + 8 * u) * OSZ;
+  }
   const size_t img = (size_t)n * H * W * 64 * OSZ;
   unsigned char* outn = reinterpret_cast<unsigned char*>(p.out) + img;
   const unsigned char* resn = reinterpret_cast<const unsigned char*>(HAS_RES ? p.res : p.out) + img;
-  const unsigned lofs = (unsigned)((ox0 + c15) * 64 + cob) * OSZ;
-  auto load_res = [&](int oy) __attribute__((always_inline)) {   // (oy inside the segment: caller)
-    if (HAS_RES) {
-      const unsigned r0 = (unsigned)(oy * W) * (64 * OSZ) + lofs;
-#pragma unroll
-      for (int ph = 0; ph < NPH; ++ph) rq[ph] = *reinterpret_cast<const Quad*>(resn + (r0 + ph * (16 * 64 * OSZ)));
+  uint4 rres0 = {0u, 0u, 0u, 0u}, rres1 = {0u, 0u, 0u, 0u};   // (two named registers sets: an array here stayed in scratch memory)
+  auto crow = [&](int oy) __attribute__((always_inline)) { return oy < oy0 ? oy0 : (oy >= oy1 ? oy1 - 1 : oy); };
+  auto load_res = [&](int oy) __attribute__((always_inline)) {   // residual row oy (clamped into the segment), 16 bytes per unit
+    if (HAS_RES && !(STRIP_DIAG & 1)) {
+      const unsigned r0 = (unsigned)(crow(oy) * W) * (64 * OSZ);
+      rres0 = *reinterpret_cast<const uint4*>(resn + (r0 + gofs[0]));
+      if (NIT > 1) rres1 = *reinterpret_cast<const uint4*>(resn + (r0 + gofs[NIT - 1]));
     }
   };
-  // one quad (pixel c15 + 16 ph of row oy, four output channels) of a finished row
-  auto finish = [&](int oy, int ph, s_f32x4 a) __attribute__((always_inline)) {
-    const unsigned ro = (unsigned)(oy * W) * (64 * OSZ) + lofs;
-    s_f32x4 v = a * winv + add;
-    if (HAS_RES) v += IO::widen(rq[ph]);
-    unsigned char* dst = outn + (ro + ph * (16 * 64 * OSZ));
-    if (PREC == PREC_BF16) {
-      typedef __bf16 b2t __attribute__((ext_vector_type(2)));
-      const b2t lo = {(__bf16)v[0], (__bf16)v[1]}, hi = {(__bf16)v[2], (__bf16)v[3]};   // one v_cvt_pk_bf16_f32 each
-      *reinterpret_cast<uint2*>(dst) = uint2{__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
-    } else {
-      *reinterpret_cast<s_f32x4*>(dst) = v;
+  auto res_to_lds = [&](int oy) __attribute__((always_inline)) {
+    if (HAS_RES) {
+      *reinterpret_cast<uint4*>(rtile + (oy & 1) * TILE + a128[0]) = rres0;
+      if (NIT > 1) *reinterpret_cast<uint4*>(rtile + (oy & 1) * TILE + a128[NIT - 1]) = rres1;
     }
+  };
+  // one quad (pixel c15 + 16 ph of row oy, four output channels) of a finished row: residual from its tile, result into the row's tile
+  auto finish = [&](int oy, int ph, s_f32x4 a) __attribute__((always_inline)) {
+    s_f32x4 v = a * winv + add;
+    if (HAS_RES) v += IO::widen(*reinterpret_cast<const Quad*>(rtile + (oy & 1) * TILE + a64 + 2048 * ph));
+    typedef __bf16 b2t __attribute__((ext_vector_type(2)));
+    const b2t lo = {(__bf16)v[0], (__bf16)v[1]}, hi = {(__bf16)v[2], (__bf16)v[3]};   // one v_cvt_pk_bf16_f32 each
+    *reinterpret_cast<uint2*>(otile + (oy & 1) * TILE + a64 + 2048 * ph) = uint2{__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
     s1 += v;
     s2 += v * v;
+  };
+  auto flush = [&](int oy, int i) __attribute__((always_inline)) {   // unit i of row oy's tile to memory (after the barrier that followed its epilogue)
+    const uint4 v = *reinterpret_cast<const uint4*>(otile + (oy & 1) * TILE + a128[i]);
+    if (!(STRIP_DIAG & 2)) *reinterpret_cast<uint4*>(outn + ((unsigned)(oy * W) * (64 * OSZ) + gofs[i])) = v;
   };
 
   // ---- one step: input row iy (staged in slot `cur`) into the three accumulator sets; row iy + 1 staged into `nxt`; row iy + 4
@@ -308,6 +345,7 @@ __global__ void __launch_bounds__(256, 2) conv_strip_kernel(const ConvParams p, 
   // 4 + 4 + 1 activation slices of the next row and the four epilogue quads of the row finished last step are spread over the
   // slots, so that neither wave of a SIMD runs a long MFMA-free stretch.  EPI: the step writes a row (steps >= 3 of a segment);
   // RESLD: it fetches the residual of the row it finishes (steps >= 2).
+  static_assert(NIT <= 2, "two flush slots");
   static_assert(NPASS == 2 && NF == 24, "the slot schedule below is written for two staging passes and 24 fragments per row");
   uint4 Xf[XS][NP];
   auto mfma1 = [&](const uint4* wf, const uint4* xf, s_f32x4 c) __attribute__((always_inline)) -> s_f32x4 {
@@ -318,9 +356,9 @@ __global__ void __launch_bounds__(256, 2) conv_strip_kernel(const ConvParams p, 
     }
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(s_b8, wf[0]), __builtin_bit_cast(s_b8, xf[0]), c, 0, 0, 0);
   };
-  auto step = [&](int iy, int it, auto rot_tag, auto epi_tag, auto resld_tag) __attribute__((always_inline)) {
+  auto step = [&](int iy, int it, auto rot_tag, auto epi_tag, auto flush_tag) __attribute__((always_inline)) {
     constexpr int ROT = decltype(rot_tag)::value;
-    constexpr bool EPI = decltype(epi_tag)::value, RESLD = decltype(resld_tag)::value;
+    constexpr bool EPI = decltype(epi_tag)::value, FLUSH = decltype(flush_tag)::value;
     constexpr int A0 = (ROT + 1) % 3, A1 = ROT, A2 = (ROT + 2) % 3;
     StripRaw<PREC>* rset = raw[(ROT + 1) % 3];             // holds row iy + 1; re-filled with row iy + 4
     StripRawPair<PREC>& hset = rawh[(ROT + 1) % 3];
@@ -344,7 +382,6 @@ __global__ void __launch_bounds__(256, 2) conv_strip_kernel(const ConvParams p, 
       // slots 0 .. NPH - 1: quad ph of the row the previous step finished leaves its accumulator (set A0: ky = 2 of the step
       // before) right before this slot's fresh product overwrites it
       if (EPI && f < NPH) finish(iy - 2, f, acc[A0][f]);
-      if (RESLD && f == NPH) load_res(iy - 1);             // the residual of the row this step finishes: a whole step of cover
       acc[A2][ph] = mfma1(Wf[2][kx][kc], Xf[f % XS], acc[A2][ph]);
       acc[A1][ph] = mfma1(Wf[1][kx][kc], Xf[f % XS], acc[A1][ph]);
       acc[A0][ph] = mfma1(Wf[0][kx][kc], Xf[f % XS], fresh ? zero : acc[A0][ph]);
@@ -362,6 +399,11 @@ __global__ void __launch_bounds__(256, 2) conv_strip_kernel(const ConvParams p, 
       if (f == 20) {
         stage_halo(hset, hok && rok, nxt);
         load_halo(iy + 4, hset);
+      }
+      if (FLUSH && (f == 5 || f == 7) && (f - 5) / 2 < NIT) flush(iy - 3, (f - 5) / 2);   // the row whose epilogue ran a step ago
+      if (f == 22) {          // the residual of the row this step finishes goes into its tile; the next row's is fetched
+        res_to_lds(iy - 1);
+        load_res(iy);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -395,21 +437,28 @@ __global__ void __launch_bounds__(256, 2) conv_strip_kernel(const ConvParams p, 
     stage_halo(firsth, hok && rok, smem_s);
   }
   __syncthreads();
-  const int nsteps = oy1 - oy0 + 2;          // >= 3
+  const int nsteps = oy1 - oy0 + 2;          // >= 5 (segments have at least 3 rows: launcher)
+  load_res(oy0);
   step(oy0 - 1, 0, R0{}, std::false_type{}, std::false_type{});
   step(oy0, 1, R1{}, std::false_type{}, std::false_type{});
-  step(oy0 + 1, 2, R2{}, std::false_type{}, std::true_type{});
-  for (int it = 3; it < nsteps; it += 3) {
-    step(oy0 - 1 + it, it, R0{}, std::true_type{}, std::true_type{});
-    if (it + 1 < nsteps) step(oy0 + it, it + 1, R1{}, std::true_type{}, std::true_type{});
-    if (it + 2 < nsteps) step(oy0 + 1 + it, it + 2, R2{}, std::true_type{}, std::true_type{});
+  step(oy0 + 1, 2, R2{}, std::false_type{}, std::false_type{});
+  step(oy0 + 2, 3, R0{}, std::true_type{}, std::false_type{});
+  for (int it = 4; it < nsteps; it += 3) {
+    step(oy0 - 1 + it, it, R1{}, std::true_type{}, std::true_type{});
+    if (it + 1 < nsteps) step(oy0 + it, it + 1, R2{}, std::true_type{}, std::true_type{});
+    if (it + 2 < nsteps) step(oy0 + 1 + it, it + 2, R0{}, std::true_type{}, std::true_type{});
   }
-  // the last row (finished by the last step, in that step's ky = 2 set; its residual was fetched there)
+  // the last two rows: row oy1 - 2 waits in its tile; row oy1 - 1 sits in the last step's ky = 2 set (its residual tile was written there)
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) flush(oy1 - 2, i);
   {
     const int last = ((nsteps - 1) % 3 + 2) % 3;
 #pragma unroll
     for (int q = 0; q < NPH; ++q) finish(oy1 - 1, q, last == 0 ? acc[0][q] : (last == 1 ? acc[1][q] : acc[2][q]));
   }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) flush(oy1 - 1, i);
 
   // ---- GroupNorm partial sums of this segment's outputs: the 16 pixel lanes of a k group fold into lane c15 == 0 ----
   if (p.part_out) {
@@ -456,7 +505,7 @@ static hipError_t launch_strip_t(const ConvParams& p, int wn_a, hipStream_t s, i
   const int stripsX = (p.Wout + Cfg::SW - 1) / Cfg::SW, segs = (p.Hout + rows - 1) / rows;
   if (tiles) *tiles = stripsX * segs;
   const dim3 grid(p.N * stripsX * segs);
-  const size_t lds = (size_t)Cfg::LDS_BYTES + 64 * Cfg::OPP;
+  const size_t lds = (size_t)Cfg::LDS_BYTES;
   if (p.res) hipLaunchKernelGGL((conv_strip_kernel<PREC, KCH, NPH, true>), grid, dim3(256), lds, s, p, rows, wn_a);
   else hipLaunchKernelGGL((conv_strip_kernel<PREC, KCH, NPH, false>), grid, dim3(256), lds, s, p, rows, wn_a);
   return hipGetLastError();
