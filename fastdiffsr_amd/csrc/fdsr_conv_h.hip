@@ -346,11 +346,13 @@ __global__ void __launch_bounds__(512, 2) conv_mfma_h_kernel(const ConvParams p)
   // (sum, sumsq): the consumer's GroupNorm statistics, reduced in a fixed order. ----
   const int co = co0 + wn * 32 + r31;
   const bool cok = co < p.Cout;
-  float add = 0.f;
-  if (cok) {
-    add = p.bias[co];
-    if (RIDER) add += p.bias_r[co];
-    if (p.temb) add += p.temb[(size_t)n * p.temb_stride + p.temb_off + co];
+  float add;
+  {   // unconditional loads (clamped channel, noise shift through a 0 / 1 factor): one round trip, not three
+    const int cs = cok ? co : 0;
+    const float* tembp = p.temb ? p.temb + (size_t)n * p.temb_stride + p.temb_off : p.bias;
+    add = p.bias[cs];
+    if (RIDER) add += p.bias_r[cs];
+    add += (p.temb ? 1.f : 0.f) * tembp[cs];
   }
   float s1 = 0.f, s2 = 0.f;
   const float winv_m = p.w_inv_scale_dev ? *p.w_inv_scale_dev : p.w_inv_scale;   // uniform: a scalar load

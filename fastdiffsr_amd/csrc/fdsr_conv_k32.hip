@@ -522,21 +522,24 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_k32_kernel(const ConvParams p
   }
 
   // ---- epilogue: lane = pixel c15 (+ 16 ph) of row wm + mb*WM, output channels cob + 16 ch + 0..3 ----
+  // bias (+ the rider's) + noise shift of this lane's output channels.  Every load is issued unconditionally (a clamped channel, the
+  // noise shift through a 0 / 1 factor): with `if (p.temb)` / `if (cok)` around them the compiler put an s_waitcnt vmcnt(0) behind each
+  // of the eight pairs -- eight exposed round trips at the end of every tile, with nothing else running on the CU.
   k_f32x4 add[2];
   bool cok[2];
+  const float* tembp = p.temb ? p.temb + (size_t)n * p.temb_stride + p.temb_off : p.bias;
+  const float tmul = p.temb ? 1.f : 0.f;
 #pragma unroll
   for (int ch = 0; ch < 2; ++ch) {
     const int co = cob + 16 * ch;
     cok[ch] = co < p.Cout;   // Cout % 4 == 0 (launcher)
-    add[ch] = k_f32x4{0.f, 0.f, 0.f, 0.f};
-    if (cok[ch]) {
+    const int cs = cok[ch] ? co : 0;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float a = p.bias[co + r];
-        if (RIDER) a += p.bias_r[co + r];
-        if (p.temb) a += p.temb[(size_t)n * p.temb_stride + p.temb_off + co + r];
-        add[ch][r] = a;
-      }
+    for (int r = 0; r < 4; ++r) {
+      float a = p.bias[cs + r];
+      if (RIDER) a += p.bias_r[cs + r];
+      a += tmul * tembp[cs + r];
+      add[ch][r] = a;
     }
   }
   const float winv_m = p.w_inv_scale_dev ? *p.w_inv_scale_dev : p.w_inv_scale;
@@ -876,19 +879,15 @@ __global__ void __launch_bounds__(512, 2) conv_up2_k32_kernel(const ConvParams p
   const float winv = p.w_inv_scale_dev ? *p.w_inv_scale_dev : p.w_inv_scale;
   k_f32x4 add[2];
   bool cok[2];
+  const float* tembp = p.temb ? p.temb + (size_t)n * p.temb_stride + p.temb_off : p.bias;   // (all loads unconditional: see conv_k32_kernel)
+  const float tmul = p.temb ? 1.f : 0.f;
 #pragma unroll
   for (int ch = 0; ch < 2; ++ch) {
     const int co = cob + 16 * ch;
     cok[ch] = co < p.Cout;
-    add[ch] = k_f32x4{0.f, 0.f, 0.f, 0.f};
-    if (cok[ch]) {
+    const int cs = cok[ch] ? co : 0;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float a = p.bias[co + r];
-        if (p.temb) a += p.temb[(size_t)n * p.temb_stride + p.temb_off + co + r];
-        add[ch][r] = a;
-      }
-    }
+    for (int r = 0; r < 4; ++r) add[ch][r] = p.bias[cs + r] + tmul * tembp[cs + r];
   }
   k_f32x4 s1[2], s2[2];
 #pragma unroll

@@ -55,7 +55,9 @@ struct StripCfg {
   static constexpr int RES_OFF = OUT_OFF + 2 * TILE_BYTES;
   static constexpr int LDS_BYTES = RES_OFF + 2 * TILE_BYTES;
   static constexpr int NIT = SW * 64 * OSZ / 16 / 256; // 16-byte units of a row tile per thread
-  static_assert(OSZ == 2, "the epilogue tiles below are laid out for bf16 rows (128 bytes per pixel)");
+  static constexpr int PB = 64 * OSZ;                  // bytes per pixel of a row tile
+  static constexpr int UPP = PB / 16;                  // 16-byte units per pixel
+  static_assert(NIT >= 1 && NIT <= 4 && 256 % UPP == 0, "row-tile map");
   static constexpr int PPP = 256 / OPP;            // pixels staged per pass
   static constexpr int NPASS = SW / PPP;
   static constexpr int NF = 3 * KCH * NPH;         // activation fragments per step
@@ -115,8 +117,8 @@ template <> struct StripRawPair<PREC_F16X3> {
 // s_waitcnt vmcnt(0) at the next use -- which here would wait for the row fetched three steps ahead.  (First versions of this
 // kernel: 46 - 63 % of the wave cycles parked.)  Hence HAS_RES as a template parameter, the peeled first steps (no epilogue yet) and
 // the halo columns split over all four waves (wave w activates slice w of both halo pixels of every row: no wave-dependent branch).
-template <int PREC, int KCH, int NPH, bool HAS_RES>
-__global__ void __launch_bounds__(256, 2) conv_strip_kernel(const ConvParams p, const int seg_rows, const int wn_a) {
+template <int PREC, int KCH, int NPH, bool HAS_RES, int LB = 2>   // LB: workgroups per CU the registers are budgeted for (256 / 512 VGPRs)
+__global__ void __launch_bounds__(256, LB) conv_strip_kernel(const ConvParams p, const int seg_rows, const int wn_a) {
   using Cfg = StripCfg<PREC, KCH, NPH>;
   constexpr int NP = Cfg::NP, RB = Cfg::RB, SW = Cfg::SW, OPP = Cfg::OPP, PPP = Cfg::PPP, NPASS = Cfg::NPASS, NF = Cfg::NF;
   constexpr int XS = STRIP_XS < NF ? STRIP_XS : NF;
@@ -296,46 +298,62 @@ __global__ void __launch_bounds__(256, 2) conv_strip_kernel(const ConvParams p, 
   // unit u ^ ((px >> 1) & 7): conflict free for the 8-byte accumulator-side accesses and the 16-byte row-side ones.
   unsigned char* otile = smem_s + Cfg::OUT_OFF;
   unsigned char* rtile = smem_s + Cfg::RES_OFF;
-  const int a64 = c15 * 128 + 16 * (((4 * w + g) >> 1) ^ ((c15 >> 1) & 7)) + 8 * (g & 1);   // + 2048 ph: quad ph of this lane
+  constexpr int PB = Cfg::PB, UPP = Cfg::UPP;
+  // 16-byte unit u of pixel px sits at unit u ^ tsw(px): conflict free for the accumulator-side accesses (8 bytes per lane in bf16,
+  // 16 in the fp32-output modes) and for the 16-byte row-side ones (replayed in tests/test_k32_maps.py)
+  auto tsw = [](int px) { return OSZ == 2 ? ((px >> 1) & 7) : 2 * (px & 7); };
+  const int aq = OSZ == 2 ? c15 * PB + 16 * (((4 * w + g) >> 1) ^ tsw(c15)) + 8 * (g & 1)      // + 16 PB ph: quad ph of this lane
+                          : c15 * PB + 16 * ((4 * w + g) ^ tsw(c15));
   int a128[NIT];
   unsigned gofs[NIT];            // byte offset of this thread's unit i inside an output row of the strip
 #pragma unroll
   for (int i = 0; i < NIT; ++i) {
-    const int px = tid / 8 + 32 * i, u = tid % 8;
-    a128[i] = px * 128 + 16 * (u ^ ((px >> 1) & 7));
-    gofs[i] = (unsigned)((ox0 + px) * 64 + 8 * u) * OSZ;
+    const int px = tid / UPP + (256 / UPP) * i, u = tid % UPP;
+    a128[i] = px * PB + 16 * (u ^ tsw(px));
+    gofs[i] = (unsigned)((ox0 + px) * PB + 16 * u);
   }
-  const size_t img = (size_t)n * H * W * 64 * OSZ;
+  const size_t img = (size_t)n * H * W * PB;
   unsigned char* outn = reinterpret_cast<unsigned char*>(p.out) + img;
   const unsigned char* resn = reinterpret_cast<const unsigned char*>(HAS_RES ? p.res : p.out) + img;
-  uint4 rres0 = {0u, 0u, 0u, 0u}, rres1 = {0u, 0u, 0u, 0u};   // (two named registers sets: an array here stayed in scratch memory)
+  const uint4 z4 = {0u, 0u, 0u, 0u};
+  uint4 rres0 = z4, rres1 = z4, rres2 = z4, rres3 = z4;   // (named register sets: an array here stayed in scratch memory)
   auto crow = [&](int oy) __attribute__((always_inline)) { return oy < oy0 ? oy0 : (oy >= oy1 ? oy1 - 1 : oy); };
   auto load_res = [&](int oy) __attribute__((always_inline)) {   // residual row oy (clamped into the segment), 16 bytes per unit
     if (HAS_RES && !(STRIP_DIAG & 1)) {
-      const unsigned r0 = (unsigned)(crow(oy) * W) * (64 * OSZ);
+      const unsigned r0 = (unsigned)(crow(oy) * W) * PB;
       rres0 = *reinterpret_cast<const uint4*>(resn + (r0 + gofs[0]));
-      if (NIT > 1) rres1 = *reinterpret_cast<const uint4*>(resn + (r0 + gofs[NIT - 1]));
+      if (NIT > 1) rres1 = *reinterpret_cast<const uint4*>(resn + (r0 + gofs[NIT > 1 ? 1 : 0]));
+      if (NIT > 2) rres2 = *reinterpret_cast<const uint4*>(resn + (r0 + gofs[NIT > 2 ? 2 : 0]));
+      if (NIT > 3) rres3 = *reinterpret_cast<const uint4*>(resn + (r0 + gofs[NIT > 3 ? 3 : 0]));
     }
   };
   auto res_to_lds = [&](int oy) __attribute__((always_inline)) {
     if (HAS_RES) {
-      *reinterpret_cast<uint4*>(rtile + (oy & 1) * TILE + a128[0]) = rres0;
-      if (NIT > 1) *reinterpret_cast<uint4*>(rtile + (oy & 1) * TILE + a128[NIT - 1]) = rres1;
+      unsigned char* t = rtile + (oy & 1) * TILE;
+      *reinterpret_cast<uint4*>(t + a128[0]) = rres0;
+      if (NIT > 1) *reinterpret_cast<uint4*>(t + a128[NIT > 1 ? 1 : 0]) = rres1;
+      if (NIT > 2) *reinterpret_cast<uint4*>(t + a128[NIT > 2 ? 2 : 0]) = rres2;
+      if (NIT > 3) *reinterpret_cast<uint4*>(t + a128[NIT > 3 ? 3 : 0]) = rres3;
     }
   };
   // one quad (pixel c15 + 16 ph of row oy, four output channels) of a finished row: residual from its tile, result into the row's tile
   auto finish = [&](int oy, int ph, s_f32x4 a) __attribute__((always_inline)) {
     s_f32x4 v = a * winv + add;
-    if (HAS_RES) v += IO::widen(*reinterpret_cast<const Quad*>(rtile + (oy & 1) * TILE + a64 + 2048 * ph));
-    typedef __bf16 b2t __attribute__((ext_vector_type(2)));
-    const b2t lo = {(__bf16)v[0], (__bf16)v[1]}, hi = {(__bf16)v[2], (__bf16)v[3]};   // one v_cvt_pk_bf16_f32 each
-    *reinterpret_cast<uint2*>(otile + (oy & 1) * TILE + a64 + 2048 * ph) = uint2{__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
+    if (HAS_RES) v += IO::widen(*reinterpret_cast<const Quad*>(rtile + (oy & 1) * TILE + aq + 16 * PB * ph));
+    unsigned char* dst = otile + (oy & 1) * TILE + aq + 16 * PB * ph;
+    if (OSZ == 2) {
+      typedef __bf16 b2t __attribute__((ext_vector_type(2)));
+      const b2t lo = {(__bf16)v[0], (__bf16)v[1]}, hi = {(__bf16)v[2], (__bf16)v[3]};   // one v_cvt_pk_bf16_f32 each
+      *reinterpret_cast<uint2*>(dst) = uint2{__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
+    } else {
+      *reinterpret_cast<s_f32x4*>(dst) = v;
+    }
     s1 += v;
     s2 += v * v;
   };
   auto flush = [&](int oy, int i) __attribute__((always_inline)) {   // unit i of row oy's tile to memory (after the barrier that followed its epilogue)
     const uint4 v = *reinterpret_cast<const uint4*>(otile + (oy & 1) * TILE + a128[i]);
-    if (!(STRIP_DIAG & 2)) *reinterpret_cast<uint4*>(outn + ((unsigned)(oy * W) * (64 * OSZ) + gofs[i])) = v;
+    if (!(STRIP_DIAG & 2)) *reinterpret_cast<uint4*>(outn + ((unsigned)(oy * W) * PB + gofs[i])) = v;
   };
 
   // ---- one step: input row iy (staged in slot `cur`) into the three accumulator sets; row iy + 1 staged into `nxt`; row iy + 4
@@ -345,7 +363,6 @@ __global__ void __launch_bounds__(256, 2) conv_strip_kernel(const ConvParams p, 
   // 4 + 4 + 1 activation slices of the next row and the four epilogue quads of the row finished last step are spread over the
   // slots, so that neither wave of a SIMD runs a long MFMA-free stretch.  EPI: the step writes a row (steps >= 3 of a segment);
   // RESLD: it fetches the residual of the row it finishes (steps >= 2).
-  static_assert(NIT <= 2, "two flush slots");
   static_assert(NPASS == 2 && NF == 24, "the slot schedule below is written for two staging passes and 24 fragments per row");
   uint4 Xf[XS][NP];
   auto mfma1 = [&](const uint4* wf, const uint4* xf, s_f32x4 c) __attribute__((always_inline)) -> s_f32x4 {
@@ -400,7 +417,10 @@ __global__ void __launch_bounds__(256, 2) conv_strip_kernel(const ConvParams p, 
         stage_halo(hset, hok && rok, nxt);
         load_halo(iy + 4, hset);
       }
-      if (FLUSH && (f == 5 || f == 7) && (f - 5) / 2 < NIT) flush(iy - 3, (f - 5) / 2);   // the row whose epilogue ran a step ago
+      if (FLUSH && f == 5) flush(iy - 3, 0);               // the row whose epilogue ran a step ago
+      if (FLUSH && f == 7 && NIT > 1) flush(iy - 3, NIT > 1 ? 1 : 0);
+      if (FLUSH && f == 9 && NIT > 2) flush(iy - 3, NIT > 2 ? 2 : 0);
+      if (FLUSH && f == 13 && NIT > 3) flush(iy - 3, NIT > 3 ? 3 : 0);
       if (f == 22) {          // the residual of the row this step finishes goes into its tile; the next row's is fetched
         res_to_lds(iy - 1);
         load_res(iy);
@@ -476,12 +496,14 @@ __global__ void __launch_bounds__(256, 2) conv_strip_kernel(const ConvParams p, 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// g_tun.strip bits: 1 bf16 launches, 2 f16x3 launches
-static int strip_seg_rows(const ConvParams& p, int SW) {
-  // strips x segments: enough workgroups for two per CU (512), segments as long as that allows (each costs two extra steps)
+// g_tun.strip bits: 1 bf16 launches (two workgroups per CU), 2 f16x3 launches (one per CU: hi / lo weight planes = 144 registers)
+static long strip_min_wgs(int prec) { return prec == PREC_BF16 ? g_tun.strip_min_wgs : g_tun.strip_min_wgs / 2; }
+
+static int strip_seg_rows(const ConvParams& p, int SW, int prec) {
+  // strips x segments: enough workgroups to fill the chip (bf16: two per CU), segments as long as that allows (each costs two extra steps)
   const long strips = (long)p.N * ((p.Wout + SW - 1) / SW);
   int rows = p.Hout;
-  while (rows > 16 && strips * ((p.Hout + rows - 1) / rows) < g_tun.strip_min_wgs) rows = (rows + 1) / 2;
+  while (rows > 16 && strips * ((p.Hout + rows - 1) / rows) < strip_min_wgs(prec)) rows = (rows + 1) / 2;
   return rows;
 }
 
@@ -489,37 +511,45 @@ bool conv_strip_ok(ConvKind kind, int prec, const ConvParams& p) {
   if (!(g_tun.strip & (prec == PREC_BF16 ? 1 : 2))) return false;
   if (kind != CONV3_S1 || p.ksplit > 1 || p.Cout != 64 || p.Cout_pad != 64) return false;
   if (p.xr0 || !p.gn_scale || p.gn_plain || p.drop_mask) return false;
-  if (p.Hin != p.Hout || p.Win != p.Wout || p.Wout % 64 || (size_t)p.Hout * p.Wout * 64 * 4 >= (1ull << 31)) return false;
+  if (p.Hin != p.Hout || p.Win != p.Wout || p.Wout % 64 || p.Hout < 3 || (size_t)p.Hout * p.Wout * 64 * 4 >= (1ull << 31)) return false;
   if (prec == PREC_BF16 && p.out_f32) return false;
   const int Cin = p.C0 + p.C1;
   if (Cin != p.Cin_pad || Cin != 64) return false;
   if (p.C0 % 8 || p.C1 % 8) return false;
   const long wgs = (long)p.N * ((p.Wout + 63) / 64) * ((p.Hout + 15) / 16);
-  return wgs >= g_tun.strip_min_wgs;   // (a small grid keeps the split-K tile kernels)
+  return wgs >= strip_min_wgs(prec);   // (a small grid keeps the split-K tile kernels)
 }
 
-template <int PREC, int KCH, int NPH>
+template <int PREC, int KCH, int NPH, int LB>
 static hipError_t launch_strip_t(const ConvParams& p, int wn_a, hipStream_t s, int* tiles) {
   using Cfg = StripCfg<PREC, KCH, NPH>;
-  const int rows = strip_seg_rows(p, Cfg::SW);
+  const int rows = strip_seg_rows(p, Cfg::SW, PREC);
   const int stripsX = (p.Wout + Cfg::SW - 1) / Cfg::SW, segs = (p.Hout + rows - 1) / rows;
   if (tiles) *tiles = stripsX * segs;
   const dim3 grid(p.N * stripsX * segs);
   const size_t lds = (size_t)Cfg::LDS_BYTES;
-  if (p.res) hipLaunchKernelGGL((conv_strip_kernel<PREC, KCH, NPH, true>), grid, dim3(256), lds, s, p, rows, wn_a);
-  else hipLaunchKernelGGL((conv_strip_kernel<PREC, KCH, NPH, false>), grid, dim3(256), lds, s, p, rows, wn_a);
+  if (p.res) hipLaunchKernelGGL((conv_strip_kernel<PREC, KCH, NPH, true, LB>), grid, dim3(256), lds, s, p, rows, wn_a);
+  else hipLaunchKernelGGL((conv_strip_kernel<PREC, KCH, NPH, false, LB>), grid, dim3(256), lds, s, p, rows, wn_a);
   return hipGetLastError();
 }
 
 hipError_t launch_conv_strip(int prec, const ConvParams& p, int wn_a, hipStream_t s, int* tiles) {
-  if (prec == PREC_BF16) return launch_strip_t<PREC_BF16, 2, 4>(p, wn_a, s, tiles);
+  if (prec == PREC_BF16) return launch_strip_t<PREC_BF16, 2, 4, 2>(p, wn_a, s, tiles);
+  if (prec == PREC_F16X3) return launch_strip_t<PREC_F16X3, 2, 4, 1>(p, wn_a, s, tiles);
   return hipErrorInvalidValue;
 }
 
-hipError_t kernels_strip_init() {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_strip_kernel<PREC_BF16, 2, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+template <int PREC, int KCH, int NPH, int LB>
+static hipError_t init_strip_t() {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_strip_kernel<PREC, KCH, NPH, false, LB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e != hipSuccess) return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(conv_strip_kernel<PREC_BF16, 2, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(conv_strip_kernel<PREC, KCH, NPH, true, LB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+hipError_t kernels_strip_init() {
+  hipError_t e = init_strip_t<PREC_BF16, 2, 4, 2>();
+  if (e != hipSuccess) return e;
+  return init_strip_t<PREC_F16X3, 2, 4, 1>();
 }
 
 }  // namespace fdsr

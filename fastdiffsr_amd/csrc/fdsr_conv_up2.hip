@@ -188,10 +188,11 @@ __global__ void __launch_bounds__(512, 2) conv_up2_h_kernel(const ConvParams p) 
   const int co = co0 + wn * 32 + r31;
   const bool cok = co < p.Cout;
   const float winv = p.w_inv_scale_dev ? *p.w_inv_scale_dev : p.w_inv_scale;   // device value: forms re-packed after optimiser steps
-  float add = 0.f;
-  if (cok) {
-    add = p.bias[co];
-    if (p.temb) add += p.temb[(size_t)n * p.temb_stride + p.temb_off + co];
+  float add;
+  {   // unconditional loads (clamped channel, noise shift through a 0 / 1 factor)
+    const int cs = cok ? co : 0;
+    const float* tembp = p.temb ? p.temb + (size_t)n * p.temb_stride + p.temb_off : p.bias;
+    add = p.bias[cs] + (p.temb ? 1.f : 0.f) * tembp[cs];
   }
   float s1 = 0.f, s2 = 0.f;
   const bool interior = (oy0 + TH <= p.Hin) && (ox0 + TW <= p.Win) && (co0 + BN <= p.Cout);

@@ -13,7 +13,7 @@ from fastdiffsr_amd.schedule import schedule_buffers, sampling_scalars
 
 pytestmark = pytest.mark.gpu
 TOL_FWD, TOL_LOOP = 1e-4, 1e-3
-PRECS = ['bf16']
+PRECS = ['bf16', 'f16x3']
 
 
 @pytest.fixture(scope='module')
