@@ -26,8 +26,19 @@
 namespace fdsr {
 
 typedef float s_f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned s_u32x4 __attribute__((ext_vector_type(4)));   // (native vectors: arrays of HIP's uint4 struct were left in scratch memory)
 typedef _Float16 s_h8 __attribute__((ext_vector_type(8)));
 typedef __bf16 s_b8 __attribute__((ext_vector_type(8)));
+
+// compile-time loop: f(integral_constant<int, I>) for I in [I0, N) -- the step's slots and items are indexed by true constants (a
+// `#pragma unroll` over them gave up on the larger instantiations and left the weight fragments in scratch memory)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
 
 __device__ __forceinline__ float silu_s(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
@@ -41,43 +52,67 @@ __device__ __forceinline__ float silu_s(float v) { return v * __builtin_amdgcn_r
 #define STRIP_PIN 1
 #endif
 
-template <int PREC, int KCH, int NPH>
+// One instantiation = (arithmetic, channels of the two concatenated input tensors C0 | C1, channels of the rider's two raw input
+// tensors CR0 | CR1 or 0, 16-pixel blocks per strip row).  SW = 64 pixels: a staging pass of the 256 threads covers 32 channels of
+// the row, so a tensor of C channels takes C / 32 passes.
+template <int PREC, int C0_, int C1_, int CR0_, int CR1_, int NPH>
 struct StripCfg {
   static constexpr int NP = PREC == PREC_F16X3 ? 2 : 1;
-  static constexpr int CIN = 32 * KCH, SW = 16 * NPH, HWD = SW + 2;
+  static constexpr int ESZ = PREC == PREC_BF16 ? 2 : 4;   // bytes per activation element in HBM
+  static constexpr int C0 = C0_, C1 = C1_, CIN = C0_ + C1_, KCH = CIN / 32, SW = 16 * NPH, HWD = SW + 2;
   static constexpr int OPP = CIN / 8;              // 8-channel units ("octs") per pixel and plane
   static constexpr int RB = 16 * OPP * NP;         // LDS bytes per staged pixel: [plane][oct] x 16 B, swizzled
   static constexpr int SLOT_BYTES = HWD * RB;
-  static constexpr int GTAB_OFF = 2 * SLOT_BYTES;      // GroupNorm table: 64 OPP bytes
+  static constexpr int NP0 = C0_ / 32, NP1 = C1_ / 32, NPM = NP0 + NP1;   // staging passes of the two input tensors
+  static constexpr int NF = 3 * KCH * NPH;         // activation fragments per step (three MFMAs each)
+  // rider: a 1x1 convolution over a second, raw input (the ResnetBlock's res_conv, unet.py:104-120) accumulated into the same rows
+  static constexpr int CR0 = CR0_, CR1 = CR1_, CR = CR0_ + CR1_, KCR = CR / 32;
+  static constexpr int RRB = CR * 2;               // bytes per pixel of a staged rider row (bf16 only, one plane, no halo)
+  static constexpr int RSLOT_BYTES = SW * RRB;
+  static constexpr int NR0 = CR0_ / 32, NR1 = CR1_ / 32, NPR = NR0 + NR1;
+  static constexpr int NFR = KCR * NPH;            // rider fragments per step (one MFMA each)
+  static constexpr int NT = NF + NFR;              // slots per step
+  // LDS: two activation row slots | two rider row slots | GroupNorm table | two output-row tiles | two residual-row tiles
+  static constexpr int RSLOT_OFF = 2 * SLOT_BYTES;
+  static constexpr int GTAB_OFF = RSLOT_OFF + 2 * RSLOT_BYTES;
   static constexpr int OSZ = PREC == PREC_BF16 ? 2 : 4;   // bytes per output / residual element
-  static constexpr int TILE_BYTES = SW * 64 * OSZ;     // one output (or residual) row of the strip, [pixel][64 couts], 16-byte units swizzled
-  static constexpr int OUT_OFF = GTAB_OFF + 64 * OPP;  // two output-row tiles, then two residual-row tiles
-  static constexpr int RES_OFF = OUT_OFF + 2 * TILE_BYTES;
-  static constexpr int LDS_BYTES = RES_OFF + 2 * TILE_BYTES;
-  static constexpr int NIT = SW * 64 * OSZ / 16 / 256; // 16-byte units of a row tile per thread
   static constexpr int PB = 64 * OSZ;                  // bytes per pixel of a row tile
   static constexpr int UPP = PB / 16;                  // 16-byte units per pixel
+  static constexpr int TILE_BYTES = SW * PB;           // one output (or residual) row of the strip, [pixel][64 couts], 16-byte units swizzled
+  static constexpr int OUT_OFF = GTAB_OFF + 64 * OPP;
+  static constexpr int RES_OFF = OUT_OFF + 2 * TILE_BYTES;
+  static constexpr int NIT = SW * PB / 16 / 256;       // 16-byte units of a row tile per thread
+  static_assert(NPH == 4, "a staging pass = 32 channels of a 64-pixel row");
+  static_assert(C0_ % 32 == 0 && C1_ % 32 == 0 && CR0_ % 32 == 0 && CR1_ % 32 == 0 && C0_ > 0, "whole 32-channel chunks");
+  static_assert(256 % (C0_ / 8) == 0 && (C1_ == 0 || 256 % (C1_ / 8) == 0) && (CR0_ == 0 || 256 % (CR0_ / 8) == 0) &&
+                (CR1_ == 0 || 256 % (CR1_ / 8) == 0), "a thread keeps one oct index per tensor");
+  static_assert(RB == 128 || RB == 256 || RB == 384 || RB == 512, "swizzles below are verified for these pixel strides");
+  static_assert(CR == 0 || (PREC == PREC_BF16 && (RRB == 256 || RRB == 384)), "riders: bf16 only (one weight scale)");
   static_assert(NIT >= 1 && NIT <= 4 && 256 % UPP == 0, "row-tile map");
-  static constexpr int PPP = 256 / OPP;            // pixels staged per pass
-  static constexpr int NPASS = SW / PPP;
-  static constexpr int NF = 3 * KCH * NPH;         // activation fragments per step
-  static_assert(256 % OPP == 0 && SW % PPP == 0 && 64 % OPP == 0, "staging map");
-  static_assert(RB == 128 || RB == 256 || RB == 512, "swizzles below are verified for these pixel strides");
-  static_assert(SLOT_BYTES + 16 * (NPH - 1) * RB < 65536, "fragment offsets must fit the ds_read immediate");
+  static_assert(SLOT_BYTES + 16 * (NPH - 1) * RB < 65536 && RSLOT_BYTES < 65536, "fragment offsets must fit the ds_read immediate");
+  // ---- the step's schedule: which item of vector work sits behind which slot's MFMAs ----
+  // items 0 .. NIT-1: a flush unit; then per main pass 5 (four activation slices, write + re-fetch); a halo item per input tensor;
+  // a write + re-fetch per rider pass; the residual item.  Spread evenly over the slots behind the epilogue quads (slots 0 .. NPH-1).
+  static constexpr int NITEMS = NIT + 5 * NPM + (C1_ ? 2 : 1) + NPR + 1;
+  static constexpr int slot_of(int j) { return NPH + (j * (NT - NPH)) / NITEMS; }
+  static constexpr int first_item(int f) {       // the first item whose slot is >= f (items of slot f: [first_item(f), first_item(f + 1)))
+    int j = 0;
+    while (j < NITEMS && slot_of(j) < f) ++j;
+    return j;
+  }
 };
 
 // 16-byte unit XOR of a staged pixel (conflict-free ds_read_b128 / ds_write_b128 on the instruction's lane groups for all three
 // kx shifts; replayed lane by lane in tests/test_k32_maps.py)
 template <int RB>
 __device__ __forceinline__ int strip_swz(int px) {
-  return RB == 128 ? 2 * ((px >> 1) & 3) : 2 * (px & 7);
+  return (RB == 128 || RB == 384) ? 2 * ((px >> 1) & 3) : 2 * (px & 7);
 }
 
 // what a thread fetches of one input row: an oct (eight channels of one pixel) per staging pass, two channels of a halo pixel
 template <int PREC> struct StripRaw;
 template <> struct StripRaw<PREC_BF16> {
   uint4 v;
-  static constexpr int ESZ = 2;
   __device__ __forceinline__ void load(const unsigned char* ptr) { v = *reinterpret_cast<const uint4*>(ptr); }
   __device__ __forceinline__ void pair(int k, float& a, float& b) const {
     const unsigned u = k == 0 ? v.x : (k == 1 ? v.y : (k == 2 ? v.z : v.w));
@@ -87,7 +122,6 @@ template <> struct StripRaw<PREC_BF16> {
 };
 template <> struct StripRaw<PREC_F16X3> {
   s_f32x4 a4, b4;
-  static constexpr int ESZ = 4;
   __device__ __forceinline__ void load(const unsigned char* ptr) {
     a4 = *reinterpret_cast<const s_f32x4*>(ptr);
     b4 = *reinterpret_cast<const s_f32x4*>(ptr + 16);
@@ -117,18 +151,19 @@ template <> struct StripRawPair<PREC_F16X3> {
 // s_waitcnt vmcnt(0) at the next use -- which here would wait for the row fetched three steps ahead.  (First versions of this
 // kernel: 46 - 63 % of the wave cycles parked.)  Hence HAS_RES as a template parameter, the peeled first steps (no epilogue yet) and
 // the halo columns split over all four waves (wave w activates slice w of both halo pixels of every row: no wave-dependent branch).
-template <int PREC, int KCH, int NPH, bool HAS_RES, int LB = 2>   // LB: workgroups per CU the registers are budgeted for (256 / 512 VGPRs)
+template <int PREC, int C0_, int C1_, int CR0_, int CR1_, int NPH, bool HAS_RES, int LB>   // LB: workgroups per CU the registers are budgeted for (256 / 512 VGPRs)
 __global__ void __launch_bounds__(256, LB) conv_strip_kernel(const ConvParams p, const int seg_rows, const int wn_a) {
-  using Cfg = StripCfg<PREC, KCH, NPH>;
-  constexpr int NP = Cfg::NP, RB = Cfg::RB, SW = Cfg::SW, OPP = Cfg::OPP, PPP = Cfg::PPP, NPASS = Cfg::NPASS, NF = Cfg::NF;
+  using Cfg = StripCfg<PREC, C0_, C1_, CR0_, CR1_, NPH>;
+  constexpr int NP = Cfg::NP, RB = Cfg::RB, SW = Cfg::SW, OPP = Cfg::OPP, KCH = Cfg::KCH, NF = Cfg::NF, ESZ = Cfg::ESZ;
+  constexpr int NP0 = Cfg::NP0, NP1 = Cfg::NP1, NPM = Cfg::NPM, KCR = Cfg::KCR, NPR = Cfg::NPR, NR0 = Cfg::NR0, NFR = Cfg::NFR, NT = Cfg::NT;
+  constexpr int RRB = Cfg::RRB;
+  constexpr bool CAT = C1_ > 0, RIDER = Cfg::CR > 0;
   constexpr int XS = STRIP_XS < NF ? STRIP_XS : NF;
-  constexpr int ESZ = StripRaw<PREC>::ESZ;
   using IO = ActIO<PREC>;
   typedef typename IO::Quad Quad;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_s[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c15 = lane & 15, g = lane >> 4;
-  const int Cin = p.C0 + p.C1;
   const int H = p.Hout, W = p.Wout;          // stride 1, padding 1: the input has the output's size (launcher)
 
   const int stripsX = W / SW, segs = (H + seg_rows - 1) / seg_rows;
@@ -145,56 +180,86 @@ __global__ void __launch_bounds__(256, LB) conv_strip_kernel(const ConvParams p,
   const int ox0 = sx * SW, oy0 = seg * seg_rows;
   const int oy1 = oy0 + seg_rows < H ? oy0 + seg_rows : H;   // this segment's output rows [oy0, oy1)
 
-  // ---- staging identity: thread -> (oct o of the input channels, pixel pp + i PPP of the strip row) ----
-  const int o = tid % OPP, pp = tid / OPP;
-  const unsigned char* tb;     // this thread's channels of pixel (0, 0) of image n
-  unsigned pixb;               // bytes per pixel of the tensor it reads
-  if (8 * o < p.C0) {
-    tb = reinterpret_cast<const unsigned char*>(p.x0) + ((size_t)n * H * W * p.C0 + 8 * o) * ESZ;
-    pixb = p.C0 * ESZ;
-  } else {
-    tb = reinterpret_cast<const unsigned char*>(p.x1) + ((size_t)n * H * W * p.C1 + 8 * o - p.C0) * ESZ;
-    pixb = p.C1 * ESZ;
-  }
+  // ---- staging identity per input tensor t (0: x0, 1: x1): thread -> oct ot[t] of that tensor's channels, pixel ppx[t] + i PPP[t] ----
+  constexpr int OPPt[2] = {C0_ / 8, CAT ? C1_ / 8 : 1};
+  const unsigned char* tb[2];      // this thread's channels of pixel (0, 0) of image n in tensor t
+  int ot[2], ppx[2], og[2];        // og: the oct's index in the concatenated pixel row (GroupNorm table, LDS unit)
+  ot[0] = tid % OPPt[0]; ppx[0] = tid / OPPt[0]; og[0] = ot[0];
+  tb[0] = reinterpret_cast<const unsigned char*>(p.x0) + ((size_t)n * H * W * C0_ + 8 * ot[0]) * ESZ;
+  if (CAT) {
+    ot[1] = tid % OPPt[1]; ppx[1] = tid / OPPt[1]; og[1] = C0_ / 8 + ot[1];
+    tb[1] = reinterpret_cast<const unsigned char*>(p.x1) + ((size_t)n * H * W * C1_ + 8 * ot[1]) * ESZ;
+  } else { ot[1] = 0; ppx[1] = 0; og[1] = 0; tb[1] = tb[0]; }
+  constexpr unsigned PIXB[2] = {C0_ * ESZ, (CAT ? C1_ : C0_) * ESZ};   // bytes per pixel of tensor t
   // GroupNorm scale / shift of image n as an LDS table [oct][slice] x (sc0, sc1, sh0, sh1): an activation slice reads its four values
   // when it runs instead of holding sixteen registers for the whole strip
   float* gtab = reinterpret_cast<float*>(smem_s + Cfg::GTAB_OFF);
   if (tid < 4 * OPP) {
     const int c = 8 * (tid >> 2) + 2 * (tid & 3);
-    const float* ps = p.gn_scale + (size_t)n * Cin + c;
-    const float* ph = p.gn_shift + (size_t)n * Cin + c;
+    const float* ps = p.gn_scale + (size_t)n * Cfg::CIN + c;
+    const float* ph = p.gn_shift + (size_t)n * Cfg::CIN + c;
     *reinterpret_cast<s_f32x4*>(gtab + 4 * tid) = s_f32x4{ps[0], ps[1], ph[0], ph[1]};
   }
   __syncthreads();
-  const float* gmine = gtab + 16 * o;
-  // the two halo columns of a row (2 OPP octs): wave w activates slice w (channels 2 w, 2 w + 1 of every oct) of both, lane hl =
-  // lane % (2 OPP) -> (column hl / OPP, oct hl % OPP == o); the other lanes of the wave repeat them (same address, same value)
-  const int hside = ((lane % (2 * OPP)) / OPP) & 1;
-  const int hix = hside ? ox0 + SW : ox0 - 1;
-  const bool hok = hix >= 0 && hix < W;
-  const unsigned hcol = (unsigned)(hok ? hix : ox0) * pixb + 2 * w * ESZ;
-  const int hpx = hside ? SW + 1 : 0;
-  const int hdst = hpx * RB + 16 * (o ^ strip_swz<RB>(hpx)) + 4 * w;   // (the lo plane: ^ 16 OPP)
+  // the two halo columns of a row (2 OPPt octs per tensor): wave w activates slice w (channels 2 w, 2 w + 1 of every oct) of both, lane
+  // hl = lane % (2 OPPt) -> (column hl / OPPt, oct hl % OPPt == ot); the other lanes of the wave repeat them (same address, same value)
+  int hdst[2];
+  unsigned hcol[2];
+  bool hok[2];
+#pragma unroll
+  for (int t = 0; t < (CAT ? 2 : 1); ++t) {
+    const int hside = ((lane % (2 * OPPt[t])) / OPPt[t]) & 1;
+    const int hix = hside ? ox0 + SW : ox0 - 1;
+    hok[t] = hix >= 0 && hix < W;
+    hcol[t] = (unsigned)(hok[t] ? hix : ox0) * PIXB[t] + 2 * w * ESZ;
+    const int hpx = hside ? SW + 1 : 0;
+    hdst[t] = hpx * RB + 16 * (og[t] ^ strip_swz<RB>(hpx)) + 4 * w;   // (the lo plane: ^ 16 OPP)
+  }
 
-  StripRaw<PREC> raw[3][NPASS];      // three rows in flight: set = (row's step) % 3
-  StripRawPair<PREC> rawh[3];
+  StripRaw<PREC> raw[3][NPM];        // three rows in flight: set = (row's step) % 3; passes of tensor 0, then of tensor 1
+  StripRawPair<PREC> rawh[3][CAT ? 2 : 1];
+  s_u32x4 rraw[3][RIDER ? NPR : 1];    // the rider's raw row, 16 bytes per pass
   // Row iy of the input, re-fetched into the register set of the row just staged (the row three steps on): the strip reads every
   // input byte exactly once, so its loads are bound by what is in flight per CU.  Rows outside the image or past the segment are
   // fetched from a clamped row (cache hits) and zeroed when staged.
-  auto row_off = [&](int iy) __attribute__((always_inline)) {
+  auto crow_in = [&](int iy) __attribute__((always_inline)) {
     const int hi = oy1 < H - 1 ? oy1 : H - 1;
-    const int r = iy < 0 ? 0 : (iy > hi ? hi : iy);
-    return (unsigned)(r * W) * pixb;
+    return iy < 0 ? 0 : (iy > hi ? hi : iy);
   };
-  auto load_pass = [&](int iy, StripRaw<PREC>* set, int i) __attribute__((always_inline)) {
-    set[i].load(tb + (row_off(iy) + (unsigned)(ox0 + pp + i * PPP) * pixb));
+  auto load_pass = [&](int iy, StripRaw<PREC>* set, int q) __attribute__((always_inline)) {   // pass q: tensor 0's NP0 passes, then tensor 1's
+    const int t = q < NP0 ? 0 : 1, i = q < NP0 ? q : q - NP0;
+    set[q].load(tb[t] + ((unsigned)(crow_in(iy) * W) + (unsigned)(ox0 + ppx[t] + i * (256 / OPPt[t]))) * PIXB[t]);
   };
-  auto load_halo = [&](int iy, StripRawPair<PREC>& d) __attribute__((always_inline)) { d.load(tb + (row_off(iy) + hcol)); };
+  auto load_halo = [&](int iy, StripRawPair<PREC>* set, int t) __attribute__((always_inline)) {
+    set[t].load(tb[t] + ((unsigned)(crow_in(iy) * W) * PIXB[t] + hcol[t]));
+  };
+  // rider rows (raw, no halo: a 1x1 convolution): pass r = 32 channels of the 64-pixel row, tensor xr0's passes first
+  constexpr int OPRt[2] = {RIDER ? CR0_ / 8 : 1, RIDER && CR1_ ? CR1_ / 8 : 1};
+  const unsigned char* rb[2] = {nullptr, nullptr};
+  int rdst[RIDER ? NPR : 1];
+  unsigned rsrc[RIDER ? NPR : 1];
+  if (RIDER) {
+#pragma unroll
+    for (int r = 0; r < NPR; ++r) {
+      const int t = r < NR0 ? 0 : 1, i = r < NR0 ? r : r - NR0;
+      const int o = tid % OPRt[t], px = tid / OPRt[t] + i * (256 / OPRt[t]);
+      const int ogr = (t ? CR0_ / 8 : 0) + o;
+      rdst[r] = px * RRB + 16 * (ogr ^ strip_swz<RRB>(px));
+      rsrc[r] = (unsigned)(ox0 + px) * (unsigned)((t ? CR1_ : CR0_) * 2) + 16 * o;
+    }
+    rb[0] = reinterpret_cast<const unsigned char*>(p.xr0) + (size_t)n * H * W * CR0_ * 2;
+    rb[1] = CR1_ ? reinterpret_cast<const unsigned char*>(p.xr1) + (size_t)n * H * W * CR1_ * 2 : rb[0];
+  }
+  auto load_rider = [&](int iy, s_u32x4* set, int r) __attribute__((always_inline)) {
+    const int t = r < NR0 ? 0 : 1;
+    const int hi = oy1 - 1, rr = iy < oy0 ? oy0 : (iy > hi ? hi : iy);      // (rider rows are the segment's output rows)
+    set[r] = *reinterpret_cast<const s_u32x4*>(rb[t] + ((unsigned)(rr * W) * (unsigned)((t ? CR1_ : CR0_) * 2) + rsrc[r]));
+  };
   // GroupNorm apply + Swish (unet.py:89-101) + conversion, in SLICES of two channels (a slice is what the step schedule below places
   // between two MFMAs); a finished oct is written to its swizzled unit(s) of the slot
   struct Staged { unsigned hi[4]; unsigned lo[PREC == PREC_F16X3 ? 4 : 1]; };
-  auto act_pair = [&](float a, float b, int k, unsigned& hi, unsigned& lo) __attribute__((always_inline)) {
-    const s_f32x4 gt = *reinterpret_cast<const s_f32x4*>(gmine + 4 * k);
+  auto act_pair = [&](float a, float b, const float* gt4, unsigned& hi, unsigned& lo) __attribute__((always_inline)) {
+    const s_f32x4 gt = *reinterpret_cast<const s_f32x4*>(gt4);
     if (STRIP_DIAG & 4) {
       a = a * gt[0] + gt[2];
       b = b * gt[1] + gt[3];
@@ -216,10 +281,10 @@ __global__ void __launch_bounds__(256, LB) conv_strip_kernel(const ConvParams p,
       hi = __builtin_bit_cast(unsigned, h);
     }
   };
-  auto act_slice = [&](const StripRaw<PREC>& r, Staged& d, int k) __attribute__((always_inline)) {
+  auto act_slice = [&](const StripRaw<PREC>& r, Staged& d, int t, int k) __attribute__((always_inline)) {
     float a, b;
     r.pair(k, a, b);
-    act_pair(a, b, k, d.hi[k], d.lo[PREC == PREC_F16X3 ? k : 0]);
+    act_pair(a, b, gtab + 16 * og[t] + 4 * k, d.hi[k], d.lo[PREC == PREC_F16X3 ? k : 0]);
   };
   auto write_oct = [&](const Staged& d, bool ok, unsigned char* slot, int dofs) __attribute__((always_inline)) {
     const uint4 z = {0u, 0u, 0u, 0u};             // zero padding: rows outside the image
@@ -227,24 +292,26 @@ __global__ void __launch_bounds__(256, LB) conv_strip_kernel(const ConvParams p,
     if (PREC == PREC_F16X3)
       *reinterpret_cast<uint4*>(slot + (dofs ^ (16 * OPP))) = ok ? uint4{d.lo[0], d.lo[1], d.lo[2], d.lo[3]} : z;   // unit + OPP: the lo plane
   };
-  auto stage_halo = [&](const StripRawPair<PREC>& r, bool ok, unsigned char* slot) __attribute__((always_inline)) {
+  auto stage_halo = [&](const StripRawPair<PREC>& r, int t, bool ok, unsigned char* slot) __attribute__((always_inline)) {
     float a, b;
     r.pair(a, b);
     unsigned hi, lo = 0;
-    act_pair(a, b, w, hi, lo);
-    *reinterpret_cast<unsigned*>(slot + hdst) = ok ? hi : 0u;
-    if (PREC == PREC_F16X3) *reinterpret_cast<unsigned*>(slot + (hdst ^ (16 * OPP))) = ok ? lo : 0u;
+    act_pair(a, b, gtab + 16 * og[t] + 4 * w, hi, lo);
+    *reinterpret_cast<unsigned*>(slot + hdst[t]) = ok ? hi : 0u;
+    if (PREC == PREC_F16X3) *reinterpret_cast<unsigned*>(slot + (hdst[t] ^ (16 * OPP))) = ok ? lo : 0u;
   };
-  int pdst[NPASS];
+  int pdst[NPM];
 #pragma unroll
-  for (int i = 0; i < NPASS; ++i) {
-    const int px = 1 + pp + i * PPP;
-    pdst[i] = px * RB + 16 * (o ^ strip_swz<RB>(px));
+  for (int q = 0; q < NPM; ++q) {
+    const int t = q < NP0 ? 0 : 1, i = q < NP0 ? q : q - NP0;
+    const int px = 1 + ppx[t] + i * (256 / OPPt[t]);
+    pdst[q] = px * RB + 16 * (og[t] ^ strip_swz<RB>(px));
   }
-  Staged stg[NPASS];
+  Staged stg;          // (one oct is in the making at a time: the schedule finishes a pass's four slices and its write before the next)
 
   // ---- weight fragments, resident: [ky][kx][32-channel chunk][plane]; lane (g, c15) = cout 16 w + c15, channels 32 kc + 8 g .. + 7 ----
   uint4 Wf[3][3][KCH][NP];
+  uint4 Wr[RIDER ? KCR : 1];
   {
     const uint4* wq = reinterpret_cast<const uint4*>(p.wq);
     const int nk16 = p.Cin_pad / 16, co32 = w >> 1, cot = co32 / wn_a, wna = co32 % wn_a;
@@ -257,6 +324,11 @@ __global__ void __launch_bounds__(256, LB) conv_strip_kernel(const ConvParams p,
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl) Wf[tap / 3][tap % 3][kc][pl] = src[pl * 64];
       }
+    if (RIDER) {   // the 1x1 conv's own fragments [cot][kc16][wn] (one tap)
+      const uint4* wr = reinterpret_cast<const uint4*>(p.wq_r);
+#pragma unroll
+      for (int kc = 0; kc < KCR; ++kc) Wr[kc] = wr[(((size_t)cot * p.nkr + 2 * kc + (g >> 1)) * wn_a + wna) * (NP * 64) + wlane];
+    }
   }
 
   // ---- activation fragment addresses inside a slot: lane -> pixel c15 + kx (+ 16 ph), channels 32 kc + 8 g .. + 7 ----
@@ -270,6 +342,11 @@ __global__ void __launch_bounds__(256, LB) conv_strip_kernel(const ConvParams p,
         const int px = c15 + kx;
         xa[kx][kc][pl] = px * RB + 16 * ((pl * OPP + 4 * kc + g) ^ strip_swz<RB>(px));
       }
+  int xr[RIDER ? KCR : 1];     // rider fragments: pixel c15 (+ 16 ph) of the rider row, channels 32 kc + 8 g .. + 7
+  if (RIDER) {
+#pragma unroll
+    for (int kc = 0; kc < KCR; ++kc) xr[kc] = c15 * RRB + 16 * ((4 * kc + g) ^ strip_swz<RRB>(c15));
+  }
 
   s_f32x4 acc[3][NPH];
 #pragma unroll
@@ -280,11 +357,15 @@ __global__ void __launch_bounds__(256, LB) conv_strip_kernel(const ConvParams p,
   // ---- epilogue: lane = pixel c15 (+ 16 ph) of the row, output channels cob .. cob + 3 ----
   const int cob = 16 * w + 4 * g;
   s_f32x4 add;
+  {
+    const float* tembp = p.temb ? p.temb + (size_t)n * p.temb_stride + p.temb_off : p.bias;   // (unconditional loads)
+    const float tmul = p.temb ? 1.f : 0.f;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    float a = p.bias[cob + r];
-    if (p.temb) a += p.temb[(size_t)n * p.temb_stride + p.temb_off + cob + r];
-    add[r] = a;
+    for (int r = 0; r < 4; ++r) {
+      float a = p.bias[cob + r];
+      if (RIDER) a += p.bias_r[cob + r];
+      add[r] = a + tmul * tembp[cob + r];
+    }
   }
   const float winv = p.w_inv_scale_dev ? *p.w_inv_scale_dev : p.w_inv_scale;
   constexpr int OSZ = Cfg::OSZ, NIT = Cfg::NIT, TILE = Cfg::TILE_BYTES;
@@ -292,10 +373,9 @@ __global__ void __launch_bounds__(256, LB) conv_strip_kernel(const ConvParams p,
   // The finished row leaves through LDS: a wave owns 16 of the 64 output channels, so its accumulator layout reaches memory in
   // 32-byte pieces (bf16) -- and the residual arrives in the same pieces.  Measured at B = 64: the residual launches took 400 us
   // against 300 us with EITHER their residual loads OR their stores left out, at exactly the algorithmic HBM traffic: the load /
-  // store path was bound by the number of requests, not by bytes.  So: the accumulator lanes write their quads (8 bytes) into a
+  // store path was bound by the number of requests, not by bytes.  So: the accumulator lanes write their quads into a
   // [pixel][64 couts] row tile, and after the step's barrier every thread moves NIT whole 16-byte units of it (a pixel's 128 bytes =
-  // 8 consecutive threads); the residual row comes the same way in reverse, two steps ahead.  16-byte unit u of pixel px sits at
-  // unit u ^ ((px >> 1) & 7): conflict free for the 8-byte accumulator-side accesses and the 16-byte row-side ones.
+  // 8 consecutive threads); the residual row comes the same way in reverse, two steps ahead.
   unsigned char* otile = smem_s + Cfg::OUT_OFF;
   unsigned char* rtile = smem_s + Cfg::RES_OFF;
   constexpr int PB = Cfg::PB, UPP = Cfg::UPP;
@@ -357,13 +437,12 @@ __global__ void __launch_bounds__(256, LB) conv_strip_kernel(const ConvParams p,
   };
 
   // ---- one step: input row iy (staged in slot `cur`) into the three accumulator sets; row iy + 1 staged into `nxt`; row iy + 4
-  // fetched; output row iy - 2 (finished by the step before) written.  ROT = step % 3 names the accumulator sets and the raw
-  // register sets statically: ky = 0 -> (ROT + 1) % 3 (a fresh row), ky = 1 -> ROT, ky = 2 -> (ROT + 2) % 3.
-  // The step is NF slots of [next fragment read | three MFMAs (ky = 2, 1, 0 on one fragment) | ONE item of vector work], fenced: the
-  // 4 + 4 + 1 activation slices of the next row and the four epilogue quads of the row finished last step are spread over the
-  // slots, so that neither wave of a SIMD runs a long MFMA-free stretch.  EPI: the step writes a row (steps >= 3 of a segment);
-  // RESLD: it fetches the residual of the row it finishes (steps >= 2).
-  static_assert(NPASS == 2 && NF == 24, "the slot schedule below is written for two staging passes and 24 fragments per row");
+  // fetched; output row iy - 2 (finished by the step before) leaves its accumulators.  ROT = step % 3 names the accumulator sets and
+  // the raw register sets statically: ky = 0 -> (ROT + 1) % 3 (a fresh row), ky = 1 -> ROT, ky = 2 -> (ROT + 2) % 3.
+  // The step is NT slots of [next fragment read | the fragment's MFMAs (ky = 2, 1, 0; a rider fragment: one) | its items of vector
+  // work], fenced: the activation slices of the next row, the epilogue quads of the row finished last step, the row tiles' traffic are
+  // spread over the slots (Cfg::slot_of), so that no wave runs a long MFMA-free stretch.  EPI: the step runs the epilogue of a row
+  // (steps >= 3 of a segment); FLUSH: it moves a row's tile to memory (steps >= 4).
   uint4 Xf[XS][NP];
   auto mfma1 = [&](const uint4* wf, const uint4* xf, s_f32x4 c) __attribute__((always_inline)) -> s_f32x4 {
     if (PREC == PREC_F16X3) {   // small terms first: lo(x) hi(w), hi(x) lo(w), hi(x) hi(w)
@@ -378,55 +457,72 @@ __global__ void __launch_bounds__(256, LB) conv_strip_kernel(const ConvParams p,
     constexpr bool EPI = decltype(epi_tag)::value, FLUSH = decltype(flush_tag)::value;
     constexpr int A0 = (ROT + 1) % 3, A1 = ROT, A2 = (ROT + 2) % 3;
     StripRaw<PREC>* rset = raw[(ROT + 1) % 3];             // holds row iy + 1; re-filled with row iy + 4
-    StripRawPair<PREC>& hset = rawh[(ROT + 1) % 3];
+    StripRawPair<PREC>* hset = rawh[(ROT + 1) % 3];
+    s_u32x4* rrs = rraw[(ROT + 1) % 3];
     unsigned char* cur = smem_s + (it & 1) * Cfg::SLOT_BYTES;
     unsigned char* nxt = smem_s + ((it & 1) ^ 1) * Cfg::SLOT_BYTES;
+    unsigned char* rcur = smem_s + Cfg::RSLOT_OFF + (it & 1) * Cfg::RSLOT_BYTES;
+    unsigned char* rnxt = smem_s + Cfg::RSLOT_OFF + ((it & 1) ^ 1) * Cfg::RSLOT_BYTES;
     const bool rok = iy + 1 >= 0 && iy + 1 < H;            // the row being staged lies inside the image
-    auto load_x = [&](int f) __attribute__((always_inline)) {   // fragment f = (kx, kc, ph), ph fastest
-      const int ph = f % NPH, kc = (f / NPH) % KCH, kx = f / (NPH * KCH);
+    auto load_x = [&](auto fc) __attribute__((always_inline)) {   // fragment f: (kx, kc, ph), ph fastest; f >= NF: the rider's (kc, ph)
+      constexpr int f = decltype(fc)::value;
+      if constexpr (f < NF) {
+        constexpr int ph = f % NPH, kc = (f / NPH) % KCH, kx = f / (NPH * KCH);
 #pragma unroll
-      for (int pl = 0; pl < NP; ++pl)
-        Xf[f % XS][pl] = *reinterpret_cast<const uint4*>(cur + xa[kx][kc][pl] + ph * 16 * RB);
+        for (int pl = 0; pl < NP; ++pl)
+          Xf[f % XS][pl] = *reinterpret_cast<const uint4*>(cur + xa[kx][kc][pl] + ph * 16 * RB);
+      } else if constexpr (f < NT) {
+        constexpr int ph = (f - NF) % NPH, kc = (f - NF) / NPH;
+        Xf[f % XS][0] = *reinterpret_cast<const uint4*>(rcur + xr[kc] + ph * 16 * RRB);
+      }
     };
-#pragma unroll
-    for (int f = 0; f < XS - 1; ++f) load_x(f);
-#pragma unroll
-    for (int f = 0; f < NF; ++f) {
-      const int ph = f % NPH, kc = (f / NPH) % KCH, kx = f / (NPH * KCH);
-      if (f + XS - 1 < NF) load_x(f + XS - 1);
-      const bool fresh = kx == 0 && kc == 0;               // the first product of a new output row starts from zero
-      const s_f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-      // slots 0 .. NPH - 1: quad ph of the row the previous step finished leaves its accumulator (set A0: ky = 2 of the step
-      // before) right before this slot's fresh product overwrites it
-      if (EPI && f < NPH) finish(iy - 2, f, acc[A0][f]);
-      acc[A2][ph] = mfma1(Wf[2][kx][kc], Xf[f % XS], acc[A2][ph]);
-      acc[A1][ph] = mfma1(Wf[1][kx][kc], Xf[f % XS], acc[A1][ph]);
-      acc[A0][ph] = mfma1(Wf[0][kx][kc], Xf[f % XS], fresh ? zero : acc[A0][ph]);
-      // ---- this slot's item of vector work ----
-      if (f >= 4 && f <= 10 && (f & 1) == 0) act_slice(rset[0], stg[0], (f - 4) >> 1);   // slots 4, 6, 8, 10
-      if (f == 11) {
-        write_oct(stg[0], rok, nxt, pdst[0]);
-        load_pass(iy + 4, rset, 0);
-      }
-      if (f >= 12 && f <= 18 && (f & 1) == 0) act_slice(rset[1], stg[1], (f - 12) >> 1);   // slots 12, 14, 16, 18
-      if (f == 19) {
-        write_oct(stg[1], rok, nxt, pdst[1]);
-        load_pass(iy + 4, rset, 1);
-      }
-      if (f == 20) {
-        stage_halo(hset, hok && rok, nxt);
-        load_halo(iy + 4, hset);
-      }
-      if (FLUSH && f == 5) flush(iy - 3, 0);               // the row whose epilogue ran a step ago
-      if (FLUSH && f == 7 && NIT > 1) flush(iy - 3, NIT > 1 ? 1 : 0);
-      if (FLUSH && f == 9 && NIT > 2) flush(iy - 3, NIT > 2 ? 2 : 0);
-      if (FLUSH && f == 13 && NIT > 3) flush(iy - 3, NIT > 3 ? 3 : 0);
-      if (f == 22) {          // the residual of the row this step finishes goes into its tile; the next row's is fetched
-        res_to_lds(iy - 1);
+    auto item = [&](auto jc) __attribute__((always_inline)) {   // item j of the step's vector work (order: Cfg::NITEMS)
+      constexpr int j = decltype(jc)::value;
+      constexpr int J1 = NIT, J2 = J1 + 5 * NPM, J3 = J2 + (CAT ? 2 : 1), J4 = J3 + NPR;
+      if constexpr (j < J1) {
+        if (FLUSH) flush(iy - 3, j);                       // the row whose epilogue ran a step ago
+      } else if constexpr (j < J2) {
+        constexpr int q = (j - J1) / 5, k = (j - J1) % 5, t = q < NP0 ? 0 : 1;
+        if constexpr (k < 4) act_slice(rset[q], stg, t, k);
+        else {
+          write_oct(stg, rok, nxt, pdst[q]);
+          load_pass(iy + 4, rset, q);
+        }
+      } else if constexpr (j < J3) {
+        constexpr int t = j - J2;
+        stage_halo(hset[t], t, hok[t] && rok, nxt);
+        load_halo(iy + 4, hset, t);
+      } else if constexpr (j < J4) {
+        constexpr int r = j - J3;
+        *reinterpret_cast<s_u32x4*>(rnxt + rdst[r]) = rrs[r];
+        load_rider(iy + 4, rrs, r);
+      } else {
+        res_to_lds(iy - 1);    // the residual of the row this step finishes goes into its tile; the next row's is fetched
         load_res(iy);
       }
+    };
+    static_for<0, XS - 1>(load_x);
+    static_for<0, NT>([&](auto fc) __attribute__((always_inline)) {
+      constexpr int f = decltype(fc)::value;
+      load_x(std::integral_constant<int, f + XS - 1>{});
+      // slots 0 .. NPH - 1: quad ph of the row the previous step finished leaves its accumulator (set A0: ky = 2 of the step
+      // before) right before this slot's fresh product overwrites it
+      if constexpr (EPI && f < NPH) finish(iy - 2, f, acc[A0][f]);
+      if constexpr (f < NF) {
+        constexpr int ph = f % NPH, kc = (f / NPH) % KCH, kx = f / (NPH * KCH);
+        constexpr bool fresh = kx == 0 && kc == 0;         // the first product of a new output row starts from zero
+        const s_f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        acc[A2][ph] = mfma1(Wf[2][kx][kc], Xf[f % XS], acc[A2][ph]);
+        acc[A1][ph] = mfma1(Wf[1][kx][kc], Xf[f % XS], acc[A1][ph]);
+        acc[A0][ph] = mfma1(Wf[0][kx][kc], Xf[f % XS], fresh ? zero : acc[A0][ph]);
+      } else {               // the rider's 1x1 product of input row iy belongs to output row iy
+        constexpr int ph = (f - NF) % NPH, kc = (f - NF) / NPH;
+        acc[A1][ph] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(s_b8, Wr[kc]), __builtin_bit_cast(s_b8, Xf[f % XS][0]),
+                                                            acc[A1][ph], 0, 0, 0);
+      }
+      static_for<Cfg::first_item(f), Cfg::first_item(f + 1)>(item);
       __builtin_amdgcn_sched_barrier(0);
-    }
+    });
     __syncthreads();
   };
   typedef std::integral_constant<int, 0> R0;
@@ -436,25 +532,41 @@ __global__ void __launch_bounds__(256, LB) conv_strip_kernel(const ConvParams p,
   // ---- the strip segment: input rows oy0 - 1 .. oy1 ----
   {
     // rows oy0 - 1 (staged here), oy0, oy0 + 1, oy0 + 2 in flight before the first step; the set of a row = its step % 3
-    StripRaw<PREC> first[NPASS];
-    StripRawPair<PREC> firsth;
+    StripRaw<PREC> first[NPM];
+    StripRawPair<PREC> firsth[CAT ? 2 : 1];
+    s_u32x4 firstr[RIDER ? NPR : 1];
 #pragma unroll
-    for (int i = 0; i < NPASS; ++i) load_pass(oy0 - 1, first, i);
-    load_halo(oy0 - 1, firsth);
+    for (int q = 0; q < NPM; ++q) load_pass(oy0 - 1, first, q);
+#pragma unroll
+    for (int t = 0; t < (CAT ? 2 : 1); ++t) load_halo(oy0 - 1, firsth, t);
+    if (RIDER) {
+#pragma unroll
+      for (int r = 0; r < NPR; ++r) load_rider(oy0 - 1, firstr, r);
+    }
 #pragma unroll
     for (int r = 1; r <= 3; ++r) {
 #pragma unroll
-      for (int i = 0; i < NPASS; ++i) load_pass(oy0 - 1 + r, raw[r % 3], i);
-      load_halo(oy0 - 1 + r, rawh[r % 3]);
+      for (int q = 0; q < NPM; ++q) load_pass(oy0 - 1 + r, raw[r % 3], q);
+#pragma unroll
+      for (int t = 0; t < (CAT ? 2 : 1); ++t) load_halo(oy0 - 1 + r, rawh[r % 3], t);
+      if (RIDER) {
+#pragma unroll
+        for (int q = 0; q < NPR; ++q) load_rider(oy0 - 1 + r, rraw[r % 3], q);
+      }
     }
     const bool rok = oy0 - 1 >= 0;
 #pragma unroll
-    for (int i = 0; i < NPASS; ++i) {
+    for (int q = 0; q < NPM; ++q) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) act_slice(first[i], stg[i], k);
-      write_oct(stg[i], rok, smem_s, pdst[i]);
+      for (int k = 0; k < 4; ++k) act_slice(first[q], stg, q < NP0 ? 0 : 1, k);
+      write_oct(stg, rok, smem_s, pdst[q]);
     }
-    stage_halo(firsth, hok && rok, smem_s);
+#pragma unroll
+    for (int t = 0; t < (CAT ? 2 : 1); ++t) stage_halo(firsth[t], t, hok[t] && rok, smem_s);
+    if (RIDER) {
+#pragma unroll
+      for (int r = 0; r < NPR; ++r) *reinterpret_cast<s_u32x4*>(smem_s + Cfg::RSLOT_OFF + rdst[r]) = firstr[r];
+    }
   }
   __syncthreads();
   const int nsteps = oy1 - oy0 + 2;          // >= 5 (segments have at least 3 rows: launcher)
@@ -496,60 +608,85 @@ __global__ void __launch_bounds__(256, LB) conv_strip_kernel(const ConvParams p,
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// g_tun.strip bits: 1 bf16 launches (two workgroups per CU), 2 f16x3 launches (one per CU: hi / lo weight planes = 144 registers)
-static long strip_min_wgs(int prec) { return prec == PREC_BF16 ? g_tun.strip_min_wgs : g_tun.strip_min_wgs / 2; }
+// g_tun.strip bits: 1 bf16 64 -> 64 launches (two workgroups per CU), 2 the f16x3 ones (one per CU: hi / lo weight planes = 144
+// registers), 4 (A/B) bf16 64 -> 64 on one workgroup per CU, 8 the bf16 launches with a concatenated input (64 + 64 -> 64,
+// 128 + 64 -> 64 under bit 32: 144 / 216 weight registers, one workgroup per CU), 16 the bf16 launches with a res_conv rider
+static bool strip_wide(const ConvParams& p, int prec) { return prec != PREC_BF16 || (g_tun.strip & 4) || p.C1 || p.xr0; }
+static long strip_min_wgs(const ConvParams& p, int prec) { return strip_wide(p, prec) ? g_tun.strip_min_wgs / 2 : g_tun.strip_min_wgs; }
 
 static int strip_seg_rows(const ConvParams& p, int SW, int prec) {
-  // strips x segments: enough workgroups to fill the chip (bf16: two per CU), segments as long as that allows (each costs two extra steps)
+  // strips x segments: enough workgroups to fill the chip (two per CU where the registers allow), segments as long as that allows
+  // (each costs two extra steps)
   const long strips = (long)p.N * ((p.Wout + SW - 1) / SW);
   int rows = p.Hout;
-  while (rows > 16 && strips * ((p.Hout + rows - 1) / rows) < strip_min_wgs(prec)) rows = (rows + 1) / 2;
+  while (rows > 16 && strips * ((p.Hout + rows - 1) / rows) < strip_min_wgs(p, prec)) rows = (rows + 1) / 2;
   return rows;
 }
 
 bool conv_strip_ok(ConvKind kind, int prec, const ConvParams& p) {
-  if (!(g_tun.strip & (prec == PREC_BF16 ? 1 : 2))) return false;
   if (kind != CONV3_S1 || p.ksplit > 1 || p.Cout != 64 || p.Cout_pad != 64) return false;
-  if (p.xr0 || !p.gn_scale || p.gn_plain || p.drop_mask) return false;
-  if (p.Hin != p.Hout || p.Win != p.Wout || p.Wout % 64 || p.Hout < 3 || (size_t)p.Hout * p.Wout * 64 * 4 >= (1ull << 31)) return false;
+  if (!p.gn_scale || p.gn_plain || p.drop_mask) return false;
+  if (p.Hin != p.Hout || p.Win != p.Wout || p.Wout % 64 || p.Hout < 3 || (size_t)p.Hout * p.Wout * 192 * 4 >= (1ull << 31)) return false;
   if (prec == PREC_BF16 && p.out_f32) return false;
   const int Cin = p.C0 + p.C1;
-  if (Cin != p.Cin_pad || Cin != 64) return false;
-  if (p.C0 % 8 || p.C1 % 8) return false;
+  if (Cin != p.Cin_pad) return false;
+  bool shape;
+  if (p.xr0) {        // 64 -> 64 with a rider over (64 | 64) or (128 | 64) raw channels
+    shape = prec == PREC_BF16 && (g_tun.strip & 16) && !p.res && p.C0 == 64 && p.C1 == 0 && p.Cr1 == 64 && (p.Cr0 == 64 || p.Cr0 == 128) &&
+            p.nkr * 16 == p.Cr0 + p.Cr1;
+  } else if (p.C1) {  // concatenated input (64 | 64) or (128 | 64), no residual (block1 of the up path)
+    shape = prec == PREC_BF16 && !p.res && p.C1 == 64 && ((p.C0 == 64 && (g_tun.strip & 8)) || (p.C0 == 128 && (g_tun.strip & 32)));   // (bit 32: 216 weight registers, spills)
+  } else {
+    shape = p.C0 == 64 && (g_tun.strip & (prec == PREC_BF16 ? 1 : 2));
+  }
+  if (!shape) return false;
   const long wgs = (long)p.N * ((p.Wout + 63) / 64) * ((p.Hout + 15) / 16);
-  return wgs >= strip_min_wgs(prec);   // (a small grid keeps the split-K tile kernels)
+  return wgs >= strip_min_wgs(p, prec);   // (a small grid keeps the split-K tile kernels)
 }
 
-template <int PREC, int KCH, int NPH, int LB>
+template <int PREC, int C0_, int C1_, int CR0_, int CR1_, bool HAS_RES, int LB>
 static hipError_t launch_strip_t(const ConvParams& p, int wn_a, hipStream_t s, int* tiles) {
-  using Cfg = StripCfg<PREC, KCH, NPH>;
+  using Cfg = StripCfg<PREC, C0_, C1_, CR0_, CR1_, 4>;
   const int rows = strip_seg_rows(p, Cfg::SW, PREC);
   const int stripsX = (p.Wout + Cfg::SW - 1) / Cfg::SW, segs = (p.Hout + rows - 1) / rows;
   if (tiles) *tiles = stripsX * segs;
-  const dim3 grid(p.N * stripsX * segs);
-  const size_t lds = (size_t)Cfg::LDS_BYTES;
-  if (p.res) hipLaunchKernelGGL((conv_strip_kernel<PREC, KCH, NPH, true, LB>), grid, dim3(256), lds, s, p, rows, wn_a);
-  else hipLaunchKernelGGL((conv_strip_kernel<PREC, KCH, NPH, false, LB>), grid, dim3(256), lds, s, p, rows, wn_a);
+  const size_t lds = (size_t)Cfg::RES_OFF + (HAS_RES ? 2 * Cfg::TILE_BYTES : 0);
+  hipLaunchKernelGGL((conv_strip_kernel<PREC, C0_, C1_, CR0_, CR1_, 4, HAS_RES, LB>), dim3(p.N * stripsX * segs), dim3(256), lds, s, p, rows, wn_a);
   return hipGetLastError();
 }
 
 hipError_t launch_conv_strip(int prec, const ConvParams& p, int wn_a, hipStream_t s, int* tiles) {
-  if (prec == PREC_BF16) return launch_strip_t<PREC_BF16, 2, 4, 2>(p, wn_a, s, tiles);
-  if (prec == PREC_F16X3) return launch_strip_t<PREC_F16X3, 2, 4, 1>(p, wn_a, s, tiles);
-  return hipErrorInvalidValue;
+  if (prec == PREC_F16X3) {
+    return p.res ? launch_strip_t<PREC_F16X3, 64, 0, 0, 0, true, 1>(p, wn_a, s, tiles) : launch_strip_t<PREC_F16X3, 64, 0, 0, 0, false, 1>(p, wn_a, s, tiles);
+  }
+  if (prec != PREC_BF16) return hipErrorInvalidValue;
+  if (p.xr0) {
+    return p.Cr0 == 64 ? launch_strip_t<PREC_BF16, 64, 0, 64, 64, false, 1>(p, wn_a, s, tiles) : launch_strip_t<PREC_BF16, 64, 0, 128, 64, false, 1>(p, wn_a, s, tiles);
+  }
+  if (p.C1) {
+    return p.C0 == 64 ? launch_strip_t<PREC_BF16, 64, 64, 0, 0, false, 1>(p, wn_a, s, tiles) : launch_strip_t<PREC_BF16, 128, 64, 0, 0, false, 1>(p, wn_a, s, tiles);
+  }
+  if (g_tun.strip & 4)
+    return p.res ? launch_strip_t<PREC_BF16, 64, 0, 0, 0, true, 1>(p, wn_a, s, tiles) : launch_strip_t<PREC_BF16, 64, 0, 0, 0, false, 1>(p, wn_a, s, tiles);
+  return p.res ? launch_strip_t<PREC_BF16, 64, 0, 0, 0, true, 2>(p, wn_a, s, tiles) : launch_strip_t<PREC_BF16, 64, 0, 0, 0, false, 2>(p, wn_a, s, tiles);
 }
 
-template <int PREC, int KCH, int NPH, int LB>
+template <int PREC, int C0_, int C1_, int CR0_, int CR1_, bool HAS_RES, int LB>
 static hipError_t init_strip_t() {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_strip_kernel<PREC, KCH, NPH, false, LB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e != hipSuccess) return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(conv_strip_kernel<PREC, KCH, NPH, true, LB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(conv_strip_kernel<PREC, C0_, C1_, CR0_, CR1_, 4, HAS_RES, LB>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
 hipError_t kernels_strip_init() {
-  hipError_t e = init_strip_t<PREC_BF16, 2, 4, 2>();
-  if (e != hipSuccess) return e;
-  return init_strip_t<PREC_F16X3, 2, 4, 1>();
+  hipError_t e;
+#define X(...) if ((e = init_strip_t<__VA_ARGS__>()) != hipSuccess) return e;
+  X(PREC_BF16, 64, 0, 0, 0, false, 2) X(PREC_BF16, 64, 0, 0, 0, true, 2)
+  X(PREC_BF16, 64, 0, 0, 0, false, 1) X(PREC_BF16, 64, 0, 0, 0, true, 1)
+  X(PREC_F16X3, 64, 0, 0, 0, false, 1) X(PREC_F16X3, 64, 0, 0, 0, true, 1)
+  X(PREC_BF16, 64, 64, 0, 0, false, 1) X(PREC_BF16, 128, 64, 0, 0, false, 1)
+  X(PREC_BF16, 64, 0, 64, 64, false, 1) X(PREC_BF16, 64, 0, 128, 64, false, 1)
+#undef X
+  return hipSuccess;
 }
 
 }  // namespace fdsr

@@ -38,7 +38,7 @@ def test_strip_form_vs_oracle(full, prec, min_wgs):
     cfg, eng, sd = full
     eng.set_precision(prec)
     tol = TOL_FWD if prec == 'f16x3' else 0.25
-    _lib.debug_option('strip', 3)
+    _lib.debug_option('strip', 63 - 4)
     _lib.debug_option('strip_min_wgs', min_wgs)
     _lib.debug_option('splitk', 0)          # (a launch with a K split keeps the tile kernels)
     try:
@@ -60,7 +60,7 @@ def test_strip_form_vs_oracle(full, prec, min_wgs):
             assert torch.equal(eng.unet_forward(x.cuda(), nl.cuda()), out)              # ordered reductions only
             _lib.debug_option('strip', 0)                                               # the same launches on the tile kernels
             out_d = eng.unet_forward(x.cuda(), nl.cuda())
-            _lib.debug_option('strip', 3)
+            _lib.debug_option('strip', 63 - 4)
             dd = (out_d - out).abs().max().item()
             assert dd > 0.0                                                             # (0.0: the form was never taken)
             if prec == 'f16x3':
@@ -71,7 +71,7 @@ def test_strip_form_vs_oracle(full, prec, min_wgs):
     finally:
         eng.set_debug(False)
         eng.set_precision('f16x3')
-        _lib.debug_option('strip', 1)
+        _lib.debug_option('strip', 27)
         _lib.debug_option('strip_min_wgs', 512)
         _lib.debug_option('splitk', 1)
 
@@ -83,7 +83,7 @@ def test_strip_form_loop_and_graph(full, prec):
     from oracle import fdsr_oracle as O
     cfg, eng, sd = full
     eng.set_precision(prec)
-    _lib.debug_option('strip', 3)
+    _lib.debug_option('strip', 63 - 4)
     _lib.debug_option('strip_min_wgs', 1)
     _lib.debug_option('splitk', 0)
     try:
@@ -103,6 +103,6 @@ def test_strip_form_loop_and_graph(full, prec):
         assert torch.equal(g1.cpu(), outl)
     finally:
         eng.set_precision('f16x3')
-        _lib.debug_option('strip', 1)
+        _lib.debug_option('strip', 27)
         _lib.debug_option('strip_min_wgs', 512)
         _lib.debug_option('splitk', 1)
