@@ -196,7 +196,7 @@ def family_label(precision):
     return ' + '.join(names)
 
 
-def conv_roofline(prof, precision, B, S, dt_total, round_tag='r04'):
+def conv_roofline(prof, precision, B, S, dt_total, round_tag='r05'):
     """Roofline of the dominant kernel family = every 3x3 convolution launch (implicit-GEMM MFMA kernels incl. the
     sub-pixel upsample form and the 6-channel input conv): algorithmic FLOPs / HIP-event time around those launches."""
     ach = prof['conv_flops'] / (prof['conv_ms'] * 1e-3) / 1e12
@@ -774,10 +774,15 @@ def main():
     if distributed:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         with _StdoutToStderr():
+            t_i0 = time.perf_counter()
             dist.init_process_group('nccl', device_id=dev)
+            dist.barrier()                       # communicator up on every rank (RCCL builds it lazily on the first collective)
+            torch.cuda.synchronize(dev)
+            t_b0 = time.perf_counter()
             sd = parallel.broadcast_state_dict(sd, cfg, src=0, device=dev)
             dist.barrier()
             torch.cuda.synchronize(dev)
+            t_init, t_bcast = t_b0 - t_i0, time.perf_counter() - t_b0   # (outside the timed region; reported so that a scaling miss can be attributed)
     eng = Engine(cfg)
     eng.load_state_dict(sd)
     bufs, sp = schedule_buffers(FASTDIFFSR_SCHEDULE_VAL)
@@ -849,7 +854,8 @@ def main():
             res['debug_options'] = list(args.debug_option)
         if distributed:   # every rank loaded what rank 0 broadcast: its hash is checked against rank 0's own arrays
             res['weights'] = {'sha256_rank0_source': weights_sha_rank0, 'sha256_after_broadcast': state_dict_sha256(sd),
-                              'broadcast_bytes': int(sum(np.asarray(v).nbytes for v in sd.values()))}
+                              'broadcast_bytes': int(sum(np.asarray(v).nbytes for v in sd.values())),
+                              'broadcast_seconds_rank0': t_bcast, 'communicator_init_seconds_rank0': t_init}
         if prof and prof['conv_ms'] > 0:
             res['roofline'] = conv_roofline(prof, args.precision, B, S, dt)
         if dist_recs is not None:

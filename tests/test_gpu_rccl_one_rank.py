@@ -39,6 +39,8 @@ def test_bench_rccl_path_with_one_rank():
     w = res['weights']
     assert w['sha256_after_broadcast'] == w['sha256_rank0_source']    # what RCCL delivered is what rank 0 built
     assert w['broadcast_bytes'] > 90e6                                # the packed fp32 state, one message
+    assert 0 < w['broadcast_seconds_rank0'] < 60 and w['communicator_init_seconds_rank0'] > 0
+    assert res['per_rank']['min'] <= res['per_rank']['max'] and res['per_rank']['unit'].startswith('images/s')
     assert 'parallelism' in res['config'] and res['config']['parallelism'].startswith('dp1')
     # under torch.distributed every rank also measures configs[3] (bf16 B=64/GPU, hipGraph) and configs[4] (data-parallel training
     # step, B=32/GPU, gradient all-reduce through RCCL): the multi-GPU lines of the driver's scaling run carry them
