@@ -535,171 +535,6 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const ConvParams p, 
   }
 }
 
-// Split-K second phase AND the consumer's GroupNorm finalisation in one launch (small grids: B = 1 .. 4, where the reference's own
-// val loop runs, sr_mfe.py:274-284; 37 reduce + 45 finalize launches per forward were 31 % of the B = 1 kernel time).  No
-// cross-workgroup hand-off: a workgroup OWNS one GroupNorm group of one image -- it sums the K slices (in slice order) for the
-// group's channels over ALL pixels, applies bias + noise shift + residual, stores the output, and, having seen every element of its
-// group, folds the statistics (fixed order: per-lane fp32 sums of a few pixels, then fp64) and writes the consumer's scale / shift for
-// its channels (torch.nn.GroupNorm: biased variance, eps inside the sqrt; reference unet.py:93).  It also leaves ONE partial tile
-// (the per-channel totals) for later consumers of the tensor (skip connections).  Workgroups blockIdx.x >= C / cpg finalise the
-// groups that lie in the consumer's second input (the skip tensor of a concatenated GroupNorm) from its producers' partial tiles,
-// as gn_finalize_kernel does.  Groups never straddle the two tensors (launcher).
-__global__ void __launch_bounds__(1024) splitk_reduce_gn_kernel(const ConvParams p) {
-  __shared__ float sred[16][16][8];          // [wave][quad of the group][(sum, sumsq) x 4 channels]
-  __shared__ double sd[1024][2];
-  __shared__ double gsum[2];
-  const int tid = threadIdx.x, n = blockIdx.y;
-  const int Cg = p.Cout + p.fgn_C1, cpg = Cg / p.fgn_G;
-  const int ng0 = p.Cout / cpg;
-  const int HW = p.Hout * p.Wout;
-  double gs = 0.0, gq = 0.0;                 // (thread 0) the group's sum / sum of squares
-  int cbase;                                 // first channel of the group in the consumer's concatenated input
-  if ((int)blockIdx.x < ng0) {
-    const int c0 = blockIdx.x * cpg;         // the group's channels in this conv's output
-    cbase = c0;
-    const int cq = cpg >> 2, q = tid % cq, pg = tid / cq, npg = 1024 / cq;
-    f32x4 add = *reinterpret_cast<const f32x4*>(p.bias + c0 + q * 4);
-    if (p.xr0) add += *reinterpret_cast<const f32x4*>(p.bias_r + c0 + q * 4);
-    if (p.temb) add += *reinterpret_cast<const f32x4*>(p.temb + (size_t)n * p.temb_stride + p.temb_off + c0 + q * 4);
-    const float winv = p.xr0 ? (p.w_inv_scale_r_dev ? *p.w_inv_scale_r_dev : p.w_inv_scale_r) : (p.w_inv_scale_dev ? *p.w_inv_scale_dev : p.w_inv_scale);
-    const size_t slice = (size_t)p.N * HW * p.Cout;
-    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
-    // U pixels x KSM slices = 16 quads in flight per thread and trip (a trip is one memory round trip: with one pixel per trip the
-    // 128 x 128 maps took 16 dependent round trips); slices are added in slice order
-    auto sweep = [&](auto u_tag, auto k_tag) __attribute__((always_inline)) {
-      constexpr int U = decltype(u_tag)::value, KSM = decltype(k_tag)::value;
-      for (int px0 = pg; px0 < HW; px0 += U * npg) {
-        f32x4 sl[U][KSM], rs[U];
-        size_t o[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int px = px0 + u * npg;
-          o[u] = ((size_t)n * HW + (px < HW ? px : pg)) * p.Cout + c0 + q * 4;      // (clamped: every load is issued)
-#pragma unroll
-          for (int k = 0; k < KSM; ++k) sl[u][k] = *reinterpret_cast<const f32x4*>(p.kscratch + (k < p.ksplit ? k : 0) * slice + o[u]);
-          if (p.res) rs[u] = p.out_bf16 ? ActIO<PREC_BF16>::widen(ActIO<PREC_BF16>::load4(p.res, o[u])) : *reinterpret_cast<const f32x4*>(p.res + o[u]);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          if (px0 + u * npg >= HW) continue;
-          f32x4 a = sl[u][0];
-#pragma unroll
-          for (int k = 1; k < KSM; ++k)
-            if (k < p.ksplit) a += sl[u][k];
-          a = a * winv + add;
-          if (p.res) a += rs[u];
-          if (p.out_bf16) {   // bf16 mode: the output is a bf16 tensor
-            uint2 pk;
-            pk.x = (unsigned)f32_to_bf16_bits(a[0]) | ((unsigned)f32_to_bf16_bits(a[1]) << 16);
-            pk.y = (unsigned)f32_to_bf16_bits(a[2]) | ((unsigned)f32_to_bf16_bits(a[3]) << 16);
-            *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p.out) + o[u]) = pk;
-          } else {
-            *reinterpret_cast<f32x4*>(p.out + o[u]) = a;
-          }
-          s1 += a;
-          s2 += a * a;
-        }
-      }
-    };
-    typedef std::integral_constant<int, 1> I1;
-    typedef std::integral_constant<int, 2> I2;
-    typedef std::integral_constant<int, 4> I4;
-    typedef std::integral_constant<int, 8> I8;
-    typedef std::integral_constant<int, 16> I16;
-    if (p.ksplit <= 2) sweep(I8{}, I2{});
-    else if (p.ksplit <= 4) sweep(I4{}, I4{});
-    else if (p.ksplit <= 8) sweep(I2{}, I8{});
-    else sweep(I1{}, I16{});
-    // fold: the lanes of a wave that hold the same quad (stride cq), then the 16 waves in order, in fp64
-    float v[8] = {s1[0], s2[0], s1[1], s2[1], s1[2], s2[2], s1[3], s2[3]};
-#pragma unroll
-    for (int e = 0; e < 8; ++e)
-      for (int m = cq; m < 64; m <<= 1) v[e] += __shfl_xor(v[e], m, 64);
-    const int lane = tid & 63, wave = tid >> 6;
-    if (lane < cq) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) sred[wave][lane][e] = v[e];
-    }
-    __syncthreads();
-    if (tid < cq * 8) {          // thread = (quad, value): the 16 waves' partial sums in wave order
-      const int qq = tid >> 3, e = tid & 7;
-      double t = 0.0;
-#pragma unroll
-      for (int wv = 0; wv < 16; ++wv) t += (double)sred[wave * 0 + wv][qq][e];
-      sd[tid][0] = t;
-    }
-    __syncthreads();
-    if (tid < cpg) {             // per-channel totals: the tensor's single partial tile, for later consumers
-      const int qq = tid >> 2, r = tid & 3;
-      const double a = sd[qq * 8 + 2 * r][0], b = sd[qq * 8 + 2 * r + 1][0];
-      if (p.part_out) {
-        float* dst = p.part_out + ((size_t)n * p.Cout + c0 + tid) * 2;
-        dst[0] = (float)a;
-        dst[1] = (float)b;
-      }
-    }
-    if (tid == 0) {
-      for (int c = 0; c < cpg; ++c) {
-        const int qq = c >> 2, r = c & 3;
-        gs += sd[qq * 8 + 2 * r][0];
-        gq += sd[qq * 8 + 2 * r + 1][0];
-      }
-    }
-  } else {
-    // a group of the consumer's second input: fold its producers' partial tiles (gn_finalize_kernel's scheme)
-    const int g1 = blockIdx.x - ng0, c0 = g1 * cpg;
-    cbase = p.Cout + c0;
-    const int S = 1024 / cpg, ch = tid % cpg, sl = tid / cpg;
-    double a = 0.0, b = 0.0;
-    if (sl < S) {
-      const float* src = p.fgn_part1 + ((size_t)n * p.fgn_nt1 * p.fgn_C1 + c0 + ch) * 2;
-      for (int t = sl; t < p.fgn_nt1; t += S) {
-        const float2 v2 = *reinterpret_cast<const float2*>(src + (size_t)t * p.fgn_C1 * 2);
-        a += (double)v2.x;
-        b += (double)v2.y;
-      }
-    }
-    sd[tid][0] = a;
-    sd[tid][1] = b;
-    __syncthreads();
-    if (tid < 64) {
-      double ga = 0.0, gb = 0.0;
-#pragma unroll
-      for (int k = 0; k < 16; ++k) { ga += sd[tid + 64 * k][0]; gb += sd[tid + 64 * k][1]; }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) { ga += __shfl_xor(ga, o, 64); gb += __shfl_xor(gb, o, 64); }
-      gs = ga;
-      gq = gb;
-    }
-  }
-  if (tid == 0) {
-    const double inv = 1.0 / ((double)cpg * (double)HW);
-    const double mean = gs * inv;
-    double var = gq * inv - mean * mean;
-    var = var < 0.0 ? 0.0 : var;
-    gsum[0] = mean;
-    gsum[1] = 1.0 / sqrt(var + (double)p.fgn_eps);
-  }
-  __syncthreads();
-  if (tid < cpg) {
-    const int cc = cbase + tid;
-    const float sc = (float)gsum[1] * p.fgn_gamma[cc];
-    p.fgn_scale[(size_t)n * Cg + cc] = sc;
-    p.fgn_shift[(size_t)n * Cg + cc] = p.fgn_beta[cc] - (float)gsum[0] * sc;
-  }
-}
-
-// does a split-K launch with these parameters take the fused reduce + GroupNorm launch?
-bool splitk_fuse_gn_ok(const ConvParams& p) {
-  if (!g_tun.fuse_gn || p.ksplit <= 1 || p.ksplit > 16 || !p.fgn_scale || p.fgn_G <= 0) return false;
-  const int Cg = p.Cout + p.fgn_C1;
-  if (Cg % p.fgn_G) return false;
-  const int cpg = Cg / p.fgn_G;
-  if (cpg % 4 || cpg > 64 || 1024 % cpg || p.Cout % cpg || p.fgn_C1 % cpg) return false;
-  if (p.fgn_C1 && (!p.fgn_part1 || p.fgn_nt1 <= 0)) return false;
-  return true;
-}
-
 template <int KS, int STRIDE, bool UP, int TH, int WN, int PREC, int KSUB, bool RIDER = false>
 static hipError_t launch_h_t(const ConvParams& p, hipStream_t s, int* tiles) {
   using Cfg = ConvHCfg<KS, STRIDE, UP, TH, WN, PREC, KSUB>;
@@ -719,11 +554,6 @@ static hipError_t launch_h_t(const ConvParams& p, hipStream_t s, int* tiles) {
   }
   if (sk > 1 && (g_tun.knockout & 2)) {   // timing-only probe: the reduce launch left out (results are garbage)
     if (tiles) *tiles = ((p.Wout + 31) / 32) * ((p.Hout + 1) / 2);
-  } else if (sk > 1 && splitk_fuse_gn_ok(q)) {
-    if (tiles) *tiles = 1;      // the tensor's partial sums: one tile of per-channel totals
-    const int Cg = q.Cout + q.fgn_C1;
-    hipLaunchKernelGGL(splitk_reduce_gn_kernel, dim3(q.fgn_G, p.N), dim3(1024), 0, s, q);
-    (void)Cg;
   } else if (sk > 1) {
     const int rt = ((p.Wout + 31) / 32) * ((p.Hout + 1) / 2);
     if (tiles) *tiles = rt;

@@ -870,13 +870,11 @@ int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, 
       return fail(h, FDSR_E_INVALID, "train mode with dropout runs on the fp32-grade kernels: fdsr_set_precision(FDSR_PREC_F32 or _F16X3)");
     h->drop_step += 1;
   }
-  long gn_done = -1;
   for (size_t oi = 0; oi < h->ops.size(); ++oi) {
     const Op& op = h->ops[oi];
     const int Hi = H >> op.lvl_in, Wi = W >> op.lvl_in;
     switch (op.kind) {
       case Op::GN_FINALIZE: {
-        if ((long)oi == gn_done) break;      // finalised by the split-K reduce launch of its producer
         GnFinalizeParams g{};
         g.part0 = PART(op.src0); g.nt0 = sp.tensor_nt[op.src0]; g.C0 = op.C0;
         g.part1 = PART(op.src1); g.nt1 = op.src1 >= 0 ? sp.tensor_nt[op.src1] : 0; g.C1 = op.C1;
@@ -993,20 +991,6 @@ int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, 
           } else {
             p.ksplit = (op.ck == CONV3_UP) ? 1 : sp.op_ksplit[oi];
             p.kscratch = reinterpret_cast<float*>(ws + sp.off_splitk);
-            // a split-K launch whose output feeds the NEXT op's GroupNorm: its reduce launch finalises that GroupNorm too
-            if (p.ksplit > 1 && !h->keep_stats && p.part_out && oi + 1 < h->ops.size()) {
-              const Op& gno = h->ops[oi + 1];
-              if (gno.kind == Op::GN_FINALIZE && gno.src0 == op.dst && gno.film_off < 0 && gno.C0 == op.Cout &&
-                  (gno.src1 < 0 || (PART(gno.src1) && sp.tensor_nt[gno.src1] > 0))) {
-                p.fgn_gamma = P(gno.gamma); p.fgn_beta = P(gno.beta);
-                p.fgn_scale = reinterpret_cast<float*>(ws + sp.gn_off[gno.gn_slot]);
-                p.fgn_shift = p.fgn_scale + (size_t)N * (gno.C0 + gno.C1);
-                p.fgn_part1 = PART(gno.src1); p.fgn_nt1 = gno.src1 >= 0 ? sp.tensor_nt[gno.src1] : 0; p.fgn_C1 = gno.src1 >= 0 ? gno.C1 : 0;
-                p.fgn_G = G; p.fgn_eps = 1e-5f;
-                if (splitk_fuse_gn_ok(p)) gn_done = (long)oi + 1;
-                else p.fgn_scale = nullptr;
-              }
-            }
             HIPCHK(h, launch_conv_h(op.ck, h->prec, p, st, &nt));
           }
         } else {

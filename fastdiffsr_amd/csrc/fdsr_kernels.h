@@ -57,14 +57,6 @@ struct ConvParams {
   float w_inv_scale_r;               // the rider's accumulator un-scaling; the accumulator is brought to THIS scale when the
   const float* w_inv_scale_r_dev;    // K loop passes from the main chunks to the rider chunks (powers of two: exact)
   int* sat_flag;                     // f16x3: set to 1 when a RAW input value exceeds the f16 range (null: no check)
-  // split-K launches whose output feeds a GroupNorm right away: the reduce launch also finalises that GroupNorm (see
-  // splitk_reduce_gn_kernel): gamma / beta / scale / shift of the CONSUMER's GroupNorm over (this output: Cout channels | a second
-  // tensor: fgn_C1 channels with per-tile partial sums fgn_part1[N][fgn_nt1][fgn_C1][2]); fgn_scale == null: off
-  const float* fgn_gamma; const float* fgn_beta;
-  float* fgn_scale; float* fgn_shift;
-  const float* fgn_part1;
-  int fgn_nt1, fgn_C1, fgn_G;
-  float fgn_eps;
   int stagger;                       // small-workgroup k32 form: workgroups in an odd slot of their CU start this many 64-cycle sleeps per K chunk late
 };
 
@@ -86,7 +78,6 @@ struct Tunables {
   int k32 = 1275;           // v_mfma_f32_16x16x32 form (fdsr_conv_k32.hip) of the stride-1 3x3 launches that fit it; bits: 1 f16x3, 2 bf16, 4 the 16-row tile with a rider, 8 the 2-row-per-wave tiles of small grids, 16 the sub-pixel upsample convs, 32 the small-workgroup form (4 waves, two workgroups per CU; 6-row tiles in f16x3, 8-row tiles in bf16) of the rider-less 64-cout launches of large grids in f16x3, 128 in bf16 too, 64 the f16x3 launches with a rider too (rider chunks first), 512 the bf16 ones with a rider (off: slower), 1024 the 8-wave rider kernels with the rider chunks first (launches without a K split); 0 never
   int k32_stagger = 0;      // ... start delay of the CU's odd workgroup slot, in 64-cycle units per K chunk (0: none)
   long k32_sb_min_wgs = 1024;   // ... from this many workgroups on (a small grid wants all eight waves of a CU on its one tile)
-  int fuse_gn = 1;          // split-K launches: one reduce + GroupNorm-finalise launch instead of two (0: splitk_reduce, then gn_finalize)
   int strip = 27;           // column-strip form (fdsr_conv_strip.hip: weights in registers, one input row per step) of the 64-cout launches: bit 1 bf16 64 -> 64, 2 f16x3 64 -> 64, 4 (A/B) bf16 on one workgroup per CU, 8 bf16 (64 | 64) -> 64, 16 bf16 64 -> 64 with a res_conv rider, 32 bf16 (128 | 64) -> 64
   long strip_min_wgs = 512; // ... from this many strip segments of >= 16 rows on (two workgroups per CU)
   int tail = 1;             // the input / output convs of the 16-bit modes on their own kernels (fdsr_conv_tail.hip); 0: the general ones
@@ -126,8 +117,6 @@ hipError_t kernels_tail_init();
 // K=32 MFMA form of the stride-1 3x3 launches (fdsr_conv_k32.hip): same ConvParams, same packed weights; launch_conv_h
 // dispatches to it when conv_k32_ok() (wave tile of 4 x 32 pixels, whole 32-channel chunks on both sides of a concat seam).
 bool conv_k32_ok(int TH, int WN, int prec, const ConvParams& p);
-// split-K launches: does the reduce launch also finalise the consumer's GroupNorm (ConvParams::fgn_*, splitk_reduce_gn_kernel)?
-bool splitk_fuse_gn_ok(const ConvParams& p);
 hipError_t launch_conv_k32(int TH, int WN, int prec, const ConvParams& q, int nwg, hipStream_t s);
 // ... as 256-thread workgroups, two per CU, for the 64-cout launches of large grids (k32 bit 32): asked before a tile is picked
 bool conv_k32_small_ok(ConvKind kind, int prec, const ConvParams& p);

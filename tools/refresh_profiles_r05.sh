@@ -27,8 +27,6 @@ stats f16x3_b1_graph --batch 1 --graph --steps 20 --warmup 3
 # kernel choice outside the tuned 256 x 256 shapes: infer.py's 512 x 512 B = 1 and a 128 x 128 B = 16 batch (which kernels the launch rules pick there)
 stats f16x3_b1_512_graph --size 512 --batch 1 --graph --steps 3 --warmup 1
 stats f16x3_b16_128 --size 128 --batch 16 --steps 3 --warmup 1
-# B = 1 with the two-launch reduce / finalize path, for the before / after of the fused launch
-stats f16x3_b1_graph_unfused --batch 1 --graph --steps 20 --warmup 3 --debug-option fuse_gn=0
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_train -o t -- python3 $R/bench.py --train --precision f16x3 --steps 2 --warmup 1 > $O/stats_train.log 2>&1 < /dev/null
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_train32 -o t -- python3 $R/bench.py --train --precision f32 --steps 2 --warmup 1 > $O/stats_train32.log 2>&1 < /dev/null
