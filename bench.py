@@ -177,6 +177,7 @@ def kernel_source_hash():
 
 KNOCKOUT = False   # --debug-option knockout=...: timing-only probes whose results are garbage
 K32_BITS = 1275     # Tunables::k32 default (include/fdsr.h); --debug-option k32=... overrides it for the labels below
+STRIP_BITS = 27     # Tunables::strip default: the column-strip form of the 64-cout launches (fdsr_conv_strip.hip)
 
 
 def family_label(precision):
@@ -185,6 +186,8 @@ def family_label(precision):
         return 'conv_mfma_f32_kernel'
     bit = 1 if precision == 'f16x3' else 2
     names = []
+    if STRIP_BITS & (2 if precision == 'f16x3' else (1 | 8 | 16 | 32)):
+        names.append('conv_strip_kernel')
     if K32_BITS & bit:
         names.append('conv_k32_kernel')
         if K32_BITS & 16:
@@ -759,12 +762,14 @@ def main():
 
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    global K32_BITS, KNOCKOUT
+    global K32_BITS, STRIP_BITS, KNOCKOUT
     for item in args.debug_option:
         k, v = item.split('=')
         _lib.debug_option(k, int(v))
         if k == 'k32':
             K32_BITS = int(v)
+        if k == 'strip':
+            STRIP_BITS = int(v)
         if k == 'knockout' and int(v):
             KNOCKOUT = True
     cfg = UNetConfig(**FASTDIFFSR_UNET)
