@@ -45,8 +45,14 @@ __device__ __forceinline__ float silu_s(float v) { return v * __builtin_amdgcn_r
 #ifndef STRIP_XS      // activation-fragment slots in registers: XS - 1 fragments ahead of their MFMAs
 #define STRIP_XS 4
 #endif
+#ifndef STRIP_XS1     // ... of the one-workgroup-per-CU instantiations (512 registers: a single wave per SIMD has nobody to cover an LDS wait)
+#define STRIP_XS1 4
+#endif
 #ifndef STRIP_DIAG    // timing-only diagnostic builds (results are garbage): 1 no residual loads, 2 no output stores, 4 no activation math
 #define STRIP_DIAG 0
+#endif
+#ifndef STRIP_FENCE3  // fence behind each of a slot's three MFMA groups (the item's three stages stay between them)
+#define STRIP_FENCE3 1
 #endif
 #ifndef STRIP_PIN     // keep the fragment reads ahead of the MFMAs (sched_barrier that VALU / SALU may cross)
 #define STRIP_PIN 1
@@ -158,7 +164,7 @@ __global__ void __launch_bounds__(256, LB) conv_strip_kernel(const ConvParams p,
   constexpr int NP0 = Cfg::NP0, NP1 = Cfg::NP1, NPM = Cfg::NPM, KCR = Cfg::KCR, NPR = Cfg::NPR, NR0 = Cfg::NR0, NFR = Cfg::NFR, NT = Cfg::NT;
   constexpr int RRB = Cfg::RRB;
   constexpr bool CAT = C1_ > 0, RIDER = Cfg::CR > 0;
-  constexpr int XS = STRIP_XS < NF ? STRIP_XS : NF;
+  constexpr int XS = (LB == 1 ? STRIP_XS1 : STRIP_XS) < NF ? (LB == 1 ? STRIP_XS1 : STRIP_XS) : NF;
   using IO = ActIO<PREC>;
   typedef typename IO::Quad Quad;
 
@@ -258,15 +264,25 @@ __global__ void __launch_bounds__(256, LB) conv_strip_kernel(const ConvParams p,
   // GroupNorm apply + Swish (unet.py:89-101) + conversion, in SLICES of two channels (a slice is what the step schedule below places
   // between two MFMAs); a finished oct is written to its swizzled unit(s) of the slot
   struct Staged { unsigned hi[4]; unsigned lo[PREC == PREC_F16X3 ? 4 : 1]; };
-  auto act_pair = [&](float a, float b, const float* gt4, unsigned& hi, unsigned& lo) __attribute__((always_inline)) {
+  // ... in three stages, one behind each of a slot's three MFMA groups (an in-order wave issues the next MFMA only after the
+  // vector instructions in front of it: one lump of ~17 behind three back-to-back MFMAs left the matrix pipe idle for their length).
+  // Same operations in the same order as silu_s(a * sc + sh): bit-identical.
+  struct ActTmp { float y0, y1, t0, t1; };
+  auto act_s0 = [&](float a, float b, const float* gt4, ActTmp& m) __attribute__((always_inline)) {   // GroupNorm apply, exponent argument
     const s_f32x4 gt = *reinterpret_cast<const s_f32x4*>(gt4);
-    if (STRIP_DIAG & 4) {
-      a = a * gt[0] + gt[2];
-      b = b * gt[1] + gt[3];
-    } else {
-      a = silu_s(a * gt[0] + gt[2]);
-      b = silu_s(b * gt[1] + gt[3]);
+    m.y0 = a * gt[0] + gt[2];
+    m.y1 = b * gt[1] + gt[3];
+    m.t0 = m.y0 * -1.44269504088896340736f;
+    m.t1 = m.y1 * -1.44269504088896340736f;
+  };
+  auto act_s1 = [&](ActTmp& m) __attribute__((always_inline)) {                                      // sigmoid: the four transcendentals
+    if (!(STRIP_DIAG & 4)) {
+      m.t0 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(m.t0));
+      m.t1 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(m.t1));
     }
+  };
+  auto act_s2 = [&](const ActTmp& m, unsigned& hi, unsigned& lo) __attribute__((always_inline)) {    // Swish product, conversion
+    const float a = (STRIP_DIAG & 4) ? m.y0 : m.y0 * m.t0, b = (STRIP_DIAG & 4) ? m.y1 : m.y1 * m.t1;
     if (PREC == PREC_F16X3) {
       const float ca = __builtin_amdgcn_fmed3f(a, -65504.f, 65504.f), cb = __builtin_amdgcn_fmed3f(b, -65504.f, 65504.f);
       typedef _Float16 h2t __attribute__((ext_vector_type(2)));
@@ -281,10 +297,15 @@ __global__ void __launch_bounds__(256, LB) conv_strip_kernel(const ConvParams p,
       hi = __builtin_bit_cast(unsigned, h);
     }
   };
-  auto act_slice = [&](const StripRaw<PREC>& r, Staged& d, int t, int k) __attribute__((always_inline)) {
-    float a, b;
-    r.pair(k, a, b);
-    act_pair(a, b, gtab + 16 * og[t] + 4 * k, d.hi[k], d.lo[PREC == PREC_F16X3 ? k : 0]);
+  ActTmp atmp;
+  auto act_slice = [&](const StripRaw<PREC>& r, Staged& d, int t, int k, int stage) __attribute__((always_inline)) {   // stage 0 .. 2, or -1: all
+    if (stage <= 0) {
+      float a, b;
+      r.pair(k, a, b);
+      act_s0(a, b, gtab + 16 * og[t] + 4 * k, atmp);
+    }
+    if (stage < 0 || stage == 1) act_s1(atmp);
+    if (stage < 0 || stage == 2) act_s2(atmp, d.hi[k], d.lo[PREC == PREC_F16X3 ? k : 0]);
   };
   auto write_oct = [&](const Staged& d, bool ok, unsigned char* slot, int dofs) __attribute__((always_inline)) {
     const uint4 z = {0u, 0u, 0u, 0u};             // zero padding: rows outside the image
@@ -292,13 +313,19 @@ __global__ void __launch_bounds__(256, LB) conv_strip_kernel(const ConvParams p,
     if (PREC == PREC_F16X3)
       *reinterpret_cast<uint4*>(slot + (dofs ^ (16 * OPP))) = ok ? uint4{d.lo[0], d.lo[1], d.lo[2], d.lo[3]} : z;   // unit + OPP: the lo plane
   };
-  auto stage_halo = [&](const StripRawPair<PREC>& r, int t, bool ok, unsigned char* slot) __attribute__((always_inline)) {
-    float a, b;
-    r.pair(a, b);
-    unsigned hi, lo = 0;
-    act_pair(a, b, gtab + 16 * og[t] + 4 * w, hi, lo);
-    *reinterpret_cast<unsigned*>(slot + hdst[t]) = ok ? hi : 0u;
-    if (PREC == PREC_F16X3) *reinterpret_cast<unsigned*>(slot + (hdst[t] ^ (16 * OPP))) = ok ? lo : 0u;
+  auto stage_halo = [&](const StripRawPair<PREC>& r, int t, bool ok, unsigned char* slot, int stage) __attribute__((always_inline)) {
+    if (stage <= 0) {
+      float a, b;
+      r.pair(a, b);
+      act_s0(a, b, gtab + 16 * og[t] + 4 * w, atmp);
+    }
+    if (stage < 0 || stage == 1) act_s1(atmp);
+    if (stage < 0 || stage == 2) {
+      unsigned hi, lo = 0;
+      act_s2(atmp, hi, lo);
+      *reinterpret_cast<unsigned*>(slot + hdst[t]) = ok ? hi : 0u;
+      if (PREC == PREC_F16X3) *reinterpret_cast<unsigned*>(slot + (hdst[t] ^ (16 * OPP))) = ok ? lo : 0u;
+    }
   };
   int pdst[NPM];
 #pragma unroll
@@ -476,27 +503,30 @@ __global__ void __launch_bounds__(256, LB) conv_strip_kernel(const ConvParams p,
         Xf[f % XS][0] = *reinterpret_cast<const uint4*>(rcur + xr[kc] + ph * 16 * RRB);
       }
     };
-    auto item = [&](auto jc) __attribute__((always_inline)) {   // item j of the step's vector work (order: Cfg::NITEMS)
-      constexpr int j = decltype(jc)::value;
+    auto item = [&](auto jc, auto sc) __attribute__((always_inline)) {   // item j of the step's vector work (order: Cfg::NITEMS), stage 0 .. 2 of its slot (-1: all)
+      constexpr int j = decltype(jc)::value, stage = decltype(sc)::value;
       constexpr int J1 = NIT, J2 = J1 + 5 * NPM, J3 = J2 + (CAT ? 2 : 1), J4 = J3 + NPR;
+      constexpr bool last = stage < 0 || stage == 2;       // items that are not activation math run behind the slot's last MFMA group
       if constexpr (j < J1) {
-        if (FLUSH) flush(iy - 3, j);                       // the row whose epilogue ran a step ago
+        if (FLUSH && last) flush(iy - 3, j);               // the row whose epilogue ran a step ago
       } else if constexpr (j < J2) {
         constexpr int q = (j - J1) / 5, k = (j - J1) % 5, t = q < NP0 ? 0 : 1;
-        if constexpr (k < 4) act_slice(rset[q], stg, t, k);
-        else {
+        if constexpr (k < 4) act_slice(rset[q], stg, t, k, stage);
+        else if constexpr (last) {
           write_oct(stg, rok, nxt, pdst[q]);
           load_pass(iy + 4, rset, q);
         }
       } else if constexpr (j < J3) {
         constexpr int t = j - J2;
-        stage_halo(hset[t], t, hok[t] && rok, nxt);
-        load_halo(iy + 4, hset, t);
+        stage_halo(hset[t], t, hok[t] && rok, nxt, stage);
+        if constexpr (last) load_halo(iy + 4, hset, t);
       } else if constexpr (j < J4) {
         constexpr int r = j - J3;
-        *reinterpret_cast<s_u32x4*>(rnxt + rdst[r]) = rrs[r];
-        load_rider(iy + 4, rrs, r);
-      } else {
+        if constexpr (last) {
+          *reinterpret_cast<s_u32x4*>(rnxt + rdst[r]) = rrs[r];
+          load_rider(iy + 4, rrs, r);
+        }
+      } else if constexpr (last) {
         res_to_lds(iy - 1);    // the residual of the row this step finishes goes into its tile; the next row's is fetched
         load_res(iy);
       }
@@ -508,19 +538,30 @@ __global__ void __launch_bounds__(256, LB) conv_strip_kernel(const ConvParams p,
       // slots 0 .. NPH - 1: quad ph of the row the previous step finished leaves its accumulator (set A0: ky = 2 of the step
       // before) right before this slot's fresh product overwrites it
       if constexpr (EPI && f < NPH) finish(iy - 2, f, acc[A0][f]);
+      constexpr int J0 = Cfg::first_item(f), J1e = Cfg::first_item(f + 1);
+      static_assert(J1e - J0 <= 1, "one item per slot (the activation stages share one set of temporaries)");
+      typedef std::integral_constant<int, 0> S0;
+      typedef std::integral_constant<int, 1> S1;
+      typedef std::integral_constant<int, 2> S2;
+      typedef std::integral_constant<int, -1> SA;
       if constexpr (f < NF) {
         constexpr int ph = f % NPH, kc = (f / NPH) % KCH, kx = f / (NPH * KCH);
         constexpr bool fresh = kx == 0 && kc == 0;         // the first product of a new output row starts from zero
         const s_f32x4 zero = {0.f, 0.f, 0.f, 0.f};
         acc[A2][ph] = mfma1(Wf[2][kx][kc], Xf[f % XS], acc[A2][ph]);
+        static_for<J0, J1e>([&](auto jc) __attribute__((always_inline)) { item(jc, S0{}); });
+        if (STRIP_FENCE3) __builtin_amdgcn_sched_barrier(0);
         acc[A1][ph] = mfma1(Wf[1][kx][kc], Xf[f % XS], acc[A1][ph]);
+        static_for<J0, J1e>([&](auto jc) __attribute__((always_inline)) { item(jc, S1{}); });
+        if (STRIP_FENCE3) __builtin_amdgcn_sched_barrier(0);
         acc[A0][ph] = mfma1(Wf[0][kx][kc], Xf[f % XS], fresh ? zero : acc[A0][ph]);
+        static_for<J0, J1e>([&](auto jc) __attribute__((always_inline)) { item(jc, S2{}); });
       } else {               // the rider's 1x1 product of input row iy belongs to output row iy
         constexpr int ph = (f - NF) % NPH, kc = (f - NF) / NPH;
         acc[A1][ph] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(s_b8, Wr[kc]), __builtin_bit_cast(s_b8, Xf[f % XS][0]),
                                                             acc[A1][ph], 0, 0, 0);
+        static_for<J0, J1e>([&](auto jc) __attribute__((always_inline)) { item(jc, SA{}); });
       }
-      static_for<Cfg::first_item(f), Cfg::first_item(f + 1)>(item);
       __builtin_amdgcn_sched_barrier(0);
     });
     __syncthreads();
@@ -558,11 +599,11 @@ __global__ void __launch_bounds__(256, LB) conv_strip_kernel(const ConvParams p,
 #pragma unroll
     for (int q = 0; q < NPM; ++q) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) act_slice(first[q], stg, q < NP0 ? 0 : 1, k);
+      for (int k = 0; k < 4; ++k) act_slice(first[q], stg, q < NP0 ? 0 : 1, k, -1);
       write_oct(stg, rok, smem_s, pdst[q]);
     }
 #pragma unroll
-    for (int t = 0; t < (CAT ? 2 : 1); ++t) stage_halo(firsth[t], t, hok[t] && rok, smem_s);
+    for (int t = 0; t < (CAT ? 2 : 1); ++t) stage_halo(firsth[t], t, hok[t] && rok, smem_s, -1);
     if (RIDER) {
 #pragma unroll
       for (int r = 0; r < NPR; ++r) *reinterpret_cast<s_u32x4*>(smem_s + Cfg::RSLOT_OFF + rdst[r]) = firstr[r];
