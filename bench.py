@@ -177,7 +177,7 @@ def kernel_source_hash():
 
 KNOCKOUT = False   # --debug-option knockout=...: timing-only probes whose results are garbage
 K32_BITS = 1275     # Tunables::k32 default (include/fdsr.h); --debug-option k32=... overrides it for the labels below
-STRIP_BITS = 27     # Tunables::strip default: the column-strip form of the 64-cout launches (fdsr_conv_strip.hip)
+STRIP_BITS = 91     # Tunables::strip default: the column-strip form of the 64-cout launches (fdsr_conv_strip.hip)
 
 
 def family_label(precision):

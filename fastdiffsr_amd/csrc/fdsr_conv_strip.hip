@@ -179,6 +179,9 @@ __global__ void __launch_bounds__(256, LB) conv_strip_kernel(const ConvParams p,
     const int q8 = nwg >> 3, r8 = nwg & 7, xcd = b & 7, k = b >> 3;
     bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
   }
+  const int ncg = p.Cout / 64;               // groups of 64 output channels: one workgroup each (128-cout launches: two read the same rows)
+  const int cg = bid % ncg;
+  bid /= ncg;
   const int sx = bid % stripsX;
   bid /= stripsX;
   const int seg = bid % segs;
@@ -341,7 +344,7 @@ __global__ void __launch_bounds__(256, LB) conv_strip_kernel(const ConvParams p,
   uint4 Wr[RIDER ? KCR : 1];
   {
     const uint4* wq = reinterpret_cast<const uint4*>(p.wq);
-    const int nk16 = p.Cin_pad / 16, co32 = w >> 1, cot = co32 / wn_a, wna = co32 % wn_a;
+    const int nk16 = p.Cin_pad / 16, co32 = 2 * cg + (w >> 1), cot = co32 / wn_a, wna = co32 % wn_a;
     const int wlane = 32 * (g & 1) + 16 * (w & 1) + c15;
 #pragma unroll
     for (int kc = 0; kc < KCH; ++kc)
@@ -382,7 +385,7 @@ __global__ void __launch_bounds__(256, LB) conv_strip_kernel(const ConvParams p,
     for (int ph = 0; ph < NPH; ++ph) acc[a][ph] = s_f32x4{0.f, 0.f, 0.f, 0.f};
 
   // ---- epilogue: lane = pixel c15 (+ 16 ph) of the row, output channels cob .. cob + 3 ----
-  const int cob = 16 * w + 4 * g;
+  const int cob = 64 * cg + 16 * w + 4 * g;     // (in the launch's Cout channels; inside this workgroup's 64: 16 w + 4 g)
   s_f32x4 add;
   {
     const float* tembp = p.temb ? p.temb + (size_t)n * p.temb_stride + p.temb_off : p.bias;   // (unconditional loads)
@@ -411,15 +414,16 @@ __global__ void __launch_bounds__(256, LB) conv_strip_kernel(const ConvParams p,
   auto tsw = [](int px) { return OSZ == 2 ? ((px >> 1) & 7) : 2 * (px & 7); };
   const int aq = OSZ == 2 ? c15 * PB + 16 * (((4 * w + g) >> 1) ^ tsw(c15)) + 8 * (g & 1)      // + 16 PB ph: quad ph of this lane
                           : c15 * PB + 16 * ((4 * w + g) ^ tsw(c15));
+  const unsigned GPB = (unsigned)p.Cout * OSZ;   // bytes per pixel of the output / residual tensors (the row tiles hold this workgroup's 64 channels: PB)
   int a128[NIT];
   unsigned gofs[NIT];            // byte offset of this thread's unit i inside an output row of the strip
 #pragma unroll
   for (int i = 0; i < NIT; ++i) {
     const int px = tid / UPP + (256 / UPP) * i, u = tid % UPP;
     a128[i] = px * PB + 16 * (u ^ tsw(px));
-    gofs[i] = (unsigned)((ox0 + px) * PB + 16 * u);
+    gofs[i] = (unsigned)((ox0 + px) * GPB + 64 * cg * OSZ + 16 * u);
   }
-  const size_t img = (size_t)n * H * W * PB;
+  const size_t img = (size_t)n * H * W * GPB;
   unsigned char* outn = reinterpret_cast<unsigned char*>(p.out) + img;
   const unsigned char* resn = reinterpret_cast<const unsigned char*>(HAS_RES ? p.res : p.out) + img;
   const uint4 z4 = {0u, 0u, 0u, 0u};
@@ -427,7 +431,7 @@ __global__ void __launch_bounds__(256, LB) conv_strip_kernel(const ConvParams p,
   auto crow = [&](int oy) __attribute__((always_inline)) { return oy < oy0 ? oy0 : (oy >= oy1 ? oy1 - 1 : oy); };
   auto load_res = [&](int oy) __attribute__((always_inline)) {   // residual row oy (clamped into the segment), 16 bytes per unit
     if (HAS_RES && !(STRIP_DIAG & 1)) {
-      const unsigned r0 = (unsigned)(crow(oy) * W) * PB;
+      const unsigned r0 = (unsigned)(crow(oy) * W) * GPB;
       rres0 = *reinterpret_cast<const uint4*>(resn + (r0 + gofs[0]));
       if (NIT > 1) rres1 = *reinterpret_cast<const uint4*>(resn + (r0 + gofs[NIT > 1 ? 1 : 0]));
       if (NIT > 2) rres2 = *reinterpret_cast<const uint4*>(resn + (r0 + gofs[NIT > 2 ? 2 : 0]));
@@ -460,7 +464,7 @@ __global__ void __launch_bounds__(256, LB) conv_strip_kernel(const ConvParams p,
   };
   auto flush = [&](int oy, int i) __attribute__((always_inline)) {   // unit i of row oy's tile to memory (after the barrier that followed its epilogue)
     const uint4 v = *reinterpret_cast<const uint4*>(otile + (oy & 1) * TILE + a128[i]);
-    if (!(STRIP_DIAG & 2)) *reinterpret_cast<uint4*>(outn + ((unsigned)(oy * W) * PB + gofs[i])) = v;
+    if (!(STRIP_DIAG & 2)) *reinterpret_cast<uint4*>(outn + ((unsigned)(oy * W) * GPB + gofs[i])) = v;
   };
 
   // ---- one step: input row iy (staged in slot `cur`) into the three accumulator sets; row iy + 1 staged into `nxt`; row iy + 4
@@ -651,28 +655,31 @@ __global__ void __launch_bounds__(256, LB) conv_strip_kernel(const ConvParams p,
 // ---------------------------------------------------------------------------------------------------------------------------
 // g_tun.strip bits: 1 bf16 64 -> 64 launches (two workgroups per CU), 2 the f16x3 ones (one per CU: hi / lo weight planes = 144
 // registers), 4 (A/B) bf16 64 -> 64 on one workgroup per CU, 8 the bf16 launches with a concatenated input (64 + 64 -> 64,
-// 128 + 64 -> 64 under bit 32: 144 / 216 weight registers, one workgroup per CU), 16 the bf16 launches with a res_conv rider
-static bool strip_wide(const ConvParams& p, int prec) { return prec != PREC_BF16 || (g_tun.strip & 4) || p.C1 || p.xr0; }
+// 128 + 64 -> 64 under bit 32: 144 / 216 weight registers, one workgroup per CU), 16 the bf16 launches with a res_conv rider,
+// 64 the bf16 128-cout launches 128 -> 128 and 64 -> 128 (two workgroups of 64 couts per strip)
+static bool strip_wide(const ConvParams& p, int prec) { return prec != PREC_BF16 || (g_tun.strip & 4) || p.C1 || p.xr0 || p.C0 > 64; }
 static long strip_min_wgs(const ConvParams& p, int prec) { return strip_wide(p, prec) ? g_tun.strip_min_wgs / 2 : g_tun.strip_min_wgs; }
 
 static int strip_seg_rows(const ConvParams& p, int SW, int prec) {
   // strips x segments: enough workgroups to fill the chip (two per CU where the registers allow), segments as long as that allows
   // (each costs two extra steps)
-  const long strips = (long)p.N * ((p.Wout + SW - 1) / SW);
+  const long strips = (long)p.N * ((p.Wout + SW - 1) / SW) * (p.Cout / 64);
   int rows = p.Hout;
   while (rows > 16 && strips * ((p.Hout + rows - 1) / rows) < strip_min_wgs(p, prec)) rows = (rows + 1) / 2;
   return rows;
 }
 
 bool conv_strip_ok(ConvKind kind, int prec, const ConvParams& p) {
-  if (kind != CONV3_S1 || p.ksplit > 1 || p.Cout != 64 || p.Cout_pad != 64) return false;
+  if (kind != CONV3_S1 || p.ksplit > 1 || (p.Cout != 64 && p.Cout != 128) || p.Cout_pad != p.Cout) return false;
   if (!p.gn_scale || p.gn_plain || p.drop_mask) return false;
   if (p.Hin != p.Hout || p.Win != p.Wout || p.Wout % 64 || p.Hout < 3 || (size_t)p.Hout * p.Wout * 192 * 4 >= (1ull << 31)) return false;
   if (prec == PREC_BF16 && p.out_f32) return false;
   const int Cin = p.C0 + p.C1;
   if (Cin != p.Cin_pad) return false;
   bool shape;
-  if (p.xr0) {        // 64 -> 64 with a rider over (64 | 64) or (128 | 64) raw channels
+  if (p.Cout == 128) {   // the 128-cout level: two workgroups of 64 couts read the same rows; 128 -> 128 (144 weight registers) and 64 -> 128, bf16
+    shape = prec == PREC_BF16 && (g_tun.strip & 64) && !p.xr0 && p.C1 == 0 && (p.C0 == 64 || p.C0 == 128);
+  } else if (p.xr0) {        // 64 -> 64 with a rider over (64 | 64) or (128 | 64) raw channels
     shape = prec == PREC_BF16 && (g_tun.strip & 16) && !p.res && p.C0 == 64 && p.C1 == 0 && p.Cr1 == 64 && (p.Cr0 == 64 || p.Cr0 == 128) &&
             p.nkr * 16 == p.Cr0 + p.Cr1;
   } else if (p.C1) {  // concatenated input (64 | 64) or (128 | 64), no residual (block1 of the up path)
@@ -681,7 +688,7 @@ bool conv_strip_ok(ConvKind kind, int prec, const ConvParams& p) {
     shape = p.C0 == 64 && (g_tun.strip & (prec == PREC_BF16 ? 1 : 2));
   }
   if (!shape) return false;
-  const long wgs = (long)p.N * ((p.Wout + 63) / 64) * ((p.Hout + 15) / 16);
+  const long wgs = (long)p.N * ((p.Wout + 63) / 64) * ((p.Hout + 15) / 16) * (p.Cout / 64);
   return wgs >= strip_min_wgs(p, prec);   // (a small grid keeps the split-K tile kernels)
 }
 
@@ -692,7 +699,7 @@ static hipError_t launch_strip_t(const ConvParams& p, int wn_a, hipStream_t s, i
   const int stripsX = (p.Wout + Cfg::SW - 1) / Cfg::SW, segs = (p.Hout + rows - 1) / rows;
   if (tiles) *tiles = stripsX * segs;
   const size_t lds = (size_t)Cfg::RES_OFF + (HAS_RES ? 2 * Cfg::TILE_BYTES : 0);
-  hipLaunchKernelGGL((conv_strip_kernel<PREC, C0_, C1_, CR0_, CR1_, 4, HAS_RES, LB>), dim3(p.N * stripsX * segs), dim3(256), lds, s, p, rows, wn_a);
+  hipLaunchKernelGGL((conv_strip_kernel<PREC, C0_, C1_, CR0_, CR1_, 4, HAS_RES, LB>), dim3(p.N * stripsX * segs * (p.Cout / 64)), dim3(256), lds, s, p, rows, wn_a);
   return hipGetLastError();
 }
 
@@ -701,6 +708,8 @@ hipError_t launch_conv_strip(int prec, const ConvParams& p, int wn_a, hipStream_
     return p.res ? launch_strip_t<PREC_F16X3, 64, 0, 0, 0, true, 1>(p, wn_a, s, tiles) : launch_strip_t<PREC_F16X3, 64, 0, 0, 0, false, 1>(p, wn_a, s, tiles);
   }
   if (prec != PREC_BF16) return hipErrorInvalidValue;
+  if (p.C0 == 128 && !p.C1)   // (Cout 128)
+    return p.res ? launch_strip_t<PREC_BF16, 128, 0, 0, 0, true, 1>(p, wn_a, s, tiles) : launch_strip_t<PREC_BF16, 128, 0, 0, 0, false, 1>(p, wn_a, s, tiles);
   if (p.xr0) {
     return p.Cr0 == 64 ? launch_strip_t<PREC_BF16, 64, 0, 64, 64, false, 1>(p, wn_a, s, tiles) : launch_strip_t<PREC_BF16, 64, 0, 128, 64, false, 1>(p, wn_a, s, tiles);
   }
@@ -726,6 +735,7 @@ hipError_t kernels_strip_init() {
   X(PREC_F16X3, 64, 0, 0, 0, false, 1) X(PREC_F16X3, 64, 0, 0, 0, true, 1)
   X(PREC_BF16, 64, 64, 0, 0, false, 1) X(PREC_BF16, 128, 64, 0, 0, false, 1)
   X(PREC_BF16, 64, 0, 64, 64, false, 1) X(PREC_BF16, 64, 0, 128, 64, false, 1)
+  X(PREC_BF16, 128, 0, 0, 0, false, 1) X(PREC_BF16, 128, 0, 0, 0, true, 1)
 #undef X
   return hipSuccess;
 }

@@ -1,6 +1,8 @@
-"""The column-strip form of the 64 -> 64 stride-1 3x3 launches (fdsr_conv_strip.hip: weights in registers, one input row per step,
-three output rows per fragment read).  Large grids take it by default (`strip` bits: 1 bf16, 2 f16x3; `strip_min_wgs`); here it is
-forced onto every grid size: layer by layer against the oracle (maps 128 x 128 and 64 x 192: one and three strips per row, segments
+"""The column-strip form of the stride-1 3x3 launches at 64 (and, in bf16, 128) output channels (fdsr_conv_strip.hip: weights in
+registers, one input row per step, three output rows per fragment read).  Large grids take it by default (`strip` bits: 1 bf16
+64 -> 64, 2 f16x3 64 -> 64, 8 bf16 (64|64) -> 64, 16 bf16 with a res_conv rider, 32 bf16 (128|64) -> 64 [off by default: spills], 64 bf16
+128 -> 128 and 64 -> 128 as two workgroups of 64 couts; `strip_min_wgs`); here every bit is on and the form is forced onto every grid
+size: layer by layer against the oracle (maps 128 x 128 and 64 x 192: one and three strips per row, segments
 of 16 .. 128 rows, image borders on both sides of a strip), against the tile kernels on the same input, bitwise reruns, the 20-step
 loop eager and as a hipGraph.  Same bounds as every other conv kernel: layerwise 1e-4 * max(1, |ref|) in f16x3, 0.25 in bf16 (judged
 on PSNR elsewhere), loop 1e-3 (north_star).  Reference: fastdiffsr_modules/unet.py:89-120."""
@@ -38,7 +40,7 @@ def test_strip_form_vs_oracle(full, prec, min_wgs):
     cfg, eng, sd = full
     eng.set_precision(prec)
     tol = TOL_FWD if prec == 'f16x3' else 0.25
-    _lib.debug_option('strip', 63 - 4)
+    _lib.debug_option('strip', 127 - 4)
     _lib.debug_option('strip_min_wgs', min_wgs)
     _lib.debug_option('splitk', 0)          # (a launch with a K split keeps the tile kernels)
     try:
@@ -60,7 +62,7 @@ def test_strip_form_vs_oracle(full, prec, min_wgs):
             assert torch.equal(eng.unet_forward(x.cuda(), nl.cuda()), out)              # ordered reductions only
             _lib.debug_option('strip', 0)                                               # the same launches on the tile kernels
             out_d = eng.unet_forward(x.cuda(), nl.cuda())
-            _lib.debug_option('strip', 63 - 4)
+            _lib.debug_option('strip', 127 - 4)
             dd = (out_d - out).abs().max().item()
             assert dd > 0.0                                                             # (0.0: the form was never taken)
             if prec == 'f16x3':
@@ -71,7 +73,7 @@ def test_strip_form_vs_oracle(full, prec, min_wgs):
     finally:
         eng.set_debug(False)
         eng.set_precision('f16x3')
-        _lib.debug_option('strip', 27)
+        _lib.debug_option('strip', 91)
         _lib.debug_option('strip_min_wgs', 512)
         _lib.debug_option('splitk', 1)
 
@@ -83,7 +85,7 @@ def test_strip_form_loop_and_graph(full, prec):
     from oracle import fdsr_oracle as O
     cfg, eng, sd = full
     eng.set_precision(prec)
-    _lib.debug_option('strip', 63 - 4)
+    _lib.debug_option('strip', 127 - 4)
     _lib.debug_option('strip_min_wgs', 1)
     _lib.debug_option('splitk', 0)
     try:
@@ -103,6 +105,6 @@ def test_strip_form_loop_and_graph(full, prec):
         assert torch.equal(g1.cpu(), outl)
     finally:
         eng.set_precision('f16x3')
-        _lib.debug_option('strip', 27)
+        _lib.debug_option('strip', 91)
         _lib.debug_option('strip_min_wgs', 512)
         _lib.debug_option('splitk', 1)
