@@ -54,9 +54,6 @@ __device__ __forceinline__ float silu_s(float v) { return v * __builtin_amdgcn_r
 #ifndef STRIP_FENCE3  // fence behind each of a slot's three MFMA groups (the item's three stages stay between them)
 #define STRIP_FENCE3 1
 #endif
-#ifndef STRIP_PIN     // keep the fragment reads ahead of the MFMAs (sched_barrier that VALU / SALU may cross)
-#define STRIP_PIN 1
-#endif
 
 // One instantiation = (arithmetic, channels of the two concatenated input tensors C0 | C1, channels of the rider's two raw input
 // tensors CR0 | CR1 or 0, 16-pixel blocks per strip row).  SW = 64 pixels: a staging pass of the 256 threads covers 32 channels of
