@@ -170,7 +170,7 @@ def kernel_source_hash():
     import hashlib
     d = os.path.join(ROOT, 'fastdiffsr_amd', 'csrc')
     h = hashlib.sha256()
-    for f in ('fdsr_act_io.h', 'fdsr_conv_h.hip', 'fdsr_conv_k32.hip', 'fdsr_conv_tail.hip', 'fdsr_conv_small.hip', 'fdsr_conv_strip.hip', 'fdsr_conv_up2.hip', 'fdsr_kernels.h', 'fdsr_kernels.hip'):
+    for f in ('fdsr_act_io.h', 'fdsr_conv_h.hip', 'fdsr_conv_k32.hip', 'fdsr_conv_tail.hip', 'fdsr_conv_strip.hip', 'fdsr_conv_up2.hip', 'fdsr_kernels.h', 'fdsr_kernels.hip'):
         h.update(f.encode() + b'\0' + open(os.path.join(d, f), 'rb').read() + b'\0')
     return h.hexdigest()
 

@@ -635,7 +635,6 @@ hipError_t launch_conv_h(ConvKind kind, int prec, const ConvParams& p, hipStream
   // 1x1: stage 64 input channels per barrier when the (concatenated) input allows it
   const int ksub = (kind == CONV1 && p.Cin_pad % 64 == 0 && (p.C1 == 0 || p.C0 % 64 == 0)) ? 4 : 1;
   // 64-cout launches of large grids: the small-workgroup form of the 16x16x32 kernel (two workgroups per CU) with tile rows of its own
-  if (WN == 8 && ksub == 1 && conv_small_ok(kind, prec, p)) return launch_conv_small(p, s, tiles);   // (256-cout launches of small grids: no K split over workgroups)
   if ((WN == 2 || WN == 4) && ksub == 1 && conv_strip_ok(kind, prec, p)) return launch_conv_strip(prec, p, WN, s, tiles);   // (64- and 128-cout launches)
   if (WN == 2 && ksub == 1 && conv_k32_small_ok(kind, prec, p)) return launch_conv_k32_small(prec, p, s, tiles);
   TH = pick_th(kind, WN, ksub, p);
@@ -674,8 +673,7 @@ hipError_t kernels_h_init() {
   FDSR_CONVH_RIDER_SHAPES(XR)
 #undef XR
   if ((e = kernels_k32_init()) != hipSuccess) return e;
-  if ((e = kernels_strip_init()) != hipSuccess) return e;
-  return kernels_small_init();
+  return kernels_strip_init();
 }
 
 }  // namespace fdsr

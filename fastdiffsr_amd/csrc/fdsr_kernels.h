@@ -78,8 +78,6 @@ struct Tunables {
   int k32 = 1275;           // v_mfma_f32_16x16x32 form (fdsr_conv_k32.hip) of the stride-1 3x3 launches that fit it; bits: 1 f16x3, 2 bf16, 4 the 16-row tile with a rider, 8 the 2-row-per-wave tiles of small grids, 16 the sub-pixel upsample convs, 32 the small-workgroup form (4 waves, two workgroups per CU; 6-row tiles in f16x3, 8-row tiles in bf16) of the rider-less 64-cout launches of large grids in f16x3, 128 in bf16 too, 64 the f16x3 launches with a rider too (rider chunks first), 512 the bf16 ones with a rider (off: slower), 1024 the 8-wave rider kernels with the rider chunks first (launches without a K split); 0 never
   int k32_stagger = 0;      // ... start delay of the CU's odd workgroup slot, in 64-cycle units per K chunk (0: none)
   long k32_sb_min_wgs = 1024;   // ... from this many workgroups on (a small grid wants all eight waves of a CU on its one tile)
-  int small = 1;            // small-map form (fdsr_conv_small.hip) of the f16x3 256-cout launches of small grids: K split inside the workgroup
-  long small_max_wgs = 1024;   // ... up to this many workgroups (N x pixel tiles of 2 x 32 x 8 cout blocks)
   int strip = 91;           // column-strip form (fdsr_conv_strip.hip: weights in registers, one input row per step) of the 64-cout launches: bit 1 bf16 64 -> 64, 2 f16x3 64 -> 64, 4 (A/B) bf16 on one workgroup per CU, 8 bf16 (64 | 64) -> 64, 16 bf16 64 -> 64 with a res_conv rider, 32 bf16 (128 | 64) -> 64, 64 bf16 128 -> 128 / 64 -> 128
   long strip_min_wgs = 512; // ... from this many strip segments of >= 16 rows on (two workgroups per CU)
   int tail = 1;             // the input / output convs of the 16-bit modes on their own kernels (fdsr_conv_tail.hip); 0: the general ones
@@ -129,11 +127,6 @@ hipError_t kernels_k32_init();
 bool conv_strip_ok(ConvKind kind, int prec, const ConvParams& p);
 hipError_t launch_conv_strip(int prec, const ConvParams& p, int wn_a, hipStream_t s, int* tiles);
 hipError_t kernels_strip_init();
-// Small-map form of the 256-cout launches of small grids (fdsr_conv_small.hip; f16x3): the K split inside the workgroup, one launch
-// instead of split-K conv + reduce; asked first
-bool conv_small_ok(ConvKind kind, int prec, const ConvParams& p);
-hipError_t launch_conv_small(const ConvParams& p, hipStream_t s, int* tiles);
-hipError_t kernels_small_init();
 // ... and of the sub-pixel upsample kernel (fdsr_conv_up2.hip): k32 bit 16
 bool conv_up2_k32_ok(int prec, const ConvParams& p);
 hipError_t launch_conv_up2_k32(int TH, int WN, int prec, const ConvParams& q, int nwg, hipStream_t s);

@@ -473,8 +473,6 @@ int set_tunable(const char* name, long long v) {
   else if (n == "k32") g_tun.k32 = (int)v;
   else if (n == "k32_sb_min_wgs") g_tun.k32_sb_min_wgs = (long)v;
   else if (n == "k32_stagger") g_tun.k32_stagger = (int)v;
-  else if (n == "small") g_tun.small = (int)v;
-  else if (n == "small_max_wgs") g_tun.small_max_wgs = (long)v;
   else if (n == "strip") g_tun.strip = (int)v;
   else if (n == "strip_min_wgs") g_tun.strip_min_wgs = (long)v;
   else if (n == "sat_guard") g_tun.sat_guard = (int)v;
