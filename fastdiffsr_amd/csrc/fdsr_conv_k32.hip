@@ -65,6 +65,9 @@ __device__ __forceinline__ float silu_k(float v) { return v * __builtin_amdgcn_r
 #ifndef K32_PEEL      // rider-less kernels: the last chunk is a code copy of its own that also fetches the residual tile
 #define K32_PEEL 1
 #endif
+#ifndef K32_GNB_DIAG    // timing probes of the GroupNorm-backward epilogue (results are garbage): 1 no swish' arithmetic, 2 no x / mask loads
+#define K32_GNB_DIAG 0
+#endif
 #ifndef K32_RFIRST   // small-workgroup rider kernels: rider chunks first
 #define K32_RFIRST 1
 #endif
@@ -103,7 +106,8 @@ __device__ __forceinline__ int k32_slot(int slot, int hx) {
   return PREC == PREC_F16X3 ? (slot ^ (hx & 7)) : (slot ^ ((hx >> 1) & 3));
 }
 
-template <int TH, int WN, int PREC, bool RIDER, int NW = 8, bool RF = (NW == 4)>   // RF: rider chunks first (launches without a K split)
+// GNB: the GroupNorm-backward epilogue of the training step's input-gradient launches (ConvParams::gb_*)
+template <int TH, int WN, int PREC, bool RIDER, int NW = 8, bool RF = (NW == 4), bool GNB = false>   // RF: rider chunks first (launches without a K split)
 __global__ void __launch_bounds__(64 * NW, 2) conv_k32_kernel(const ConvParams p) {
   using Cfg = ConvK32Cfg<TH, WN, PREC, NW>;
   constexpr int TW = Cfg::TW, KC = Cfg::KC, NP = Cfg::NP, ROWB = Cfg::ROWB, HWD = Cfg::HWD, NPIX = Cfg::NPIX;
@@ -622,8 +626,86 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_k32_kernel(const ConvParams p
           }
     }
   };
-  if (PREC == PREC_BF16 && !p.out_f32) epilogue(std::true_type{});
-  else epilogue(std::false_type{});
+  // GroupNorm backward, first half (fp32 output, no residual, no K split: the launcher checks): per output quad the raw forward input
+  // x and the dropout bytes are fetched one tile row ahead of the arithmetic; every load is unconditional on a clamped address.
+  auto epilogue_gnb = [&](auto int_tag) __attribute__((always_inline)) {
+    constexpr bool INTERIOR = decltype(int_tag)::value;   // (a compile-time copy of `interior`: the whole-tile path has no branch at all)
+    const int Ct = p.Cout, cpg = Ct / p.gb_G;
+    const bool hm = p.gb_mask != nullptr;
+    const unsigned char* mk = hm ? p.gb_mask : reinterpret_cast<const unsigned char*>(p.gb_scale);
+    const float ds = p.gb_drop;
+    // one half of the lane's output channels at a time: the per-channel constants of both halves, the x tile and the accumulators
+    // together do not fit the register file
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) {
+      const int cs = cok[ch] ? cob + 16 * ch : 0;
+      const k_f32x4 gsc = *reinterpret_cast<const k_f32x4*>(p.gb_scale + (size_t)n * Ct + cs);
+      const k_f32x4 gsh = *reinterpret_cast<const k_f32x4*>(p.gb_shift + (size_t)n * Ct + cs);
+      k_f32x4 gme, grs;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int grp = (cs + r) / cpg;
+        gme[r] = p.gb_stats[((size_t)n * p.gb_G + grp) * 2];
+        grs[r] = p.gb_stats[((size_t)n * p.gb_G + grp) * 2 + 1];
+      }
+      const float* xb;
+      int xcs;
+      if (cs < p.gb_C0) { xb = p.gb_x0 + cs; xcs = p.gb_C0; }
+      else { xb = p.gb_x1 + (cs - p.gb_C0); xcs = Ct - p.gb_C0; }
+      k_f32x4 xq[MB][2];
+      unsigned mq[MB][2];
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        const int oy = min(oy0 + wm + mb * WM, p.Hout - 1);
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
+          const size_t pix = (size_t)(n * p.Hout + oy) * p.Wout + min(ox0 + 16 * ph + c15, p.Wout - 1);
+          if (K32_GNB_DIAG & 2) { xq[mb][ph] = gsc; mq[mb][ph] = 0x01010101u; continue; }
+          xq[mb][ph] = *reinterpret_cast<const k_f32x4*>(xb + pix * xcs);
+          mq[mb][ph] = *reinterpret_cast<const unsigned*>(mk + (hm ? pix * Ct + cs : (size_t)0));
+        }
+      }
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        const int oy = oy0 + wm + mb * WM;
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
+          const int ox = ox0 + 16 * ph + c15;
+          const bool ok = INTERIOR || (cok[ch] && oy < p.Hout && ox < p.Wout);
+          const k_f32x4 v = acc[mb][ph][ch] * winv + add[ch];
+          const k_f32x4 x = xq[mb][ph];
+          const unsigned m = mq[mb][ph];
+          k_f32x4 gq, gx;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float d = v[r];
+            if (hm) d = ((m >> (8 * r)) & 0xffu) ? d * ds : 0.f;
+            const float xh = (x[r] - gme[r]) * grs[r];
+            float gg = d;
+            if (!p.gb_plain && !(K32_GNB_DIAG & 1)) {
+              const float u = fmaf(x[r], gsc[r], gsh[r]);
+              const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-u));   // (the forward's own sigmoid: silu_k)
+              gg = d * (sg * (1.0f + u * (1.0f - sg)));     // d/du [u * sigmoid(u)]
+            }
+            gq[r] = gg;
+            gx[r] = gg * xh;
+          }
+          if (ok) {
+            *reinterpret_cast<k_f32x4*>(p.out + obase + mb * rstride + ph * pstride + 16 * ch) = gq;
+            s1[ch] += gq;
+            s2[ch] += gx;
+          }
+        }
+      }
+    }
+  };
+  if constexpr (GNB) {
+    if (interior) epilogue_gnb(std::true_type{});
+    else epilogue_gnb(std::false_type{});
+  } else {
+    if (PREC == PREC_BF16 && !p.out_f32) epilogue(std::true_type{});
+    else epilogue(std::false_type{});
+  }
   if (p.part_out) {
     // Per-channel (sum, sumsq) of this wave's 4 x 32 pixels: the 16 lanes of a k group hold 16 values each
     // (value v = ch*8 + r*2 + stat); a halving butterfly over the pixel lanes leaves lane c15 with the total of value c15.
@@ -992,11 +1074,18 @@ bool conv_k32_ok(int TH, int WN, int prec, const ConvParams& p) {
   return true;
 }
 
-template <int TH, int WN, int PREC, bool RIDER, int NW = 8, bool RF = (NW == 4)>
+template <int TH, int WN, int PREC, bool RIDER, int NW = 8, bool RF = (NW == 4), bool GNB = false>
 static hipError_t launch_k32_t(const ConvParams& q, int nwg, hipStream_t s) {
   using Cfg = ConvK32Cfg<TH, WN, PREC, NW>;
-  hipLaunchKernelGGL((conv_k32_kernel<TH, WN, PREC, RIDER, NW, RF>), dim3(nwg), dim3(Cfg::NT), (size_t)Cfg::LDS_BYTES, s, q);
+  hipLaunchKernelGGL((conv_k32_kernel<TH, WN, PREC, RIDER, NW, RF, GNB>), dim3(nwg), dim3(Cfg::NT), (size_t)Cfg::LDS_BYTES, s, q);
   return hipGetLastError();
+}
+
+// the GroupNorm-backward epilogue: f16x3, fp32 output, no rider, no residual, no K split, whole groups of the Cout channels
+static bool k32_gnb_ok(int prec, const ConvParams& q) {
+  if (prec != PREC_F16X3 || !q.out_f32 || q.xr0 || q.res || q.ksplit > 1 || !q.gb_scale || !q.gb_shift || !q.gb_stats) return false;
+  if (q.gb_G <= 0 || q.Cout % q.gb_G || q.Cout % 4) return false;
+  return q.gb_x1 ? (q.gb_C0 % 4 == 0 && q.gb_C0 > 0 && q.gb_C0 < q.Cout) : q.gb_C0 == q.Cout;
 }
 
 // The small-workgroup form (NW = 4, two workgroups per CU) of the 64-cout launches: 6-row tiles (what two double-buffered f16x3 halo
@@ -1024,6 +1113,7 @@ hipError_t launch_conv_k32_small(int prec, const ConvParams& p, hipStream_t s, i
   ConvParams q = p;
   q.out_bf16 = (prec == PREC_BF16 && !p.out_f32) ? 1 : 0;
   q.stagger = g_tun.k32_stagger;
+  if (q.gb_x0) return k32_gnb_ok(prec, q) ? launch_k32_t<6, 2, PREC_F16X3, false, 4, true, true>(q, nwg, s) : hipErrorInvalidValue;
   if (prec == PREC_F16X3)
     return q.xr0 ? launch_k32_t<6, 2, PREC_F16X3, true, 4>(q, nwg, s) : launch_k32_t<6, 2, PREC_F16X3, false, 4>(q, nwg, s);
   return q.xr0 ? launch_k32_t<6, 2, PREC_BF16, true, 4>(q, nwg, s) : launch_k32_t<8, 2, PREC_BF16, false, 4>(q, nwg, s);
@@ -1032,6 +1122,7 @@ hipError_t launch_conv_k32_small(int prec, const ConvParams& p, hipStream_t s, i
 hipError_t launch_conv_k32(int TH, int WN, int prec, const ConvParams& q, int nwg, hipStream_t s) {
 #define X(TH_, WN_)                                                                                             \
   if (TH == TH_ && WN == WN_) {                                                                                 \
+    if (q.gb_x0) return k32_gnb_ok(prec, q) ? launch_k32_t<TH_, WN_, PREC_F16X3, false, 8, false, true>(q, nwg, s) : hipErrorInvalidValue; \
     if (q.xr0 && q.ksplit <= 1 && (g_tun.k32 & 1024))                                                           \
       return prec == PREC_F16X3 ? launch_k32_t<TH_, WN_, PREC_F16X3, true, 8, true>(q, nwg, s)                  \
                                 : launch_k32_t<TH_, WN_, PREC_BF16, true, 8, true>(q, nwg, s);                  \
@@ -1045,9 +1136,9 @@ hipError_t launch_conv_k32(int TH, int WN, int prec, const ConvParams& q, int nw
   return hipErrorInvalidValue;
 }
 
-template <int TH, int WN, int PREC, bool RIDER, int NW = 8, bool RF = (NW == 4)>
+template <int TH, int WN, int PREC, bool RIDER, int NW = 8, bool RF = (NW == 4), bool GNB = false>
 static hipError_t init_k32_t() {
-  auto kfn = conv_k32_kernel<TH, WN, PREC, RIDER, NW, RF>;
+  auto kfn = conv_k32_kernel<TH, WN, PREC, RIDER, NW, RF, GNB>;
   return hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
@@ -1070,11 +1161,13 @@ hipError_t kernels_k32_init() {
   if ((e = init_k32_t<TH_, WN_, PREC_BF16, false>()) != hipSuccess) return e;              \
   if ((e = init_k32_t<TH_, WN_, PREC_BF16, true>()) != hipSuccess) return e;                \
   if ((e = init_k32_t<TH_, WN_, PREC_F16X3, true, 8, true>()) != hipSuccess) return e;     \
+  if ((e = init_k32_t<TH_, WN_, PREC_F16X3, false, 8, false, true>()) != hipSuccess) return e; \
   if ((e = init_k32_t<TH_, WN_, PREC_BF16, true, 8, true>()) != hipSuccess) return e;
   FDSR_K32_SHAPES(X)
 #undef X
   if ((e = init_k32_t<6, 2, PREC_F16X3, false, 4>()) != hipSuccess) return e;
   if ((e = init_k32_t<6, 2, PREC_F16X3, true, 4>()) != hipSuccess) return e;
+  if ((e = init_k32_t<6, 2, PREC_F16X3, false, 4, true, true>()) != hipSuccess) return e;
   if ((e = init_k32_t<6, 2, PREC_BF16, true, 4>()) != hipSuccess) return e;
   return hipSuccess;
 }

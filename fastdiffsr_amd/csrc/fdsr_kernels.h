@@ -58,6 +58,18 @@ struct ConvParams {
   const float* w_inv_scale_r_dev;    // K loop passes from the main chunks to the rider chunks (powers of two: exact)
   int* sat_flag;                     // f16x3: set to 1 when a RAW input value exceeds the f16 range (null: no check)
   int stagger;                       // small-workgroup k32 form: workgroups in an odd slot of their CU start this many 64-cycle sleeps per K chunk late
+  // Training, input-gradient launches of a GroupNorm'd convolution (f16x3 16x16x32 kernels only, fdsr_conv_k32.hip): the epilogue turns
+  // the gradient w.r.t. the ACTIVATED input, dA = this convolution's output, into g = dA * keep/(1-p) * swish'(u) (u = x*scale + shift),
+  // stores g instead of dA and emits the per-tile channel sums (sum g, sum g*xhat) through part_out -- the reduction pass of the
+  // GroupNorm backward (gn_bwd_reduce_kernel: one more read of x, dA and the mask) inside the launch that produces dA.
+  const float* gb_x0;                // null: off.  The forward GroupNorm's raw input (gb_x0: gb_C0 channels | gb_x1: Cout - gb_C0)
+  const float* gb_x1;
+  int gb_C0, gb_G, gb_plain;         // gb_G groups over Cout channels; gb_plain: GroupNorm only (no Swish)
+  const float* gb_scale;             // [N][Cout] the forward's per-channel scale / shift (as gn_scale / gn_shift)
+  const float* gb_shift;
+  const float* gb_stats;             // [N][G][2] mean, rstd
+  const unsigned char* gb_mask;      // [N][Hout][Wout][Cout] dropout keep bytes or null
+  float gb_drop;                     // 1/(1-p)
 };
 
 enum Precision { PREC_F32 = 0, PREC_F16X3 = 1, PREC_BF16 = 2 };
@@ -74,6 +86,7 @@ struct Tunables {
   int wgrad_form = 0;       // f16x3 weight gradients: 0 default (8-wave in-row), 1 4-wave everywhere, 2 8-wave without the interleave
   int wgrad_colsum = 1;     // column sums of dy fused into the in-row weight-gradient kernel
   int wgrad_f32 = 0;        // f16x3 steps keep exact-fp32 weight gradients
+  int gnb_fuse = 1;         // f16x3 steps: the reduce half of the GroupNorm backward inside the input-gradient launch (ConvParams::gb_*)
   long long wgrad_big_bytes = 1ll << 32;   // tensors from this size on take the 4-wave weight-gradient kernel (64-bit offsets)
   int k32 = 1275;           // v_mfma_f32_16x16x32 form (fdsr_conv_k32.hip) of the stride-1 3x3 launches that fit it; bits: 1 f16x3, 2 bf16, 4 the 16-row tile with a rider, 8 the 2-row-per-wave tiles of small grids, 16 the sub-pixel upsample convs, 32 the small-workgroup form (4 waves, two workgroups per CU; 6-row tiles in f16x3, 8-row tiles in bf16) of the rider-less 64-cout launches of large grids in f16x3, 128 in bf16 too, 64 the f16x3 launches with a rider too (rider chunks first), 512 the bf16 ones with a rider (off: slower), 1024 the 8-wave rider kernels with the rider chunks first (launches without a K split); 0 never
   int k32_stagger = 0;      // ... start delay of the CU's odd workgroup slot, in 64-cycle units per K chunk (0: none)
@@ -103,6 +116,7 @@ hipError_t kernels_init();
 // 16-bit-operand MFMA convolutions (fp32-grade f16x3 split, or plain bf16).
 void conv_h_config(ConvKind kind, int Cout, int* TH, int* WN);   // BN = 32*WN, K-chunk = 16
 hipError_t launch_conv_h(ConvKind kind, int prec, const ConvParams& p, hipStream_t s, int* tiles_per_image);
+bool conv_h_gnb_ok(ConvKind kind, int prec, const ConvParams& p);   // ConvParams::gb_* honoured by the kernel this launch lands on
 // K-loop split factor of a 16-bit conv launch (1 = none): a pure function of the shape, so the
 // workspace planner and the launcher agree.  Only grids that would leave most of the 256 CUs idle split.
 int conv_h_ksplit(ConvKind kind, int N, int Hout, int Wout, int Cout, int Cout_pad, int Cin_pad, int C0, int C1);

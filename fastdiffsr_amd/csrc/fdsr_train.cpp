@@ -68,7 +68,7 @@ int make_train_plan(fdsr_handle h, int N, int H, int W, TrainPlan* tp) {
     if (op.ck == CONV3_S2) tmpZ = std::max(tmpZ, (size_t)N * Hi * Wi * op.Cout * sizeof(float));
     wg = std::max(wg, wgrad_scratch_floats(op.ck, N, Ho, Wo, Cin, op.Cout) * sizeof(float));
     dbl = std::max(dbl, colsum_scratch_doubles(N, Ho * Wo, std::max(op.Cout, 8)) * sizeof(double));
-    if (op.gn_slot >= 0) dbl = std::max(dbl, gn_bwd_scratch_doubles(N, Hi * Wi, Cin) * sizeof(double));
+    if (op.gn_slot >= 0) dbl = std::max(dbl, gn_bwd_scratch_doubles(N, Hi, Wi, Cin) * sizeof(double));
   }
   dbl = std::max(dbl, loss_partial_count((size_t)N * H * W) * sizeof(double));
   auto take = [&](size_t b) { const size_t r = off; off += align_up(b, 256); return r; };
@@ -277,8 +277,11 @@ int launch_dgrad(fdsr_handle h, ConvKind ck, const float* dy, int K, int Hs, int
 }
 
 // the same on the f16x3 kernels (fp32-grade: three f16 MFMAs per product), fragments from d_wtq
+// gb (optional): the GroupNorm-backward fields (ConvParams::gb_*, part_out) of a launch whose output is the gradient w.r.t. a
+// GroupNorm'd + activated input; *gb_tiles returns the tiles per image of the per-tile sums, 0 when the kernel this launch lands on
+// has no such epilogue (the fields are then left out and the caller runs the reduce pass).
 int launch_dgrad_h(fdsr_handle h, const Op& op, const float* dy, int K, int Hs, int Ws, size_t qoff, int Csub, float* out,
-                   bool accumulate, int N, hipStream_t st) {
+                   bool accumulate, int N, hipStream_t st, const ConvParams* gb = nullptr, int* gb_tiles = nullptr) {
   const ConvKind k = op.ck == CONV1 ? CONV1 : CONV3_S1;
   int TH, WN;
   conv_h_config(k, Csub, &TH, &WN);
@@ -291,6 +294,14 @@ int launch_dgrad_h(fdsr_handle h, const Op& op, const float* dy, int K, int Hs, 
   p.w_inv_scale_dev = h->d_hscale + 2 * (size_t)op.w + 1;
   p.ksplit = 1;
   p.out_f32 = 1;
+  if (gb_tiles) *gb_tiles = 0;
+  if (gb && gb_tiles && g_tun.gnb_fuse && conv_h_gnb_ok(k, PREC_F16X3, p)) {
+    p.gb_x0 = gb->gb_x0; p.gb_x1 = gb->gb_x1; p.gb_C0 = gb->gb_C0; p.gb_G = gb->gb_G; p.gb_plain = gb->gb_plain;
+    p.gb_scale = gb->gb_scale; p.gb_shift = gb->gb_shift; p.gb_stats = gb->gb_stats; p.gb_mask = gb->gb_mask; p.gb_drop = gb->gb_drop;
+    p.part_out = gb->part_out;
+    HIPCHK(h, launch_conv_h(k, PREC_F16X3, p, st, gb_tiles));
+    return FDSR_OK;
+  }
   HIPCHK(h, launch_conv_h(k, PREC_F16X3, p, st, nullptr));
   return FDSR_OK;
 }
@@ -486,8 +497,27 @@ int train_grads_impl(fdsr_handle h, const float* x_nchw, const float* hr_nchw, c
       return launch_dgrad(h, op.ck, dyp, K, Hs, Ws, h->d_wt + (src == 0 ? h->wt_off0[op.w] : h->wt_off1[op.w]), Csub, outp, acc, N, st);
     };
     if (op.gn_slot >= 0) {
-      if ((rc = dgrad(dy, Ho, Wo, 0, Cin, tmpA, false))) return rc;
       GnBwdParams g{};
+      // f16x3: the first half of the GroupNorm backward (g = dA * dropout * swish'(u) and its per-tile channel sums) runs in the epilogue
+      // of the launch that produces dA, where that launch is a 16x16x32 kernel
+      int gb_tiles = 0;
+      {
+        const size_t qo = h->wtq_off0[op.w];
+        if (h->prec == PREC_F16X3 && qo != SIZE_MAX) {
+          ConvParams gb{};
+          gb.gb_x0 = TP(op.src0); gb.gb_x1 = TP(op.src1); gb.gb_C0 = op.C0; gb.gb_G = G; gb.gb_plain = op.gn_plain ? 1 : 0;
+          gb.gb_scale = reinterpret_cast<const float*>(ws + sp.gn_off[op.gn_slot]);
+          gb.gb_shift = gb.gb_scale + (size_t)N * Cin;
+          gb.gb_stats = reinterpret_cast<const float*>(ws + sp.gn_stats_off[op.gn_slot]);
+          if (sp.training && op.drop_slot >= 0) {
+            gb.gb_mask = reinterpret_cast<const unsigned char*>(ws + sp.drop_off[op.drop_slot]);
+            gb.gb_drop = 1.0f / (1.0f - h->cfg.dropout);
+          }
+          gb.part_out = gn_bwd_tile_part(dbl);
+          if ((rc = launch_dgrad_h(h, op, dy, K, Ho, Wo, qo, Cin, tmpA, false, N, st, &gb, &gb_tiles))) return rc;
+        } else if ((rc = dgrad(dy, Ho, Wo, 0, Cin, tmpA, false))) return rc;
+      }
+      if (gb_tiles > 0) { g.g_part = gn_bwd_tile_part(dbl); g.g_nt = gb_tiles; }
       g.dA = tmpA; g.x0 = TP(op.src0); g.x1 = TP(op.src1); g.C0 = op.C0; g.C1 = op.C1;
       g.scale = reinterpret_cast<const float*>(ws + sp.gn_off[op.gn_slot]);
       g.shift = g.scale + (size_t)N * Cin;
@@ -498,7 +528,7 @@ int train_grads_impl(fdsr_handle h, const float* x_nchw, const float* hr_nchw, c
       g.assign1 = op.src1 >= 0 && first(op.src1) ? 1 : 0;
       g.dgamma = DG(op.gamma); g.dbeta = DG(op.beta);
       g.scratch = dbl;
-      g.N = N; g.HW = Hi * Wi; g.G = G; g.plain = op.gn_plain ? 1 : 0;
+      g.N = N; g.HW = Hi * Wi; g.H = Hi; g.G = G; g.plain = op.gn_plain ? 1 : 0;
       if (sp.training && op.drop_slot >= 0) {
         g.drop_mask = reinterpret_cast<const unsigned char*>(ws + sp.drop_off[op.drop_slot]);
         g.drop_scale = 1.0f / (1.0f - h->cfg.dropout);

@@ -56,12 +56,18 @@ struct GnBwdParams {
   int assign0, assign1;           // 1: this is the first contribution to that gradient tensor, store instead of accumulate
   float* dgamma; float* dbeta;    // [C], written (=)
   double* scratch;                // gn_bwd_scratch_doubles()
-  int N, HW, G;
+  int N, HW, H, G;                // H: rows of the map (HW / H columns)
   int plain;                      // 1: GroupNorm only (no Swish)
   const unsigned char* drop_mask; // train-mode dropout after the Swish (block2): keep bytes [N][HW][C0] or null
   float drop_scale;               // 1 / (1 - p)
+  // The input-gradient launch already did the first half (ConvParams::gb_*, fdsr_conv_k32.hip): dA then holds g itself and g_part the
+  // per-tile channel sums [N][g_nt][C][2] (sum g, sum g*xhat) -- the reduce pass is left out, the apply pass reads neither the mask nor
+  // scale / shift.  g_part lives at the head of `scratch` (gn_bwd_tile_part()).
+  const float* g_part;            // null: dA is the raw gradient w.r.t. the activated input
+  int g_nt;
 };
-size_t gn_bwd_scratch_doubles(int N, int HW, int C);
+size_t gn_bwd_scratch_doubles(int N, int H, int W, int C);
+inline float* gn_bwd_tile_part(double* scratch) { return reinterpret_cast<float*>(scratch); }   // room for ceil(W/32) * ceil(H/2) tiles per image
 hipError_t launch_gn_bwd(const GnBwdParams& p, hipStream_t s);
 
 // ---- convolution weight gradient -----------------------------------------------------------------------------

@@ -274,9 +274,14 @@ hipError_t launch_add_slice(const float* src, float* dst, size_t npix, int Cs, i
 // ---------------------------------------------------------------------------
 #define FDSR_GNB_SLICES 64
 // scratch: part [N][SLICES][C][2] | tot [N][C][2] | gm [N][G][2]   (doubles)
-size_t gn_bwd_scratch_doubles(int N, int HW, int C) {
-  (void)HW;
-  return (size_t)N * FDSR_GNB_SLICES * C * 2 + (size_t)N * C * 2 + (size_t)N * C * 2;
+// (the partial region also holds the fused form's fp32 tile sums: tiles of >= 2 rows x 32 pixels)
+static size_t gn_bwd_max_tiles(int H, int W) { return (size_t)((W + 31) / 32) * ((H + 1) / 2); }
+static size_t gn_bwd_part_doubles(int N, int H, int W, int C) {
+  const size_t slices = std::max<size_t>(FDSR_GNB_SLICES, (gn_bwd_max_tiles(H, W) + 1) / 2);
+  return (size_t)N * slices * C * 2;
+}
+size_t gn_bwd_scratch_doubles(int N, int H, int W, int C) {
+  return gn_bwd_part_doubles(N, H, W, C) + (size_t)N * C * 2 + (size_t)N * C * 2;
 }
 
 // dA arrives already multiplied by the dropout factor (keep / (1-p)) of this element when dropout is on
@@ -372,6 +377,48 @@ __global__ void __launch_bounds__(256) gn_bwd_finalize_kernel(const GnBwdParams 
   }
 }
 
+// The fused form's finalisation (GnBwdParams::g_part): grid (N, G), one workgroup per group of one image.  Thread (ch, slice) adds the
+// tiles slice, slice + S, ... of channel ch in double, the S (a power of two) slices are folded pairwise in LDS -- a fixed order.
+__global__ void __launch_bounds__(256) gn_bwd_finalize_tiles_kernel(const GnBwdParams p, double* __restrict__ tot, double* __restrict__ gm) {
+  __shared__ double sd[256][2];
+  const int n = blockIdx.x, g = blockIdx.y, tid = threadIdx.x, C = p.C0 + p.C1, cpg = C / p.G;   // cpg <= 64 (launcher)
+  int S = 1;
+  while (S * 2 * cpg <= 256) S *= 2;
+  const int ch = tid % cpg, slice = tid / cpg, c = g * cpg + ch;
+  double a = 0.0, b = 0.0;
+  if (slice < S) {
+    const float* src = p.g_part + ((size_t)n * p.g_nt * C + c) * 2;
+#pragma unroll 4
+    for (int t = slice; t < p.g_nt; t += S) {
+      const float2 v = *reinterpret_cast<const float2*>(src + (size_t)t * C * 2);
+      a += (double)v.x;
+      b += (double)v.y;
+    }
+  }
+  sd[tid][0] = a;
+  sd[tid][1] = b;
+  __syncthreads();
+  for (int h = S >> 1; h >= 1; h >>= 1) {
+    if (slice < h) { sd[tid][0] += sd[tid + h * cpg][0]; sd[tid][1] += sd[tid + h * cpg][1]; }
+    __syncthreads();
+  }
+  if (tid < cpg) {
+    tot[((size_t)n * C + c) * 2] = sd[tid][0];
+    tot[((size_t)n * C + c) * 2 + 1] = sd[tid][1];
+  }
+  if (tid == 0) {
+    double m1 = 0.0, m2 = 0.0;
+    for (int k = 0; k < cpg; ++k) {
+      const double gam = (double)p.gamma[g * cpg + k];
+      m1 += gam * sd[k][0];
+      m2 += gam * sd[k][1];
+    }
+    const double inv = 1.0 / ((double)cpg * (double)p.HW);
+    gm[((size_t)n * p.G + g) * 2] = m1 * inv;
+    gm[((size_t)n * p.G + g) * 2 + 1] = m2 * inv;
+  }
+}
+
 // dgamma[c] = sum_n s2[n][c], dbeta[c] = sum_n s1[n][c] (in image order)
 __global__ void __launch_bounds__(256) gn_bwd_affine_kernel(const double* __restrict__ tot, int N, int C, float* __restrict__ dgamma,
                                                             float* __restrict__ dbeta) {
@@ -383,7 +430,8 @@ __global__ void __launch_bounds__(256) gn_bwd_affine_kernel(const double* __rest
   dgamma[c] = (float)b;
 }
 
-// elementwise: dx += rstd * (gamma*g - m1 - xhat*m2)
+// elementwise: dx += rstd * (gamma*g - m1 - xhat*m2)      (GREADY: dA holds g already, see GnBwdParams::g_part)
+template <bool GREADY>
 __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const GnBwdParams p, const double* __restrict__ gm, size_t total) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;   // over [N][HW][C/4]
   if (i >= total) return;
@@ -395,13 +443,16 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const GnBwdParams p, 
   if (c < p.C0) { xs = p.x0; dxs = p.dx0; Cs = p.C0; cc = c; assign = p.assign0; } else { xs = p.x1; dxs = p.dx1; Cs = p.C1; cc = c - p.C0; assign = p.assign1; }
   const f32x4 x = *reinterpret_cast<const f32x4*>(xs + pix * Cs + cc);
   f32x4 d = *reinterpret_cast<const f32x4*>(p.dA + pix * C + c);
-  if (p.drop_mask) {
+  if (!GREADY && p.drop_mask) {
     const unsigned m = *reinterpret_cast<const unsigned*>(p.drop_mask + pix * C + c);
 #pragma unroll
     for (int e = 0; e < 4; ++e) d[e] = ((m >> (8 * e)) & 0xffu) ? d[e] * p.drop_scale : 0.f;
   }
-  const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + n * C + c);
-  const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + n * C + c);
+  f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = sc;
+  if (!GREADY) {
+    sc = *reinterpret_cast<const f32x4*>(p.scale + n * C + c);
+    sh = *reinterpret_cast<const f32x4*>(p.shift + n * C + c);
+  }
   f32x4 o = {0.f, 0.f, 0.f, 0.f};
   if (!assign) o = *reinterpret_cast<const f32x4*>(dxs + pix * Cs + cc);
 #pragma unroll
@@ -409,7 +460,7 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const GnBwdParams p, 
     const int g = (c + e) / cpg;
     const float mean = p.stats[(n * p.G + g) * 2], rstd = p.stats[(n * p.G + g) * 2 + 1];
     float gg, xh;
-    gnb_elem(x[e], d[e], sc[e], sh[e], mean, rstd, p.plain, gg, xh);
+    gnb_elem(x[e], d[e], sc[e], sh[e], mean, rstd, GREADY ? 1 : p.plain, gg, xh);
     const float m1 = (float)gm[(n * p.G + g) * 2], m2 = (float)gm[(n * p.G + g) * 2 + 1];
     o[e] += rstd * (p.gamma[c + e] * gg - m1 - xh * m2);
   }
@@ -418,15 +469,22 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const GnBwdParams p, 
 
 hipError_t launch_gn_bwd(const GnBwdParams& p, hipStream_t s) {
   const int C = p.C0 + p.C1;
-  if ((p.C0 & 3) || (p.C1 & 3) || C % p.G) return hipErrorInvalidValue;
+  if ((p.C0 & 3) || (p.C1 & 3) || C % p.G || p.H <= 0 || p.HW % p.H) return hipErrorInvalidValue;
   double* part = p.scratch;
-  double* tot = part + (size_t)p.N * FDSR_GNB_SLICES * C * 2;
+  double* tot = part + gn_bwd_part_doubles(p.N, p.H, p.HW / p.H, C);
   double* gm = tot + (size_t)p.N * C * 2;
+  const size_t total = (size_t)p.N * p.HW * (C >> 2);
+  if (p.g_part) {   // the input-gradient launch did the reduction (per-tile sums) and left g in dA
+    if (C / p.G > 64 || p.g_nt <= 0 || (size_t)p.g_nt > gn_bwd_max_tiles(p.H, p.HW / p.H) || p.g_part != gn_bwd_tile_part(p.scratch)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(gn_bwd_finalize_tiles_kernel, dim3(p.N, p.G), dim3(256), 0, s, p, tot, gm);
+    hipLaunchKernelGGL(gn_bwd_affine_kernel, dim3((C + 255) / 256), dim3(256), 0, s, tot, p.N, C, p.dgamma, p.dbeta);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, gm, total);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(FDSR_GNB_SLICES, p.N), dim3(256), 0, s, p, part);
   hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(p.N), dim3(256), 0, s, p, part, tot, gm);
   hipLaunchKernelGGL(gn_bwd_affine_kernel, dim3((C + 255) / 256), dim3(256), 0, s, tot, p.N, C, p.dgamma, p.dbeta);
-  const size_t total = (size_t)p.N * p.HW * (C >> 2);
-  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, gm, total);
+  hipLaunchKernelGGL(gn_bwd_apply_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, gm, total);
   return hipGetLastError();
 }
 

@@ -368,12 +368,13 @@ def test_autograd_compatible_loss_fills_param_grads():
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize('option', [('wgrad_form', 1), ('wgrad_form', 2), ('wgrad_colsum', 0), ('wgrad_f32', 1), ('wgrad_big_bytes', 1 << 20)])
+@pytest.mark.parametrize('option', [('wgrad_form', 1), ('wgrad_form', 2), ('wgrad_colsum', 0), ('wgrad_f32', 1), ('wgrad_big_bytes', 1 << 20), ('gnb_fuse', 0)])
 def test_every_weight_gradient_kernel_form_meets_the_golden(option):
     """The f16x3 step picks its weight-gradient kernel per layer (8-wave in-row with fused column sums by default); the A/B
     options (fdsr_debug_option) force the other forms -- 4-wave, 8-wave without the interleave, separate column-sum pass,
-    exact-fp32 weight gradients, and the ">= 4 GiB tensor" fallback (threshold lowered to 1 MiB: every large layer takes the
-    64-bit-offset kernel) -- and each must reproduce the reference's 273 gradients and its Adam update (a fresh process per
+    exact-fp32 weight gradients, the ">= 4 GiB tensor" fallback (threshold lowered to 1 MiB: every large layer takes the
+    64-bit-offset kernel), and the GroupNorm backward with its reduction as a pass of its own instead of inside the
+    input-gradient launch -- and each must reproduce the reference's 273 gradients and its Adam update (a fresh process per
     option, so that nothing else in this session runs under it)."""
     import subprocess
     import sys
@@ -422,6 +423,47 @@ def test_f16x3_step_on_ragged_shapes_matches_the_exact_fp32_step(shape):
         if scale > 1e-3 * gmax:
             worst = max(worst, d / scale)
     print(f'ragged {shape}: worst relative gradient difference {worst:.2e} (tensors above 1e-3 of the largest gradient)')
+
+
+@pytest.mark.parametrize('shape', [(3, 40, 56), (2, 64, 64)])
+def test_gn_backward_inside_the_input_gradient_launch_equals_the_separate_pass(shape):
+    """f16x3 step: the first half of the GroupNorm + Swish (+ Dropout) backward -- g = dA * keep/(1-p) * swish'(u) and the
+    per-channel sums of g and g*xhat -- runs in the epilogue of the 16x16x32 convolution launch that produces dA
+    (ConvParams::gb_*; default), or as gn_bwd_reduce_kernel over dA (`gnb_fuse=0`).  Same masks, same inputs: every gradient
+    agrees to fp32 summation-order noise, on whole tiles and on a shape whose tiles are ragged on both axes, and the fused
+    form is the one that ran (it is not bit-identical: the sums are taken per tile, not per pixel slice)."""
+    from fastdiffsr_amd import _lib
+    from fastdiffsr_amd.engine import Engine
+    B, H, W = shape
+    cfg = UNetConfig(in_channel=6, out_channel=3, inner_channel=32, norm_groups=32, channel_mults=(1, 2, 4), attn_res=(16,),
+                     res_blocks=1, dropout=0.2, image_size=32)
+    sd = synth_state_dict(cfg, 7)
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(B, 6, H, W, generator=g).cuda()
+    nl = (torch.rand(B, generator=g) * 0.5 + 0.4).cuda()
+    tgt = torch.randn(B, 3, H, W, generator=g).cuda()
+    grads = {}
+    try:
+        for fuse in (1, 0):
+            _lib.debug_option('gnb_fuse', fuse)
+            eng = Engine(cfg)
+            eng.load_state_dict(sd)
+            eng.set_precision('f16x3')
+            eng.set_training(True)
+            eng.set_seed(99)
+            loss = eng.train_grads(x, nl, tgt, 'l1', 1.0 / x[:, :3].numel())
+            grads[fuse] = (loss, {k: eng.get_grad(k).copy() for k, _, live in eng.schema() if live})
+    finally:
+        _lib.debug_option('gnb_fuse', 1)
+    assert grads[0][0] == grads[1][0]                    # the forward is the same launch set
+    gmax = max(float(np.abs(a).max()) for a in grads[0][1].values())
+    differs = False
+    for k, a in grads[0][1].items():
+        b = grads[1][1][k]
+        d = float(np.abs(a - b).max())
+        assert d <= 2e-5 * float(np.abs(a).max()) + 1e-7 * gmax, (k, d, float(np.abs(a).max()), gmax)
+        differs = differs or d > 0
+    assert differs, 'gnb_fuse=1 ran the separate reduce pass'
 
 
 @pytest.mark.parametrize('prec', ['f32', 'f16x3'])
