@@ -550,7 +550,7 @@ static hipError_t launch_h_t(const ConvParams& p, hipStream_t s, int* tiles) {
     const hipError_t e = launch_conv_k32(TH, WN, PREC, q, nwg, s);   // the 16x16x32 form (fdsr_conv_k32.hip): same grid, same outputs
     if (e != hipSuccess) return e;
   } else {
-    if (p.gb_x0) return hipErrorInvalidValue;   // the GroupNorm-backward epilogue lives in the 16x16x32 kernels only (conv_h_gnb_ok)
+    if (p.gb_x0 || p.drop_mask) return hipErrorInvalidValue;   // the GroupNorm-backward epilogue and the dropout staging live in the 16x16x32 kernels only (conv_h_gnb_ok / conv_h_drop_ok)
     hipLaunchKernelGGL(kfn, dim3(nwg), dim3(Cfg::NT), lds, s, q);
   }
   if (sk > 1 && (g_tun.knockout & 2)) {   // timing-only probe: the reduce launch left out (results are garbage)
@@ -634,6 +634,16 @@ int conv_h_ksplit(ConvKind kind, int N, int Hout, int Wout, int Cout, int Cout_p
 // before it sets the gb_* fields; a launch that carries them and lands elsewhere fails.
 bool conv_h_gnb_ok(ConvKind kind, int prec, const ConvParams& p) {
   if (kind != CONV3_S1 || prec != PREC_F16X3 || p.xr0 || p.res || p.ksplit > 1 || !p.out_f32 || p.gn_scale) return false;
+  int TH, WN;
+  conv_h_config(kind, p.Cout, &TH, &WN);
+  if (WN == 2 && conv_k32_small_ok(kind, prec, p)) return true;
+  TH = pick_th(kind, WN, 1, p);
+  return conv_k32_ok(TH, WN, prec, p);
+}
+
+// the same question for train-mode dropout applied in the staging (ConvParams::drop_mask in a 16-bit launch)
+bool conv_h_drop_ok(ConvKind kind, int prec, const ConvParams& p) {
+  if (kind != CONV3_S1 || !conv_k32_drop_ok(prec, p)) return false;
   int TH, WN;
   conv_h_config(kind, p.Cout, &TH, &WN);
   if (WN == 2 && conv_k32_small_ok(kind, prec, p)) return true;

@@ -107,7 +107,8 @@ __device__ __forceinline__ int k32_slot(int slot, int hx) {
 }
 
 // GNB: the GroupNorm-backward epilogue of the training step's input-gradient launches (ConvParams::gb_*)
-template <int TH, int WN, int PREC, bool RIDER, int NW = 8, bool RF = (NW == 4), bool GNB = false>   // RF: rider chunks first (launches without a K split)
+// DROP: train-mode Dropout between the Swish and the convolution applied in the staging (ConvParams::drop_mask; f16x3 training forwards)
+template <int TH, int WN, int PREC, bool RIDER, int NW = 8, bool RF = (NW == 4), bool GNB = false, bool DROP = false>   // RF: rider chunks first (launches without a K split)
 __global__ void __launch_bounds__(64 * NW, 2) conv_k32_kernel(const ConvParams p) {
   using Cfg = ConvK32Cfg<TH, WN, PREC, NW>;
   constexpr int TW = Cfg::TW, KC = Cfg::KC, NP = Cfg::NP, ROWB = Cfg::ROWB, HWD = Cfg::HWD, NPIX = Cfg::NPIX;
@@ -179,6 +180,7 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_k32_kernel(const ConvParams p
 
   using IO = ActIO<PREC>;
   typedef typename IO::Quad Quad;
+  struct QM { Quad q; unsigned m; };   // a staged quad and (DROP) the four dropout bytes of its channels; `m` is never materialised otherwise
   // RFIRST (the small-workgroup rider kernels): the rider's chunks run BEFORE the main chunks, so that their whole-chunk prefetch set is
   // dead when the main loop starts and that loop is the rider-less one (two-half staging, peeled last chunk) -- the round-3 plan.
   constexpr bool RFIRST = RIDER && RF && K32_RFIRST != 0;
@@ -187,14 +189,14 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_k32_kernel(const ConvParams p
   typedef std::integral_constant<int, 0> I_0;
   typedef std::integral_constant<int, NA> I_A;
   typedef std::integral_constant<int, NIN> I_N;
-  Quad rin[NA];
-  Quad rr1[RIDER && SPLIT ? NIN : 1];          // rider chunks are fetched whole: first set (rin itself when not SPLIT)
-  Quad rin2[RIDER && K32_RIDER2 && NW == 8 ? NIN : 1];   // (small workgroups: one set -- the CU's other workgroup covers the latency)   // second prefetch set of the rider chunks
+  QM rin[NA];
+  QM rr1[RIDER && SPLIT ? NIN : 1];          // rider chunks are fetched whole: first set (rin itself when not SPLIT)
+  QM rin2[RIDER && K32_RIDER2 && NW == 8 ? NIN : 1];   // (small workgroups: one set -- the CU's other workgroup covers the latency)   // second prefetch set of the rider chunks
   k_f32x4 rsc = {1.f, 1.f, 1.f, 1.f}, rsh = {0.f, 0.f, 0.f, 0.f};
   const int nk = p.Cin_pad / KC;               // main chunks; nk .. nk + nkr - 1 are the rider's (raw second input, centre tap)
   const int nk16 = p.Cin_pad / 16;
   const int nkr = RIDER ? p.nkr / 2 : 0;
-  auto prefetch_rng = [&](int kc, Quad* rin, auto i0_tag, auto i1_tag, bool load_gn) __attribute__((always_inline)) {
+  auto prefetch_rng = [&](int kc, QM* rin, auto i0_tag, auto i1_tag, bool load_gn) __attribute__((always_inline)) {
     constexpr int I0 = decltype(i0_tag)::value, I1 = decltype(i1_tag)::value;
     int cbase = kc * KC;
     const float* base;
@@ -212,20 +214,29 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_k32_kernel(const ConvParams p
       rsh = *reinterpret_cast<const k_f32x4*>(p.gn_shift + (size_t)n * Cin + cbase + q * 4);
     }
 #pragma unroll
-    for (int i = I0; i < I1; ++i)
-      rin[i - I0] = IO::load4(base, (size_t)(in_pix[i] < 0 ? 0 : in_pix[i]) * Cs + cc);
+    for (int i = I0; i < I1; ++i) {
+      const size_t pi = (size_t)(in_pix[i] < 0 ? 0 : in_pix[i]);
+      rin[i - I0].q = IO::load4(base, pi * Cs + cc);
+      if (DROP)   // the dropout bytes of these four channels ([N][H][W][C0], single input); a rider chunk reads element 0 (unused): a select, not a branch
+        rin[i - I0].m = *reinterpret_cast<const unsigned*>(p.drop_mask + ((RIDER && kc >= nk) ? (size_t)0 : pi * Cs + cc));
+    }
   };
-  auto prefetch_to = [&](int kc, Quad* rin) __attribute__((always_inline)) { prefetch_rng(kc, rin, I_0{}, I_N{}, true); };
-  auto stage_rng = [&](int kc, unsigned char* buf, const Quad* rin, auto i0_tag, auto i1_tag) __attribute__((always_inline)) {
+  auto prefetch_to = [&](int kc, QM* rin) __attribute__((always_inline)) { prefetch_rng(kc, rin, I_0{}, I_N{}, true); };
+  auto stage_rng = [&](int kc, unsigned char* buf, const QM* rin, auto i0_tag, auto i1_tag) __attribute__((always_inline)) {
     constexpr int I0 = decltype(i0_tag)::value, I1 = decltype(i1_tag)::value;
     const k_f32x4 sc = rsc, sh = rsh;
 #pragma unroll
     for (int i = I0; i < I1; ++i) {
       if (NIN * RPP > NPIX && i == NIN - 1 && row0 + i * RPP >= NPIX) continue;   // only the last pass can overrun
-      k_f32x4 v = IO::widen(rin[i - I0]);
+      k_f32x4 v = IO::widen(rin[i - I0].q);
       if (gn && !(RIDER && kc >= nk)) {
         v = v * sc + sh;
         if (!p.gn_plain) { v.x = silu_k(v.x); v.y = silu_k(v.y); v.z = silu_k(v.z); v.w = silu_k(v.w); }
+        if (DROP) {   // train-mode Dropout(p) behind the Swish: keep bytes are 0 / 1
+          const unsigned m = rin[i - I0].m;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] *= (float)((m >> (8 * e)) & 0xffu) * p.drop_scale;
+        }
       } else if (PREC == PREC_F16X3 && p.sat_flag) {
         sat_check(p.sat_flag, v, 65504.f);
       }
@@ -267,7 +278,7 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_k32_kernel(const ConvParams p
       }
     }
   };
-  auto stage_from = [&](int kc, unsigned char* buf, const Quad* rin) __attribute__((always_inline)) { stage_rng(kc, buf, rin, I_0{}, I_N{}); };
+  auto stage_from = [&](int kc, unsigned char* buf, const QM* rin) __attribute__((always_inline)) { stage_rng(kc, buf, rin, I_0{}, I_N{}); };
 
   // ---- weight fragments: ring slot s holds tap t with t % R == s; [cout half][plane] ----
   const uint4* wq = reinterpret_cast<const uint4*>(p.wq);
@@ -309,14 +320,14 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_k32_kernel(const ConvParams p
   }
   if (RFIRST) {   // (never split in K: kc0 = 0, kc1 = nk + nkr)
     {
-      Quad r0[NIN];
+      QM r0[NIN];
       prefetch_to(nk, r0);
       stage_from(nk, sBuf0, r0);
     }
     prefetch_to(nkr > 1 ? nk + 1 : 0, rr1);   // the second rider chunk -- or, after a single one, the first main chunk (fetched whole)
   } else if (SPLIT) {
     {   // the first chunk is fetched whole (the accumulators are not live yet)
-      Quad r0[NIN];
+      QM r0[NIN];
       prefetch_to(kc0, r0);
       stage_from(kc0, sBuf0, r0);
     }
@@ -495,7 +506,7 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_k32_kernel(const ConvParams p
     const int k0 = kc0 > nk ? kc0 : nk;
     constexpr int AH = K32_RIDER2 && NW == 8 ? 2 : 1;
     if (AH == 2 && k0 + 2 < kc1) prefetch_to(k0 + 2, rin2);
-    auto rider_chunk = [&](int kc, Quad* r1) __attribute__((always_inline)) {   // r1 holds chunk kc + 1
+    auto rider_chunk = [&](int kc, QM* r1) __attribute__((always_inline)) {   // r1 holds chunk kc + 1
       unsigned char* cur = ((kc - kc0) & 1) ? sBuf1 : sBuf0;
       unsigned char* nxt = ((kc - kc0) & 1) ? sBuf0 : sBuf1;
 #pragma unroll
@@ -514,7 +525,7 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_k32_kernel(const ConvParams p
       }
       __syncthreads();
     };
-    Quad* rfirst = SPLIT ? rr1 : rin;
+    QM* rfirst = SPLIT ? rr1 : rin;
     if (AH == 2) {
       for (int kc = k0; kc < kc1; kc += 2) {
         rider_chunk(kc, rfirst);
@@ -1074,11 +1085,17 @@ bool conv_k32_ok(int TH, int WN, int prec, const ConvParams& p) {
   return true;
 }
 
-template <int TH, int WN, int PREC, bool RIDER, int NW = 8, bool RF = (NW == 4), bool GNB = false>
+template <int TH, int WN, int PREC, bool RIDER, int NW = 8, bool RF = (NW == 4), bool GNB = false, bool DROP = false>
 static hipError_t launch_k32_t(const ConvParams& q, int nwg, hipStream_t s) {
   using Cfg = ConvK32Cfg<TH, WN, PREC, NW>;
-  hipLaunchKernelGGL((conv_k32_kernel<TH, WN, PREC, RIDER, NW, RF, GNB>), dim3(nwg), dim3(Cfg::NT), (size_t)Cfg::LDS_BYTES, s, q);
+  hipLaunchKernelGGL((conv_k32_kernel<TH, WN, PREC, RIDER, NW, RF, GNB, DROP>), dim3(nwg), dim3(Cfg::NT), (size_t)Cfg::LDS_BYTES, s, q);
   return hipGetLastError();
+}
+
+// train-mode dropout in the staging: f16x3, one GroupNorm'd + Swish'd input, no K split, a rider only in the rider-first form
+bool conv_k32_drop_ok(int prec, const ConvParams& q) {
+  if (prec != PREC_F16X3 || !q.drop_mask || !q.gn_scale || q.gn_plain || q.C1 != 0 || q.ksplit > 1 || q.gb_x0) return false;
+  return !q.xr0 || (g_tun.k32 & 1024);
 }
 
 // the GroupNorm-backward epilogue: f16x3, fp32 output, no rider, no residual, no K split, whole groups of the Cout channels
@@ -1114,6 +1131,10 @@ hipError_t launch_conv_k32_small(int prec, const ConvParams& p, hipStream_t s, i
   q.out_bf16 = (prec == PREC_BF16 && !p.out_f32) ? 1 : 0;
   q.stagger = g_tun.k32_stagger;
   if (q.gb_x0) return k32_gnb_ok(prec, q) ? launch_k32_t<6, 2, PREC_F16X3, false, 4, true, true>(q, nwg, s) : hipErrorInvalidValue;
+  if (q.drop_mask) {
+    if (!conv_k32_drop_ok(prec, q)) return hipErrorInvalidValue;
+    return q.xr0 ? launch_k32_t<6, 2, PREC_F16X3, true, 4, true, false, true>(q, nwg, s) : launch_k32_t<6, 2, PREC_F16X3, false, 4, true, false, true>(q, nwg, s);
+  }
   if (prec == PREC_F16X3)
     return q.xr0 ? launch_k32_t<6, 2, PREC_F16X3, true, 4>(q, nwg, s) : launch_k32_t<6, 2, PREC_F16X3, false, 4>(q, nwg, s);
   return q.xr0 ? launch_k32_t<6, 2, PREC_BF16, true, 4>(q, nwg, s) : launch_k32_t<8, 2, PREC_BF16, false, 4>(q, nwg, s);
@@ -1123,6 +1144,11 @@ hipError_t launch_conv_k32(int TH, int WN, int prec, const ConvParams& q, int nw
 #define X(TH_, WN_)                                                                                             \
   if (TH == TH_ && WN == WN_) {                                                                                 \
     if (q.gb_x0) return k32_gnb_ok(prec, q) ? launch_k32_t<TH_, WN_, PREC_F16X3, false, 8, false, true>(q, nwg, s) : hipErrorInvalidValue; \
+    if (q.drop_mask) {                                                                                          \
+      if (!conv_k32_drop_ok(prec, q)) return hipErrorInvalidValue;                                              \
+      return q.xr0 ? launch_k32_t<TH_, WN_, PREC_F16X3, true, 8, true, false, true>(q, nwg, s)                  \
+                   : launch_k32_t<TH_, WN_, PREC_F16X3, false, 8, false, false, true>(q, nwg, s);               \
+    }                                                                                                           \
     if (q.xr0 && q.ksplit <= 1 && (g_tun.k32 & 1024))                                                           \
       return prec == PREC_F16X3 ? launch_k32_t<TH_, WN_, PREC_F16X3, true, 8, true>(q, nwg, s)                  \
                                 : launch_k32_t<TH_, WN_, PREC_BF16, true, 8, true>(q, nwg, s);                  \
@@ -1136,9 +1162,9 @@ hipError_t launch_conv_k32(int TH, int WN, int prec, const ConvParams& q, int nw
   return hipErrorInvalidValue;
 }
 
-template <int TH, int WN, int PREC, bool RIDER, int NW = 8, bool RF = (NW == 4), bool GNB = false>
+template <int TH, int WN, int PREC, bool RIDER, int NW = 8, bool RF = (NW == 4), bool GNB = false, bool DROP = false>
 static hipError_t init_k32_t() {
-  auto kfn = conv_k32_kernel<TH, WN, PREC, RIDER, NW, RF, GNB>;
+  auto kfn = conv_k32_kernel<TH, WN, PREC, RIDER, NW, RF, GNB, DROP>;
   return hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
@@ -1162,12 +1188,16 @@ hipError_t kernels_k32_init() {
   if ((e = init_k32_t<TH_, WN_, PREC_BF16, true>()) != hipSuccess) return e;                \
   if ((e = init_k32_t<TH_, WN_, PREC_F16X3, true, 8, true>()) != hipSuccess) return e;     \
   if ((e = init_k32_t<TH_, WN_, PREC_F16X3, false, 8, false, true>()) != hipSuccess) return e; \
+  if ((e = init_k32_t<TH_, WN_, PREC_F16X3, false, 8, false, false, true>()) != hipSuccess) return e; \
+  if ((e = init_k32_t<TH_, WN_, PREC_F16X3, true, 8, true, false, true>()) != hipSuccess) return e; \
   if ((e = init_k32_t<TH_, WN_, PREC_BF16, true, 8, true>()) != hipSuccess) return e;
   FDSR_K32_SHAPES(X)
 #undef X
   if ((e = init_k32_t<6, 2, PREC_F16X3, false, 4>()) != hipSuccess) return e;
   if ((e = init_k32_t<6, 2, PREC_F16X3, true, 4>()) != hipSuccess) return e;
   if ((e = init_k32_t<6, 2, PREC_F16X3, false, 4, true, true>()) != hipSuccess) return e;
+  if ((e = init_k32_t<6, 2, PREC_F16X3, false, 4, true, false, true>()) != hipSuccess) return e;
+  if ((e = init_k32_t<6, 2, PREC_F16X3, true, 4, true, false, true>()) != hipSuccess) return e;
   if ((e = init_k32_t<6, 2, PREC_BF16, true, 4>()) != hipSuccess) return e;
   return hipSuccess;
 }

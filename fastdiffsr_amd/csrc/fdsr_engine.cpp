@@ -937,16 +937,10 @@ int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, 
           unsigned char* mask = reinterpret_cast<unsigned char*>(ws + sp.drop_off[op.drop_slot]);
           HIPCHK(h, launch_dropout_mask(mask, (size_t)N * Hi * Wi * op.C0, h->drop_seed, h->drop_step, (unsigned)op.drop_slot,
                                         h->cfg.dropout, st, (size_t)g_tun.drop_image_offset * Hi * Wi * op.C0));
-          const float dscale = 1.0f / (1.0f - h->cfg.dropout);
-          if (h->prec == PREC_F32) {           // the fp32 kernel applies the mask in its staging
-            p.drop_mask = mask;
-            p.drop_scale = dscale;
-          } else {                             // f16x3: the dropped activation is materialised and read raw
-            float* a = reinterpret_cast<float*>(ws + sp.off_dropA);
-            HIPCHK(h, launch_gn_silu_drop(p.x0, p.gn_scale, p.gn_shift, mask, dscale, a, N, Hi * Wi, op.C0, st));
-            p.x0 = a;
-            p.gn_scale = p.gn_shift = nullptr;
-          }
+          // the fp32 kernel and the f16x3 16x16x32 kernels apply the mask in their staging; a 16-bit launch that lands elsewhere reads
+          // the materialised dropped activation raw (decided below, once the launch's shape fields are set)
+          p.drop_mask = mask;
+          p.drop_scale = 1.0f / (1.0f - h->cfg.dropout);
         }
         // bf16 mode keeps every activation but the packed input and eps as bf16 in HBM
         p.out_f32 = (op.dst == h->t_eps) ? 1 : 0;
@@ -956,6 +950,19 @@ int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, 
         p.Hout = H >> op.lvl_out; p.Wout = W >> op.lvl_out;
         p.C0 = op.C0; p.C1 = op.C1; p.Cout = op.Cout;
         p.Cin_pad = w.cin_pad; p.Cout_pad = w.cout_pad;
+        if (p.drop_mask && h->prec != PREC_F32) {
+          ConvParams t = p;                    // as launch_conv_h will see it
+          t.Cin_pad = w.h_cin_pad; t.Cout_pad = w.h_cout_pad;
+          t.ksplit = sp.op_ksplit[oi];
+          const bool staged = g_tun.drop_stage && h->prec == PREC_F16X3 && w.h_ok && op.ck == CONV3_S1 && conv_h_drop_ok(op.ck, h->prec, t);
+          if (!staged) {
+            float* a = reinterpret_cast<float*>(ws + sp.off_dropA);
+            HIPCHK(h, launch_gn_silu_drop(p.x0, p.gn_scale, p.gn_shift, p.drop_mask, p.drop_scale, a, N, Hi * Wi, op.C0, st));
+            p.x0 = a;
+            p.gn_scale = p.gn_shift = nullptr;
+            p.drop_mask = nullptr;
+          }
+        }
         const bool timed = h->profiling && h->prof_step && op.ck != CONV1;
         if (timed) {
           if (h->ev_used + 2 > h->ev_pool.size()) {

@@ -43,7 +43,8 @@ struct ConvParams {
   int out_f32;
   int out_bf16;
   // train-mode Dropout(p) between Swish and the conv of block2 (unet.py:89-101): a = swish(gn(x)) * keep * 1/(1-p).
-  // keep is a byte per element of the input tensor (dropout_mask_kernel); fp32 kernel only.
+  // keep is a byte per element of the input tensor (dropout_mask_kernel); the fp32 kernel and the f16x3 16x16x32 kernels
+  // (conv_h_drop_ok) apply it in their staging.
   const unsigned char* drop_mask;   // [N][Hin][Win][C0] or null
   float drop_scale;
   // "rider" (16-bit 3x3 stride-1 kernels only): a 1x1 convolution over a second, raw input (xr0 | xr1) accumulated into the same
@@ -86,6 +87,7 @@ struct Tunables {
   int wgrad_form = 0;       // f16x3 weight gradients: 0 default (8-wave in-row), 1 4-wave everywhere, 2 8-wave without the interleave
   int wgrad_colsum = 1;     // column sums of dy fused into the in-row weight-gradient kernel
   int wgrad_f32 = 0;        // f16x3 steps keep exact-fp32 weight gradients
+  int drop_stage = 1;       // f16x3 training forwards: Dropout applied in the staging of the 16x16x32 kernels (0: the dropped activation is materialised first)
   int gnb_fuse = 1;         // f16x3 steps: the reduce half of the GroupNorm backward inside the input-gradient launch (ConvParams::gb_*)
   long long wgrad_big_bytes = 1ll << 32;   // tensors from this size on take the 4-wave weight-gradient kernel (64-bit offsets)
   int k32 = 1275;           // v_mfma_f32_16x16x32 form (fdsr_conv_k32.hip) of the stride-1 3x3 launches that fit it; bits: 1 f16x3, 2 bf16, 4 the 16-row tile with a rider, 8 the 2-row-per-wave tiles of small grids, 16 the sub-pixel upsample convs, 32 the small-workgroup form (4 waves, two workgroups per CU; 6-row tiles in f16x3, 8-row tiles in bf16) of the rider-less 64-cout launches of large grids in f16x3, 128 in bf16 too, 64 the f16x3 launches with a rider too (rider chunks first), 512 the bf16 ones with a rider (off: slower), 1024 the 8-wave rider kernels with the rider chunks first (launches without a K split); 0 never
@@ -117,6 +119,8 @@ hipError_t kernels_init();
 void conv_h_config(ConvKind kind, int Cout, int* TH, int* WN);   // BN = 32*WN, K-chunk = 16
 hipError_t launch_conv_h(ConvKind kind, int prec, const ConvParams& p, hipStream_t s, int* tiles_per_image);
 bool conv_h_gnb_ok(ConvKind kind, int prec, const ConvParams& p);   // ConvParams::gb_* honoured by the kernel this launch lands on
+bool conv_h_drop_ok(ConvKind kind, int prec, const ConvParams& p);  // ConvParams::drop_mask (train-mode dropout in the staging) honoured by a 16-bit launch
+bool conv_k32_drop_ok(int prec, const ConvParams& q);
 // K-loop split factor of a 16-bit conv launch (1 = none): a pure function of the shape, so the
 // workspace planner and the launcher agree.  Only grids that would leave most of the 256 CUs idle split.
 int conv_h_ksplit(ConvKind kind, int N, int Hout, int Wout, int Cout, int Cout_pad, int Cin_pad, int C0, int C1);

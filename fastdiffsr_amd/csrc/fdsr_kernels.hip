@@ -470,6 +470,7 @@ int set_tunable(const char* name, long long v) {
   else if (n == "wgrad_colsum") g_tun.wgrad_colsum = (int)v;
   else if (n == "wgrad_f32") g_tun.wgrad_f32 = (int)v;
   else if (n == "gnb_fuse") g_tun.gnb_fuse = (int)v;
+  else if (n == "drop_stage") g_tun.drop_stage = (int)v;
   else if (n == "wgrad_big_bytes") g_tun.wgrad_big_bytes = v;
   else if (n == "k32") g_tun.k32 = (int)v;
   else if (n == "k32_sb_min_wgs") g_tun.k32_sb_min_wgs = (long)v;

@@ -215,7 +215,8 @@ int fdsr_check_saturation(fdsr_handle h, void* hip_stream);
 /* -- introspection for parity tests and bench.py -------------------------- */
 /* Debug / A-B options of the launchers (process-wide; nothing in the library reads the environment).  Names:
  * "rider" (0|1|2|3), "up2" (0|1), "th_min_wgs", "splitk" (0|1), "sk_target", "wgrad_form" (0 default | 1 four-wave | 2 eight-wave
- * plain), "wgrad_colsum" (0|1), "wgrad_f32" (0|1), "gnb_fuse" (0|1: f16x3 training steps run the reduce half of the GroupNorm backward in the epilogue of the
+ * plain), "wgrad_colsum" (0|1), "wgrad_f32" (0|1), "drop_stage" (0|1: f16x3 training forwards apply Dropout in the staging of the 16x16x32 kernels instead of materialising the dropped
+ * activation; default 1), "gnb_fuse" (0|1: f16x3 training steps run the reduce half of the GroupNorm backward in the epilogue of the
  * input-gradient launch; default 1), "wgrad_big_bytes", "strip" (bits: 1 bf16 64 -> 64 launches on the column-strip kernel, 2 the f16x3 ones, 4 A/B: bf16 on one workgroup per CU, 8 bf16 (64|64) -> 64, 16 bf16 64 -> 64 with a res_conv rider, 32 bf16 (128|64) -> 64, 64 bf16 128 -> 128 and 64 -> 128; default 91), "strip_min_wgs" (from this many strip segments on; default 512),
  * "k32" (bits: 1 f16x3, 2 bf16, 4 16-row tiles with a rider, 8 2-row tiles of small grids, 16 the sub-pixel upsample convs, 32 the rider-less f16x3 64-cout
  * launches of large grids on 4-wave workgroups, two per CU, 64 those with a rider too, 128 in bf16 too, 512 the bf16 launches with a rider, 1024 rider chunks first on the 8-wave rider kernels too (launches without a K split); default 1275 -- the 16x16x32-MFMA form of the

@@ -368,13 +368,14 @@ def test_autograd_compatible_loss_fills_param_grads():
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize('option', [('wgrad_form', 1), ('wgrad_form', 2), ('wgrad_colsum', 0), ('wgrad_f32', 1), ('wgrad_big_bytes', 1 << 20), ('gnb_fuse', 0)])
+@pytest.mark.parametrize('option', [('wgrad_form', 1), ('wgrad_form', 2), ('wgrad_colsum', 0), ('wgrad_f32', 1), ('wgrad_big_bytes', 1 << 20), ('gnb_fuse', 0), ('drop_stage', 0), ('splitk', 0)])
 def test_every_weight_gradient_kernel_form_meets_the_golden(option):
     """The f16x3 step picks its weight-gradient kernel per layer (8-wave in-row with fused column sums by default); the A/B
     options (fdsr_debug_option) force the other forms -- 4-wave, 8-wave without the interleave, separate column-sum pass,
     exact-fp32 weight gradients, the ">= 4 GiB tensor" fallback (threshold lowered to 1 MiB: every large layer takes the
-    64-bit-offset kernel), and the GroupNorm backward with its reduction as a pass of its own instead of inside the
-    input-gradient launch -- and each must reproduce the reference's 273 gradients and its Adam update (a fresh process per
+    64-bit-offset kernel), the GroupNorm backward with its reduction as a pass of its own instead of inside the
+    input-gradient launch, the forward's Dropout as a materialised tensor instead of in the conv's staging, and no K split (at these
+    sizes the default splits K, and only launches without a split apply Dropout in their staging) -- and each must reproduce the reference's 273 gradients and its Adam update (a fresh process per
     option, so that nothing else in this session runs under it)."""
     import subprocess
     import sys
@@ -464,6 +465,50 @@ def test_gn_backward_inside_the_input_gradient_launch_equals_the_separate_pass(s
         assert d <= 2e-5 * float(np.abs(a).max()) + 1e-7 * gmax, (k, d, float(np.abs(a).max()), gmax)
         differs = differs or d > 0
     assert differs, 'gnb_fuse=1 ran the separate reduce pass'
+
+
+@pytest.mark.parametrize('shape', [(3, 40, 56), (2, 64, 64)])
+def test_dropout_in_the_conv_staging_equals_the_materialised_dropped_activation(shape):
+    """f16x3 training forward: block2's Dropout (unet.py:89-101, between the Swish and the conv) is applied to the staged quad
+    inside the 16x16x32 kernels (ConvParams::drop_mask, default), or gn_silu_drop_kernel writes swish(gn(x)) * keep / (1-p) to a
+    tensor the conv then reads raw (`drop_stage=0`).  Same seed, same masks: the forward outputs and every gradient of the step
+    agree to rounding (the two forms round the sigmoid differently, so they are not bit-identical -- which also shows that
+    the staged form ran), on whole tiles and on ragged ones, with and without a res_conv rider in the same launch."""
+    from fastdiffsr_amd import _lib
+    from fastdiffsr_amd.engine import Engine
+    B, H, W = shape
+    cfg = UNetConfig(in_channel=6, out_channel=3, inner_channel=32, norm_groups=32, channel_mults=(1, 2, 4), attn_res=(16,),
+                     res_blocks=2, dropout=0.2, image_size=32)
+    sd = synth_state_dict(cfg, 3)
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(B, 6, H, W, generator=g).cuda()
+    nl = (torch.rand(B, generator=g) * 0.5 + 0.4).cuda()
+    tgt = torch.randn(B, 3, H, W, generator=g).cuda()
+    res = {}
+    try:
+        _lib.debug_option('splitk', 0)      # (grids this small would split K, and a K-split launch reads the materialised form)
+        for staged in (1, 0):
+            _lib.debug_option('drop_stage', staged)
+            eng = Engine(cfg)
+            eng.load_state_dict(sd)
+            eng.set_precision('f16x3')
+            eng.set_training(True)
+            eng.set_seed(5)
+            y = eng.unet_forward(x, nl.view(B, 1)).cpu().numpy()
+            eng.set_seed(5)
+            loss = eng.train_grads(x, nl, tgt, 'l1', 1.0 / x[:, :3].numel())
+            res[staged] = (y, loss, {k: eng.get_grad(k).copy() for k, _, live in eng.schema() if live})
+    finally:
+        _lib.debug_option('drop_stage', 1)
+        _lib.debug_option('splitk', 1)
+    ya, yb = res[1][0], res[0][0]
+    assert np.abs(ya - yb).max() <= 2e-5 * np.abs(yb).max()
+    assert not np.array_equal(ya, yb), 'drop_stage=1 ran the materialised form'
+    assert abs(res[1][1] - res[0][1]) <= 1e-5 * abs(res[0][1])
+    gmax = max(float(np.abs(a).max()) for a in res[0][2].values())
+    for k, a in res[0][2].items():
+        d = float(np.abs(a - res[1][2][k]).max())
+        assert d <= 5e-5 * float(np.abs(a).max()) + 1e-6 * gmax, (k, d, float(np.abs(a).max()), gmax)
 
 
 @pytest.mark.parametrize('prec', ['f32', 'f16x3'])
