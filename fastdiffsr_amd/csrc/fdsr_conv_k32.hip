@@ -185,6 +185,7 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_k32_kernel(const ConvParams p
   // dead when the main loop starts and that loop is the rider-less one (two-half staging, peeled last chunk) -- the round-3 plan.
   constexpr bool RFIRST = RIDER && RF && K32_RFIRST != 0;
   constexpr bool SPLIT = K32_SPLIT != 0 && (PREC == PREC_F16X3 || K32_SPLIT_BF16 != 0) && (!RIDER || RFIRST);   // (main chunks first: the rider's whole-chunk sets would stay live across the main loop)
+  static_assert(!RFIRST || SPLIT, "the rider-first path writes whole chunks into rr1, which is sized for them only when SPLIT");
   constexpr int NA = SPLIT ? (NIN + 1) / 2 : NIN;   // quads in flight in the main loop
   typedef std::integral_constant<int, 0> I_0;
   typedef std::integral_constant<int, NA> I_A;

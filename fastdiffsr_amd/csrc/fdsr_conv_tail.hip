@@ -214,11 +214,17 @@ bool conv_in8_ok(ConvKind kind, int prec, const ConvParams& p, int cin_real) {
   return p.Cout == 16 || p.Cout == 32 || p.Cout == 48 || p.Cout == 64;
 }
 
+static int g_in8_resident[8];   // [f16x3 | bf16][couts / 16 - 1]: workgroups of conv_in8_kernel resident on the whole device (kernels_tail_init)
+
 hipError_t launch_conv_in8(int prec, const ConvParams& p, const float* wmaster, int cin_real, hipStream_t s, int* tiles) {
   const int per_img = ((p.Wout + IN_TW - 1) / IN_TW) * ((p.Hout + IN_TH - 1) / IN_TH);
   if (tiles) *tiles = per_img;
   const int ntiles = p.N * per_img;
-  const int grid = ntiles < 1024 ? ntiles : 1024;    // persistent: four 256-thread workgroups per CU set the weights up once
+  // persistent: as many workgroups as are resident at once (the register count of the instantiation decides: two per CU at 64 couts, three
+  // or four below), so that each sets its weights up and scans the range of its input exactly once
+  const int slot = (prec == PREC_F16X3 ? 0 : 4) + p.Cout / 16 - 1;
+  const int resident = (slot >= 0 && slot < 8 && g_in8_resident[slot] > 0) ? g_in8_resident[slot] : 512;
+  const int grid = ntiles < resident ? ntiles : resident;
   ConvParams q = p;
   q.out_bf16 = (prec == PREC_BF16 && !p.out_f32) ? 1 : 0;
 #define IN8_CASE(NCB_)                                                                                                     \
@@ -381,6 +387,7 @@ bool conv_out3_ok(ConvKind kind, int prec, const ConvParams& p) {
   if (!g_tun.tail || kind != CONV3_S1 || (prec != PREC_F16X3 && prec != PREC_BF16)) return false;
   if (p.Cout < 1 || p.Cout > 3 || p.C1 != 0 || (p.C0 != 32 && p.C0 != 64 && p.C0 != 96 && p.C0 != 128)) return false;   // whole 32-channel k steps
   if (p.res || p.temb || p.xr0 || p.drop_mask || p.ksplit > 1 || p.part_out || !p.out_f32) return false;
+  if (!p.gn_scale) return false;   // (a raw input would be clamped to the f16 range without the range flag: this kernel is the GroupNorm'd final conv's)
   return conv_out3_lds(p.C0) <= 80 * 1024;
 }
 
@@ -407,6 +414,19 @@ hipError_t kernels_tail_init() {
   if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_out3_kernel<PREC_BF16, NKS_>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)) != hipSuccess) return e;
   OUT3_INIT(1) OUT3_INIT(2) OUT3_INIT(3) OUT3_INIT(4)
 #undef OUT3_INIT
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+#define IN8_OCC(NCB_)                                                                                                              \
+  {                                                                                                                                \
+    int nb = 0;                                                                                                                    \
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_in8_kernel<PREC_F16X3, NCB_>, 256, 0) == hipSuccess && nb > 0)      \
+      g_in8_resident[NCB_ - 1] = nb * cus;                                                                                         \
+    nb = 0;                                                                                                                        \
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_in8_kernel<PREC_BF16, NCB_>, 256, 0) == hipSuccess && nb > 0)       \
+      g_in8_resident[4 + NCB_ - 1] = nb * cus;                                                                                     \
+  }
+  IN8_OCC(1) IN8_OCC(2) IN8_OCC(3) IN8_OCC(4)
+#undef IN8_OCC
   return hipSuccess;
 }
 
