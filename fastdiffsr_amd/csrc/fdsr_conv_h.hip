@@ -476,46 +476,91 @@ extern "C" int fdsr_diag_convh_stamps(unsigned long long* dst, size_t count) {
 // Split-K second phase: sums the ksplit partial outputs in slice order, applies bias + noise-embedding
 // shift + residual, stores NHWC and emits the per-tile channel statistics.  One workgroup per
 // 2 x 32 output pixels (the smallest conv tile, so the partials fit the same appendix) x cb channels.
+// The kernel is nothing but latency (37 of these launches per B = 1 forward): EVERY load is unconditional -- optional operands read a
+// valid stand-in address and are dropped by a select, out-of-range pixels read a clamped one -- and issued before the first use of any
+// of them: bias, rider bias, noise shift, un-scaling factor, the NS slices of a pixel quad and its residual are ONE memory round trip.
+// (With `if (p.temb)` / `if (p.res)` / `if (s < ksplit)` around the loads the compiler put an s_waitcnt vmcnt(0) behind each branch:
+// five serial round trips, 7.2 us per launch.)  NS = the K split rounded up to a power of two (slices past ksplit re-read the last one
+// and are dropped); OUT16: bf16 activations.
+// CB32: cb == 32 (every Cout that is a multiple of 32): a thread owns one channel quad of the two pixels (row 0 and row 1, column g) of the tile, and
+// the loads of both are in flight before anything is used.
+template <int NS, bool OUT16, bool CB32>
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(const ConvParams p, const int cb) {
   __shared__ float sred[256 * 8];
   const int tilesX = (p.Wout + 31) / 32;
   const int tile = blockIdx.x, n = blockIdx.y;
   const int tx = tile % tilesX, ty = tile / tilesX;
-  const int cq = cb >> 2, groups = 256 / cq, cbase = blockIdx.z * cb;
+  const int cq = CB32 ? 8 : cb >> 2, groups = CB32 ? 32 : 256 / cq, cbase = blockIdx.z * cb;
   const int tid = threadIdx.x, c4 = tid % cq, g = tid / cq;
+  const int cch = cbase + c4 * 4;
+  const bool has_r = p.xr0 != nullptr, has_t = p.temb != nullptr, has_res = p.res != nullptr;
+  // per-channel constants and the un-scaling factor.  Stand-ins are addresses nothing else loads from (the compiler would otherwise
+  // reuse the loaded value and put the real load back under a branch).
+  const f32x4 bias = *reinterpret_cast<const f32x4*>(p.bias + cch);
+  const f32x4 bias_r = *reinterpret_cast<const f32x4*>(has_r ? p.bias_r + cch : p.bias + cbase);
+  const f32x4 temb = *reinterpret_cast<const f32x4*>(has_t ? p.temb + (size_t)n * p.temb_stride + p.temb_off + cch : p.bias + cbase);
+  const float* wdev = has_r ? p.w_inv_scale_r_dev : p.w_inv_scale_dev;
+  const float wload = *(wdev ? wdev : p.bias);
+  const size_t slice = (size_t)p.N * p.Hout * p.Wout * p.Cout;
+  const int last = p.ksplit - 1;
+  const float* resp = has_res ? p.res : p.out;   // (no residual: this launch's own output location, read and dropped)
+  constexpr int NPX = CB32 ? 2 : 1;
   f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
-  if (g < groups) {
-    f32x4 add = *reinterpret_cast<const f32x4*>(p.bias + cbase + c4 * 4);
-    if (p.xr0) add += *reinterpret_cast<const f32x4*>(p.bias_r + cbase + c4 * 4);
-    if (p.temb) add += *reinterpret_cast<const f32x4*>(p.temb + (size_t)n * p.temb_stride + p.temb_off + cbase + c4 * 4);
-    const size_t slice = (size_t)p.N * p.Hout * p.Wout * p.Cout;
-    for (int px = g; px < 64; px += groups) {
+  auto pixels = [&](int px0) __attribute__((always_inline)) {
+    f32x4 sl[NPX][NS], rv[NPX];
+    size_t o[NPX];
+    bool ok[NPX];
+#pragma unroll
+    for (int i = 0; i < NPX; ++i) {
+      const int px = px0 + i * groups;
       const int oy = ty * 2 + (px >> 5), ox = tx * 32 + (px & 31);
-      if (oy >= p.Hout || ox >= p.Wout) continue;
-      const size_t o = ((size_t)(n * p.Hout + oy) * p.Wout + ox) * p.Cout + cbase + c4 * 4;
-      // all slices of this quad in flight at once (ksplit <= 16), added in slice order: the kernel is one memory round trip long
-      f32x4 sl[16];
+      ok[i] = g < groups && px < 64 && oy < p.Hout && ox < p.Wout;
+      o[i] = ((size_t)(n * p.Hout + min(oy, p.Hout - 1)) * p.Wout + min(ox, p.Wout - 1)) * p.Cout + cch;
 #pragma unroll
-      for (int s = 0; s < 16; ++s) sl[s] = s < p.ksplit ? *reinterpret_cast<const f32x4*>(p.kscratch + s * slice + o) : f32x4{0.f, 0.f, 0.f, 0.f};
-      f32x4 a = sl[0];
-#pragma unroll
-      for (int s = 1; s < 16; ++s)
-        if (s < p.ksplit) a += sl[s];
-      a = a * (p.xr0 ? (p.w_inv_scale_r_dev ? *p.w_inv_scale_r_dev : p.w_inv_scale_r) : (p.w_inv_scale_dev ? *p.w_inv_scale_dev : p.w_inv_scale)) + add;
-      if (p.out_bf16) {   // bf16 mode: residual and output are bf16 tensors
-        if (p.res) a += ActIO<PREC_BF16>::widen(ActIO<PREC_BF16>::load4(p.res, o));
-        uint2 pk;
-        pk.x = (unsigned)f32_to_bf16_bits(a[0]) | ((unsigned)f32_to_bf16_bits(a[1]) << 16);
-        pk.y = (unsigned)f32_to_bf16_bits(a[2]) | ((unsigned)f32_to_bf16_bits(a[3]) << 16);
-        *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p.out) + o) = pk;
-      } else {
-        if (p.res) a += *reinterpret_cast<const f32x4*>(p.res + o);
-        *reinterpret_cast<f32x4*>(p.out + o) = a;
-      }
-      s1 += a;
-      s2 += a * a;
+      for (int s = 0; s < NS; ++s) sl[i][s] = *reinterpret_cast<const f32x4*>(p.kscratch + (size_t)min(s, last) * slice + o[i]);
+      if (OUT16) rv[i] = ActIO<PREC_BF16>::widen(ActIO<PREC_BF16>::load4(resp, o[i]));
+      else rv[i] = *reinterpret_cast<const f32x4*>(resp + o[i]);
     }
-  }
+    __builtin_amdgcn_sched_barrier(0);   // every load above is issued before the first wait below (the scheduler otherwise waits for the constants first)
+    const float winv = wdev ? wload : (has_r ? p.w_inv_scale_r : p.w_inv_scale);
+    f32x4 add = bias;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      add[e] += has_r ? bias_r[e] : 0.f;
+      add[e] += has_t ? temb[e] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < NPX; ++i) {
+      f32x4 a = sl[i][0];
+#pragma unroll
+      for (int s = 1; s < NS; ++s)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] += s <= last ? sl[i][s][e] : 0.f;
+      a = a * winv + add;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[e] += has_res ? rv[i][e] : 0.f;
+      // (the sums take the value through a select, not under the branch of the store: with every use under `if (ok)` the compiler
+      // sinks the pixel's loads into that branch, behind the wait of the pixel before it)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v = ok[i] ? a[e] : 0.f;
+        s1[e] += v;
+        s2[e] += v * v;
+      }
+      if (ok[i]) {
+        if (OUT16) {
+          uint2 pk;
+          pk.x = (unsigned)f32_to_bf16_bits(a[0]) | ((unsigned)f32_to_bf16_bits(a[1]) << 16);
+          pk.y = (unsigned)f32_to_bf16_bits(a[2]) | ((unsigned)f32_to_bf16_bits(a[3]) << 16);
+          *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p.out) + o[i]) = pk;
+        } else {
+          *reinterpret_cast<f32x4*>(p.out + o[i]) = a;
+        }
+      }
+    }
+  };
+  if (CB32) pixels(g);   // one straight-line pass: the constants' loads and the 2 (NS + 1) pixel loads are issued together
+  else for (int px0 = g; px0 < 64; px0 += groups) pixels(px0);
   if (p.part_out) {
     if (g < groups) {
       *reinterpret_cast<f32x4*>(sred + (g * cq + c4) * 8) = s1;
@@ -533,6 +578,24 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const ConvParams p, 
       for (int e = 0; e < 4; ++e) { dst[2 * e] = a[e]; dst[2 * e + 1] = b[e]; }
     }
   }
+}
+
+static hipError_t launch_splitk_reduce(const ConvParams& q, int rt, int cb, hipStream_t s) {
+  const dim3 grid(rt, q.N, q.Cout / cb), block(256);
+#define SKR(NS_)                                                                                                   \
+  if (q.ksplit <= NS_) {                                                                                           \
+    if (cb == 32) {                                                                                                \
+      if (q.out_bf16) hipLaunchKernelGGL((splitk_reduce_kernel<NS_, true, true>), grid, block, 0, s, q, cb);       \
+      else hipLaunchKernelGGL((splitk_reduce_kernel<NS_, false, true>), grid, block, 0, s, q, cb);                 \
+    } else {                                                                                                       \
+      if (q.out_bf16) hipLaunchKernelGGL((splitk_reduce_kernel<NS_, true, false>), grid, block, 0, s, q, cb);      \
+      else hipLaunchKernelGGL((splitk_reduce_kernel<NS_, false, false>), grid, block, 0, s, q, cb);                \
+    }                                                                                                              \
+    return hipGetLastError();                                                                                      \
+  }
+  SKR(2) SKR(4) SKR(8) SKR(16)
+#undef SKR
+  return hipErrorInvalidValue;
 }
 
 template <int KS, int STRIDE, bool UP, int TH, int WN, int PREC, int KSUB, bool RIDER = false>
@@ -559,7 +622,8 @@ static hipError_t launch_h_t(const ConvParams& p, hipStream_t s, int* tiles) {
     const int rt = ((p.Wout + 31) / 32) * ((p.Hout + 1) / 2);
     if (tiles) *tiles = rt;
     const int cb = p.Cout % 32 == 0 ? 32 : p.Cout;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rt, p.N, p.Cout / cb), dim3(256), 0, s, q, cb);
+    const hipError_t e = launch_splitk_reduce(q, rt, cb, s);
+    if (e != hipSuccess) return e;
   }
   return hipGetLastError();
 }

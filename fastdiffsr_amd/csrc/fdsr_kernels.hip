@@ -406,11 +406,18 @@ __global__ void __launch_bounds__(256) gn_finalize_kernel(const GnFinalizeParams
     int nt, Cs, cc;
     if (c < p.C0) { part = p.part0; nt = p.nt0; Cs = p.C0; cc = c; } else { part = p.part1; nt = p.nt1; Cs = p.C1; cc = c - p.C0; }
     const float* src = part + ((size_t)n * nt * Cs + cc) * 2;
-#pragma unroll 4
-    for (int t = slice; t < nt; t += S) {
-      const float2 v = *reinterpret_cast<const float2*>(src + (size_t)t * Cs * 2);
-      a += (double)v.x;
-      b += (double)v.y;
+    // eight tiles per trip, all eight loads in flight before the first add (tiles past the end re-read the last one and add 0: the same
+    // sums in the same order); a trip is one memory round trip, and up to 8 S tiles -- every B = 1 shape -- need one trip only
+    for (int t0 = slice; t0 < nt; t0 += 8 * S) {
+      float2 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float2*>(src + (size_t)min(t0 + j * S, nt - 1) * Cs * 2);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const bool in = t0 + j * S < nt;
+        a += in ? (double)v[j].x : 0.0;
+        b += in ? (double)v[j].y : 0.0;
+      }
     }
   }
   sd[tid][0] = a;
