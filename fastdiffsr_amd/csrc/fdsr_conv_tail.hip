@@ -72,7 +72,14 @@ __global__ void __launch_bounds__(256, 2) conv_in8_kernel(const ConvParams p, co
   // ---- weights: lane (c15 = cout within its 16-block, g = k group) of fragment (cb, i) holds the 8 channels of tap 4 i + g of output
   // channel 16 cb + c15, scaled by a power of two so that the lo plane stays a normal f16 number ----
   float amax = 0.f;
-  for (int i = tid; i < Cout * Cin * 9; i += 256) amax = fmaxf(amax, fabsf(wm[i]));
+  {   // Cout * Cin * 9 <= 64 * 8 * 9 values: 18 per thread, every load in flight before the first max (indices past the end re-read the last value)
+    const int nw = Cout * Cin * 9;
+    float wv[18];
+#pragma unroll
+    for (int k = 0; k < 18; ++k) wv[k] = wm[min(tid + 256 * k, nw - 1)];
+#pragma unroll
+    for (int k = 0; k < 18; ++k) amax = fmaxf(amax, fabsf(wv[k]));
+  }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
   if (lane == 0) samax[wave] = amax;
@@ -93,7 +100,10 @@ __global__ void __launch_bounds__(256, 2) conv_in8_kernel(const ConvParams p, co
       const int tap = 4 * i + g, co = 16 * cb + c15;
       float v[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = (tap < 9 && j < Cin) ? wm[((size_t)co * Cin + j) * 9 + tap] * wscale : 0.f;
+      for (int j = 0; j < 8; ++j) {   // (unconditional on a clamped index: a load under `j < Cin` waits for its own round trip)
+        const float w = wm[((size_t)co * Cin + min(j, Cin - 1)) * 9 + min(tap, 8)];
+        v[j] = (tap < 9 && j < Cin) ? w * wscale : 0.f;
+      }
       to_planes<PREC>(v, Wf[cb][i]);
     }
   t_f32x4 bias4[NCB];
@@ -266,7 +276,14 @@ __global__ void __launch_bounds__(256, NKS <= 2 ? 4 : 2) conv_out3_kernel(const 
   // ---- weights as the MFMA's A operand: row = j (16 per block nb), k = channel; lane (c15 = j - 16 nb, g) of k step i holds the channels
   // 32 i + 8 g .. + 7 of (cout, tap) = j, scaled by a power of two (f16x3) so that the lo plane stays a normal f16 number ----
   float amax = 0.f;
-  for (int i = tid; i < p.Cout * Cin_real * 9; i += 256) amax = fmaxf(amax, fabsf(wm[i]));
+  {   // Cout * Cin * 9 <= 3 * 128 * 9 values: 14 per thread, every load in flight before the first max (as conv_in8_kernel)
+    const int nw = p.Cout * Cin_real * 9;
+    float wv[14];
+#pragma unroll
+    for (int k = 0; k < 14; ++k) wv[k] = wm[min(tid + 256 * k, nw - 1)];
+#pragma unroll
+    for (int k = 0; k < 14; ++k) amax = fmaxf(amax, fabsf(wv[k]));
+  }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
   if (lane == 0) samax[wave] = amax;
@@ -289,7 +306,8 @@ __global__ void __launch_bounds__(256, NKS <= 2 ? 4 : 2) conv_out3_kernel(const 
 #pragma unroll
       for (int e8 = 0; e8 < 8; ++e8) {
         const int ci = 32 * i + kq(g, e8 >> 2) + (e8 & 3);
-        v[e8] = (j < nj && ci < Cin_real) ? wm[((size_t)co * Cin_real + ci) * 9 + tap] * wscale : 0.f;
+        const float w = wm[((size_t)min(co, p.Cout - 1) * Cin_real + min(ci, Cin_real - 1)) * 9 + tap];   // (unconditional, clamped)
+        v[e8] = (j < nj && ci < Cin_real) ? w * wscale : 0.f;
       }
       to_planes<PREC>(v, Wf[nb][i]);
     }
@@ -299,9 +317,9 @@ __global__ void __launch_bounds__(256, NKS <= 2 ? 4 : 2) conv_out3_kernel(const 
   const int tx = tile % tilesX, ty = (tile / tilesX) % tilesY, n = tile / (tilesX * tilesY);
   const int oy0 = ty * OT_TH, ox0 = tx * OT_TW;
   __syncthreads();                                           // (the previous tile's partials and scale / shift have been read)
-  for (int i = tid; i < C; i += 256) {
-    gss[i] = p.gn_scale ? p.gn_scale[(size_t)n * C + i] : 1.f;
-    gss[C + i] = p.gn_scale ? p.gn_shift[(size_t)n * C + i] : 0.f;
+  if (tid < C) {   // C <= 128 (conv_out3_ok); the GroupNorm'd input is a condition of this kernel
+    gss[tid] = p.gn_scale[(size_t)n * C + tid];
+    gss[C + tid] = p.gn_shift[(size_t)n * C + tid];
   }
   __syncthreads();
   // ---- every halo pixel once: lane (pixel c15 of its 16-pixel group, k group g) reads its 8 channels of each k step, activates them,
