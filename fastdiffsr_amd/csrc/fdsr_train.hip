@@ -190,8 +190,16 @@ hipError_t launch_scale_inplace(float* x, size_t n, float f, hipStream_t s) {
 __global__ void __launch_bounds__(256) sum_rows_kernel(const float* __restrict__ S, int N, int stride, int C, float* __restrict__ out) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
+  // eight rows per trip, their loads in flight together (rows past the end re-read the last one and add 0: the same sum in the same
+  // order); one load per trip of a loop with a runtime bound is one memory round trip per image -- 9.4 us for 32 images
   float a = 0.f;
-  for (int n = 0; n < N; ++n) a += S[(size_t)n * stride + c];
+  for (int n0 = 0; n0 < N; n0 += 8) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = S[(size_t)min(n0 + j, N - 1) * stride + c];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a += n0 + j < N ? v[j] : 0.f;
+  }
   out[c] = a;
 }
 
@@ -425,7 +433,20 @@ __global__ void __launch_bounds__(256) gn_bwd_affine_kernel(const double* __rest
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
   double a = 0.0, b = 0.0;
-  for (int n = 0; n < N; ++n) { a += tot[((size_t)n * C + c) * 2]; b += tot[((size_t)n * C + c) * 2 + 1]; }
+  for (int n0 = 0; n0 < N; n0 += 8) {   // (eight images per trip: as sum_rows_kernel)
+    double va[8], vb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const size_t o = ((size_t)min(n0 + j, N - 1) * C + c) * 2;
+      va[j] = tot[o];
+      vb[j] = tot[o + 1];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      a += n0 + j < N ? va[j] : 0.0;
+      b += n0 + j < N ? vb[j] : 0.0;
+    }
+  }
   dbeta[c] = (float)a;
   dgamma[c] = (float)b;
 }
@@ -1489,7 +1510,13 @@ __global__ void __launch_bounds__(256) colsum_slices_kernel(const float* __restr
   const int c = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
   if (c >= K) return;
   double a = 0.0;
-  for (int j = 0; j < k; ++j) a += (double)part[((size_t)(n * k + j) * ncb + (c >> 6)) * 64 + (c & 63)];
+  for (int j0 = 0; j0 < k; j0 += 8) {   // (eight slices per trip, in flight together: as sum_rows_kernel)
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = part[((size_t)(n * k + min(j0 + u, k - 1)) * ncb + (c >> 6)) * 64 + (c & 63)];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a += j0 + u < k ? (double)v[u] : 0.0;
+  }
   S[(size_t)n * K + c] = (float)a;
 }
 
@@ -2052,7 +2079,14 @@ hipError_t launch_pack_conv_f32_t(const float* w, float* packed_t, int Cout, int
 __global__ void __launch_bounds__(256) hamax_kernel(const float* __restrict__ w, size_t n, unsigned* __restrict__ amax_bits) {
   __shared__ float sm[4];
   float m = 0.f;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = fmaxf(m, fabsf(w[i]));
+  const size_t step = (size_t)gridDim.x * 256;
+  for (size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x; i0 < n; i0 += 16 * step) {   // 16 loads in flight per trip (a max: re-reading the last element is harmless)
+    float v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = w[min(i0 + j * step, n - 1)];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) m = fmaxf(m, fabsf(v[j]));
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
   if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
