@@ -29,25 +29,65 @@ PEAK_16BIT_MFMA = 2500.0         # TFLOP/s dense f16/bf16 MFMA (same guide; neve
 
 
 def host_cores():
-    """CPU threads this process may really use: affinity mask capped by the cgroup CPU quota."""
-    try:
-        n = len(os.sched_getaffinity(0))
-    except Exception:
-        n = os.cpu_count() or 1
-    for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+    """CPU threads this process may really use (fastdiffsr_amd.parallel.host_cores: affinity mask capped by the cgroup quota)."""
+    from fastdiffsr_amd.parallel import host_cores as hc
+    return hc()
+
+
+class GpuTelemetry:
+    """Mean shader clock and package power of one GPU over a timed region, read from the amdgpu hwmon files of its card (no
+    subprocess, no HIP call: a sampler thread that reads two small sysfs files every `period` seconds).  The claim "this regime is
+    (not) power-bound" is then checkable from the bench line alone: `sclk_mhz` against the 2400 MHz nominal clock, `power_w` against
+    `power_cap_w`.  Every field is None where the box does not expose the file."""
+
+    def __init__(self, index=0, period=0.05):
+        import glob
+        self.period, self.samples, self._thr, self._stop = period, [], None, False
+        cards = []
+        for hw in sorted(glob.glob('/sys/class/drm/card*/device/hwmon/hwmon*')):
+            if any(os.path.exists(os.path.join(hw, f)) for f in ('power1_average', 'power1_input')):
+                cards.append(hw)
+        self.hw = cards[index] if index < len(cards) else None
+        self.cap = self._read('power1_cap', 1e-6)
+
+    def _read(self, name, scale):
+        if self.hw is None:
+            return None
         try:
-            txt = open(path).read().split()
-            if path.endswith('cpu.max'):
-                if txt[0] != 'max':
-                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
-            else:
-                q = int(txt[0])
-                per = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
-                if q > 0:
-                    n = min(n, max(1, q // per))
-        except Exception:
-            pass
-    return n
+            return float(open(os.path.join(self.hw, name)).read().split()[0]) * scale
+        except (OSError, ValueError, IndexError):
+            return None
+
+    def _loop(self):
+        while not self._stop:
+            pw = self._read('power1_average', 1e-6)
+            if pw is None:
+                pw = self._read('power1_input', 1e-6)
+            self.samples.append((self._read('freq1_input', 1e-6), pw))
+            time.sleep(self.period)
+
+    def __enter__(self):
+        import threading
+        self._stop, self.samples = False, []
+        if self.hw is not None:
+            self._thr = threading.Thread(target=self._loop, daemon=True)
+            self._thr.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop = True
+        if self._thr is not None:
+            self._thr.join()
+        return False
+
+    def summary(self):
+        def stat(i):
+            v = [x[i] for x in self.samples if x[i] is not None]
+            return (sum(v) / len(v), min(v), max(v)) if v else (None, None, None)
+        (cm, cl, ch), (pm, pl, ph) = stat(0), stat(1)
+        return {'sclk_mhz': cm, 'sclk_mhz_min': cl, 'sclk_mhz_max': ch, 'power_w': pm, 'power_w_min': pl, 'power_w_max': ph,
+                'power_cap_w': self.cap, 'samples': len(self.samples), 'period_s': self.period,
+                'source': (self.hw + '/{freq1_input,power1_average}') if self.hw else None}
 
 
 def cpu_model():
@@ -176,24 +216,25 @@ def kernel_source_hash():
 
 
 KNOCKOUT = False   # --debug-option knockout=...: timing-only probes whose results are garbage
-K32_BITS = 1275     # Tunables::k32 default (include/fdsr.h); --debug-option k32=... overrides it for the labels below
-STRIP_BITS = 91     # Tunables::strip default: the column-strip form of the 64-cout launches (fdsr_conv_strip.hip)
+from fastdiffsr_amd._lib import K32, K32_DEFAULT, STRIP, STRIP_DEFAULT, bit_names   # include/fdsr.h: enum fdsr_k32_bits / fdsr_strip_bits
+K32_BITS = K32_DEFAULT       # --debug-option k32=... overrides it for the labels below
+STRIP_BITS = STRIP_DEFAULT   # the column-strip form of the 64-cout launches (fdsr_conv_strip.hip)
 
 
 def family_label(precision):
     """Names of the kernels the 3x3 family's launches run on under the active options (what to sum in a rocprofv3 stats file)."""
     if precision == 'f32':
         return 'conv_mfma_f32_kernel'
-    bit = 1 if precision == 'f16x3' else 2
+    bit = K32['F16X3'] if precision == 'f16x3' else K32['BF16']
     names = []
-    if STRIP_BITS & (2 if precision == 'f16x3' else (1 | 8 | 16 | 32)):
+    if STRIP_BITS & (STRIP['F16X3_64'] if precision == 'f16x3' else (STRIP['BF16_64'] | STRIP['BF16_CAT64'] | STRIP['BF16_RIDER'] | STRIP['BF16_CAT128'] | STRIP['BF16_COUT128'])):
         names.append('conv_strip_kernel')
     if K32_BITS & bit:
         names.append('conv_k32_kernel')
-        if K32_BITS & 16:
+        if K32_BITS & K32['UP2']:
             names.append('conv_up2_k32_kernel')
     names.append('conv_mfma_h_kernel<3, ...>')
-    if not (K32_BITS & bit and K32_BITS & 16):
+    if not (K32_BITS & bit and K32_BITS & K32['UP2']):
         names.append('conv_up2_h_kernel')
     names.append('conv_in8_kernel + conv_out3_kernel (the two ends of the UNet)')
     return ' + '.join(names)
@@ -254,12 +295,13 @@ def whole_path(ips_per_gpu, precision, S=256):
             'ideal_fused_gbytes_per_s': ips_per_gpu * gb, 'frac_hbm_peak': ips_per_gpu * gb / 8000.0}
 
 
-def run_config(eng, dev, precision, B, S, steps, warmup, graph, noise_mode, rank=0, sync=None, want_profile=True, per_pass=None):
+def run_config(eng, dev, precision, B, S, steps, warmup, graph, noise_mode, rank=0, sync=None, want_profile=True, per_pass=None, telemetry=None):
     """Time `steps` passes of the hot path for one configuration.  Returns (seconds, out tensor, profile or None).
     With graph=True the timed region replays the captured loop; the per-launch roofline then comes from ONE extra
     eager pass after the timed region (HIP events cannot bracket launches inside a graph replay).
     per_pass: a list that receives every pass's own seconds (a synchronisation after each pass; sub-records only -- the
-    headline times its K steps in one bracket, as the contract says)."""
+    headline times its K steps in one bracket, as the contract says).  telemetry: a dict that receives the mean shader clock and
+    package power of the timed region (GpuTelemetry)."""
     from fastdiffsr_amd.synth import synth_inputs
     eng.set_precision(precision)
     if noise_mode == 'tensor':
@@ -279,6 +321,9 @@ def run_config(eng, dev, precision, B, S, steps, warmup, graph, noise_mode, rank
     profile = want_profile and not graph
     if profile:
         eng.profile_begin()
+    tel = GpuTelemetry(dev.index or 0) if telemetry is not None else None
+    if tel is not None:
+        tel.__enter__()
     t0 = time.perf_counter()
     for _ in range(steps):
         tp = time.perf_counter()
@@ -288,6 +333,9 @@ def run_config(eng, dev, precision, B, S, steps, warmup, graph, noise_mode, rank
             per_pass.append(time.perf_counter() - tp)
     sync()
     dt = time.perf_counter() - t0
+    if tel is not None:
+        tel.__exit__()
+        telemetry.update(tel.summary())
     prof = eng.profile_end() if profile else None
     prof_dt = dt
     if want_profile and graph:
@@ -529,12 +577,12 @@ def facade_records(cfg, sd, dev, S, engine_ips, n_images=256, batch=16):
 
 def sub_record(eng, dev, name, precision, B, S, steps, warmup, graph, note):
     try:
-        pp = []
-        dt, _, prof, prof_dt = run_config(eng, dev, precision, B, S, steps, warmup, graph, 'engine', per_pass=pp)
+        pp, tel = [], {}
+        dt, _, prof, prof_dt = run_config(eng, dev, precision, B, S, steps, warmup, graph, 'engine', per_pass=pp, telemetry=tel)
         ips = B * steps / dt
         r = {'value': ips, 'unit': 'images/s', 'ms_per_step': 1e3 * dt / steps, 'steps': steps, 'warmup': warmup,
              'dtype': precision, 'batch': B, 'hipgraph': bool(graph), 'workload': note, 'per_pass': pass_stats(pp, B),
-             'whole_path': whole_path(ips, precision, S)}
+             'whole_path': whole_path(ips, precision, S), 'telemetry': tel}
         if prof and prof['conv_ms'] > 0:
             r['roofline'] = conv_roofline(prof, precision, B, S, prof_dt)
             if prof_dt is None:
@@ -826,8 +874,9 @@ def main():
         return
 
     # independent per-GPU batch (weak scaling): rank r samples its own B images
+    telemetry = {}
     dt, out, prof, _ = run_config(eng, dev, args.precision, B, S, args.steps, args.warmup, args.graph, args.noise,
-                                  rank=rank, sync=sync, want_profile=not args.no_profile)
+                                  rank=rank, sync=sync, want_profile=not args.no_profile, telemetry=telemetry)
     rank_ts = [dt]
     if distributed:
         dt, rank_ts = gather_rank_times(dt, dev)
@@ -854,7 +903,10 @@ def main():
             'whole_path_tflops': ips / world * FLOPS_PER_IMAGE / 1e12,
             'whole_path': whole_path(ips / world, args.precision),
             'library': {'version': version.split(' FDSR_SRC_SHA256=')[0], 'source_sha256': version.rsplit('=', 1)[-1]},
+            # mean shader clock / package power of rank 0's GPU over the timed region (hwmon; nominal 2400 MHz): is the regime power-bound?
+            'telemetry': telemetry,
         }
+        res['library']['kernel_forms'] = {'k32': bit_names(K32, K32_BITS), 'strip': bit_names(STRIP, STRIP_BITS)}
         if args.debug_option:
             res['debug_options'] = list(args.debug_option)
         if distributed:   # every rank loaded what rank 0 broadcast: its hash is checked against rank 0's own arrays
@@ -894,6 +946,9 @@ def main():
             res['cpu_baseline'], ref = cpu_baseline(cfg, sd)
             eng.set_precision(args.precision)
             res['parity_check'] = parity_check(eng, dev, ref)
+        # calls of this process (headline, sub-records, facade records, parity check) that tripped the f16x3 range guard and were
+        # re-run on the exact-fp32 kernels (Engine.on_saturation = 'f32'): 0 = every f16x3 number above is an f16x3 number
+        res['saturation_fallbacks'] = int(Engine.saturation_fallbacks)
         print(json.dumps(res), flush=True)
     if distributed:
         dist.destroy_process_group()

@@ -37,6 +37,19 @@ class FdsrSaturated(FdsrError):
 
 FDSR_E_SATURATED = -6
 
+# include/fdsr.h: enum fdsr_k32_bits / fdsr_strip_bits (tests/test_abi_symbols.py checks the two against the header)
+K32 = {'F16X3': 1, 'BF16': 2, 'RIDER_16ROW': 4, 'SMALL_GRID_2ROW': 8, 'UP2': 16, 'SMALL_WG_F16X3': 32, 'SMALL_WG_RIDER_F16X3': 64,
+       'SMALL_WG_BF16': 128, 'SMALL_WG_RIDER_BF16': 512, 'RIDER_FIRST_8WAVE': 1024}
+K32_DEFAULT = 1 | 2 | 8 | 16 | 32 | 64 | 128 | 1024
+STRIP = {'BF16_64': 1, 'F16X3_64': 2, 'BF16_ONE_WG': 4, 'BF16_CAT64': 8, 'BF16_RIDER': 16, 'BF16_CAT128': 32, 'BF16_COUT128': 64}
+STRIP_DEFAULT = 1 | 2 | 8 | 16 | 64
+STRIP_ALL = 127
+
+
+def bit_names(table, value):
+    """'F16X3|BF16|...' for a k32 / strip option value."""
+    return '|'.join(n for n, b in table.items() if value & b) or '0'
+
 
 _lib = None
 

@@ -8,7 +8,7 @@ CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 LIB = os.path.join(CSRC, 'libfdsr_hip.so')
 # -fno-slp-vectorize: packed f32 VALU (v_pk_fma_f32 ...) next to MFMAs is slower than the scalar forms on
 # gfx950 (MI355X_MICROARCH.md, cycle constants); +0.8 % end to end in a same-box A/B
-SOURCES = [('fdsr_kernels.hip', ['-O3', '-munsafe-fp-atomics']), ('fdsr_conv_h.hip', ['-O3', '-fno-slp-vectorize']),
+SOURCES = [('fdsr_kernels.hip', ['-O3']), ('fdsr_conv_h.hip', ['-O3', '-fno-slp-vectorize']),
            ('fdsr_conv_up2.hip', ['-O3', '-fno-slp-vectorize']),
            ('fdsr_conv_k32.hip', ['-O3', '-fno-slp-vectorize']), ('fdsr_conv_strip.hip', ['-O3', '-fno-slp-vectorize']), ('fdsr_conv_tail.hip', ['-O3', '-fno-slp-vectorize']),
            ('fdsr_val.hip', ['-O3']), ('fdsr_train.hip', ['-O3']), ('fdsr_engine.cpp', ['-O2']), ('fdsr_train.cpp', ['-O2'])]

@@ -1045,7 +1045,7 @@ __global__ void __launch_bounds__(512, 2) conv_up2_k32_kernel(const ConvParams p
 }
 
 bool conv_up2_k32_ok(int prec, const ConvParams& p) {
-  if (!(g_tun.k32 & 16) || !(g_tun.k32 & (prec == PREC_BF16 ? 2 : 1))) return false;
+  if (!(g_tun.k32 & FDSR_K32_UP2) || !(g_tun.k32 & (prec == PREC_BF16 ? FDSR_K32_BF16 : FDSR_K32_F16X3))) return false;
   return p.C1 == 0 && p.C0 % 32 == 0 && p.C0 == p.Cin_pad && p.Cout % 4 == 0 && !p.gn_scale && !p.res;
 }
 
@@ -1072,9 +1072,9 @@ hipError_t launch_conv_up2_k32(int TH, int WN, int prec, const ConvParams& q, in
 
 bool conv_k32_ok(int TH, int WN, int prec, const ConvParams& p) {
   // g_tun.k32 bits (default 27 = 1|2|8|16): 1 f16x3, 2 bf16 (+2.7 % at B=64 once the ring / pinning / peeled last chunk were in), 4 the 16-row tile with a rider (measured slower: off)
-  if (!(g_tun.k32 & (prec == PREC_BF16 ? 2 : 1))) return false;
-  if (TH == 16 && p.xr0 && !(g_tun.k32 & 4)) return false;
-  if (TH * WN != 32 && !(TH * WN == 16 && (g_tun.k32 & 8))) return false;   // MB == 4 (bit 8: the 2-row tiles of small grids too)
+  if (!(g_tun.k32 & (prec == PREC_BF16 ? FDSR_K32_BF16 : FDSR_K32_F16X3))) return false;
+  if (TH == 16 && p.xr0 && !(g_tun.k32 & FDSR_K32_RIDER_16ROW)) return false;
+  if (TH * WN != 32 && !(TH * WN == 16 && (g_tun.k32 & FDSR_K32_SMALL_GRID_2ROW))) return false;   // MB == 4 (bit 8: the 2-row tiles of small grids too)
   if (WN != 2 && WN != 4 && WN != 8) return false;
   if (p.Cin_pad % 32 || (p.C0 + p.C1) != p.Cin_pad) return false;    // whole 32-channel chunks
   if (p.C1 != 0 && p.C0 % 32) return false;                          // the concat seam on a chunk boundary
@@ -1096,7 +1096,7 @@ static hipError_t launch_k32_t(const ConvParams& q, int nwg, hipStream_t s) {
 // train-mode dropout in the staging: f16x3, one GroupNorm'd + Swish'd input, no K split, a rider only in the rider-first form
 bool conv_k32_drop_ok(int prec, const ConvParams& q) {
   if (prec != PREC_F16X3 || !q.drop_mask || !q.gn_scale || q.gn_plain || q.C1 != 0 || q.ksplit > 1 || q.gb_x0) return false;
-  return !q.xr0 || (g_tun.k32 & 1024);
+  return !q.xr0 || (g_tun.k32 & FDSR_K32_RIDER_FIRST_8WAVE);
 }
 
 // the GroupNorm-backward epilogue: f16x3, fp32 output, no rider, no residual, no K split, whole groups of the Cout channels
@@ -1112,11 +1112,11 @@ static bool k32_gnb_ok(int prec, const ConvParams& q) {
 static int k32_small_rows(int prec, bool rider) { return prec == PREC_BF16 && !rider ? 8 : 6; }   // (the bf16 8-row tile with a rider spills 27 VGPRs)
 
 bool conv_k32_small_ok(ConvKind kind, int prec, const ConvParams& p) {
-  if (!(g_tun.k32 & 32) || kind != CONV3_S1 || p.ksplit > 1 || p.Cout_pad != 64) return false;
-  if (prec == PREC_BF16 && !(g_tun.k32 & 128)) return false;   // bf16: bit 128 (its 6-row tile measured -0.4 % end to end, its 8-row tile +1.0 %: on)
+  if (!(g_tun.k32 & FDSR_K32_SMALL_WG_F16X3) || kind != CONV3_S1 || p.ksplit > 1 || p.Cout_pad != 64) return false;
+  if (prec == PREC_BF16 && !(g_tun.k32 & FDSR_K32_SMALL_WG_BF16)) return false;   // bf16: bit 128 (its 6-row tile measured -0.4 % end to end, its 8-row tile +1.0 %: on)
   // launches with a rider: bit 64 in f16x3 (on since the rider chunks run FIRST on this form: +0.7 % end to end over the 32x32x16 rider
   // kernel; main chunks first it measured 4 - 7 % slower on those launches), bit 512 in bf16 (off: -0.4 %)
-  if (p.xr0 && !(g_tun.k32 & (prec == PREC_BF16 ? 512 : 64))) return false;
+  if (p.xr0 && !(g_tun.k32 & (prec == PREC_BF16 ? FDSR_K32_SMALL_WG_RIDER_BF16 : FDSR_K32_SMALL_WG_RIDER_F16X3))) return false;
   if (!conv_k32_ok(8, 4, prec, p)) return false;          // the form's own conditions (an MB = 4 shape: no tile-size bits involved)
   const int th = k32_small_rows(prec, p.xr0 != nullptr);
   const long wgs = (long)p.N * ((p.Wout + 31) / 32) * ((p.Hout + th - 1) / th);
@@ -1150,7 +1150,7 @@ hipError_t launch_conv_k32(int TH, int WN, int prec, const ConvParams& q, int nw
       return q.xr0 ? launch_k32_t<TH_, WN_, PREC_F16X3, true, 8, true, false, true>(q, nwg, s)                  \
                    : launch_k32_t<TH_, WN_, PREC_F16X3, false, 8, false, false, true>(q, nwg, s);               \
     }                                                                                                           \
-    if (q.xr0 && q.ksplit <= 1 && (g_tun.k32 & 1024))                                                           \
+    if (q.xr0 && q.ksplit <= 1 && (g_tun.k32 & FDSR_K32_RIDER_FIRST_8WAVE))                                                           \
       return prec == PREC_F16X3 ? launch_k32_t<TH_, WN_, PREC_F16X3, true, 8, true>(q, nwg, s)                  \
                                 : launch_k32_t<TH_, WN_, PREC_BF16, true, 8, true>(q, nwg, s);                  \
     if (q.xr0) return prec == PREC_F16X3 ? launch_k32_t<TH_, WN_, PREC_F16X3, true>(q, nwg, s)                  \

@@ -183,8 +183,10 @@ __global__ void __launch_bounds__(256, LB) conv_strip_kernel(const ConvParams p,
   bid /= stripsX;
   const int seg = bid % segs;
   const int n = bid / segs;
-  const int ox0 = sx * SW, oy0 = seg * seg_rows;
-  const int oy1 = oy0 + seg_rows < H ? oy0 + seg_rows : H;   // this segment's output rows [oy0, oy1)
+  // balanced segments: rows [seg H / segs, (seg + 1) H / segs) -- every segment has floor or ceil of H / segs rows (>= 4 for the
+  // launcher's seg_rows >= 9; a remainder of ONE row, e.g. H = 136 at seg_rows = 9, would break the peeled steps and the tail below)
+  const int ox0 = sx * SW, oy0 = (int)((long)seg * H / segs);
+  const int oy1 = (int)((long)(seg + 1) * H / segs);          // this segment's output rows [oy0, oy1)
 
   // ---- staging identity per input tensor t (0: x0, 1: x1): thread -> oct ot[t] of that tensor's channels, pixel ppx[t] + i PPP[t] ----
   constexpr int OPPt[2] = {C0_ / 8, CAT ? C1_ / 8 : 1};
@@ -611,7 +613,7 @@ __global__ void __launch_bounds__(256, LB) conv_strip_kernel(const ConvParams p,
     }
   }
   __syncthreads();
-  const int nsteps = oy1 - oy0 + 2;          // >= 5 (segments have at least 3 rows: launcher)
+  const int nsteps = oy1 - oy0 + 2;          // >= 5 (segments have at least 3 rows: balanced above, conv_strip_ok for the whole map)
   load_res(oy0);
   step(oy0 - 1, 0, R0{}, std::false_type{}, std::false_type{});
   step(oy0, 1, R1{}, std::false_type{}, std::false_type{});
@@ -654,7 +656,7 @@ __global__ void __launch_bounds__(256, LB) conv_strip_kernel(const ConvParams p,
 // registers), 4 (A/B) bf16 64 -> 64 on one workgroup per CU, 8 the bf16 launches with a concatenated input (64 + 64 -> 64,
 // 128 + 64 -> 64 under bit 32: 144 / 216 weight registers, one workgroup per CU), 16 the bf16 launches with a res_conv rider,
 // 64 the bf16 128-cout launches 128 -> 128 and 64 -> 128 (two workgroups of 64 couts per strip)
-static bool strip_wide(const ConvParams& p, int prec) { return prec != PREC_BF16 || (g_tun.strip & 4) || p.C1 || p.xr0 || p.C0 > 64; }
+static bool strip_wide(const ConvParams& p, int prec) { return prec != PREC_BF16 || (g_tun.strip & FDSR_STRIP_BF16_ONE_WG) || p.C1 || p.xr0 || p.C0 > 64; }
 static long strip_min_wgs(const ConvParams& p, int prec) { return strip_wide(p, prec) ? g_tun.strip_min_wgs / 2 : g_tun.strip_min_wgs; }
 
 static int strip_seg_rows(const ConvParams& p, int SW, int prec) {
@@ -675,14 +677,14 @@ bool conv_strip_ok(ConvKind kind, int prec, const ConvParams& p) {
   if (Cin != p.Cin_pad) return false;
   bool shape;
   if (p.Cout == 128) {   // the 128-cout level: two workgroups of 64 couts read the same rows; 128 -> 128 (144 weight registers) and 64 -> 128, bf16
-    shape = prec == PREC_BF16 && (g_tun.strip & 64) && !p.xr0 && p.C1 == 0 && (p.C0 == 64 || p.C0 == 128);
+    shape = prec == PREC_BF16 && (g_tun.strip & FDSR_STRIP_BF16_COUT128) && !p.xr0 && p.C1 == 0 && (p.C0 == 64 || p.C0 == 128);
   } else if (p.xr0) {        // 64 -> 64 with a rider over (64 | 64) or (128 | 64) raw channels
-    shape = prec == PREC_BF16 && (g_tun.strip & 16) && !p.res && p.C0 == 64 && p.C1 == 0 && p.Cr1 == 64 && (p.Cr0 == 64 || p.Cr0 == 128) &&
+    shape = prec == PREC_BF16 && (g_tun.strip & FDSR_STRIP_BF16_RIDER) && !p.res && p.C0 == 64 && p.C1 == 0 && p.Cr1 == 64 && (p.Cr0 == 64 || p.Cr0 == 128) &&
             p.nkr * 16 == p.Cr0 + p.Cr1;
   } else if (p.C1) {  // concatenated input (64 | 64) or (128 | 64), no residual (block1 of the up path)
-    shape = prec == PREC_BF16 && !p.res && p.C1 == 64 && ((p.C0 == 64 && (g_tun.strip & 8)) || (p.C0 == 128 && (g_tun.strip & 32)));   // (bit 32: 216 weight registers, spills)
+    shape = prec == PREC_BF16 && !p.res && p.C1 == 64 && ((p.C0 == 64 && (g_tun.strip & FDSR_STRIP_BF16_CAT64)) || (p.C0 == 128 && (g_tun.strip & FDSR_STRIP_BF16_CAT128)));   // (bit 32: 216 weight registers, spills)
   } else {
-    shape = p.C0 == 64 && (g_tun.strip & (prec == PREC_BF16 ? 1 : 2));
+    shape = p.C0 == 64 && (g_tun.strip & (prec == PREC_BF16 ? FDSR_STRIP_BF16_64 : FDSR_STRIP_F16X3_64));
   }
   if (!shape) return false;
   const long wgs = (long)p.N * ((p.Wout + 63) / 64) * ((p.Hout + 15) / 16) * (p.Cout / 64);
@@ -713,7 +715,7 @@ hipError_t launch_conv_strip(int prec, const ConvParams& p, int wn_a, hipStream_
   if (p.C1) {
     return p.C0 == 64 ? launch_strip_t<PREC_BF16, 64, 64, 0, 0, false, 1>(p, wn_a, s, tiles) : launch_strip_t<PREC_BF16, 128, 64, 0, 0, false, 1>(p, wn_a, s, tiles);
   }
-  if (g_tun.strip & 4)
+  if (g_tun.strip & FDSR_STRIP_BF16_ONE_WG)
     return p.res ? launch_strip_t<PREC_BF16, 64, 0, 0, 0, true, 1>(p, wn_a, s, tiles) : launch_strip_t<PREC_BF16, 64, 0, 0, 0, false, 1>(p, wn_a, s, tiles);
   return p.res ? launch_strip_t<PREC_BF16, 64, 0, 0, 0, true, 2>(p, wn_a, s, tiles) : launch_strip_t<PREC_BF16, 64, 0, 0, 0, false, 2>(p, wn_a, s, tiles);
 }

@@ -224,7 +224,12 @@ bool conv_in8_ok(ConvKind kind, int prec, const ConvParams& p, int cin_real) {
   return p.Cout == 16 || p.Cout == 32 || p.Cout == 48 || p.Cout == 64;
 }
 
-static int g_in8_resident[8];   // [f16x3 | bf16][couts / 16 - 1]: workgroups of conv_in8_kernel resident on the whole device (kernels_tail_init)
+// [f16x3 | bf16][couts / 16 - 1]: workgroups of conv_in8_kernel resident on the whole device.  Queried once (kernels_tail_init) on the
+// device that is current then and used for every device of the process: one process drives one GPU here, and the GPUs of a node are
+// the same part.  The kernel has static LDS only (the launch passes 0 dynamic bytes, as the query does).  A value that is too large only
+// repeats a workgroup's weight set-up, one that is too small leaves CUs idle: performance, never correctness; the grid is clamped to the
+// tile count below.
+static int g_in8_resident[8];
 
 hipError_t launch_conv_in8(int prec, const ConvParams& p, const float* wmaster, int cin_real, hipStream_t s, int* tiles) {
   const int per_img = ((p.Wout + IN_TW - 1) / IN_TW) * ((p.Hout + IN_TH - 1) / IN_TH);

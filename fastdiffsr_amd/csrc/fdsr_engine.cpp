@@ -1010,9 +1010,17 @@ int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, 
           if (ridden) f += conv_flops(h->ops[op.rider], N, H, W);
           if (op.src0 == h->t_in) f *= (double)h->cfg.in_channel / h->CP;
           h->prof_flops += f;
-          // algorithmic bytes: input read once + output written once
-          h->prof_bytes += 4.0 * N * ((double)Hi * Wi * (op.C0 + op.C1) + (double)p.Hout * p.Wout * op.Cout);
-          if (ridden) h->prof_bytes += 4.0 * N * (double)Hi * Wi * (h->ops[op.rider].C0 + h->ops[op.rider].C1);
+          // algorithmic bytes (ideal-fused): every input element read once, the output written once, the residual read
+          // once, in the element size the active mode keeps that tensor in (bf16 mode: 2 bytes for everything but the packed
+          // network input and eps), plus the GroupNorm partial-sum appendix this launch writes (it stands where 8d has a second
+          // read of each GroupNorm input: [N][tiles][Cout][2] fp32)
+          const double esz = h->prec == PREC_BF16 ? 2.0 : 4.0;
+          const double esz_in = op.src0 == h->t_in ? 4.0 : esz, esz_out = p.out_f32 ? 4.0 : esz;
+          const double out_elems = (double)N * p.Hout * p.Wout * op.Cout;
+          h->prof_bytes += esz_in * N * (double)Hi * Wi * (op.src0 == h->t_in ? h->CP : op.C0 + op.C1) + esz_out * out_elems;
+          if (ridden) h->prof_bytes += esz * N * (double)Hi * Wi * (h->ops[op.rider].C0 + h->ops[op.rider].C1);
+          else if (op.res >= 0) h->prof_bytes += esz * out_elems;
+          if (p.part_out) h->prof_bytes += 8.0 * N * (double)nt * op.Cout;
         }
         break;
       }

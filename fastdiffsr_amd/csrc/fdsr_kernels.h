@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "../../include/fdsr.h"   // fdsr_k32_bits / fdsr_strip_bits
 
 namespace fdsr {
 
@@ -90,10 +91,10 @@ struct Tunables {
   int drop_stage = 1;       // f16x3 training forwards: Dropout applied in the staging of the 16x16x32 kernels (0: the dropped activation is materialised first)
   int gnb_fuse = 1;         // f16x3 steps: the reduce half of the GroupNorm backward inside the input-gradient launch (ConvParams::gb_*)
   long long wgrad_big_bytes = 1ll << 32;   // tensors from this size on take the 4-wave weight-gradient kernel (64-bit offsets)
-  int k32 = 1275;           // v_mfma_f32_16x16x32 form (fdsr_conv_k32.hip) of the stride-1 3x3 launches that fit it; bits: 1 f16x3, 2 bf16, 4 the 16-row tile with a rider, 8 the 2-row-per-wave tiles of small grids, 16 the sub-pixel upsample convs, 32 the small-workgroup form (4 waves, two workgroups per CU; 6-row tiles in f16x3, 8-row tiles in bf16) of the rider-less 64-cout launches of large grids in f16x3, 128 in bf16 too, 64 the f16x3 launches with a rider too (rider chunks first), 512 the bf16 ones with a rider (off: slower), 1024 the 8-wave rider kernels with the rider chunks first (launches without a K split); 0 never
+  int k32 = FDSR_K32_DEFAULT;           // v_mfma_f32_16x16x32 form (fdsr_conv_k32.hip) of the stride-1 3x3 launches that fit it; bits: 1 f16x3, 2 bf16, 4 the 16-row tile with a rider, 8 the 2-row-per-wave tiles of small grids, 16 the sub-pixel upsample convs, 32 the small-workgroup form (4 waves, two workgroups per CU; 6-row tiles in f16x3, 8-row tiles in bf16) of the rider-less 64-cout launches of large grids in f16x3, 128 in bf16 too, 64 the f16x3 launches with a rider too (rider chunks first), 512 the bf16 ones with a rider (off: slower), 1024 the 8-wave rider kernels with the rider chunks first (launches without a K split); 0 never
   int k32_stagger = 0;      // ... start delay of the CU's odd workgroup slot, in 64-cycle units per K chunk (0: none)
   long k32_sb_min_wgs = 1024;   // ... from this many workgroups on (a small grid wants all eight waves of a CU on its one tile)
-  int strip = 91;           // column-strip form (fdsr_conv_strip.hip: weights in registers, one input row per step) of the 64-cout launches: bit 1 bf16 64 -> 64, 2 f16x3 64 -> 64, 4 (A/B) bf16 on one workgroup per CU, 8 bf16 (64 | 64) -> 64, 16 bf16 64 -> 64 with a res_conv rider, 32 bf16 (128 | 64) -> 64, 64 bf16 128 -> 128 / 64 -> 128
+  int strip = FDSR_STRIP_DEFAULT;           // column-strip form (fdsr_conv_strip.hip: weights in registers, one input row per step) of the 64-cout launches: bit 1 bf16 64 -> 64, 2 f16x3 64 -> 64, 4 (A/B) bf16 on one workgroup per CU, 8 bf16 (64 | 64) -> 64, 16 bf16 64 -> 64 with a res_conv rider, 32 bf16 (128 | 64) -> 64, 64 bf16 128 -> 128 / 64 -> 128
   long strip_min_wgs = 512; // ... from this many strip segments of >= 16 rows on (two workgroups per CU)
   int tail = 1;             // the input / output convs of the 16-bit modes on their own kernels (fdsr_conv_tail.hip); 0: the general ones
   int knockout = 0;         // TIMING-ONLY probes, results are garbage: bit 1 leaves the gn_finalize launches out, bit 2 the splitk_reduce launches

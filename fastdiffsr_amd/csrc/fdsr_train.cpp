@@ -295,7 +295,9 @@ int launch_dgrad_h(fdsr_handle h, const Op& op, const float* dy, int K, int Hs, 
   p.ksplit = 1;
   p.out_f32 = 1;
   if (gb_tiles) *gb_tiles = 0;
-  if (gb && gb_tiles && g_tun.gnb_fuse && conv_h_gnb_ok(k, PREC_F16X3, p)) {
+  // (gn_bwd_finalize_tiles_kernel holds at most 64 channels of a group: wider groups -- norm_groups small against the channel
+  // count -- take the separate reduce pass)
+  if (gb && gb_tiles && g_tun.gnb_fuse && gb->gb_G > 0 && Csub / gb->gb_G <= 64 && conv_h_gnb_ok(k, PREC_F16X3, p)) {
     p.gb_x0 = gb->gb_x0; p.gb_x1 = gb->gb_x1; p.gb_C0 = gb->gb_C0; p.gb_G = gb->gb_G; p.gb_plain = gb->gb_plain;
     p.gb_scale = gb->gb_scale; p.gb_shift = gb->gb_shift; p.gb_stats = gb->gb_stats; p.gb_mask = gb->gb_mask; p.gb_drop = gb->gb_drop;
     p.part_out = gb->part_out;

@@ -181,11 +181,20 @@ class ThreadedBatchLoader:
         self.ds, self.bs, self.shuffle, self.gen, self.depth = dataset, int(batch_size), bool(shuffle), generator, depth
         # stage(key, [arrays], owner=) -> what the batch carries for that key: default the stacked array; the GPU loops pass val.HipOps.stage_host,
         # which stacks straight into pinned memory ON THE LOADER THREAD (the consumer then only issues the asynchronous copy)
-        self.stage = (lambda key, arrays: stage(key, arrays, owner=id(self))) if stage else (lambda key, arrays: np.stack(arrays))
+        ops = getattr(stage, '__self__', None)           # a bound HipOps.stage_host: rings named by a token that is never reused
+        self._ops = ops if hasattr(ops, 'release') else None
+        self.owner = ops.new_owner() if hasattr(ops, 'new_owner') else id(self)
+        self.stage = (lambda key, arrays: stage(key, arrays, owner=self.owner)) if stage else (lambda key, arrays: np.stack(arrays))
         self.pool = ThreadPoolExecutor(max_workers=max(1, int(workers)))
 
     def __len__(self):
         return (len(self.ds) + self.bs - 1) // self.bs
+
+    def close(self):
+        """Give the pinned staging rings back (the loader itself lives for the whole run: one ring set, reused every epoch)."""
+        if self._ops is not None:
+            self._ops.release(self.owner)
+        self.pool.shutdown(wait=False)
 
     def __iter__(self):
         n = len(self.ds)

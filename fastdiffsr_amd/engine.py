@@ -126,6 +126,7 @@ class Engine:
         return t.contiguous()
 
     _warned_saturated = False
+    saturation_fallbacks = 0       # calls (all engines of the process) re-run on the exact-fp32 kernels after the f16x3 range guard tripped
 
     def _with_range_fallback(self, call):
         """Run `call()`; if the f16x3 range guard trips and the policy says so, run it again in exact fp32."""
@@ -134,6 +135,7 @@ class Engine:
         except _lib.FdsrSaturated:
             if self.on_saturation != 'f32':
                 raise
+        Engine.saturation_fallbacks += 1
         if not Engine._warned_saturated:
             import warnings
             warnings.warn('fastdiffsr_amd: a raw convolution input exceeded the f16 range in f16x3 mode; this call was re-run on the '

@@ -33,6 +33,48 @@ def init_process_group():
     return backend
 
 
+def host_cores():
+    """CPU threads this process may really use: affinity mask capped by the cgroup CPU quota (v2 `cpu.max`, v1 cfs quota)."""
+    import os
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+        try:
+            txt = open(path).read().split()
+            if path.endswith('cpu.max'):
+                if txt[0] != 'max':
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return n
+
+
+def local_world_size():
+    """Ranks that share this host's cores: LOCAL_WORLD_SIZE (torch.distributed.run sets it), else WORLD_SIZE (one node), else 1."""
+    import os
+    for k in ('LOCAL_WORLD_SIZE', 'WORLD_SIZE'):
+        v = os.environ.get(k)
+        if v and v.isdigit() and int(v) > 0:
+            return int(v)
+    return 1
+
+
+def host_threads_per_rank(cap=8, floor=2, cores=None, ranks=None):
+    """Loader / writer threads ONE rank starts (the reference: DataLoader workers, data/__init__.py:9-18): this rank's share of
+    the cores the job may use -- host_cores() / local ranks, minus the rank's own sampling thread -- within [floor, cap].  On a
+    16-core lease an 8-rank run gets 2 per rank (16 loader threads in all), not 8 x 8."""
+    cores = host_cores() if cores is None else int(cores)
+    ranks = local_world_size() if ranks is None else max(1, int(ranks))
+    return max(int(floor), min(int(cap), cores // ranks - 1))
+
+
 def shard_range(total, rank, world):
     """Contiguous, balanced [lo, hi) slice of `total` images for `rank`."""
     base, rem = divmod(int(total), int(world))

@@ -20,9 +20,16 @@ from . import val as V
 from .config import load_config
 from .dataset import create_dataset
 from .model import create_model
-from .parallel import shard_range
+from .parallel import host_threads_per_rank, shard_range
 
 logger = logging.getLogger('base')
+
+
+def loader_workers(num_workers):
+    """Loader threads of this rank: the config's `num_workers` (the reference's DataLoader workers, data/__init__.py:9-15; per
+    process there, one process in all) but never more than this rank's share of the usable cores."""
+    share = host_threads_per_rank(cap=16, floor=2)
+    return max(2, min(int(num_workers or 0) or share, share))
 
 
 def run(opt, precision='f16x3', rank=0, world=1, log=print, val_batch=1, max_val_images=None, diffusion=None, ops=None):
@@ -38,7 +45,7 @@ def run(opt, precision='f16x3', rank=0, world=1, log=print, val_batch=1, max_val
     # one rank: the loader threads stack every batch straight into pinned memory (ops.stage_host); several ranks: every rank decodes the
     # whole batch (same shuffle seed), keeps its slice and stages that
     loader = ThreadedBatchLoader(train_set, train_opt['batch_size'], shuffle=train_opt['use_shuffle'],
-                                 workers=max(2, int(train_opt['num_workers'] or 0)), generator=gen if world > 1 else None,
+                                 workers=loader_workers(train_opt.get('num_workers')), generator=gen if world > 1 else None,
                                  stage=ops.stage_host if world == 1 else None)
     own_model = diffusion is None
     if own_model:
@@ -92,6 +99,7 @@ def run(opt, precision='f16x3', rank=0, world=1, log=print, val_batch=1, max_val
             if current_step % opt['train']['save_checkpoint_freq'] == 0 and rank == 0:
                 log('Saving models and training states.')
                 diffusion.save_network(current_epoch, current_step)
+    loader.close()
     if rank == 0:
         log('End of training.')
     return diffusion, history

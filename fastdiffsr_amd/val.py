@@ -15,6 +15,7 @@ same `{results}/{step}_{idx}_sr.tif` outputs.  Differences, all opt-in or harmle
   * under `torch.distributed.run` the images are sharded over the ranks and the metric sums all-reduced
 """
 import argparse
+import itertools
 import logging
 import os
 import time
@@ -27,7 +28,7 @@ from .config import load_config
 from .data import lr_to_sr
 from .dataset import create_dataset
 from .model import create_model
-from .parallel import shard_range
+from .parallel import host_threads_per_rank, shard_range
 
 logger = logging.getLogger('base')
 
@@ -44,10 +45,25 @@ class HipOps:
         import threading
         self.device = torch.device(device)
         self._cond = threading.Condition()
-        self._up = {}       # (key, shape) -> ring of pinned staging buffers (H2D)
+        self._owners = itertools.count(1)
+        self._up = {}       # (owner, key, shape) -> ring of pinned staging buffers (H2D)
         self._down = {}     # (tag, shape, dtype) -> ring of pinned landing buffers (D2H)
 
     RING = 6            # pinned staging buffers per (owner, key, shape): more than any loader keeps staged ahead of its consumer (depth + 1 <= 4)
+    STAGE_TIMEOUT = 120.0   # seconds a loader thread waits for a free staging buffer before it raises (a consumer that died with batches staged)
+
+    def new_owner(self):
+        """A token naming one loader's rings: monotonically increasing, never reused (id() of a dead loader can come back)."""
+        with self._cond:
+            return next(self._owners)
+
+    def release(self, owner):
+        """Drop the staging rings of a finished loader (pinned memory; a validation pass inside a training run makes a new loader
+        every time).  Copies still in flight keep their buffers alive through the caching host allocator's stream bookkeeping."""
+        with self._cond:
+            for rkey in [k for k in self._up if k[0] == owner]:
+                del self._up[rkey]
+            self._cond.notify_all()
 
     def stage_host(self, key, arrays, owner=None):
         """Stack a batch's uint8 images (list of numpy arrays, or one stacked array) into a pinned staging buffer -- called on a
@@ -67,7 +83,10 @@ class HipOps:
                 free = [(ring['next'] + i) % self.RING for i in range(self.RING) if not ring['held'][(ring['next'] + i) % self.RING]]
                 if free:
                     break
-                self._cond.wait()        # every buffer holds a staged batch that has not been uploaded yet
+                # every buffer holds a staged batch that has not been uploaded yet
+                if not self._cond.wait(self.STAGE_TIMEOUT):
+                    raise RuntimeError('no free staging buffer for %r after %.0f s: its %d staged batches were never uploaded '
+                                       '(did the consumer stop?)' % (rkey, self.STAGE_TIMEOUT, self.RING))
             slot = free[0]
             ring['held'][slot] = True
             ring['next'] = (slot + 1) % self.RING
@@ -131,6 +150,7 @@ class _Loader:
 
     def __init__(self, dataset, lo, hi, batch, pool, ops, depth=2):
         self.ds, self.pool, self.depth, self.ops = dataset, pool, depth, ops
+        self.owner = ops.new_owner() if hasattr(ops, 'new_owner') else id(self)
         self.batches = [list(range(b0, min(b0 + batch, hi))) for b0 in range(lo, hi, batch)]
         self.futs = {}
         self.next = 0
@@ -142,7 +162,7 @@ class _Loader:
         out = {'Index': [it['Index'] for it in items]}
         for key in ('HR', 'SR', 'LR'):
             if key in items[0]:
-                out[key] = self.ops.stage_host(key, [it[key] for it in items], owner=id(self))
+                out[key] = self.ops.stage_host(key, [it[key] for it in items], owner=self.owner)
         return out
 
     def _submit_until(self, k):
@@ -153,6 +173,17 @@ class _Loader:
 
     def __len__(self):
         return len(self.batches)
+
+    def close(self):
+        """End of the pass (also an aborted one): wait for the collate jobs still queued, then give the staging rings back."""
+        for f in list(self.futs.values()):
+            try:
+                f.result()
+            except Exception:
+                pass
+        self.futs.clear()
+        if hasattr(self.ops, 'release'):
+            self.ops.release(self.owner)
 
     def prefetch(self, k):
         """Hand the decode + collate jobs of batches <= k to the pool.  Called by the loop right BEFORE it enters a long GPU call: the
@@ -210,7 +241,8 @@ def run(opt, batch=1, cond_from_lr=False, precision='f16x3', results=None, max_i
     rres = int(val_opt['r_resolution'])
     per_image = {}                     # index -> 8 numbers (bic mse/psnr/ssim/ergas, sr mse/psnr/ssim/ergas); summed in index order
     t_sample = 0.0
-    n_workers = workers if workers else max(2, min(8, (os.cpu_count() or 4)))
+    # loader / writer threads of THIS rank: its share of the cores the job may use (affinity, cgroup quota, ranks on the host)
+    n_workers = workers if workers else host_threads_per_rank(cap=8, floor=2)
     pool = ThreadPoolExecutor(max_workers=n_workers)
     jobs = queue.Queue()
     errors = []
@@ -259,9 +291,11 @@ def run(opt, batch=1, cond_from_lr=False, precision='f16x3', results=None, max_i
     old_switch = sys.getswitchinterval()
     sys.setswitchinterval(2e-4)
     clock['setup'] = time.perf_counter() - t_run0
-    loader = _Loader(dataset, lo, hi, batch, pool, ops)
+    loader = None
     slot_free = [None] * 3
     try:
+        loader = _Loader(dataset, lo, hi, batch, pool, ops)
+
         def stage(k):
             """Batch k on the device as the model tensors: issued BEFORE the previous batch is sampled, so the bytes are
             there when its loop ends (the copies and the two small kernels sit in front of that loop on the stream)."""
@@ -320,6 +354,8 @@ def run(opt, batch=1, cond_from_lr=False, precision='f16x3', results=None, max_i
         tt = time.perf_counter()
         jobs.put(None)
         finisher.join()
+        if loader is not None:
+            loader.close()
         for f in saves:
             f.result()
         pool.shutdown(wait=True)
@@ -367,7 +403,7 @@ def main(argv=None, diffusion=None, ops=None):
     ap.add_argument('--max-images', type=int, default=None)
     ap.add_argument('--no-save', action='store_true')
     ap.add_argument('--infer', action='store_true', help="the reference's infer.py: png outputs and timing, no metrics")
-    ap.add_argument('--workers', type=int, default=None, help='loader / writer threads (default: max(2, min(8, cores)))')
+    ap.add_argument('--workers', type=int, default=None, help='loader / writer threads of this rank (default: its share of the usable cores, 2 .. 8)')
     ap.add_argument('--rng', default=None, choices=['torch', 'engine'],
                     help="sampling noise: 'torch' (default; torch.randn in the reference's order, reproducible under torch.manual_seed) "
                          "or 'engine' (Philox inside the HIP loop: nothing pre-drawn)")

@@ -212,6 +212,32 @@ int fdsr_resize_bicubic_u8(fdsr_handle h, const uint8_t* src_nhwc, int batch, in
  * outputs are then not fp32-grade: re-run them after fdsr_set_precision(FDSR_PREC_F32), which has no such limit). */
 int fdsr_check_saturation(fdsr_handle h, void* hip_stream);
 
+/* Bits of the "k32" and "strip" options of fdsr_debug_option (which kernel form a stride-1 3x3 launch lands on; every setting
+ * computes the same function within the tested bounds).  fastdiffsr_amd/_lib.py mirrors the names for the tests and bench.py. */
+enum fdsr_k32_bits {
+  FDSR_K32_F16X3 = 1,              /* the 16x16x32-MFMA form in f16x3 */
+  FDSR_K32_BF16 = 2,               /* ... and in bf16 */
+  FDSR_K32_RIDER_16ROW = 4,        /* the 16-row tile with a res_conv rider */
+  FDSR_K32_SMALL_GRID_2ROW = 8,    /* the 2-row-per-wave tiles of small grids */
+  FDSR_K32_UP2 = 16,               /* the sub-pixel upsample convs */
+  FDSR_K32_SMALL_WG_F16X3 = 32,    /* rider-less 64-cout launches of large grids on 4-wave workgroups, two per CU (f16x3) */
+  FDSR_K32_SMALL_WG_RIDER_F16X3 = 64,   /* ... those with a rider too, rider chunks first (f16x3) */
+  FDSR_K32_SMALL_WG_BF16 = 128,    /* the small-workgroup form in bf16 (8-row tiles) */
+  FDSR_K32_SMALL_WG_RIDER_BF16 = 512,   /* ... with a rider in bf16 (off by default: slower) */
+  FDSR_K32_RIDER_FIRST_8WAVE = 1024,    /* rider chunks first on the 8-wave rider kernels (launches without a K split) */
+  FDSR_K32_DEFAULT = 1 | 2 | 8 | 16 | 32 | 64 | 128 | 1024     /* 1275 */
+};
+enum fdsr_strip_bits {
+  FDSR_STRIP_BF16_64 = 1,          /* bf16 64 -> 64 launches on the column-strip kernel (two workgroups per CU) */
+  FDSR_STRIP_F16X3_64 = 2,         /* the f16x3 64 -> 64 launches (one workgroup per CU: hi / lo weight planes) */
+  FDSR_STRIP_BF16_ONE_WG = 4,      /* A/B: bf16 64 -> 64 on one workgroup per CU */
+  FDSR_STRIP_BF16_CAT64 = 8,       /* bf16 (64 | 64) -> 64 */
+  FDSR_STRIP_BF16_RIDER = 16,      /* bf16 64 -> 64 with a res_conv rider */
+  FDSR_STRIP_BF16_CAT128 = 32,     /* bf16 (128 | 64) -> 64 (off by default: 216 weight registers spill) */
+  FDSR_STRIP_BF16_COUT128 = 64,    /* bf16 128 -> 128 and 64 -> 128 as two workgroups of 64 couts per strip */
+  FDSR_STRIP_DEFAULT = 1 | 2 | 8 | 16 | 64                     /* 91 */
+};
+
 /* -- introspection for parity tests and bench.py -------------------------- */
 /* Debug / A-B options of the launchers (process-wide; nothing in the library reads the environment).  Names:
  * "rider" (0|1|2|3), "up2" (0|1), "th_min_wgs", "splitk" (0|1), "sk_target", "wgrad_form" (0 default | 1 four-wave | 2 eight-wave

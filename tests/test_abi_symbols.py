@@ -85,3 +85,15 @@ def test_debug_options_are_an_abi_call_not_environment():
     for f in os.listdir(csrc):
         if f.endswith(('.hip', '.cpp', '.h')):
             assert 'getenv' not in open(os.path.join(csrc, f)).read(), f
+
+
+def test_kernel_form_bits_match_the_header():
+    """enum fdsr_k32_bits / fdsr_strip_bits of include/fdsr.h and their mirror in _lib.py (names without the prefix)."""
+    from fastdiffsr_amd import _lib
+    txt = open(os.path.join(ROOT, 'include', 'fdsr.h')).read()
+    for prefix, table, default in (('FDSR_K32_', _lib.K32, _lib.K32_DEFAULT), ('FDSR_STRIP_', _lib.STRIP, _lib.STRIP_DEFAULT)):
+        found = {m.group(1): int(m.group(2)) for m in re.finditer(prefix + r'([A-Z0-9_]+) = (\d+),', txt)}
+        assert found == table, (prefix, found)
+        expr = re.search(prefix + r'DEFAULT = ([0-9| ]+)', txt).group(1)
+        assert eval(expr) == default
+    assert _lib.bit_names(_lib.STRIP, 91) == 'BF16_64|F16X3_64|BF16_CAT64|BF16_RIDER|BF16_COUT128'

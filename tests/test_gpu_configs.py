@@ -93,9 +93,12 @@ def test_config2_bf16_b64_hipgraph_256(full):
         d, rmse = diff.abs().max().item(), diff.pow(2).mean().sqrt().item()
         print(f'configs[2] bf16 B=64 graph: image {i} vs oracle PSNR delta {dps:+.5f} dB, max|d| {d:.3e}, rmse {rmse:.3e}')
         assert abs(dps) <= 0.01
-        # sanity only: bf16 is outside the 1e-3 bound by design (CPU bf16 autocast differs by rmse 1.9e-3,
-        # max 4.9e-2; isolated pixels can flip the x_0 clamp)
-        assert rmse <= 0.02
+        # bf16 is outside the 1e-3 bound by design (CPU bf16 autocast differs by rmse 1.9e-3 = 60.65 dB, max 4.9e-2;
+        # isolated pixels can flip the x_0 clamp).  The PSNR delta above is taken against a synthetic HR where both images sit at
+        # ~13 dB (random-init network) and cannot fail; THIS bound can: the bf16 image against the oracle's own image, data range 2
+        psnr_vs_oracle = 20 * math.log10(2.0 / max(rmse, 1e-12))
+        print(f'configs[2] bf16 B=64 graph: PSNR(bf16 out, oracle out) = {psnr_vs_oracle:.2f} dB')
+        assert psnr_vs_oracle >= 50.0
     finally:
         eng.set_precision('f32')
 
@@ -116,8 +119,10 @@ def test_config3_per_gpu_slice_bf16_b64(full):
         i = 63
         ref = _oracle_image(sd, cfg, cond[i:i + 1], noise[:, i:i + 1])
         dps = _psnr_delta(out[i:i + 1].cpu(), ref, cond[i:i + 1])
-        print(f'configs[3] slice bf16 B=64: image {i} vs oracle PSNR delta {dps:+.5f} dB')
-        assert abs(dps) <= 0.01
+        rmse = (out[i:i + 1].cpu() - ref).pow(2).mean().sqrt().item()
+        psnr_vs_oracle = 20 * math.log10(2.0 / max(rmse, 1e-12))
+        print(f'configs[3] slice bf16 B=64: image {i} vs oracle PSNR delta {dps:+.5f} dB, PSNR(bf16 out, oracle out) = {psnr_vs_oracle:.2f} dB')
+        assert abs(dps) <= 0.01 and psnr_vs_oracle >= 50.0
     finally:
         eng.set_precision('f32')
 

@@ -2,7 +2,7 @@
 4 x 32 or 2 x 32 pixels (except the 16-row tile with a rider); here it is FORCED onto every eligible launch of a small forward (largest tile regardless of the grid size, so
 the split-K, partial-tile and rider paths of the form all run), layer by layer against the oracle, in every option setting
 (bits of `k32`: 1 f16x3, 2 bf16, 4 the 16-row tile with a rider, 8 the 2-row tiles of small grids, 16 the sub-pixel upsample convs, 32 / 128 the small-workgroup form of the 64-cout tiles in f16x3 / bf16, 64 / 512 with a rider (rider chunks first), 1024 the 8-wave rider kernels rider-first too; default 1275), against the 32x32x16 kernels on the same input, and through the
-20-step loop.  Same bounds as every other conv kernel: layerwise 1e-4 * max(1, |ref|), loop 1e-3 (north_star); bf16 0.25 layerwise
+20-step loop.  Same bounds as every other conv kernel: layerwise 1e-4 * max(1, |ref|), loop 1e-3 (north_star); bf16 0.04 layerwise
 (judged on PSNR elsewhere).  Reference: fastdiffsr_modules/unet.py:89-120."""
 import pytest
 import torch
@@ -127,7 +127,7 @@ def test_subpixel_upsample_convs_on_the_form(full, prec):
     from oracle import fdsr_oracle as O
     cfg, eng, sd = full
     eng.set_precision(prec)
-    tol = TOL_FWD if prec == 'f16x3' else 0.25
+    tol = TOL_FWD if prec == 'f16x3' else 0.04
     bits = 25 if prec == 'f16x3' else 27
     _lib.debug_option('k32', bits)
     try:
@@ -170,7 +170,7 @@ def test_small_workgroup_form_vs_oracle(full, prec):
     from oracle import fdsr_oracle as O
     cfg, eng, sd = full
     eng.set_precision(prec)
-    tol = TOL_FWD if prec == 'f16x3' else 0.25
+    tol = TOL_FWD if prec == 'f16x3' else 0.04
     _lib.debug_option('k32', 1275 | 512)           # with the bf16 riders too (bit 512: off by default)
     _lib.debug_option('k32_sb_min_wgs', 1)
     _lib.debug_option('splitk', 0)          # (a launch with a K split keeps the 8-wave forms)
@@ -259,7 +259,7 @@ def test_bf16_k32_layerwise(full, forced):
         torch.cuda.synchronize()
         for L in build_layers(cfg):
             d = (eng.debug_tensor(L.name).cpu() - cap[L.name]).abs().max().item()
-            assert d <= 0.25 * max(cap[L.name].abs().max().item(), 1.0), f'{L.name}: {d}'
+            assert d <= 0.04 * max(cap[L.name].abs().max().item(), 1.0), f'{L.name}: {d}'
         eng.set_debug(False)
         assert torch.equal(eng.unet_forward(x.cuda(), nl.cuda()), out)
         _lib.debug_option('k32', 0)

@@ -236,10 +236,12 @@ def test_batch16_properties(full, prec):
     assert d_3 <= TOL_LOOP
 
 
-@pytest.mark.parametrize('prec,tol_fwd,tol_loop', [('f16x3', 1e-4, 1e-3), ('bf16', 0.25, None)])
+@pytest.mark.parametrize('prec,tol_fwd,tol_loop', [('f16x3', 1e-4, 1e-3), ('bf16', 0.03, None)])
 def test_precision_modes_layerwise_and_loop(full, golden_dir, prec, tol_fwd, tol_loop):
     """16-bit MFMA convolutions: f16x3 (hi/lo split, fp32-grade) must stay inside the fp32
-    parity bounds; bf16 is judged on PSNR (north_star: PSNR within 0.01 dB), not on 1e-3."""
+    parity bounds; bf16 is judged on PSNR (north_star: PSNR within 0.01 dB), not on 1e-3 -- but its layers must stay within
+    3 % of the layer's range (measured worst 1.1 %: bf16 has 8 mantissa bits, 2^-9 = 0.2 % per rounding) and the loop's output
+    within 50 dB of the oracle's (a bound that CAN fail: the PSNR-against-HR difference below cannot, at a random-init network's 13 dB)."""
     from oracle import fdsr_oracle as O
     cfg, eng, sd = full
     eng.set_precision(prec)
@@ -275,6 +277,11 @@ def test_precision_modes_layerwise_and_loop(full, golden_dir, prec, tol_fwd, tol
         report(f'{prec} loop64 final max|d|={d64:.3e} PSNR delta vs reference={dps:.5f} dB')
         if tol_loop is not None:
             assert per_step.max() <= tol_loop and d <= tol_loop and d64 <= tol_loop
+        else:
+            rmse64 = float(np.sqrt(np.mean((o64.numpy() - g['out64']) ** 2)))
+            psnr_vs_ref = 20 * np.log10(2.0 / rmse64)              # images live in [-1, 1]: data range 2
+            report(f'{prec} loop64 PSNR(out, reference out) = {psnr_vs_ref:.2f} dB (rmse {rmse64:.3e})')
+            assert psnr_vs_ref >= 50.0
         assert dps <= 0.01
     finally:
         eng.set_debug(False)

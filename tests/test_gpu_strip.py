@@ -4,7 +4,7 @@ registers, one input row per step, three output rows per fragment read).  Large 
 128 -> 128 and 64 -> 128 as two workgroups of 64 couts; `strip_min_wgs`); here every bit is on and the form is forced onto every grid
 size: layer by layer against the oracle (maps 128 x 128 and 64 x 192: one and three strips per row, segments
 of 16 .. 128 rows, image borders on both sides of a strip), against the tile kernels on the same input, bitwise reruns, the 20-step
-loop eager and as a hipGraph.  Same bounds as every other conv kernel: layerwise 1e-4 * max(1, |ref|) in f16x3, 0.25 in bf16 (judged
+loop eager and as a hipGraph.  Same bounds as every other conv kernel: layerwise 1e-4 * max(1, |ref|) in f16x3, 0.04 in bf16 (measured worst 0.011) (judged
 on PSNR elsewhere), loop 1e-3 (north_star).  Reference: fastdiffsr_modules/unet.py:89-120."""
 import pytest
 import torch
@@ -33,18 +33,20 @@ def full():
 
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize('prec', PRECS)
-@pytest.mark.parametrize('min_wgs', [1, 4, 12], ids=['whole-strips', 'segments-a', 'segments-b'])
+@pytest.mark.parametrize('min_wgs', [1, 4, 12, 24], ids=['whole-strips', 'segments-a', 'segments-b', 'segments-c'])
 def test_strip_form_vs_oracle(full, prec, min_wgs):
     from fastdiffsr_amd import _lib
     from oracle import fdsr_oracle as O
     cfg, eng, sd = full
     eng.set_precision(prec)
-    tol = TOL_FWD if prec == 'f16x3' else 0.25
+    tol = TOL_FWD if prec == 'f16x3' else 0.04
     _lib.debug_option('strip', 127 - 4)
     _lib.debug_option('strip_min_wgs', min_wgs)
     _lib.debug_option('splitk', 0)          # (a launch with a K split keeps the tile kernels)
     try:
-        for shape, seed in (((2, 6, 128, 128), 31), ((1, 6, 64, 192), 32)):
+        # 136 rows: 9-row segments leave a remainder of ONE row (min_wgs 12 on the two-per-CU forms, 24 on the wide ones) -- the kernel
+        # balances its segments, so no segment is shorter than its peeled steps
+        for shape, seed in (((2, 6, 128, 128), 31), ((1, 6, 64, 192), 32), ((1, 6, 136, 64), 33)):
             gen = torch.Generator().manual_seed(seed)
             x = torch.randn(*shape, generator=gen)
             nl = torch.rand(shape[0], 1, generator=gen) * 0.9 + 0.05

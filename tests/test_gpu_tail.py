@@ -36,7 +36,7 @@ def test_tail_kernels_layerwise(prec, inner, groups):
         pytest.skip('bf16 mode needs 16-aligned channel counts everywhere (48 * 2 = 96 ok, but 48 / 16 groups of 3 are not MFMA-aligned)')
     cfg, eng, sd = _engine(inner_channel=inner, norm_groups=groups)
     eng.set_precision(prec)
-    tol = TOL_FWD if prec == 'f16x3' else 0.25
+    tol = TOL_FWD if prec == 'f16x3' else 0.04
     try:
         for shape, seed in (((2, 6, 72, 104), 31), ((1, 6, 40, 24), 32)):
             gen = torch.Generator().manual_seed(seed)
