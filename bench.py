@@ -47,7 +47,18 @@ class GpuTelemetry:
         for hw in sorted(glob.glob('/sys/class/drm/card*/device/hwmon/hwmon*')):
             if any(os.path.exists(os.path.join(hw, f)) for f in ('power1_average', 'power1_input')):
                 cards.append(hw)
-        self.hw = cards[index] if index < len(cards) else None
+        # the card of HIP device `index`: by PCI address (a container may see the sysfs nodes of GPUs it was not given)
+        self.hw, self.selection = None, None
+        try:
+            pr = torch.cuda.get_device_properties(index)
+            addr = '%04x:%02x:%02x.' % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+            for hw in cards:
+                if addr in os.path.realpath(os.path.join(hw, '..', '..')):
+                    self.hw, self.selection = hw, 'pci ' + addr + '0'
+        except Exception:
+            pass
+        if self.hw is None and cards:
+            self.hw, self.selection = (cards[index] if index < len(cards) else cards[0]), 'card order (no PCI match)'
         self.cap = self._read('power1_cap', 1e-6)
 
     def _read(self, name, scale):
@@ -87,7 +98,7 @@ class GpuTelemetry:
         (cm, cl, ch), (pm, pl, ph) = stat(0), stat(1)
         return {'sclk_mhz': cm, 'sclk_mhz_min': cl, 'sclk_mhz_max': ch, 'power_w': pm, 'power_w_min': pl, 'power_w_max': ph,
                 'power_cap_w': self.cap, 'samples': len(self.samples), 'period_s': self.period,
-                'source': (self.hw + '/{freq1_input,power1_average}') if self.hw else None}
+                'source': (self.hw + '/{freq1_input,power1_average}') if self.hw else None, 'device_selected_by': self.selection}
 
 
 def cpu_model():

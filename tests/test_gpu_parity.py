@@ -271,6 +271,7 @@ def test_precision_modes_layerwise_and_loop(full, golden_dir, prec, tol_fwd, tol
         cond64, noise64 = synth_inputs(1, 64, 64, 20)
         o64 = eng.sample(cond64.cuda(), noise64.cuda()).cpu()
         d64 = np.abs(o64.numpy() - g['out64']).max()
+        rmse64 = float(np.sqrt(np.mean((o64.numpy() - g['out64']) ** 2)))     # (before tensor2img_u8 below clamps o64 in place)
         ref64 = torch.from_numpy(g['out64'])
         hr = (cond64 + 0.3 * torch.sin(torch.arange(64).float() / 5).view(1, 1, 1, 64)).clamp(-1, 1)
         dps = abs(O.psnr_u8(O.tensor2img_u8(o64[0]), O.tensor2img_u8(hr[0])) - O.psnr_u8(O.tensor2img_u8(ref64[0]), O.tensor2img_u8(hr[0])))
@@ -278,7 +279,6 @@ def test_precision_modes_layerwise_and_loop(full, golden_dir, prec, tol_fwd, tol
         if tol_loop is not None:
             assert per_step.max() <= tol_loop and d <= tol_loop and d64 <= tol_loop
         else:
-            rmse64 = float(np.sqrt(np.mean((o64.numpy() - g['out64']) ** 2)))
             psnr_vs_ref = 20 * np.log10(2.0 / rmse64)              # images live in [-1, 1]: data range 2
             report(f'{prec} loop64 PSNR(out, reference out) = {psnr_vs_ref:.2f} dB (rmse {rmse64:.3e})')
             assert psnr_vs_ref >= 50.0

@@ -33,7 +33,7 @@ def full():
 
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize('prec', PRECS)
-@pytest.mark.parametrize('min_wgs', [1, 4, 12, 24], ids=['whole-strips', 'segments-a', 'segments-b', 'segments-c'])
+@pytest.mark.parametrize('min_wgs', [1, 4, 12, 9, 18], ids=['whole-strips', 'segments-a', 'segments-b', 'segments-9row', 'segments-9row-wide'])
 def test_strip_form_vs_oracle(full, prec, min_wgs):
     from fastdiffsr_amd import _lib
     from oracle import fdsr_oracle as O
@@ -44,7 +44,7 @@ def test_strip_form_vs_oracle(full, prec, min_wgs):
     _lib.debug_option('strip_min_wgs', min_wgs)
     _lib.debug_option('splitk', 0)          # (a launch with a K split keeps the tile kernels)
     try:
-        # 136 rows: 9-row segments leave a remainder of ONE row (min_wgs 12 on the two-per-CU forms, 24 on the wide ones) -- the kernel
+        # 136 rows x 64 columns: 9-row segments leave a remainder of ONE row (min_wgs 9 on the two-per-CU forms, 18 on the wide ones) -- the kernel
         # balances its segments, so no segment is shorter than its peeled steps
         for shape, seed in (((2, 6, 128, 128), 31), ((1, 6, 64, 192), 32), ((1, 6, 136, 64), 33)):
             gen = torch.Generator().manual_seed(seed)

@@ -201,3 +201,27 @@ def test_init_weights_orthogonal_matches_reference(golden_dir):
         assert abs((v64 ** 2).sum().item() - s2) <= 1e-9 + 1e-12 * abs(s2), k
     for k in ('downs.0.weight', 'mid.0.ca.fc2.weight', 'ups.4.res_block.noise_func.noise_func.0.weight'):
         assert np.array_equal(sd[k].numpy(), g['full/' + k]), k
+
+
+def test_host_threads_follow_the_ranks_on_the_host(monkeypatch):
+    """Loader / writer pools are sized from the cores the job may really use divided by the ranks on the host (verdict r5 #5:
+    eight ranks on a 16-core lease must not start 8 x 8 loader threads)."""
+    from fastdiffsr_amd import parallel, train
+    assert parallel.host_threads_per_rank(cores=16, ranks=8) == 2          # floor
+    assert parallel.host_threads_per_rank(cores=16, ranks=1) == 8          # cap
+    assert parallel.host_threads_per_rank(cores=64, ranks=8) == 7          # share minus the rank's own sampling thread
+    assert parallel.host_threads_per_rank(cap=16, cores=192, ranks=8) == 16
+    monkeypatch.setenv('LOCAL_WORLD_SIZE', '8')
+    monkeypatch.setattr(parallel, 'host_cores', lambda: 16)
+    assert parallel.local_world_size() == 8
+    assert parallel.host_threads_per_rank() == 2
+    assert train.loader_workers(8) == 2 and train.loader_workers(None) == 2
+    monkeypatch.setenv('LOCAL_WORLD_SIZE', '1')
+    monkeypatch.setattr(parallel, 'host_cores', lambda: 32)
+    assert train.loader_workers(8) == 8 and train.loader_workers(0) == 16 and train.loader_workers(64) == 16
+    monkeypatch.delenv('LOCAL_WORLD_SIZE')
+    monkeypatch.setenv('WORLD_SIZE', '4')
+    assert parallel.local_world_size() == 4
+    monkeypatch.undo()
+    n = parallel.host_cores()
+    assert 1 <= n <= (__import__('os').cpu_count() or 1)
