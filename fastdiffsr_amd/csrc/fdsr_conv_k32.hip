@@ -68,24 +68,9 @@ __device__ __forceinline__ float silu_k(float v) { return v * __builtin_amdgcn_r
 #ifndef K32_GNB_DIAG    // timing probes of the GroupNorm-backward epilogue (results are garbage): 1 no swish' arithmetic, 2 no x / mask loads
 #define K32_GNB_DIAG 0
 #endif
-#ifndef K32_WALL_BF16   // bf16, 8-wave kernels: ALL nine taps of a chunk's weight fragments resident (72 VGPRs), each fetched one CHUNK ahead
-#define K32_WALL_BF16 1  // (a three-tap ring bounds the lead of every load of the wave to three taps: vmcnt retires in issue order)
-#endif
-#ifndef K32_WALL_RIDER  // ... in the kernels with a res_conv rider too
-#define K32_WALL_RIDER 1
-#endif
-#ifndef XS_WALL         // ... their activation-fragment slots
-#define XS_WALL 2
-#endif
-#ifndef K32_WALL_S0     // ... the next chunk's input, fetched whole at tap 0, is staged in two halves at these taps
-#define K32_WALL_S0 5
-#endif
-#ifndef K32_WALL_S1
-#define K32_WALL_S1 8
-#endif
-#ifndef K32_DIAG        // timing probes of the staging (results are garbage): 1 no GroupNorm / Swish arithmetic, 2 nothing staged inside the K loop, 4 no statistics in the epilogue
-#define K32_DIAG 0
-#endif
+#ifndef K32_DIAG        // timing-only probes of the staging (results are garbage; tools/pmc_variants.sh gives the clock beside the time -- a probe that
+#define K32_DIAG 0      // changes the operands changes the clock the chip holds): 1 no GroupNorm / Swish arithmetic, 2 nothing staged inside the K
+#endif                  // loop, 4 no statistics in the epilogue, 8 everything but the LDS store, 16 the staged values do not depend on the fetches
 #ifndef K32_RFIRST   // small-workgroup rider kernels: rider chunks first
 #define K32_RFIRST 1
 #endif
@@ -112,21 +97,8 @@ struct ConvK32Cfg {
   static constexpr int NIN = (NPIX + RPP - 1) / RPP;
   static constexpr int BUF_BYTES = NPIX * ROWB;
   static constexpr int LDS_BYTES = 2 * BUF_BYTES;
-  // Weight fragments in registers: a ring of three taps (48 VGPRs in f16x3) -- or, bf16 on eight waves (WALL), all nine taps of the
-  // chunk (72 VGPRs), tap t of chunk k + 1 fetched right after tap t of chunk k.  Why: a wave's loads retire in issue order, so the
-  // wait for a weight fragment also waits for every load issued before it.  With a three-tap ring the next chunk's INPUT fetch
-  // (HBM / L2-miss latency, 2 us under load) has to land within three taps of MFMAs -- 2.1 us in f16x3 (three passes per product),
-  // 0.7 us in bf16, where the waves then sat parked on it (knock-out builds, profiles/r06_bf16_k32_staging_knockouts_and_big_tiles.txt:
-  // no GroupNorm / Swish arithmetic -2 .. -6 %, no fetch + staging at all -21 .. -27 % on the 128- / 256-cout launches).  With the
-  // whole chunk's weights a chunk ahead no weight wait falls inside the input fetch's first eight taps.
-  static constexpr bool WALL_OK = K32_WALL_BF16 != 0 && PREC == PREC_BF16 && NW_ == 8 && TH / (NW_ / WN) == 4;
-  template <bool RIDER> static constexpr bool wall() { return WALL_OK && (!RIDER || K32_WALL_RIDER != 0); }
-  template <bool RIDER> static constexpr int ring() { return wall<RIDER>() ? 9 : 3; }   // taps of weight fragments in registers (a ring: 9 % R == 0)
-  // activation-fragment slots: XS - 1 (tap, row) steps ahead (the bf16 8-row small-workgroup tile spills 24 VGPRs with four; the
-  // resident-weight forms have room for XS_WALL)
-  template <bool RIDER> static constexpr int xslots() {
-    return PREC == PREC_F16X3 ? XS_F16X3 : (wall<RIDER>() ? XS_WALL : (NW_ == 4 && TH == 8 ? 3 : XS_BF16));
-  }   // activation-fragment slots: XS - 1 (tap, row) steps ahead (the bf16 8-row small-workgroup tile spills 24 VGPRs with four)
+  static constexpr int R = 3;                     // taps of weight fragments in registers (a ring: 9 % R == 0)
+  static constexpr int XS = PREC == PREC_F16X3 ? XS_F16X3 : (NW_ == 4 && TH == 8 ? 3 : XS_BF16);   // activation-fragment slots: XS - 1 (tap, row) steps ahead (the bf16 8-row small-workgroup tile spills 24 VGPRs with four)
   static_assert(MB == 4 || MB == 3 || MB == 2, "wave tile = 4 (small grids: 2; small workgroups in f16x3: 3) rows of 32 pixels");
   static_assert(((TH - WM + 2) * HWD + 16) * ROWB < 65536, "fragment offsets must fit the ds_read immediate");
 };
@@ -143,8 +115,7 @@ template <int TH, int WN, int PREC, bool RIDER, int NW = 8, bool RF = (NW == 4),
 __global__ void __launch_bounds__(64 * NW, 2) conv_k32_kernel(const ConvParams p) {
   using Cfg = ConvK32Cfg<TH, WN, PREC, NW>;
   constexpr int TW = Cfg::TW, KC = Cfg::KC, NP = Cfg::NP, ROWB = Cfg::ROWB, HWD = Cfg::HWD, NPIX = Cfg::NPIX;
-  constexpr int WM = Cfg::WM, BN = Cfg::BN, MB = Cfg::MB, RPP = Cfg::RPP, NIN = Cfg::NIN;
-  constexpr int R = Cfg::template ring<RIDER>(), XS = Cfg::template xslots<RIDER>();
+  constexpr int WM = Cfg::WM, BN = Cfg::BN, MB = Cfg::MB, RPP = Cfg::RPP, NIN = Cfg::NIN, R = Cfg::R, XS = Cfg::XS;
   constexpr bool PIN = TH == 16 ? K32_PIN16 != 0 : K32_PIN != 0;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_k[];
@@ -218,11 +189,9 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_k32_kernel(const ConvParams p
   constexpr bool RFIRST = RIDER && RF && K32_RFIRST != 0;
   constexpr bool SPLIT = K32_SPLIT != 0 && (PREC == PREC_F16X3 || K32_SPLIT_BF16 != 0) && (!RIDER || RFIRST);   // (main chunks first: the rider's whole-chunk sets would stay live across the main loop)
   static_assert(!RFIRST || SPLIT, "the rider-first path writes whole chunks into rr1, which is sized for them only when SPLIT");
-  constexpr bool WALL = Cfg::template wall<RIDER>() && SPLIT;          // (main chunks after a rider's keep the ring discipline of their whole-chunk sets)
-  constexpr int NH = (NIN + 1) / 2;                  // the first half of a chunk's quads
-  constexpr int NA = SPLIT && !WALL ? NH : NIN;      // quads in flight in the main loop
+  constexpr int NA = SPLIT ? (NIN + 1) / 2 : NIN;   // quads in flight in the main loop
   typedef std::integral_constant<int, 0> I_0;
-  typedef std::integral_constant<int, NH> I_A;
+  typedef std::integral_constant<int, NA> I_A;
   typedef std::integral_constant<int, NIN> I_N;
   QM rin[NA];
   QM rr1[RIDER && SPLIT ? NIN : 1];          // rider chunks are fetched whole: first set (rin itself when not SPLIT)
@@ -264,6 +233,7 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_k32_kernel(const ConvParams p
     for (int i = I0; i < I1; ++i) {
       if (NIN * RPP > NPIX && i == NIN - 1 && row0 + i * RPP >= NPIX) continue;   // only the last pass can overrun
       k_f32x4 v = IO::widen(rin[i - I0].q);
+      if (K32_DIAG & 16) v = sc;
       if ((K32_DIAG & 1) && gn) {
         v = v + sh;
       } else if (gn && !(RIDER && kc >= nk)) {
@@ -311,7 +281,8 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_k32_kernel(const ConvParams p
         const float keep = in_pix[i] >= 0 ? 1.f : 0.f;
         v = v * keep;
         k_b4 hb = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
-        *reinterpret_cast<k_b4*>(dst) = hb;
+        if (K32_DIAG & 8) { const uint2 u = __builtin_bit_cast(uint2, hb); asm volatile("" ::"v"(u.x), "v"(u.y)); }
+        else *reinterpret_cast<k_b4*>(dst) = hb;
       }
     }
   };
@@ -341,7 +312,13 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_k32_kernel(const ConvParams p
     if (NP == 2) xoff[kx][NP - 1] = xoff[kx][0] ^ 64;
   }
 
-  k_f32x4 acc[MB][2][2];   // [row][pixel half][cout half]; zeroed behind the prologue's staging (its registers are free by then)
+  k_f32x4 acc[MB][2][2];   // [row][pixel half][cout half]
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+      for (int ch = 0; ch < 2; ++ch) acc[mb][ph][ch] = k_f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int kc0 = ksi * nkt / SK, kc1 = (ksi + 1) * nkt / SK;   // this slice's chunks
   if (RFIRST || (RIDER && kc0 >= nk)) load_w(RFIRST ? nk : kc0, 0, 0);
@@ -369,12 +346,6 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_k32_kernel(const ConvParams p
     if (kc0 + 1 < kc1) prefetch_to(kc0 + 1, rin);
   }
   __syncthreads();
-#pragma unroll
-  for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-    for (int ph = 0; ph < 2; ++ph)
-#pragma unroll
-      for (int ch = 0; ch < 2; ++ch) acc[mb][ph][ch] = k_f32x4{0.f, 0.f, 0.f, 0.f};
 
   uint4 Xf[XS][2][NP];   // [slot][pixel half][plane]: a ring over (tap, row) steps, XS - 1 steps ahead of the MFMAs
   const unsigned char* xptr[3][NP];
@@ -415,8 +386,7 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_k32_kernel(const ConvParams p
   const size_t obase = ((size_t)(n * p.Hout + oy0 + wm) * p.Wout + ox0 + c15) * p.Cout + cob;
   const size_t rstride = (size_t)WM * p.Wout * p.Cout, pstride = (size_t)16 * p.Cout;
   constexpr bool PEEL = K32_PEEL != 0 && (!RIDER || RFIRST);
-  constexpr int RG = MB;
-  Quad rv[RG][2][2];   // residual tile [row][pixel half][cout half]
+  Quad rv[MB][2][2];   // residual tile [row][pixel half][cout half]
   const bool res_early = PEEL && p.res && interior && SK == 1;   // ... fetched during the last chunk, into registers the loop no longer needs
   auto load_res = [&](auto q0_tag, auto q1_tag) __attribute__((always_inline)) {
     constexpr int Q0 = decltype(q0_tag)::value, Q1 = decltype(q1_tag)::value;
@@ -426,7 +396,7 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_k32_kernel(const ConvParams p
       rv[mb][ph][ch] = IO::load4(p.res, obase + mb * rstride + ph * pstride + 16 * ch);
     }
   };
-  constexpr int NQ = 4 * RG;   // residual quads per lane (fetched early)
+  constexpr int NQ = 4 * MB;   // residual quads per lane
   typedef std::integral_constant<int, (NQ < 7 ? NQ : 7)> I_7;
   typedef std::integral_constant<int, (NQ < 11 ? NQ : 11)> I_11;
   typedef std::integral_constant<int, (NQ < 15 ? NQ : 15)> I_15;
@@ -463,14 +433,7 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_k32_kernel(const ConvParams p
       // this tap's ring slot is free: fetch the tap that will use it next
       if (tap + R < 9) load_w(kc, tap + R, tap % R);
       else if (more && (tap + R - 9 == 0 || !next_rider)) load_w(kc + 1, tap + R - 9, tap % R);
-      if (WALL) {    // the next chunk's input: fetched whole at tap 0 (nothing this wave waits for in the next eight taps was issued after it), staged in two halves
-        if (tap == 0 && more) prefetch_rng(kc + 1, rin, I_0{}, I_N{}, true);
-        if (tap == K32_WALL_S0 && more && !(K32_DIAG & 2)) stage_rng(kc + 1, nxt, rin, I_0{}, I_A{});
-        if (tap == K32_WALL_S1 && more) {
-          if (!(K32_DIAG & 2)) stage_rng(kc + 1, nxt, rin + NH, I_A{}, I_N{});
-          if (next_rider && kc + 2 < kc1) prefetch_to(kc + 2, rr1);
-        }
-      } else if (SPLIT) {   // the other halo buffer is filled in two halves, each fetched four taps before it is staged
+      if (SPLIT) {   // the other halo buffer is filled in two halves, each fetched four taps before it is staged
         if (tap == 0 && more) prefetch_rng(kc + 1, rin, I_0{}, I_A{}, true);
         if (tap == 3 && more) {
           if (!(K32_DIAG & 2)) stage_rng(kc + 1, nxt, rin, I_0{}, I_A{});
@@ -643,32 +606,28 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_k32_kernel(const ConvParams p
       }
     };
     if (interior) {
+      if (p.res && !res_early) {
 #pragma unroll
-      for (int mb0 = 0; mb0 < MB; mb0 += RG) {
-        if (p.res && !res_early) {
-#pragma unroll
-          for (int mb = 0; mb < RG; ++mb)
-#pragma unroll
-            for (int ph = 0; ph < 2; ++ph)
-#pragma unroll
-              for (int ch = 0; ch < 2; ++ch) rv[mb][ph][ch] = IO::load4(p.res, obase + (mb0 + mb) * rstride + ph * pstride + 16 * ch);
-        }
-#pragma unroll
-        for (int mb = 0; mb < RG; ++mb) {
+        for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
           for (int ph = 0; ph < 2; ++ph)
 #pragma unroll
-            for (int ch = 0; ch < 2; ++ch) {
-              k_f32x4 v = acc[mb0 + mb][ph][ch] * winv + add[ch];
-              if (p.res) v += IO::widen(rv[mb][ph][ch]);
-              put4(obase + (mb0 + mb) * rstride + ph * pstride + 16 * ch, v);
-              if (!(K32_DIAG & 4)) {
-                s1[ch] += v;
-                s2[ch] += v * v;
-              }
-            }
-        }
+            for (int ch = 0; ch < 2; ++ch) rv[mb][ph][ch] = IO::load4(p.res, obase + mb * rstride + ph * pstride + 16 * ch);
       }
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+          for (int ch = 0; ch < 2; ++ch) {
+            k_f32x4 v = acc[mb][ph][ch] * winv + add[ch];
+            if (p.res) v += IO::widen(rv[mb][ph][ch]);
+            put4(obase + mb * rstride + ph * pstride + 16 * ch, v);
+            if (!(K32_DIAG & 4)) {
+              s1[ch] += v;
+              s2[ch] += v * v;
+            }
+          }
     } else {
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb)

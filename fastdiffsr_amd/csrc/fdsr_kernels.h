@@ -228,6 +228,9 @@ hipError_t launch_nhwc_to_nchw(const float* src, float* dst, int N, int C, int H
 // act_bf16: qkv and O hold bf16 (the bf16 precision mode); scores / softmax stay fp32 either way
 hipError_t launch_self_attention(const float* qkv, float* S, float* O, int N, int HW, int C, int heads, hipStream_t s, int act_bf16 = 0);
 size_t attn_scratch_floats(int N, int HW, int heads);
+// the first two thirds of the above (fp32 activations): S = softmax(Q K^T / sqrt(C / heads)), pitch round_up(HW, 16), pad columns zero --
+// the backward recomputes the probabilities with the forward's own kernels
+hipError_t launch_attn_probs(const float* qkv, float* S, int N, int HW, int C, int heads, hipStream_t s);
 // 2x2 average pool of x (optionally of swish(x*scale + shift), the activated GroupNorm output) and nearest x2
 // upsampling, materialised: the up/down ResBlocks of GDP resample h AND the skip input (gdp_modules/unet.py:369-376)
 hipError_t launch_pool2(const float* x, const float* gn_scale, const float* gn_shift, float* out, int N, int H, int W, int C,

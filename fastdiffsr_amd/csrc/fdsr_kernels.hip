@@ -1224,6 +1224,17 @@ __global__ void __launch_bounds__(64) attn_pv_bf16_kernel(const float* __restric
   }
 }
 
+hipError_t launch_attn_probs(const float* qkv, float* S, int N, int HW, int C, int heads, hipStream_t s) {
+  if (heads < 1 || C % heads || (C / heads) % 32) return hipErrorInvalidValue;
+  const int HWp = (HW + 15) / 16 * 16, ch = C / heads;
+  const float inv_div = 1.0f / sqrtf((float)ch);
+  const size_t rows = (size_t)N * heads * HW;
+  const dim3 gs((HW + 31) / 32, (HW + 31) / 32, N * heads);
+  hipLaunchKernelGGL(attn_scores_kernel, gs, dim3(64), 0, s, qkv, S, HW, HWp, C, heads, inv_div);
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, S, HW, HWp, rows);
+  return hipGetLastError();
+}
+
 hipError_t launch_self_attention(const float* qkv, float* S, float* O, int N, int HW, int C, int heads, hipStream_t s, int act_bf16) {
   if (heads < 1 || C % heads || (C / heads) % 32) return hipErrorInvalidValue;
   const int HWp = (HW + 15) / 16 * 16, ch = C / heads;

@@ -31,7 +31,7 @@ struct TrainPlan {
   std::vector<size_t> grad_off;         // per tensor: its gradient [N][HW][C] (eps: 8 channels)
   size_t grad_bytes = 0;                // all gradient tensors (one memset)
   size_t off_tmpA = 0, off_tmpZ = 0, off_S = 0, off_dtemb = 0, off_dwn = 0, off_dbn = 0, off_dbl = 0, off_wg = 0, off_csb = 0,
-         off_tb = 0, off_loss = 0, off_deps = 0, off_noise = 0;
+         off_tb = 0, off_loss = 0, off_deps = 0, off_noise = 0, off_attn = 0;
   size_t bytes = 0;                     // total workspace (forward plan + extras)
 };
 
@@ -51,9 +51,10 @@ int make_train_plan(fdsr_handle h, int N, int H, int W, TrainPlan* tp) {
     off += align_up((size_t)N * hw * tensor_channels(h, (int)t) * sizeof(float), 256);
   }
   tp->grad_bytes = off - g0;
-  size_t tmpA = 256, tmpZ = 256, wg = 256, csb = 256, dbl = 256;
+  size_t tmpA = 256, tmpZ = 256, wg = 256, csb = 256, dbl = 256, attn = 256;
   int maxC = 8;
   for (const Op& op : h->ops) {
+    if (op.kind == Op::ATTN) attn = std::max(attn, attn_bwd_scratch_floats(N, (H >> op.lvl_in) * (W >> op.lvl_in)) * sizeof(float));
     if (op.kind == Op::SLAM) {
       const int hw = (H >> op.lvl_in) * (W >> op.lvl_in);
       csb = std::max(csb, clam_slam_bwd_scratch_floats(N, hw, op.C0, op.C0 / 16) * sizeof(float));
@@ -83,6 +84,7 @@ int make_train_plan(fdsr_handle h, int N, int H, int W, TrainPlan* tp) {
   tp->off_csb = take(csb);
   tp->off_tb = take((size_t)N * 11 * h->cfg.inner_channel * sizeof(float));
   tp->off_loss = take(256);
+  tp->off_attn = take(attn);
   tp->off_noise = off;                  // the target noise of a step whose noise the engine draws itself (fdsr_train_grads_pairs)
   off += align_up((size_t)N * 3 * H * W * sizeof(float), 256);
   tp->bytes = off;
@@ -102,8 +104,10 @@ int conv_K(fdsr_handle h, const Op& op) { return op.dst == h->t_eps ? 8 : op.Cou
 
 int train_prepare(fdsr_handle h) {
   if (h->train_ready) return FDSR_OK;
-  if (h->cfg.variant != FDSR_VARIANT_FASTDIFFSR)
-    return fail(h, FDSR_E_INVALID, "the training step is implemented for the FastDiffSR variant only");
+  // FastDiffSR, and the two siblings built from the same blocks plus SelfAttention: SR3 (ddpm_modules: integer time, Swish in front of the
+  // per-block Linear) and TESR.  GDP (another UNet: FiLM GroupNorms, pooled up/down ResBlocks, multi-head attention) samples only.
+  if (h->cfg.variant == FDSR_VARIANT_GDP)
+    return fail(h, FDSR_E_INVALID, "the training step is implemented for the FastDiffSR, SR3 (ddpm) and TESR variants, not for GDP");
   for (const Op& op : h->ops)
     if (op.kind == Op::CONV && op.src0 != h->t_in && (conv_K(h, op) % 8 || (op.C0 % 16) || (op.C1 % 16)))
       return fail(h, FDSR_E_INVALID, "training needs channel counts that are multiples of 16 (layer %s)", op.name.c_str());
@@ -434,7 +438,17 @@ int train_grads_impl(fdsr_handle h, const float* x_nchw, const float* hr_nchw, c
   for (int oi = (int)h->ops.size() - 1; oi >= 0; --oi) {
     const Op& op = h->ops[oi];
     const int Hi = H >> op.lvl_in, Wi = W >> op.lvl_in;
-    if (op.kind == Op::ATTN) return fail(h, FDSR_E_INVALID, "internal: attention in the training plan");
+    if (op.kind == Op::ATTN) {   // SelfAttention core (SR3 / TESR, n_head = 1): d qkv from d O; the qkv tensor has no other reader
+      if (op.heads != 1) return fail(h, FDSR_E_INVALID, "the attention backward is implemented for one head");
+      if (!touched[op.dst]) return fail(h, FDSR_E_STATE, "internal: gradient read before it was written");
+      AttnBwdParams a{};
+      a.qkv = TP(op.src0); a.dO = GT(op.dst); a.dqkv = GT(op.src0);
+      a.scratch = reinterpret_cast<float*>(ws + tp.off_attn);
+      a.N = N; a.HW = Hi * Wi; a.C = op.C0;
+      if (!first(op.src0)) return fail(h, FDSR_E_STATE, "internal: the qkv tensor has a second reader");
+      HIPCHK(h, launch_attn_bwd(a, st));
+      continue;
+    }
     if (op.kind == Op::SLAM) {
       // the CLAM op right before shares src0: gate and map are recomputed from x
       const Op* ca = nullptr;
@@ -558,6 +572,7 @@ int train_grads_impl(fdsr_handle h, const float* x_nchw, const float* hr_nchw, c
     t.dwn = reinterpret_cast<float*>(ws + tp.off_dwn); t.dbn = reinterpret_cast<float*>(ws + tp.off_dbn);
     t.scratch = reinterpret_cast<float*>(ws + tp.off_tb);
     t.inner = h->cfg.inner_channel; t.TE = h->TE; t.N = N;
+    t.swish_block = h->sr3 ? 1 : 0;
     HIPCHK(h, launch_temb_bwd(t, st));
     for (int i = 0; i < h->n_schema; ++i) {               // scatter the concatenated tables back to the per-block tensors
       const WeightEntry& w = h->weights[i];

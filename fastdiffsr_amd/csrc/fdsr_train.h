@@ -115,6 +115,8 @@ hipError_t launch_clam_slam_bwd(const ClamSlamBwdParams& p, hipStream_t s);
 // ---- noise-level embedding backward (unet.py:22-54, :242-248) ---------------------------------------------------
 // forward: enc = [sin, cos](nl * freq); hid = swish(W1 enc + b1); t = W2 hid + b2; temb = Wn t + bn
 // dtemb [N][TE] = per-(image, channel) sums of the block1 output gradients.
+// SR3 sibling (ddpm_modules/unet.py:19-34, :81-94, :163-170): the same chain on the integer time, with the per-block Linear applied to
+// Swish(t): temb = Wn swish(t) + bn (swish_block).
 struct TembBwdParams {
   const float* freq; const float* w1; const float* b1; const float* w2; const float* b2; const float* wn;
   const float* nl;         // [N]
@@ -122,8 +124,24 @@ struct TembBwdParams {
   float* dw1; float* db1; float* dw2; float* db2; float* dwn; float* dbn;   // written (=)
   float* scratch;          // N * 11 * inner floats
   int inner, TE, N;
+  int swish_block;
 };
 hipError_t launch_temb_bwd(const TembBwdParams& p, hipStream_t s);
+
+// ---- SelfAttention backward (SR3 sibling: ddpm_modules/unet.py:99-127, n_head = 1) ---------------------------------
+// forward (fdsr_kernels.hip): S = Q K^T / sqrt(C), P = softmax_rows(S), O = P V on the NHWC qkv tensor [N][HW][q | k | v].
+// backward: P is recomputed by the forward's kernels; dP = dO V^T; dS = P (dP - rowsum(dP P)); dQ = dS K / sqrt(C);
+// dK = dS^T Q / sqrt(C); dV = P^T dO -- five fp32-MFMA products of a few MFLOP, every output element written by exactly one lane
+// (no atomics: a rerun is bitwise identical).
+struct AttnBwdParams {
+  const float* qkv;        // [N][HW][3C]
+  const float* dO;         // [N][HW][C]
+  float* dqkv;             // [N][HW][3C], written (=)
+  float* scratch;          // attn_bwd_scratch_floats(): P | dP -> dS
+  int N, HW, C;
+};
+size_t attn_bwd_scratch_floats(int N, int HW);
+hipError_t launch_attn_bwd(const AttnBwdParams& p, hipStream_t s);
 
 // ---- optimiser -----------------------------------------------------------------------------------------------
 // torch.optim.Adam (defaults of model.py:37-38: betas (0.9, 0.999), eps 1e-8, no weight decay, no amsgrad):

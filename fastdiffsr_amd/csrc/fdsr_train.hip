@@ -1934,11 +1934,17 @@ __global__ void __launch_bounds__(256) temb_bwd_image_kernel(const TembBwdParams
   float* out = p.scratch + (size_t)n * 11 * inner;
   for (int k = tid; k < inner; k += 256) {
     out[k] = enc[k];
-    out[5 * inner + k] = dt[k];
     float t = p.b2[k];                                       // t[k] = b2[k] + sum_q w2[k][q] hid[q]: the input of the per-block Linear
     for (int q = 0; q < hid; ++q) t = fmaf(p.w2[(size_t)k * hid + q], hv[q], t);
+    if (p.swish_block) {                                     // SR3: the per-block Linear sees swish(t); what arrived in dt is d swish(t)
+      const float sg = 1.0f / (1.0f + expf(-t));
+      dt[k] *= sg * (1.0f + t * (1.0f - sg));
+      t *= sg;
+    }
+    out[5 * inner + k] = dt[k];
     out[10 * inner + k] = t;
   }
+  __syncthreads();
   for (int j = tid; j < hid; j += 256) {
     float a = 0.f;                                           // dhid[j] = sum_k dt[k] * w2[k][j]
     for (int k = 0; k < inner; ++k) a = fmaf(dt[k], p.w2[(size_t)k * hid + j], a);
@@ -2007,6 +2013,96 @@ hipError_t launch_temb_bwd(const TembBwdParams& p, hipStream_t s) {
   hipLaunchKernelGGL(temb_bwd_image_kernel, dim3(p.N), dim3(256), (size_t)(2 * inner + 2 * hid + parts * inner) * sizeof(float), s, p);
   const size_t total = (size_t)p.TE * inner + p.TE + (size_t)inner * hid + inner + (size_t)hid * inner + hid;
   hipLaunchKernelGGL(temb_bwd_param_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, total);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// SelfAttention backward (SR3 sibling)
+// ---------------------------------------------------------------------------
+// C[b][m][n] = alpha * sum_k A[b](m, k) B[b](k, n) with element strides on every operand, on v_mfma_f32_32x32x2_f32: one wave per
+// 32 x 32 tile of C (the forward's attn_scores_kernel with the strides made arguments).  The products of the attention backward are a
+// few MFLOP each; the strides let P^T, dS^T and the q / k / v channel slices of the NHWC qkv tensor be read in place.
+struct SGemm {
+  const float* A; long a_sm, a_sk, a_sb;
+  const float* B; long b_sk, b_sn, b_sb;
+  float* C; long c_sm, c_sn, c_sb;
+  int M, Nn, K;
+  float alpha;
+};
+typedef float t_f32x16 __attribute__((ext_vector_type(16)));
+__global__ void __launch_bounds__(64) sgemm_strided_kernel(const SGemm g) {
+  const int lane = threadIdx.x, r31 = lane & 31, h = lane >> 5;
+  const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32, b = blockIdx.z;
+  const float* A = g.A + (size_t)b * g.a_sb + (size_t)min(m0 + r31, g.M - 1) * g.a_sm;
+  const float* B = g.B + (size_t)b * g.b_sb + (size_t)min(n0 + r31, g.Nn - 1) * g.b_sn;
+  t_f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  for (int k = 0; k < g.K; k += 8) {
+    float av[4], bv[4];
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) {   // (every load of the trip in flight before the first product)
+      const int kk = k + 4 * h + s2, kc = min(kk, g.K - 1);
+      const float a = A[(size_t)kc * g.a_sk], bb = B[(size_t)kc * g.b_sk];
+      av[s2] = kk < g.K ? a : 0.f;
+      bv[s2] = kk < g.K ? bb : 0.f;
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s2], bv[s2], acc, 0, 0, 0);
+  }
+  const int col = n0 + r31;
+  float* C = g.C + (size_t)b * g.c_sb;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int row = m0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+    if (row < g.M && col < g.Nn) C[(size_t)row * g.c_sm + (size_t)col * g.c_sn] = acc[i] * g.alpha;
+  }
+}
+
+static hipError_t launch_sgemm(const SGemm& g, int batch, hipStream_t s) {
+  hipLaunchKernelGGL(sgemm_strided_kernel, dim3((g.Nn + 31) / 32, (g.M + 31) / 32, batch), dim3(64), 0, s, g);
+  return hipGetLastError();
+}
+
+// dS[r][j] = P[r][j] (dP[r][j] - sum_j' dP[r][j'] P[r][j']), in place over dP; one wave per row, the row sum folded in a fixed order
+__global__ void __launch_bounds__(256) attn_dsoftmax_rows_kernel(const float* __restrict__ P, float* __restrict__ D, int HW, int HWp, size_t rows) {
+  const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* pr = P + row * HWp;
+  float* dr = D + row * HWp;
+  float a = 0.f;
+  for (int i = lane; i < HW; i += 64) a = fmaf(dr[i], pr[i], a);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+  for (int i = lane; i < HW; i += 64) dr[i] = pr[i] * (dr[i] - a);
+}
+
+size_t attn_bwd_scratch_floats(int N, int HW) { return 2 * attn_scratch_floats(N, HW, 1); }
+
+hipError_t launch_attn_bwd(const AttnBwdParams& p, hipStream_t s) {
+  const int N = p.N, HW = p.HW, C = p.C, HWp = (HW + 15) / 16 * 16;
+  if (C % 32) return hipErrorInvalidValue;
+  float* P = p.scratch;
+  float* D = p.scratch + attn_scratch_floats(N, HW, 1);
+  hipError_t e = launch_attn_probs(p.qkv, P, N, HW, C, 1, s);
+  if (e != hipSuccess) return e;
+  const float inv = 1.0f / sqrtf((float)C);
+  const long sq = (long)HW * 3 * C, so = (long)HW * C, sp = (long)HW * HWp;
+  // dP[i][j] = sum_c dO[i][c] V[j][c]
+  SGemm g{p.dO, C, 1, so, p.qkv + 2 * C, 1, 3L * C, sq, D, HWp, 1, sp, HW, HW, C, 1.0f};
+  if ((e = launch_sgemm(g, N, s)) != hipSuccess) return e;
+  const size_t rows = (size_t)N * HW;
+  hipLaunchKernelGGL(attn_dsoftmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, P, D, HW, HWp, rows);
+  // dQ[i][c] = inv sum_j dS[i][j] K[j][c]
+  g = SGemm{D, HWp, 1, sp, p.qkv + C, 3L * C, 1, sq, p.dqkv, 3L * C, 1, sq, HW, C, HW, inv};
+  if ((e = launch_sgemm(g, N, s)) != hipSuccess) return e;
+  // dK[j][c] = inv sum_i dS[i][j] Q[i][c]
+  g = SGemm{D, 1, HWp, sp, p.qkv, 3L * C, 1, sq, p.dqkv + C, 3L * C, 1, sq, HW, C, HW, inv};
+  if ((e = launch_sgemm(g, N, s)) != hipSuccess) return e;
+  // dV[j][c] = sum_i P[i][j] dO[i][c]
+  g = SGemm{P, 1, HWp, sp, p.dO, C, 1, so, p.dqkv + 2 * C, 3L * C, 1, sq, HW, C, HW, 1.0f};
+  if ((e = launch_sgemm(g, N, s)) != hipSuccess) return e;
   return hipGetLastError();
 }
 

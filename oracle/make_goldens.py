@@ -343,6 +343,68 @@ def train_goldens():
     print('wrote train_step.npz: l_pix', l_pix.item(), 'tensors with grad', len(names), 'without', int(out['n_params_without_grad']))
 
 
+def sr3_train_goldens():
+    """(xiii) one optimisation step of the reference's SR3 sibling (model/ddpm_modules; DDPM.optimize_parameters, model.py:47-57:
+    zero_grad, l_pix = netG(data) -> p_losses (ddpm_modules/diffusion.py:279-297), l_pix.sum() / (b*c*h*w), backward, Adam step)
+    on the SR3 test network of sr3.npz (inner 32, mults 1-2-2-4, SelfAttention at 8 x 8 and in mid[0]), dropout off, fixed t and
+    noise: the loss, a (sum, sum of squares) pair for EVERY gradient, six named gradients in full (a convolution, the attention's
+    qkv / out / norm, the time MLP, a per-block Linear) and those tensors after the step.  Pins autograd over oracle/sr3_oracle.py,
+    which the GPU tests then hold the engine's backward against."""
+    from unittest import mock
+    import_reference()
+    from model.ddpm_modules import diffusion as sr3_diffusion, unet as sr3_unet
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    cfg3 = UNetConfig(in_channel=6, out_channel=3, inner_channel=32, norm_groups=32, channel_mults=(1, 2, 2, 4),
+                      attn_res=(8,), res_blocks=1, dropout=0.2, image_size=32, variant='ddpm')
+    net3 = sr3_unet.UNet(in_channel=6, out_channel=3, norm_groups=32, inner_channel=32, channel_mults=[1, 2, 2, 4],
+                         attn_res=[8], res_blocks=1, dropout=0.2, image_size=32)
+    sd3 = synth_state_dict(cfg3, 5)
+    net3.load_state_dict({k: torch.from_numpy(v) for k, v in sd3.items()}, strict=True)
+    sched3 = dict(schedule='linear', n_timestep=12, linear_start=1e-4, linear_end=2e-2)
+    G3 = sr3_diffusion.GaussianDiffusion(net3, image_size=32, channels=3, loss_type='l1', conditional=True, schedule_opt=sched3)
+    G3.set_loss('cpu')
+    G3.set_new_noise_schedule(sched3, 'cpu')
+    G3.eval()                                           # dropout off; everything else as in training
+    g = torch.Generator().manual_seed(77)
+    hr = torch.rand(2, 3, 32, 32, generator=g) * 2 - 1
+    sr = (hr + 0.1 * torch.randn(2, 3, 32, 32, generator=g)).clamp(-1, 1)
+    nz = torch.randn(2, 3, 32, 32, generator=g)
+    t = torch.tensor([3, 9])
+    lr = 1e-4
+    opt = torch.optim.Adam(list(G3.parameters()), lr=lr)
+    opt.zero_grad()
+    with mock.patch.object(torch, 'randint', lambda *a, **k: t):
+        l_pix = G3({'HR': hr, 'SR': sr}, noise=nz)
+    b, c, h, w = hr.shape
+    l_pix = l_pix.sum() / int(b * c * h * w)
+    l_pix.backward()
+    named = dict(G3.named_parameters())
+    attn = [n for n, m in net3.named_modules() if isinstance(m, sr3_unet.SelfAttention)][0]
+    full = ['downs.0.weight', attn + '.qkv.weight', attn + '.out.weight', attn + '.norm.weight', 'time_mlp.1.weight',
+            'downs.1.res_block.mlp.1.weight']
+    out = {'hr': hr.numpy(), 'sr': sr.numpy(), 'noise': nz.numpy(), 't': t.numpy(), 'lr': np.array(lr),
+           'l_pix': np.array(l_pix.item(), dtype=np.float64), 'weights_sha256': np.array(state_dict_sha256(sd3)),
+           'full_keys': np.array(full)}
+    names, stats = [], []
+    for k, p_ in named.items():
+        if p_.grad is None:
+            continue
+        names.append(k[len('denoise_fn.'):])
+        g64 = p_.grad.double()
+        stats.append([g64.sum().item(), (g64 * g64).sum().item()])
+    out['grad_keys'] = np.array(names)
+    out['grad_stats'] = np.array(stats, dtype=np.float64)
+    for k in full:
+        out['grad/' + k] = named['denoise_fn.' + k].grad.numpy().copy()
+    opt.step()
+    for k in full:
+        out['after/' + k] = named['denoise_fn.' + k].detach().numpy().copy()
+    out['n_params_without_grad'] = np.array(sum(1 for p_ in named.values() if p_.grad is None))
+    np.savez_compressed(os.path.join(OUT, 'sr3_train_step.npz'), **out)
+    print('wrote sr3_train_step.npz: l_pix', l_pix.item(), 'tensors with grad', len(names), 'without', int(out['n_params_without_grad']))
+
+
 def init_goldens():
     """(xii) the reference's own `init_weights(netG, 'orthogonal')` (model/networks.py:46-75, called by define_G in the
     train phase, :113-115) under torch.manual_seed(1234): a (sum, sum of squares) pair for every tensor of the small
@@ -588,6 +650,8 @@ if __name__ == '__main__':
         gdp_goldens()             # only tests/golden/gdp.npz
     elif len(sys.argv) > 1 and sys.argv[1] == 'init':
         init_goldens()            # only tests/golden/init_weights.npz
+    elif len(sys.argv) > 1 and sys.argv[1] == 'sr3_train':
+        sr3_train_goldens()       # only tests/golden/sr3_train_step.npz
     elif len(sys.argv) > 1 and sys.argv[1] == 'tesr':
         tesr_goldens()            # only tests/golden/tesr.npz
     else:
@@ -595,6 +659,7 @@ if __name__ == '__main__':
         config_goldens()
         train_goldens()
         tesr_goldens()
+        sr3_train_goldens()
         init_goldens()
         gdp_goldens()
         metric_goldens()

@@ -103,3 +103,48 @@ def p_sample_loop(sd, cfg, tab, cond: Tensor, noise: Tensor, return_trajectory=F
             if return_trajectory:
                 traj.append(img.clone())
     return (img, traj) if return_trajectory else img
+
+
+# --------------------------------------------------------------------------
+# f-4 / f-3  one optimisation step of the SR3 sibling      ddpm_modules/diffusion.py:260-297, model/model.py:47-57
+# --------------------------------------------------------------------------
+def q_sample(tab, x_start: Tensor, t: Tensor, noise: Tensor) -> Tensor:       # diffusion.py:260-268
+    a = torch.as_tensor(tab['sqrt_alphas_cumprod'])[t].view(-1, 1, 1, 1)
+    b = torch.as_tensor(tab['sqrt_one_minus_alphas_cumprod'])[t].view(-1, 1, 1, 1)
+    return a * x_start + b * noise
+
+
+def p_losses(sd, cfg: UNetConfig, tab, hr: Tensor, sr: Tensor, t: Tensor, noise: Tensor, loss_type: str = 'l1') -> Tensor:
+    """L1(sum) between the noise and UNet(cat[SR, q_sample(HR, t)], t); t: [B] integer times (the caller's draw: the reference
+    draws torch.randint(0, T, (b,)), :283-284).  Dropout off."""
+    x_noisy = q_sample(tab, hr, t, noise)
+    rec = unet_forward(sd, cfg, torch.cat([sr, x_noisy], dim=1), t)
+    if loss_type == 'l1':
+        return F.l1_loss(noise, rec, reduction='sum')
+    if loss_type == 'l2':
+        return F.mse_loss(noise, rec, reduction='sum')
+    raise NotImplementedError()
+
+
+def train_step(sd, cfg: UNetConfig, tab, hr: Tensor, sr: Tensor, t: Tensor, noise: Tensor, lr: float, loss_type: str = 'l1',
+               betas=(0.9, 0.999), eps: float = 1e-8):
+    """DDPM.optimize_parameters from fresh Adam state, as oracle.fdsr_oracle.train_step: gradients by autograd over the restated
+    forward.  Returns (l_pix, grads {key: Tensor}, new_sd {key: Tensor}); the inv_freq buffer takes no gradient."""
+    leaves = {k: (v.detach().clone().requires_grad_(True) if not k.endswith('inv_freq') else v.detach().clone()) for k, v in sd.items()}
+    loss = p_losses(leaves, cfg, tab, hr, sr, t, noise, loss_type)
+    b, c, h, w = hr.shape
+    l_pix = loss.sum() / int(b * c * h * w)
+    l_pix.backward()
+    grads = {k: v.grad for k, v in leaves.items() if v.grad is not None}
+    b1, b2 = betas
+    new_sd = {}
+    for k, w_ in sd.items():
+        g = grads.get(k)
+        if g is None:
+            new_sd[k] = w_.detach().clone()
+            continue
+        m = (1 - b1) * g
+        v = (1 - b2) * g * g
+        denom = (v.sqrt() / (1 - b2) ** 0.5) + eps
+        new_sd[k] = w_.detach() - (lr / (1 - b1)) * (m / denom)
+    return l_pix.detach(), grads, new_sd

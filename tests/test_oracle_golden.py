@@ -315,6 +315,38 @@ def test_training_step_matches_reference(full, golden_dir):
             assert torch.equal(new_sd[k], sd[k])
 
 
+def test_sr3_training_step_matches_reference(golden_dir):
+    """oracle.sr3_oracle.train_step vs one optimisation step of the reference's SR3 sibling itself (model/ddpm_modules p_losses :279-297
+    + model.py:47-57; golden made by `oracle/make_goldens.py sr3_train`): loss, every gradient (sum / sum of squares per tensor, six
+    tensors in full: a convolution, the SelfAttention's qkv / out / norm, the time MLP, a per-block Linear), the Adam update."""
+    from oracle import sr3_oracle as S
+    g = _load(golden_dir, 'sr3_train_step.npz')
+    cfg = UNetConfig(in_channel=6, out_channel=3, inner_channel=32, norm_groups=32, channel_mults=(1, 2, 2, 4),
+                     attn_res=(8,), res_blocks=1, dropout=0.2, image_size=32, variant='ddpm')
+    sd_np = synth_state_dict(cfg, 5)
+    assert state_dict_sha256(sd_np) == str(g['weights_sha256'])
+    sd = O.to_torch_sd(sd_np)
+    tab = O.schedule_tables(dict(schedule='linear', n_timestep=12, linear_start=1e-4, linear_end=2e-2))
+    hr, sr, nz = (torch.from_numpy(g[k]) for k in ('hr', 'sr', 'noise'))
+    t = torch.from_numpy(g['t']).long()
+    l_pix, grads, new_sd = S.train_step(sd, cfg, tab, hr, sr, t, nz, lr=float(g['lr']))
+    assert abs(l_pix.item() - float(g['l_pix'])) <= 1e-6 * abs(float(g['l_pix']))
+    keys = [str(k) for k in g['grad_keys']]
+    assert sorted(keys) == sorted(grads.keys()) and int(g['n_params_without_grad']) == 0
+    for k, (s1, s2) in zip(keys, g['grad_stats']):
+        g64 = grads[k].double()
+        scale = max(np.sqrt(s2), 1e-12)
+        assert abs(g64.sum().item() - s1) <= 2e-4 * scale + 1e-9, k
+        assert abs((g64 * g64).sum().item() - s2) <= 2e-4 * s2 + 1e-18, k
+    for k in (str(x) for x in g['full_keys']):
+        ref = g['grad/' + k]
+        assert np.abs(grads[k].numpy() - ref).max() <= 2e-4 * np.abs(ref).max() + 1e-9, k
+        aft, ref_aft = new_sd[k].numpy(), g['after/' + k]
+        mask = np.abs(ref) > 1e-3 * np.abs(ref).max()
+        assert np.abs(aft - ref_aft)[mask].max() <= 2e-7, k
+        assert np.abs(aft - ref_aft).max() <= 2.1 * float(g['lr']), k
+
+
 def test_tesr_oracle_matches_reference(golden_dir):
     """oracle/tesr_oracle.py vs the reference's own model/tesr_modules (tests/golden/tesr.npz)."""
     from oracle import tesr_oracle as TO
