@@ -311,7 +311,7 @@ int build_plan(fdsr_handle h) {
       h->tensors[out].need_part = true;
       h->ops.push_back(sg);
       Op kq; kq.kind = Op::CONV; kq.name = p + ".attn.qkv"; kq.ck = CONV1; kq.src0 = out; kq.C0 = Cout; kq.Cout = 3 * Cout;
-      kq.lvl_in = kq.lvl_out = lvl; kq.gn_slot = sg.gn_slot; kq.w = wq; kq.b = -2; kq.gn_plain = true;   // -2: the shared zero bias
+      kq.lvl_in = kq.lvl_out = lvl; kq.gn_slot = sg.gn_slot; kq.gamma = gw; kq.beta = gb; kq.w = wq; kq.b = -2; kq.gn_plain = true;   // -2: the shared zero bias; gamma / beta: the GroupNorm backward of the training step reads them off the conv op
       kq.dst = new_tensor(h, 3 * Cout, lvl, p + ".attn.qkv");
       h->ops.push_back(kq);
       Op at; at.kind = Op::ATTN; at.name = p + ".attn.core"; at.src0 = kq.dst; at.C0 = Cout; at.lvl_in = lvl;

@@ -86,7 +86,11 @@ __global__ void __launch_bounds__(256) loss_grad_kernel(const float* __restrict_
     for (int c = 0; c < 3; ++c) {
       const float e = eps[p * 3 + c], t = target[(n * 3 + c) * HW + hw];
       const float d = e - t;
-      if (l2) { acc += (double)d * (double)d; lo[c] = 2.0f * d * scale; }
+      if (l2 == 2) {   // Charbonnier, eps = 1e-3 (TESR's 'l1': tesr_modules/unet.py:956-967, diffusion.py:85-90); the caller's scale carries the mean
+        const float r = sqrtf(d * d + 1e-6f);
+        acc += (double)r;
+        lo[c] = d / r * scale;
+      } else if (l2) { acc += (double)d * (double)d; lo[c] = 2.0f * d * scale; }
       else { acc += (double)fabsf(d); lo[c] = (d > 0.f ? 1.0f : (d < 0.f ? -1.0f : 0.0f)) * scale; }   // d|x|/dx, sign(0) = 0 like torch
     }
     *reinterpret_cast<f32x4*>(deps8 + p * 8) = lo;

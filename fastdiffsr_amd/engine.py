@@ -9,6 +9,9 @@ from . import _lib
 from .arch import UNetConfig
 
 
+LOSS_TYPES = {'l1': 0, 'l2': 1, 'charbonnier': 2}     # include/fdsr.h: loss_l2 of fdsr_train_grads
+
+
 def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
@@ -258,7 +261,7 @@ class Engine:
         ws = self._ws
         loss = C.c_float()
         st = torch.cuda.current_stream(x.device).cuda_stream
-        self._check_train(self.lib.fdsr_train_grads(self.h, _ptr(x), _ptr(nl), _ptr(target), {'l1': 0, 'l2': 1}[loss_type],
+        self._check_train(self.lib.fdsr_train_grads(self.h, _ptr(x), _ptr(nl), _ptr(target), LOSS_TYPES[loss_type],
                                                     C.c_float(float(loss_scale)), C.byref(loss), B, H, W, _ptr(ws), ws.numel(),
                                                     C.c_void_p(st)))
         self._keep = (x, nl, target)
@@ -285,7 +288,7 @@ class Engine:
             self._ws = torch.empty(need, dtype=torch.uint8, device=hr.device)
         ws, loss = self._ws, C.c_float()
         st = torch.cuda.current_stream(hr.device).cuda_stream
-        self._check_train(self.lib.fdsr_train_grads_pairs(self.h, _ptr(hr), _ptr(sr), _ptr(g), _ptr(noise), {'l1': 0, 'l2': 1}[loss_type],
+        self._check_train(self.lib.fdsr_train_grads_pairs(self.h, _ptr(hr), _ptr(sr), _ptr(g), _ptr(noise), LOSS_TYPES[loss_type],
                                                           C.c_float(float(loss_scale)), C.byref(loss), B, H, W, _ptr(ws), ws.numel(),
                                                           C.c_void_p(st)))
         self._keep = (hr, sr, g, noise)

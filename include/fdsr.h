@@ -298,7 +298,11 @@ int fdsr_train_workspace_bytes(fdsr_handle h, int batch, int height, int width, 
  *   x_nchw       [B,6,H,W]  cat([SR, x_noisy]) (diffusion.py:265-266), x_noisy = q_sample(img2res(HR,SR), gamma, noise)
  *   noise_level  [B]        gamma, the continuous sqrt(alpha_bar) drawn per sample (:246-255)
  *   target_nchw  [B,3,H,W]  the noise that q_sample mixed in (:259)
- *   loss_l2      0: nn.L1Loss(reduction='sum') (loss_type 'l1', :101-103); 1: nn.MSELoss(reduction='sum')
+ *   loss_l2      0: nn.L1Loss(reduction='sum') (loss_type 'l1', :101-103); 1: nn.MSELoss(reduction='sum'); 2: the SUM of the Charbonnier
+ *                terms sqrt(d^2 + 1e-6) (TESR's 'l1' is their mean, tesr_modules/unet.py:956-967: put the 1 / (b*c*h*w) of the mean into
+ *                loss_scale beside the one of model.py:50-52)
+ *   (SR3 / TESR variants: x_nchw = cat[SR, q_sample(HR, ...)] as their p_losses forms it, noise_level = the integer time t as a float
+ *    (SR3, ddpm_modules/diffusion.py:279-291) or gamma (TESR); the backward then includes the SelfAttention blocks.)
  *   loss_scale   the reference divides the summed loss by b*c*h*w before backward (model.py:50-52)
  *   loss_host    optional: receives the UNSCALED summed loss (what netG(data) returns); synchronises the stream
  * All pointers but loss_host are device pointers. */

@@ -534,6 +534,61 @@ def tesr_goldens():
     print('wrote tesr.npz: frames', frames.shape, 'loss', loss.item())
 
 
+def tesr_train_goldens():
+    """(xiv) one optimisation step of the reference's TESR sibling (model/tesr_modules p_losses :224-250 with the Charbonnier MEAN as
+    its 'l1' loss, then model.py:47-57: l_pix.sum() / (b*c*h*w), backward, Adam) on the TESR test network of tesr.npz, dropout off,
+    same inputs / draws as the loss golden there: loss, (sum, sum of squares) of EVERY gradient, five tensors in full, the update."""
+    from unittest import mock
+    import_reference()
+    from model.tesr_modules import diffusion as tdiff, unet as tunet
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    cfg = UNetConfig(in_channel=6, out_channel=3, inner_channel=32, norm_groups=32, channel_mults=(1, 2, 2, 4),
+                     attn_res=(8,), res_blocks=1, dropout=0.2, image_size=32, variant='tesr')
+    net = tunet.UNet(in_channel=6, out_channel=3, norm_groups=32, inner_channel=32, channel_mults=[1, 2, 2, 4],
+                     attn_res=[8], res_blocks=1, dropout=0.2, image_size=32)
+    sd = synth_state_dict(cfg, 9)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    sched = dict(schedule='linear', n_timestep=10, linear_start=1e-4, linear_end=2e-2)
+    G = tdiff.GaussianDiffusion(net, image_size=32, channels=3, loss_type='l1', conditional=True, schedule_opt=sched)
+    G.set_loss('cpu')
+    G.set_new_noise_schedule(sched, 'cpu')
+    G.eval()
+    tg = np.load(os.path.join(OUT, 'tesr.npz'))
+    hr, sr, nz = (torch.from_numpy(tg[k]) for k in ('hr', 'sr', 'loss_noise'))
+    gam = tg['gamma']
+    lr = 1e-4
+    opt = torch.optim.Adam(list(G.parameters()), lr=lr)
+    opt.zero_grad()
+    with mock.patch.object(np.random, 'randint', lambda a, b: 4), mock.patch.object(np.random, 'uniform', lambda a, b, size: gam):
+        l_pix = G({'HR': hr, 'SR': sr}, noise=nz)
+    b, c, h, w = hr.shape
+    l_pix = l_pix.sum() / int(b * c * h * w)
+    l_pix.backward()
+    named = dict(G.named_parameters())
+    attn = [n for n, m in net.named_modules() if isinstance(m, tunet.SelfAttention)][0]
+    full = ['downs.0.weight', attn + '.qkv.weight', attn + '.out.weight', 'noise_level_mlp.1.weight', 'final_conv.block.3.bias']
+    out = {'lr': np.array(lr), 'l_pix': np.array(l_pix.item(), dtype=np.float64), 'weights_sha256': np.array(state_dict_sha256(sd)),
+           'full_keys': np.array(full)}
+    names, stats = [], []
+    for k, p_ in named.items():
+        if p_.grad is None:
+            continue
+        names.append(k[len('denoise_fn.'):])
+        g64 = p_.grad.double()
+        stats.append([g64.sum().item(), (g64 * g64).sum().item()])
+    out['grad_keys'] = np.array(names)
+    out['grad_stats'] = np.array(stats, dtype=np.float64)
+    for k in full:
+        out['grad/' + k] = named['denoise_fn.' + k].grad.numpy().copy()
+    opt.step()
+    for k in full:
+        out['after/' + k] = named['denoise_fn.' + k].detach().numpy().copy()
+    out['n_params_without_grad'] = np.array(sum(1 for p_ in named.values() if p_.grad is None))
+    np.savez_compressed(os.path.join(OUT, 'tesr_train_step.npz'), **out)
+    print('wrote tesr_train_step.npz: l_pix', l_pix.item(), 'tensors with grad', len(names), 'without', int(out['n_params_without_grad']))
+
+
 def metric_goldens():
     """(x) the reference's own `ssim` / `calculate_ssim` / `calculate_ergas` (core/metrics.py:103-152) on fixed image pairs.
     They call cv2.getGaussianKernel, cv2.filter2D and skimage.measure.compare_mse, which this image lacks; the three are
@@ -650,6 +705,8 @@ if __name__ == '__main__':
         gdp_goldens()             # only tests/golden/gdp.npz
     elif len(sys.argv) > 1 and sys.argv[1] == 'init':
         init_goldens()            # only tests/golden/init_weights.npz
+    elif len(sys.argv) > 1 and sys.argv[1] == 'tesr_train':
+        tesr_train_goldens()      # only tests/golden/tesr_train_step.npz (reads tesr.npz)
     elif len(sys.argv) > 1 and sys.argv[1] == 'sr3_train':
         sr3_train_goldens()       # only tests/golden/sr3_train_step.npz
     elif len(sys.argv) > 1 and sys.argv[1] == 'tesr':
@@ -660,6 +717,7 @@ if __name__ == '__main__':
         train_goldens()
         tesr_goldens()
         sr3_train_goldens()
+        tesr_train_goldens()
         init_goldens()
         gdp_goldens()
         metric_goldens()

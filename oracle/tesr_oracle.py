@@ -78,3 +78,43 @@ def p_sample_loop(sd, cfg, tab, cond: Tensor, noise: Tensor, return_trajectory=F
 def charbonnier(x: Tensor, y: Tensor, eps: float = 1e-3) -> Tensor:               # tesr_modules/unet.py:956-967
     d = x - y
     return torch.mean(torch.sqrt(d * d + eps * eps))
+
+
+# --------------------------------------------------------------------------
+# f-4 / f-3  one optimisation step of the TESR sibling      tesr_modules/diffusion.py:224-250, model/model.py:47-57
+# --------------------------------------------------------------------------
+def p_losses(sd, cfg: UNetConfig, hr: Tensor, sr: Tensor, gamma: Tensor, noise: Tensor, loss_type: str = 'l1') -> Tensor:
+    """x_start is the HR image itself; q_sample as FastDiffSR's (continuous gamma); 'l1' = the Charbonnier MEAN (:85-90)."""
+    from oracle.fdsr_oracle import q_sample
+    g = gamma.view(-1, 1)
+    x_noisy = q_sample(hr, g.view(-1, 1, 1, 1), noise)
+    rec = unet_forward(sd, cfg, torch.cat([sr, x_noisy], dim=1), g)
+    if loss_type == 'l1':
+        return charbonnier(noise, rec)
+    if loss_type == 'l2':
+        return F.mse_loss(noise, rec, reduction='sum')
+    raise NotImplementedError()
+
+
+def train_step(sd, cfg: UNetConfig, hr: Tensor, sr: Tensor, gamma: Tensor, noise: Tensor, lr: float, loss_type: str = 'l1',
+               betas=(0.9, 0.999), eps: float = 1e-8):
+    """DDPM.optimize_parameters from fresh Adam state (gradients by autograd over the restated forward), as
+    oracle.fdsr_oracle.train_step.  Returns (l_pix, grads, new_sd)."""
+    leaves = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()}
+    loss = p_losses(leaves, cfg, hr, sr, gamma, noise, loss_type)
+    b, c, h, w = hr.shape
+    l_pix = loss.sum() / int(b * c * h * w)
+    l_pix.backward()
+    grads = {k: v.grad for k, v in leaves.items() if v.grad is not None}
+    b1, b2 = betas
+    new_sd = {}
+    for k, w_ in sd.items():
+        g = grads.get(k)
+        if g is None:
+            new_sd[k] = w_.detach().clone()
+            continue
+        m = (1 - b1) * g
+        v = (1 - b2) * g * g
+        denom = (v.sqrt() / (1 - b2) ** 0.5) + eps
+        new_sd[k] = w_.detach() - (lr / (1 - b1)) * (m / denom)
+    return l_pix.detach(), grads, new_sd

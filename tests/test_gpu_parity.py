@@ -192,6 +192,24 @@ def test_full_size_256_vs_oracle(full, prec):
     report(f'256x256 B=1 loop [{prec}] vs oracle max|d|={d:.3e}  PSNR(out,cond)={psnr_out:.4f} PSNR(ref,cond)={psnr_ref:.4f}')
     assert d <= TOL_LOOP
     assert abs(psnr_out - psnr_ref) <= 0.01
+    # a second image on the B = 1 kernel selection (split-K launches, 2-row tiles: other kernels than a batch takes), eager and as a
+    # replayed graph: image 3 of the B=16 test's batch, whose oracle image that test shares through the session cache
+    cond16, noise16 = synth_inputs(16, 256, 256, 20)
+    c3, n3 = cond16[3:4].contiguous(), noise16[:, 3:4].contiguous()
+    ref3 = _oracle_256(sd, cfg, 'b16_3', c3, n3)
+    eng.set_precision(prec)
+    try:
+        o3 = eng.sample(c3.cuda(), n3.cuda()).cpu()
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            eng.sample(c3.cuda(), n3.cuda(), graph=True)
+            g3 = eng.sample(c3.cuda(), n3.cuda(), graph=True).cpu()      # the second call replays
+        s.synchronize()
+    finally:
+        eng.set_precision('f32')
+    d3 = (o3 - ref3).abs().max().item()
+    report(f'256x256 B=1 loop [{prec}], second image vs oracle max|d|={d3:.3e}; graph replay == eager: {torch.equal(g3, o3)}')
+    assert d3 <= TOL_LOOP and torch.equal(g3, o3)
 
 
 @pytest.mark.parametrize('prec', ['f32', 'f16x3'])

@@ -347,6 +347,34 @@ def test_sr3_training_step_matches_reference(golden_dir):
         assert np.abs(aft - ref_aft).max() <= 2.1 * float(g['lr']), k
 
 
+def test_tesr_training_step_matches_reference(golden_dir):
+    """oracle.tesr_oracle.train_step vs one optimisation step of the reference's TESR sibling itself (tesr_modules p_losses :224-250,
+    Charbonnier mean, then model.py:47-57; golden made by `oracle/make_goldens.py tesr_train`)."""
+    from oracle import tesr_oracle as TO
+    g, tg = _load(golden_dir, 'tesr_train_step.npz'), _load(golden_dir, 'tesr.npz')
+    cfg = UNetConfig(in_channel=6, out_channel=3, inner_channel=32, norm_groups=32, channel_mults=(1, 2, 2, 4),
+                     attn_res=(8,), res_blocks=1, dropout=0.2, image_size=32, variant='tesr')
+    sd_np = synth_state_dict(cfg, 9)
+    assert state_dict_sha256(sd_np) == str(g['weights_sha256'])
+    sd = O.to_torch_sd(sd_np)
+    hr, sr, nz = (torch.from_numpy(tg[k]) for k in ('hr', 'sr', 'loss_noise'))
+    gamma = torch.FloatTensor(tg['gamma'])
+    l_pix, grads, new_sd = TO.train_step(sd, cfg, hr, sr, gamma, nz, lr=float(g['lr']))
+    assert abs(l_pix.item() - float(g['l_pix'])) <= 1e-6 * abs(float(g['l_pix']))
+    keys = [str(k) for k in g['grad_keys']]
+    assert sorted(keys) == sorted(grads.keys())
+    for k, (s1, s2) in zip(keys, g['grad_stats']):
+        g64 = grads[k].double()
+        scale = max(np.sqrt(s2), 1e-30)
+        assert abs(g64.sum().item() - s1) <= 2e-4 * scale + 1e-30, k
+        assert abs((g64 * g64).sum().item() - s2) <= 2e-4 * s2 + 1e-40, k
+    for k in (str(x) for x in g['full_keys']):
+        ref = g['grad/' + k]
+        assert np.abs(grads[k].numpy() - ref).max() <= 2e-4 * np.abs(ref).max() + 1e-30, k
+        aft, ref_aft = new_sd[k].numpy(), g['after/' + k]
+        assert np.abs(aft - ref_aft).max() <= 2.1 * float(g['lr']), k
+
+
 def test_tesr_oracle_matches_reference(golden_dir):
     """oracle/tesr_oracle.py vs the reference's own model/tesr_modules (tests/golden/tesr.npz)."""
     from oracle import tesr_oracle as TO
