@@ -576,6 +576,11 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const ConvParams p, 
       float* dst = p.part_out + (((size_t)n * gridDim.x + tile) * p.Cout + cbase + tid * 4) * 2;
 #pragma unroll
       for (int e = 0; e < 4; ++e) { dst[2 * e] = a[e]; dst[2 * e + 1] = b[e]; }
+      if (p.gsum_out) {   // the consumer-side GroupNorm (ConvParams::gsum_out): this tile's sums of the thread's two channel pairs
+        const int pair = (cbase + tid * 4) >> 1;
+        gsum_add(p.gsum_out, n, p.Cout >> 1, pair, tile, a[0] + a[1], b[0] + b[1]);
+        gsum_add(p.gsum_out, n, p.Cout >> 1, pair + 1, tile, a[2] + a[3], b[2] + b[3]);
+      }
     }
   }
 }
@@ -613,7 +618,7 @@ static hipError_t launch_h_t(const ConvParams& p, hipStream_t s, int* tiles) {
     const hipError_t e = launch_conv_k32(TH, WN, PREC, q, nwg, s);   // the 16x16x32 form (fdsr_conv_k32.hip): same grid, same outputs
     if (e != hipSuccess) return e;
   } else {
-    if (p.gb_x0 || p.drop_mask) return hipErrorInvalidValue;   // the GroupNorm-backward epilogue and the dropout staging live in the 16x16x32 kernels only (conv_h_gnb_ok / conv_h_drop_ok)
+    if (p.gb_x0 || p.drop_mask || p.gs0) return hipErrorInvalidValue;   // the GroupNorm-backward epilogue, the dropout staging and the consumer-side GroupNorm live in the 16x16x32 kernels only (conv_h_gnb_ok / conv_h_drop_ok / conv_h_gnc_ok)
     hipLaunchKernelGGL(kfn, dim3(nwg), dim3(Cfg::NT), lds, s, q);
   }
   if (sk > 1 && (g_tun.knockout & 2)) {   // timing-only probe: the reduce launch left out (results are garbage)
@@ -710,6 +715,34 @@ bool conv_h_drop_ok(ConvKind kind, int prec, const ConvParams& p) {
   if (kind != CONV3_S1 || !conv_k32_drop_ok(prec, p)) return false;
   int TH, WN;
   conv_h_config(kind, p.Cout, &TH, &WN);
+  if (WN == 2 && conv_k32_small_ok(kind, prec, p)) return true;
+  TH = pick_th(kind, WN, 1, p);
+  return conv_k32_ok(TH, WN, prec, p);
+}
+
+// the consumer-side GroupNorm (ConvParams::gs0): would this launch land on a GNC instantiation?  (the launch's dispatch, replayed)
+bool conv_h_gnc_ok(ConvKind kind, int prec, const ConvParams& p) {
+  if (!g_tun.gn_consumer || kind != CONV3_S1 || prec == PREC_F32) return false;
+  int TH, WN;
+  conv_h_config(kind, p.Cout, &TH, &WN);
+  ConvParams q = p;                       // as the other forms see a GroupNorm'd launch
+  q.gn_scale = q.gn_shift = reinterpret_cast<const float*>(p.gs_gamma);
+  if ((WN == 2 || WN == 4) && conv_strip_ok(kind, prec, q)) return false;
+  if (WN == 2 && conv_k32_small_ok(kind, prec, q)) return false;
+  TH = pick_th(kind, WN, 1, p);
+  return conv_k32_gnc_ok(TH, WN, prec, p);
+}
+
+// does this launch's kernel add its output's channel-pair sums to ConvParams::gsum_out?  A K split ends in splitk_reduce (32-channel
+// blocks); without one: the 16x16x32 kernels (tile and small-workgroup forms, and the sub-pixel upsample form)
+bool conv_h_gsum_ok(ConvKind kind, int prec, const ConvParams& p, bool sub_pixel_up2) {
+  if (!g_tun.gn_consumer || prec == PREC_F32 || (p.Cout & 3)) return false;
+  if (p.ksplit > 1) return p.Cout % 32 == 0 && !(g_tun.knockout & 2);
+  if (kind == CONV3_UP) return sub_pixel_up2 && conv_up2_k32_ok(prec, p);
+  if (kind != CONV3_S1) return false;
+  int TH, WN;
+  conv_h_config(kind, p.Cout, &TH, &WN);
+  if ((WN == 2 || WN == 4) && conv_strip_ok(kind, prec, p)) return false;
   if (WN == 2 && conv_k32_small_ok(kind, prec, p)) return true;
   TH = pick_th(kind, WN, 1, p);
   return conv_k32_ok(TH, WN, prec, p);

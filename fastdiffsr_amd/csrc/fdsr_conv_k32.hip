@@ -84,6 +84,9 @@ __device__ __forceinline__ float silu_k(float v) { return v * __builtin_amdgcn_r
 // tiles have 2 - 6 chunks: there prologue + epilogue of a one-workgroup-per-CU tile are ~40 % of its time.  Two
 // double-buffered halo images must fit 80 KB: 6-row tiles in f16x3 (2 x 8 x 34 pixels x 128 B = 69.6 KB), 8-row tiles in bf16 (43.5 KB;
 // three activation-fragment slots instead of four keep that form clear of spills: 256 VGPRs).
+// LDS behind the halo buffers of a GNC launch: pair sums (double2) of the groups the K slice touches, then the scale and shift tables
+constexpr int K32_GNC_MAXC = 1024, K32_GNC_MAXP = K32_GNC_MAXC / 2 + 32, K32_GNC_LDS = K32_GNC_MAXP * 16 + K32_GNC_MAXC * 8;
+
 template <int TH, int WN, int PREC, int NW_ = 8>
 struct ConvK32Cfg {
   static constexpr int TW = 32, NW = NW_, KC = 32;
@@ -111,7 +114,8 @@ __device__ __forceinline__ int k32_slot(int slot, int hx) {
 
 // GNB: the GroupNorm-backward epilogue of the training step's input-gradient launches (ConvParams::gb_*)
 // DROP: train-mode Dropout between the Swish and the convolution applied in the staging (ConvParams::drop_mask; f16x3 training forwards)
-template <int TH, int WN, int PREC, bool RIDER, int NW = 8, bool RF = (NW == 4), bool GNB = false, bool DROP = false>   // RF: rider chunks first (launches without a K split)
+// GNC: GroupNorm scale / shift formed HERE, in the prologue, from the producers' fixed-point pair sums (ConvParams::gs0; small grids)
+template <int TH, int WN, int PREC, bool RIDER, int NW = 8, bool RF = (NW == 4), bool GNB = false, bool DROP = false, bool GNC = false>   // RF: rider chunks first (launches without a K split)
 __global__ void __launch_bounds__(64 * NW, 2) conv_k32_kernel(const ConvParams p) {
   using Cfg = ConvK32Cfg<TH, WN, PREC, NW>;
   constexpr int TW = Cfg::TW, KC = Cfg::KC, NP = Cfg::NP, ROWB = Cfg::ROWB, HWD = Cfg::HWD, NPIX = Cfg::NPIX;
@@ -146,7 +150,7 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_k32_kernel(const ConvParams p
   const int n = pt / tilesY;
   const int oy0 = ty * TH, ox0 = tx * TW, co0 = cot * BN;
 
-  const bool gn = p.gn_scale != nullptr;
+  const bool gn = GNC ? true : p.gn_scale != nullptr;
 
   if (NW == 4 && p.stagger > 0) {
     // Two of these workgroups share a CU.  Dispatched together and running the same program they would stay in phase: both in
@@ -200,6 +204,59 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_k32_kernel(const ConvParams p
   const int nk = p.Cin_pad / KC;               // main chunks; nk .. nk + nkr - 1 are the rider's (raw second input, centre tap)
   const int nk16 = p.Cin_pad / 16;
   const int nkr = RIDER ? p.nkr / 2 : 0;
+  // ---- GNC: the scale / shift table of this workgroup's main chunks [gnc_lo, gnc_hi) in LDS behind the halo buffers ----
+  double* gnc_pr = reinterpret_cast<double*>(smem_k + Cfg::LDS_BYTES);                  // [pairs][2]
+  float* gnc_sc = reinterpret_cast<float*>(smem_k + Cfg::LDS_BYTES + K32_GNC_MAXP * 16);   // [channels]
+  float* gnc_sh = gnc_sc + K32_GNC_MAXC;
+  int gnc_lo = 0, gnc_hi = 0, gnc_cpg = 1, gnc_q0 = 0, gnc_q1 = 0;
+  constexpr int GNC_PT = (K32_GNC_MAXP + Cfg::NT - 1) / Cfg::NT;   // pairs per thread (2 at 512 threads)
+  uint4 gnc_ld[GNC ? GNC_PT : 1][GSUM_SHARDS];
+  auto gnc_issue = [&](int c_lo, int c_hi) __attribute__((always_inline)) {   // every load of the table in flight (beside the weights and the first chunk)
+    gnc_lo = c_lo; gnc_hi = c_hi;
+    gnc_cpg = Cin / p.gs_G;
+    gnc_q0 = (c_lo / gnc_cpg) * gnc_cpg / 2;                       // pairs of every group the range touches (groups may cross chunk
+    gnc_q1 = ((c_hi - 1) / gnc_cpg + 1) * gnc_cpg / 2;             // boundaries and the concat seam: 384 channels = 32 groups of 12)
+#pragma unroll
+    for (int j = 0; j < GNC_PT; ++j) {
+      const int qc = min(gnc_q0 + tid + j * Cfg::NT, gnc_q1 - 1);  // (clamped: unconditional loads)
+      const bool first = qc < (p.C0 >> 1);
+      const unsigned long long* tab = first ? p.gs0 : p.gs1;
+      const size_t idx = ((size_t)n * ((first ? p.C0 : p.C1) >> 1) + (first ? qc : qc - (p.C0 >> 1))) * (GSUM_SHARDS * 2);
+#pragma unroll
+      for (int sdx = 0; sdx < GSUM_SHARDS; ++sdx) gnc_ld[j][sdx] = *reinterpret_cast<const uint4*>(tab + idx + 2 * sdx);
+    }
+  };
+  auto gnc_finish = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < GNC_PT; ++j) {
+      const int qi = gnc_q0 + tid + j * Cfg::NT;
+      long long a = 0, b = 0;
+#pragma unroll
+      for (int sdx = 0; sdx < GSUM_SHARDS; ++sdx) {
+        a += (long long)(((unsigned long long)gnc_ld[j][sdx].y << 32) | gnc_ld[j][sdx].x);
+        b += (long long)(((unsigned long long)gnc_ld[j][sdx].w << 32) | gnc_ld[j][sdx].z);
+      }
+      if (qi < gnc_q1) {
+        gnc_pr[2 * (qi - gnc_q0)] = (double)a * (1.0 / (double)(1 << GSUM_BITS1));
+        gnc_pr[2 * (qi - gnc_q0) + 1] = (double)b * (1.0 / (double)(1 << GSUM_BITS2));
+      }
+    }
+    __syncthreads();
+    const double inv = 1.0 / ((double)gnc_cpg * (double)p.Hin * (double)p.Win);
+    for (int c = gnc_lo + tid; c < gnc_hi; c += Cfg::NT) {   // (as gn_finalize_kernel: fp64 statistics, fp32 scale / shift)
+      const int g = c / gnc_cpg, hp = gnc_cpg >> 1;
+      double s1 = 0.0, s2 = 0.0;
+      for (int k = 0; k < hp; ++k) { s1 += gnc_pr[2 * (g * hp + k - gnc_q0)]; s2 += gnc_pr[2 * (g * hp + k - gnc_q0) + 1]; }
+      const double mean = s1 * inv;
+      double var = s2 * inv - mean * mean;
+      var = var < 0.0 ? 0.0 : var;
+      const double rstd = 1.0 / sqrt(var + (double)p.gs_eps);
+      const float scv = (float)rstd * p.gs_gamma[c];
+      gnc_sc[c - gnc_lo] = scv;
+      gnc_sh[c - gnc_lo] = p.gs_beta[c] - (float)mean * scv;
+    }
+    __syncthreads();
+  };
   auto prefetch_rng = [&](int kc, QM* rin, auto i0_tag, auto i1_tag, bool load_gn) __attribute__((always_inline)) {
     constexpr int I0 = decltype(i0_tag)::value, I1 = decltype(i1_tag)::value;
     int cbase = kc * KC;
@@ -213,7 +270,7 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_k32_kernel(const ConvParams p
       else { base = p.xr1; Cs = p.Cr1; cc = cbase - p.Cr0 + q * 4; }
     } else if (cbase < p.C0) { base = p.x0; Cs = p.C0; cc = cbase + q * 4; }
     else { base = p.x1; Cs = p.C1; cc = cbase - p.C0 + q * 4; }
-    if (gg && load_gn) {
+    if (!GNC && gg && load_gn) {
       rsc = *reinterpret_cast<const k_f32x4*>(p.gn_scale + (size_t)n * Cin + cbase + q * 4);
       rsh = *reinterpret_cast<const k_f32x4*>(p.gn_shift + (size_t)n * Cin + cbase + q * 4);
     }
@@ -228,7 +285,11 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_k32_kernel(const ConvParams p
   auto prefetch_to = [&](int kc, QM* rin) __attribute__((always_inline)) { prefetch_rng(kc, rin, I_0{}, I_N{}, true); };
   auto stage_rng = [&](int kc, unsigned char* buf, const QM* rin, auto i0_tag, auto i1_tag) __attribute__((always_inline)) {
     constexpr int I0 = decltype(i0_tag)::value, I1 = decltype(i1_tag)::value;
-    const k_f32x4 sc = rsc, sh = rsh;
+    k_f32x4 sc = rsc, sh = rsh;
+    if (GNC && !(RIDER && kc >= nk)) {   // this chunk's four channels of the LDS table the prologue built
+      sc = *reinterpret_cast<const k_f32x4*>(gnc_sc + (kc * KC - gnc_lo + q * 4));
+      sh = *reinterpret_cast<const k_f32x4*>(gnc_sh + (kc * KC - gnc_lo + q * 4));
+    }
 #pragma unroll
     for (int i = I0; i < I1; ++i) {
       if (NIN * RPP > NPIX && i == NIN - 1 && row0 + i * RPP >= NPIX) continue;   // only the last pass can overrun
@@ -326,10 +387,15 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_k32_kernel(const ConvParams p
 #pragma unroll
     for (int t = 0; t < R; ++t) load_w(kc0, t, t);
   }
+  // GNC: the table's loads go out here, beside the weights and the first chunk's input; the fold and the two barriers follow the first fetch
+  const int gm0 = RFIRST ? 0 : (kc0 < nk ? kc0 : nk), gm1 = RIDER ? (kc1 < nk ? kc1 : nk) : kc1;   // this workgroup's main chunks
+  const bool gnc_on = GNC && gm1 > gm0;
+  if (gnc_on) gnc_issue(gm0 * KC, gm1 * KC < Cin ? gm1 * KC : Cin);
   if (RFIRST) {   // (never split in K: kc0 = 0, kc1 = nk + nkr)
     {
       QM r0[NIN];
       prefetch_to(nk, r0);
+      if (gnc_on) gnc_finish();
       stage_from(nk, sBuf0, r0);
     }
     prefetch_to(nkr > 1 ? nk + 1 : 0, rr1);   // the second rider chunk -- or, after a single one, the first main chunk (fetched whole)
@@ -337,11 +403,13 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_k32_kernel(const ConvParams p
     {   // the first chunk is fetched whole (the accumulators are not live yet)
       QM r0[NIN];
       prefetch_to(kc0, r0);
+      if (gnc_on) gnc_finish();
       stage_from(kc0, sBuf0, r0);
     }
     if (RIDER && kc0 >= nk && kc0 + 1 < kc1) prefetch_to(kc0 + 1, rr1);   // (a slice that starts among the rider chunks)
   } else {
     prefetch_to(kc0, rin);
+    if (gnc_on) gnc_finish();
     stage_from(kc0, sBuf0, rin);
     if (kc0 + 1 < kc1) prefetch_to(kc0 + 1, rin);
   }
@@ -752,13 +820,19 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_k32_kernel(const ConvParams p
       sp[(wm * BN + wn * 32 + 16 * ch + 4 * g + r) * 2 + st] = vals[0];
     }
     __syncthreads();
+    float a_keep = 0.f, b_keep = 0.f;
     if (tid < BN && co0 + tid < p.Cout) {
       float a = 0.f, b = 0.f;
 #pragma unroll
       for (int w = 0; w < WM; ++w) { a += sp[(w * BN + tid) * 2 + 0]; b += sp[(w * BN + tid) * 2 + 1]; }
+      a_keep = a; b_keep = b;
       float* dst = p.part_out + (((size_t)n * (tilesX * tilesY) + ty * tilesX + tx) * p.Cout + co0 + tid) * 2;
       dst[0] = a;
       dst[1] = b;
+    }
+    if (p.gsum_out) {   // the consumer-side GroupNorm: even threads add their channel pair's sums (Cout is even: launcher)
+      const float a2 = a_keep + __shfl_xor(a_keep, 1, 64), b2 = b_keep + __shfl_xor(b_keep, 1, 64);
+      if (tid < BN && !(tid & 1) && co0 + tid < p.Cout) gsum_add(p.gsum_out, n, p.Cout >> 1, (co0 + tid) >> 1, ty * tilesX + tx, a2, b2);
     }
   }
 }
@@ -1042,13 +1116,19 @@ __global__ void __launch_bounds__(512, 2) conv_up2_k32_kernel(const ConvParams p
       sp[(wm * BN + wn * 32 + 16 * ch + 4 * g + r) * 2 + st] = vals[0];
     }
     __syncthreads();
+    float a_keep = 0.f, b_keep = 0.f;
     if (tid < BN && co0 + tid < p.Cout) {
       float a = 0.f, b = 0.f;
 #pragma unroll
       for (int w = 0; w < WM; ++w) { a += sp[(w * BN + tid) * 2 + 0]; b += sp[(w * BN + tid) * 2 + 1]; }
+      a_keep = a; b_keep = b;
       float* dst = p.part_out + (((size_t)n * (tilesX * tilesY * 2) + (ty * tilesX + tx) * 2 + py) * p.Cout + co0 + tid) * 2;
       dst[0] = a;
       dst[1] = b;
+    }
+    if (p.gsum_out) {   // the consumer-side GroupNorm (as conv_k32_kernel)
+      const float a2 = a_keep + __shfl_xor(a_keep, 1, 64), b2 = b_keep + __shfl_xor(b_keep, 1, 64);
+      if (tid < BN && !(tid & 1) && co0 + tid < p.Cout) gsum_add(p.gsum_out, n, p.Cout >> 1, (co0 + tid) >> 1, (ty * tilesX + tx) * 2 + py, a2, b2);
     }
   }
 }
@@ -1095,10 +1175,10 @@ bool conv_k32_ok(int TH, int WN, int prec, const ConvParams& p) {
   return true;
 }
 
-template <int TH, int WN, int PREC, bool RIDER, int NW = 8, bool RF = (NW == 4), bool GNB = false, bool DROP = false>
+template <int TH, int WN, int PREC, bool RIDER, int NW = 8, bool RF = (NW == 4), bool GNB = false, bool DROP = false, bool GNC = false>
 static hipError_t launch_k32_t(const ConvParams& q, int nwg, hipStream_t s) {
   using Cfg = ConvK32Cfg<TH, WN, PREC, NW>;
-  hipLaunchKernelGGL((conv_k32_kernel<TH, WN, PREC, RIDER, NW, RF, GNB, DROP>), dim3(nwg), dim3(Cfg::NT), (size_t)Cfg::LDS_BYTES, s, q);
+  hipLaunchKernelGGL((conv_k32_kernel<TH, WN, PREC, RIDER, NW, RF, GNB, DROP, GNC>), dim3(nwg), dim3(Cfg::NT), (size_t)Cfg::LDS_BYTES + (GNC ? K32_GNC_LDS : 0), s, q);
   return hipGetLastError();
 }
 
@@ -1150,7 +1230,33 @@ hipError_t launch_conv_k32_small(int prec, const ConvParams& p, hipStream_t s, i
   return q.xr0 ? launch_k32_t<6, 2, PREC_BF16, true, 4>(q, nwg, s) : launch_k32_t<8, 2, PREC_BF16, false, 4>(q, nwg, s);
 }
 
+// the consumer-side GroupNorm (ConvParams::gs0): the 2-row-per-wave tiles of small grids (MB = 2: 32 accumulator registers leave the room),
+// sampling launches only (no GroupNorm-backward epilogue, no dropout staging)
+#define FDSR_K32_GNC_SHAPES(X) X(8, 2) X(4, 4) X(2, 8)
+bool conv_k32_gnc_ok(int TH, int WN, int prec, const ConvParams& p) {
+  if (TH * WN != 16 || !conv_k32_ok(TH, WN, prec, p)) return false;
+  if (p.gb_x0 || p.drop_mask || p.gn_plain || (p.C0 & 1) || (p.C1 & 1)) return false;
+  const int Cin = p.C0 + p.C1;
+  return Cin <= K32_GNC_MAXC && p.gs_G > 0 && Cin % p.gs_G == 0 && ((Cin / p.gs_G) & 1) == 0;
+}
+
 hipError_t launch_conv_k32(int TH, int WN, int prec, const ConvParams& q, int nwg, hipStream_t s) {
+  if (q.gs0) {
+    if (!conv_k32_gnc_ok(TH, WN, prec, q)) return hipErrorInvalidValue;
+    const bool rf = q.xr0 && q.ksplit <= 1 && (g_tun.k32 & FDSR_K32_RIDER_FIRST_8WAVE);
+#define X(TH_, WN_)                                                                                                      \
+    if (TH == TH_ && WN == WN_) {                                                                                        \
+      if (rf) return prec == PREC_F16X3 ? launch_k32_t<TH_, WN_, PREC_F16X3, true, 8, true, false, false, true>(q, nwg, s)   \
+                                        : launch_k32_t<TH_, WN_, PREC_BF16, true, 8, true, false, false, true>(q, nwg, s);    \
+      if (q.xr0) return prec == PREC_F16X3 ? launch_k32_t<TH_, WN_, PREC_F16X3, true, 8, false, false, false, true>(q, nwg, s)  \
+                                           : launch_k32_t<TH_, WN_, PREC_BF16, true, 8, false, false, false, true>(q, nwg, s);   \
+      return prec == PREC_F16X3 ? launch_k32_t<TH_, WN_, PREC_F16X3, false, 8, false, false, false, true>(q, nwg, s)      \
+                                : launch_k32_t<TH_, WN_, PREC_BF16, false, 8, false, false, false, true>(q, nwg, s);       \
+    }
+    FDSR_K32_GNC_SHAPES(X)
+#undef X
+    return hipErrorInvalidValue;
+  }
 #define X(TH_, WN_)                                                                                             \
   if (TH == TH_ && WN == WN_) {                                                                                 \
     if (q.gb_x0) return k32_gnb_ok(prec, q) ? launch_k32_t<TH_, WN_, PREC_F16X3, false, 8, false, true>(q, nwg, s) : hipErrorInvalidValue; \
@@ -1172,9 +1278,9 @@ hipError_t launch_conv_k32(int TH, int WN, int prec, const ConvParams& q, int nw
   return hipErrorInvalidValue;
 }
 
-template <int TH, int WN, int PREC, bool RIDER, int NW = 8, bool RF = (NW == 4), bool GNB = false, bool DROP = false>
+template <int TH, int WN, int PREC, bool RIDER, int NW = 8, bool RF = (NW == 4), bool GNB = false, bool DROP = false, bool GNC = false>
 static hipError_t init_k32_t() {
-  auto kfn = conv_k32_kernel<TH, WN, PREC, RIDER, NW, RF, GNB, DROP>;
+  auto kfn = conv_k32_kernel<TH, WN, PREC, RIDER, NW, RF, GNB, DROP, GNC>;
   return hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
@@ -1202,6 +1308,15 @@ hipError_t kernels_k32_init() {
   if ((e = init_k32_t<TH_, WN_, PREC_F16X3, true, 8, true, false, true>()) != hipSuccess) return e; \
   if ((e = init_k32_t<TH_, WN_, PREC_BF16, true, 8, true>()) != hipSuccess) return e;
   FDSR_K32_SHAPES(X)
+#undef X
+#define X(TH_, WN_)                                                                                                     \
+  if ((e = init_k32_t<TH_, WN_, PREC_F16X3, false, 8, false, false, false, true>()) != hipSuccess) return e;            \
+  if ((e = init_k32_t<TH_, WN_, PREC_F16X3, true, 8, false, false, false, true>()) != hipSuccess) return e;             \
+  if ((e = init_k32_t<TH_, WN_, PREC_F16X3, true, 8, true, false, false, true>()) != hipSuccess) return e;              \
+  if ((e = init_k32_t<TH_, WN_, PREC_BF16, false, 8, false, false, false, true>()) != hipSuccess) return e;             \
+  if ((e = init_k32_t<TH_, WN_, PREC_BF16, true, 8, false, false, false, true>()) != hipSuccess) return e;              \
+  if ((e = init_k32_t<TH_, WN_, PREC_BF16, true, 8, true, false, false, true>()) != hipSuccess) return e;
+  FDSR_K32_GNC_SHAPES(X)
 #undef X
   if ((e = init_k32_t<6, 2, PREC_F16X3, false, 4>()) != hipSuccess) return e;
   if ((e = init_k32_t<6, 2, PREC_F16X3, true, 4>()) != hipSuccess) return e;

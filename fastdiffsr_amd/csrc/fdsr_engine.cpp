@@ -762,6 +762,15 @@ int make_shape_plan(fdsr_handle h, int N, int H, int W, ShapePlan* sp) {
     if (sk > 1) sk_bytes = std::max(sk_bytes, (size_t)sk * N * Ho * Wo * op.Cout * sizeof(float));
   }
   sp->off_splitk = off;  off += align_up(sk_bytes, 256);
+  sp->gsum_off.assign(h->tensors.size(), 0);
+  sp->tensor_gsum.assign(h->tensors.size(), 0);
+  sp->off_gsum = off;
+  for (size_t t = 0; t < h->tensors.size(); ++t)
+    if (h->tensors[t].need_part && h->tensors[t].C > 0 && !(h->tensors[t].C & 1)) {
+      sp->gsum_off[t] = off;
+      off += align_up((size_t)N * (h->tensors[t].C / 2) * GSUM_SHARDS * 2 * sizeof(unsigned long long), 256);
+    }
+  sp->gsum_bytes = off - sp->off_gsum;
   const size_t arena0 = off;
   sp->tensor_off.assign(h->tensors.size(), 0);
   sp->part_off.assign(h->tensors.size(), 0);
@@ -864,6 +873,32 @@ int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, 
     int rc = fill_temb(h, reinterpret_cast<float*>(ws + sp.off_temb), N, nl_dev, nl_scalar, st);
     if (rc) return rc;
   }
+  // consumer-side GroupNorm: sampling forwards of the 16-bit modes only (a training forward keeps the statistics for its backward, a debug
+  // forward keeps every layer); the producers' tables start from zero
+  const bool gsum_on = g_tun.gn_consumer && h->prec != PREC_F32 && !h->training && !h->keep_stats && !h->debug && sp.gsum_bytes > 0 &&
+                       !(g_tun.knockout & 1);
+  auto GSUM = [&](int t) -> unsigned long long* {
+    return (gsum_on && t >= 0 && sp.gsum_off[t]) ? reinterpret_cast<unsigned long long*>(ws + sp.gsum_off[t]) : nullptr;
+  };
+  std::fill(sp.tensor_gsum.begin(), sp.tensor_gsum.end(), 0);
+  if (gsum_on) HIPCHK(h, hipMemsetAsync(ws + sp.off_gsum, 0, sp.gsum_bytes, st));
+  int pending_gn = -1;              // a GN_FINALIZE op whose launch waits for its consumer's verdict (index into h->ops)
+  auto launch_finalize = [&](const Op& op) -> int {
+    const int Hi = H >> op.lvl_in, Wi = W >> op.lvl_in;
+    GnFinalizeParams g{};
+    g.part0 = PART(op.src0); g.nt0 = sp.tensor_nt[op.src0]; g.C0 = op.C0;
+    g.part1 = PART(op.src1); g.nt1 = op.src1 >= 0 ? sp.tensor_nt[op.src1] : 0; g.C1 = op.C1;
+    if (!g.part0 || g.nt0 <= 0 || (op.src1 >= 0 && (!g.part1 || g.nt1 <= 0)))
+      return fail(h, FDSR_E_STATE, "internal: GroupNorm input of %s has no partial sums", op.name.c_str());
+    g.gamma = P(op.gamma); g.beta = P(op.beta);
+    g.scale = reinterpret_cast<float*>(ws + sp.gn_off[op.gn_slot]);
+    g.shift = g.scale + (size_t)N * (op.C0 + op.C1);
+    g.stats = h->keep_stats ? reinterpret_cast<float*>(ws + sp.gn_stats_off[op.gn_slot]) : nullptr;
+    if (op.film_off >= 0) { g.film = temb; g.film_stride = temb_row ? 0 : h->TE; g.film_off = op.film_off; }
+    g.N = N; g.G = G; g.HW = Hi * Wi; g.eps = 1e-5f;
+    if (!(g_tun.knockout & 1)) HIPCHK(h, launch_gn_finalize(g, st));   // (knockout: timing-only probe, results are garbage)
+    return FDSR_OK;
+  };
   const bool dropout_on = h->training && h->n_drop_slots > 0;
   if (dropout_on) {
     if (h->prec == PREC_BF16)
@@ -873,20 +908,17 @@ int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, 
   for (size_t oi = 0; oi < h->ops.size(); ++oi) {
     const Op& op = h->ops[oi];
     const int Hi = H >> op.lvl_in, Wi = W >> op.lvl_in;
+    if (pending_gn >= 0 && op.kind != Op::CONV && op.kind != Op::GN_FINALIZE) {   // (only a conv can stand in for the finalisation)
+      int rc = launch_finalize(h->ops[pending_gn]); if (rc) return rc; pending_gn = -1;
+    }
     switch (op.kind) {
       case Op::GN_FINALIZE: {
-        GnFinalizeParams g{};
-        g.part0 = PART(op.src0); g.nt0 = sp.tensor_nt[op.src0]; g.C0 = op.C0;
-        g.part1 = PART(op.src1); g.nt1 = op.src1 >= 0 ? sp.tensor_nt[op.src1] : 0; g.C1 = op.C1;
-        if (!g.part0 || g.nt0 <= 0 || (op.src1 >= 0 && (!g.part1 || g.nt1 <= 0)))
-          return fail(h, FDSR_E_STATE, "internal: GroupNorm input of %s has no partial sums", op.name.c_str());
-        g.gamma = P(op.gamma); g.beta = P(op.beta);
-        g.scale = reinterpret_cast<float*>(ws + sp.gn_off[op.gn_slot]);
-        g.shift = g.scale + (size_t)N * (op.C0 + op.C1);
-        g.stats = h->keep_stats ? reinterpret_cast<float*>(ws + sp.gn_stats_off[op.gn_slot]) : nullptr;
-        if (op.film_off >= 0) { g.film = temb; g.film_stride = temb_row ? 0 : h->TE; g.film_off = op.film_off; }
-        g.N = N; g.G = G; g.HW = Hi * Wi; g.eps = 1e-5f;
-        if (!(g_tun.knockout & 1)) HIPCHK(h, launch_gn_finalize(g, st));   // (knockout: timing-only probe, results are garbage)
+        if (pending_gn >= 0) { int rc = launch_finalize(h->ops[pending_gn]); if (rc) return rc; pending_gn = -1; }
+        // Where every source's producer filled its table of pair sums, the launch waits for the consumer conv (the next op of this
+        // GroupNorm slot): a consumer that forms scale / shift itself (conv_h_gnc_ok) makes it unnecessary
+        const bool tabled = gsum_on && op.film_off < 0 && sp.tensor_gsum[op.src0] && (op.src1 < 0 || sp.tensor_gsum[op.src1]);
+        if (tabled) pending_gn = (int)oi;
+        else { int rc = launch_finalize(op); if (rc) return rc; }
         break;
       }
       case Op::CONV: {
@@ -970,6 +1002,24 @@ int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, 
           }
           HIPCHK(h, hipEventRecord(h->ev_pool[h->ev_used++], st));
         }
+        // consumer-side GroupNorm: the finalisation of this conv's GroupNorm is still pending (its sources carry tables of pair sums):
+        // a launch that lands on a GNC kernel forms scale / shift itself; anything else gets the finalisation launch now
+        bool gnc = false;
+        ConvParams gcp{};
+        if (pending_gn >= 0) {
+          const Op& gop = h->ops[pending_gn];
+          if (op.gn_slot >= 0 && gop.gn_slot == op.gn_slot && h->prec != PREC_F32 && w.h_ok && op.ck == CONV3_S1 && !p.drop_mask) {
+            gcp = p;
+            gcp.Cin_pad = w.h_cin_pad; gcp.Cout_pad = w.h_cout_pad;
+            gcp.ksplit = sp.op_ksplit[oi];
+            gcp.gn_scale = gcp.gn_shift = nullptr;
+            gcp.gs0 = GSUM(gop.src0); gcp.gs1 = GSUM(gop.src1);
+            gcp.gs_gamma = P(gop.gamma); gcp.gs_beta = P(gop.beta); gcp.gs_eps = 1e-5f; gcp.gs_G = G;
+            gnc = gcp.gs0 && (gop.src1 < 0 || gcp.gs1) && conv_h_gnc_ok(op.ck, h->prec, gcp);
+          }
+          if (!gnc) { int rc = launch_finalize(gop); if (rc) return rc; }
+          pending_gn = -1;
+        }
         // the two ends of the UNet in the 16-bit modes: bandwidth-shaped kernels of their own (fdsr_conv_tail.hip), weights read
         // from the fp32 master copy (always current, also right after optimiser steps)
         const float* wmaster = h->master_off[op.w] != SIZE_MAX ? h->d_master + h->master_off[op.w] : nullptr;
@@ -994,10 +1044,22 @@ int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, 
             p.w_inv_scale_dev = up2_dev ? h->d_up2_inv + op.w : nullptr;
             p.wq = h->d_wq + w.up2_off[h->prec];
             p.w_inv_scale = w.up2_inv_scale[h->prec];
+            if (gsum_on && p.part_out && GSUM(op.dst) && conv_h_gsum_ok(CONV3_UP, h->prec, p, true)) {
+              p.gsum_out = GSUM(op.dst);
+              sp.tensor_gsum[op.dst] = 1;
+            }
             HIPCHK(h, launch_conv_up2_h(h->prec, p, st, &nt));
           } else {
             p.ksplit = (op.ck == CONV3_UP) ? 1 : sp.op_ksplit[oi];
             p.kscratch = reinterpret_cast<float*>(ws + sp.off_splitk);
+            if (gnc) {   // scale / shift from the sources' tables, in the kernel's prologue
+              p.gn_scale = p.gn_shift = nullptr;
+              p.gs0 = gcp.gs0; p.gs1 = gcp.gs1; p.gs_gamma = gcp.gs_gamma; p.gs_beta = gcp.gs_beta; p.gs_eps = gcp.gs_eps; p.gs_G = gcp.gs_G;
+            }
+            if (gsum_on && p.part_out && GSUM(op.dst) && conv_h_gsum_ok(op.ck, h->prec, p, false)) {
+              p.gsum_out = GSUM(op.dst);
+              sp.tensor_gsum[op.dst] = 1;
+            }
             HIPCHK(h, launch_conv_h(op.ck, h->prec, p, st, &nt));
           }
         } else {
@@ -1049,6 +1111,7 @@ int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, 
       }
     }
   }
+  if (pending_gn >= 0) { int rc = launch_finalize(h->ops[pending_gn]); if (rc) return rc; }
   return FDSR_OK;
 }
 

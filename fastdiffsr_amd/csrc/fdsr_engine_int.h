@@ -82,6 +82,11 @@ struct ShapePlan {
   bool training = false;
   std::vector<size_t> gn_stats_off;   // per GroupNorm slot: (mean, rstd) [N][G][2], written when the engine keeps statistics
   std::vector<int> tensor_nt;      // tiles per image its producer actually used (set at launch)
+  // consumer-side GroupNorm (ConvParams::gsum_out / gs0): per tensor that feeds a GroupNorm, its table of fixed-point channel-pair sums
+  // [N][C/2][GSUM_SHARDS][2] int64 in one arena that a single memset clears at the start of a forward
+  std::vector<size_t> gsum_off;    // (0 = none)
+  size_t off_gsum = 0, gsum_bytes = 0;
+  std::vector<char> tensor_gsum;   // this forward's producer of the tensor filled its table (set at launch)
 };
 
 struct GraphEntry {

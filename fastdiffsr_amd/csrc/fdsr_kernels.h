@@ -72,7 +72,22 @@ struct ConvParams {
   const float* gb_stats;             // [N][G][2] mean, rstd
   const unsigned char* gb_mask;      // [N][Hout][Wout][Cout] dropout keep bytes or null
   float gb_drop;                     // 1/(1-p)
+  // GroupNorm statistics WITHOUT a finalisation launch (small grids, where a dependent launch costs ~5 us whatever it does -- 45 of the 139
+  // launches of a B = 1 step were gn_finalize): a producer adds the (sum, sum of squares) of every channel PAIR of its output tile, as
+  // fixed-point int64 (GSUM_BITS1 / GSUM_BITS2 fraction bits; integer adds commute, so a rerun is bitwise identical), to one of
+  // GSUM_SHARDS shards of the tensor's table gsum[n][pair][shard][2] with agent-scope atomics; the consumer (the MB = 2 instantiations of
+  // conv_k32_kernel, GNC) folds the pairs of the groups its K slice touches and forms scale / shift itself, in an LDS table, in its
+  // prologue.  Pair granularity: a skip tensor is normalised under two groupings (alone, and concatenated behind another tensor).
+  unsigned long long* gsum_out;      // producer side: this launch's output tensor's table, or null
+  const unsigned long long* gs0;     // consumer side: the tables of x0 / x1 (gs0 null: scale / shift come from gn_scale / gn_shift)
+  const unsigned long long* gs1;
+  const float* gs_gamma;             // [C0 + C1]
+  const float* gs_beta;
+  float gs_eps;
+  int gs_G;                          // groups over the C0 + C1 concatenated channels
 };
+enum { GSUM_SHARDS = 4, GSUM_BITS1 = 16, GSUM_BITS2 = 12 };
+// producer epilogues: v = (sum, sumsq) of one channel pair over this workgroup's pixels -> the table (fdsr_act_io.h: gsum_add)
 
 enum Precision { PREC_F32 = 0, PREC_F16X3 = 1, PREC_BF16 = 2 };
 
@@ -99,6 +114,7 @@ struct Tunables {
   int tail = 1;             // the input / output convs of the 16-bit modes on their own kernels (fdsr_conv_tail.hip); 0: the general ones
   int knockout = 0;         // TIMING-ONLY probes, results are garbage: bit 1 leaves the gn_finalize launches out, bit 2 the splitk_reduce launches
                             // (the upper bound of what fusing them into their producers could save; EXPERIMENTS round 4)
+  int gn_consumer = 1;      // small grids: GroupNorm scale / shift formed in the consumer conv's prologue from the producers' fixed-point group sums (no gn_finalize launch)
   int sat_guard = 1;        // f16x3: sticky device flag when a RAW conv input exceeds the f16 range
   int drop_image_offset = 0;   // tests: the batch is images [offset, offset + N) of a larger one (its dropout masks follow)
   unsigned epoch = 0;
@@ -139,6 +155,11 @@ bool conv_k32_ok(int TH, int WN, int prec, const ConvParams& p);
 hipError_t launch_conv_k32(int TH, int WN, int prec, const ConvParams& q, int nwg, hipStream_t s);
 // ... as 256-thread workgroups, two per CU, for the 64-cout launches of large grids (k32 bit 32): asked before a tile is picked
 bool conv_k32_small_ok(ConvKind kind, int prec, const ConvParams& p);
+// would launch_conv_h run this GroupNorm'd launch on a kernel that forms scale / shift itself (ConvParams::gs0)?  Asked by the engine
+// before it decides to skip the gn_finalize launch; does this launch's kernel add its output's pair sums to ConvParams::gsum_out?
+bool conv_h_gnc_ok(ConvKind kind, int prec, const ConvParams& p);
+bool conv_h_gsum_ok(ConvKind kind, int prec, const ConvParams& p, bool sub_pixel_up2);
+bool conv_k32_gnc_ok(int TH, int WN, int prec, const ConvParams& p);
 hipError_t launch_conv_k32_small(int prec, const ConvParams& p, hipStream_t s, int* tiles);
 hipError_t kernels_k32_init();
 // Column-strip form of the 64-cout launches (fdsr_conv_strip.hip): same ConvParams, the same packed weights (wn_a: the WN they

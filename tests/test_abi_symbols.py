@@ -75,7 +75,7 @@ def test_debug_options_are_an_abi_call_not_environment():
     from fastdiffsr_amd import _lib
     lib = _lib.load()
     defaults = {'rider': 2, 'up2': 1, 'splitk': 1, 'sk_target': 256, 'th_min_wgs': 256, 'strip': 91, 'strip_min_wgs': 512,
-                'wgrad_form': 0, 'wgrad_colsum': 1, 'wgrad_f32': 0, 'gnb_fuse': 1, 'drop_stage': 1, 'wgrad_big_bytes': 1 << 32, 'sat_guard': 1, 'tail': 1, 'k32': 1275, 'k32_sb_min_wgs': 1024, 'k32_stagger': 0, 'drop_image_offset': 0}
+                'wgrad_form': 0, 'wgrad_colsum': 1, 'wgrad_f32': 0, 'gnb_fuse': 1, 'drop_stage': 1, 'wgrad_big_bytes': 1 << 32, 'sat_guard': 1, 'gn_consumer': 1, 'tail': 1, 'k32': 1275, 'k32_sb_min_wgs': 1024, 'k32_stagger': 0, 'drop_image_offset': 0}
     for name, value in defaults.items():          # every documented name is accepted (set to its default)
         assert lib.fdsr_debug_option(name.encode(), value) == 0, name
     assert lib.fdsr_debug_option(b'no_such_option', 1) == -1          # FDSR_E_INVALID

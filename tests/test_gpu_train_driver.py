@@ -1,5 +1,6 @@
 """`python -m fastdiffsr_amd.train -c <config>` = the train phase of the reference's sr_mfe.py (:69-251): iterations with
-log lines, the validation pass every val_freq (val schedule, then back), checkpoints every save_checkpoint_freq, resume."""
+log lines, the validation pass every val_freq (val schedule, then back), checkpoints every save_checkpoint_freq, resume -- for
+which_model_G 'fastdiffsr' and for the SR3 sibling 'ddpm' (model/networks.py:82-119: the reference trains both through the same loop)."""
 import json
 import os
 import sys
@@ -13,7 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def _config(root, exp):
+def _config(root, exp, which='fastdiffsr'):
     sched = dict(schedule='linear_cosine', n_timestep=20, linear_start=1e-6, linear_end=1e-2)
     return {
         "name": "sr_fastdiffsr_train", "phase": "train", "gpu_ids": [0],
@@ -22,7 +23,7 @@ def _config(root, exp):
                                "r_resolution": 64, "batch_size": 2, "num_workers": 0, "use_shuffle": True, "data_len": -1},
                      "val": {"name": "v", "mode": "LRHR", "dataroot": root, "datatype": "img", "l_resolution": 16,
                              "r_resolution": 64, "data_len": 2}},
-        "model": {"which_model_G": "fastdiffsr", "finetune_norm": False,
+        "model": {"which_model_G": which, "finetune_norm": False,
                   "unet": {"in_channel": 6, "out_channel": 3, "inner_channel": 32, "channel_multiplier": [1, 2, 2],
                            "attn_res": [16], "res_blocks": 1, "dropout": 0.2},
                   "beta_schedule": {"train": dict(sched), "val": dict(sched)},
@@ -33,7 +34,8 @@ def _config(root, exp):
         "wandb": {"project": "x"}}
 
 
-def test_train_driver_iterations_val_checkpoint_resume(tmp_path):
+@pytest.mark.parametrize('which', ['fastdiffsr', 'ddpm'])
+def test_train_driver_iterations_val_checkpoint_resume(tmp_path, which):
     from fastdiffsr_amd import train
     from fastdiffsr_amd.config import load_config
     from test_val_host import make_dataset
@@ -42,7 +44,7 @@ def test_train_driver_iterations_val_checkpoint_resume(tmp_path):
     os.chdir(tmp_path)                       # the parser creates experiments/<name>_<timestamp>/ under the cwd (core/logger.py:37-43)
     try:
         cpath = tmp_path / 'train.json'
-        cpath.write_text(json.dumps(_config(root, 'a')))
+        cpath.write_text(json.dumps(_config(root, 'a', which)))
         opt = load_config(str(cpath), phase='train')
         torch.manual_seed(3)
         np.random.seed(3)
@@ -60,7 +62,7 @@ def test_train_driver_iterations_val_checkpoint_resume(tmp_path):
         assert len([f for f in os.listdir(opt['path']['results']) if f.endswith('_sr.tif')]) == 10
         assert diffusion.schedule_phase == 'train'                     # switched back after the validation pass
         # resume: begin_step / begin_epoch restored, two more iterations run
-        cfg2 = _config(root, 'b')
+        cfg2 = _config(root, 'b', which)
         cfg2['path']['resume_state'] = os.path.join(ck, 'I4_E2')
         cfg2['train'].update(n_iter=6, val_freq=100, save_checkpoint_freq=100)
         cpath2 = tmp_path / 'resume.json'
