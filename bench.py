@@ -251,7 +251,7 @@ def family_label(precision):
     return ' + '.join(names)
 
 
-def conv_roofline(prof, precision, B, S, dt_total, round_tag='r05'):
+def conv_roofline(prof, precision, B, S, dt_total, round_tag='r06'):
     """Roofline of the dominant kernel family = every 3x3 convolution launch (implicit-GEMM MFMA kernels incl. the
     sub-pixel upsample form and the 6-channel input conv): algorithmic FLOPs / HIP-event time around those launches."""
     ach = prof['conv_flops'] / (prof['conv_ms'] * 1e-3) / 1e12

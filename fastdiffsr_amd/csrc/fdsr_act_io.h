@@ -17,12 +17,20 @@ __device__ __forceinline__ void sat_check(int* flag, f32x4_io v, float lim) {
   const float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
   if (m > lim) *flag = 1;
 }
-// one channel pair's (sum, sumsq) of a producer tile -> the tensor's fixed-point table (ConvParams::gsum_out); `shard` spreads the adders
+// the XCD this wave runs on (HW_REG_XCC_ID[3:0]): the shard of the consumer-side GroupNorm tables its workgroup adds to
+__device__ __forceinline__ int xcc_id() {
+  unsigned v;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+  return (int)(v & (GSUM_SHARDS - 1));
+}
+// one channel pair's (sum, sumsq) of a producer tile -> this XCD's shard of the tensor's fixed-point table (ConvParams::gsum_out).
+// Workgroup-scope atomics carry no sc1: the XCD's L2 executes them (all adders of the shard share that L2), ~10 ns each instead of a
+// memory-side read-modify-write per adder; the end of the kernel writes the lines back for the consumer launch.
 __device__ __forceinline__ void gsum_add(unsigned long long* tab, int n, int npairs, int pair, int shard, float s1, float s2) {
-  unsigned long long* g = tab + (((size_t)n * npairs + pair) * GSUM_SHARDS + (shard & (GSUM_SHARDS - 1))) * 2;
+  unsigned long long* g = tab + (((size_t)n * GSUM_SHARDS + shard) * npairs + pair) * 2;
   const long long a = __float2ll_rn(s1 * (float)(1 << GSUM_BITS1)), b = __float2ll_rn(s2 * (float)(1 << GSUM_BITS2));
-  __hip_atomic_fetch_add(g, (unsigned long long)a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_fetch_add(g + 1, (unsigned long long)b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_fetch_add(g, (unsigned long long)a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  __hip_atomic_fetch_add(g + 1, (unsigned long long)b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 template <int PREC> struct ActIO;
 template <> struct ActIO<PREC_F16X3> {

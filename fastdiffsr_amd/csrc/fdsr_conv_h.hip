@@ -578,8 +578,9 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const ConvParams p, 
       for (int e = 0; e < 4; ++e) { dst[2 * e] = a[e]; dst[2 * e + 1] = b[e]; }
       if (p.gsum_out) {   // the consumer-side GroupNorm (ConvParams::gsum_out): this tile's sums of the thread's two channel pairs
         const int pair = (cbase + tid * 4) >> 1;
-        gsum_add(p.gsum_out, n, p.Cout >> 1, pair, tile, a[0] + a[1], b[0] + b[1]);
-        gsum_add(p.gsum_out, n, p.Cout >> 1, pair + 1, tile, a[2] + a[3], b[2] + b[3]);
+        const int xcd = xcc_id();
+        gsum_add(p.gsum_out, n, p.Cout >> 1, pair, xcd, a[0] + a[1], b[0] + b[1]);
+        gsum_add(p.gsum_out, n, p.Cout >> 1, pair + 1, xcd, a[2] + a[3], b[2] + b[3]);
       }
     }
   }

@@ -85,7 +85,7 @@ __device__ __forceinline__ float silu_k(float v) { return v * __builtin_amdgcn_r
 // double-buffered halo images must fit 80 KB: 6-row tiles in f16x3 (2 x 8 x 34 pixels x 128 B = 69.6 KB), 8-row tiles in bf16 (43.5 KB;
 // three activation-fragment slots instead of four keep that form clear of spills: 256 VGPRs).
 // LDS behind the halo buffers of a GNC launch: pair sums (double2) of the groups the K slice touches, then the scale and shift tables
-constexpr int K32_GNC_MAXC = 1024, K32_GNC_MAXP = K32_GNC_MAXC / 2 + 32, K32_GNC_LDS = K32_GNC_MAXP * 16 + K32_GNC_MAXC * 8;
+constexpr int K32_GNC_MAXC = 1024, K32_GNC_MAXP = K32_GNC_MAXC / 2 + 32, K32_GNC_LDS = K32_GNC_MAXP * 32 + K32_GNC_MAXC * 8;
 
 template <int TH, int WN, int PREC, int NW_ = 8>
 struct ConvK32Cfg {
@@ -205,12 +205,14 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_k32_kernel(const ConvParams p
   const int nk16 = p.Cin_pad / 16;
   const int nkr = RIDER ? p.nkr / 2 : 0;
   // ---- GNC: the scale / shift table of this workgroup's main chunks [gnc_lo, gnc_hi) in LDS behind the halo buffers ----
-  double* gnc_pr = reinterpret_cast<double*>(smem_k + Cfg::LDS_BYTES);                  // [pairs][2]
-  float* gnc_sc = reinterpret_cast<float*>(smem_k + Cfg::LDS_BYTES + K32_GNC_MAXP * 16);   // [channels]
+  double* gnc_pr = reinterpret_cast<double*>(smem_k + Cfg::LDS_BYTES);                  // [pairs][shard half][2]
+  float* gnc_sc = reinterpret_cast<float*>(smem_k + Cfg::LDS_BYTES + K32_GNC_MAXP * 32);   // [channels]
   float* gnc_sh = gnc_sc + K32_GNC_MAXC;
   int gnc_lo = 0, gnc_hi = 0, gnc_cpg = 1, gnc_q0 = 0, gnc_q1 = 0;
-  constexpr int GNC_PT = (K32_GNC_MAXP + Cfg::NT - 1) / Cfg::NT;   // pairs per thread (2 at 512 threads)
-  uint4 gnc_ld[GNC ? GNC_PT : 1][GSUM_SHARDS];
+  constexpr int GNC_PT = (2 * K32_GNC_MAXP + Cfg::NT - 1) / Cfg::NT;   // units per thread: a unit = one pair x four of its eight shards
+  uint4 gnc_ld[GNC ? GNC_PT : 1][GSUM_SHARDS / 2];
+  constexpr int GNC_CT = (K32_GNC_MAXC + Cfg::NT - 1) / Cfg::NT;   // channels per thread
+  float gnc_gam[GNC ? GNC_CT : 1], gnc_bet[GNC ? GNC_CT : 1];      // (fetched with the table: one round trip, not two)
   auto gnc_issue = [&](int c_lo, int c_hi) __attribute__((always_inline)) {   // every load of the table in flight (beside the weights and the first chunk)
     gnc_lo = c_lo; gnc_hi = c_hi;
     gnc_cpg = Cin / p.gs_G;
@@ -218,42 +220,52 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_k32_kernel(const ConvParams p
     gnc_q1 = ((c_hi - 1) / gnc_cpg + 1) * gnc_cpg / 2;             // boundaries and the concat seam: 384 channels = 32 groups of 12)
 #pragma unroll
     for (int j = 0; j < GNC_PT; ++j) {
-      const int qc = min(gnc_q0 + tid + j * Cfg::NT, gnc_q1 - 1);  // (clamped: unconditional loads)
+      const int u = tid + j * Cfg::NT, qc = min(gnc_q0 + (u >> 1), gnc_q1 - 1);  // (clamped: unconditional loads)
       const bool first = qc < (p.C0 >> 1);
       const unsigned long long* tab = first ? p.gs0 : p.gs1;
-      const size_t idx = ((size_t)n * ((first ? p.C0 : p.C1) >> 1) + (first ? qc : qc - (p.C0 >> 1))) * (GSUM_SHARDS * 2);
+      const int np = (first ? p.C0 : p.C1) >> 1, ql = first ? qc : qc - (p.C0 >> 1);
 #pragma unroll
-      for (int sdx = 0; sdx < GSUM_SHARDS; ++sdx) gnc_ld[j][sdx] = *reinterpret_cast<const uint4*>(tab + idx + 2 * sdx);
+      for (int sdx = 0; sdx < GSUM_SHARDS / 2; ++sdx)
+        gnc_ld[j][sdx] = *reinterpret_cast<const uint4*>(tab + (((size_t)n * GSUM_SHARDS + (u & 1) * (GSUM_SHARDS / 2) + sdx) * np + ql) * 2);
+    }
+#pragma unroll
+    for (int j = 0; j < GNC_CT; ++j) {
+      const int cc = min(c_lo + tid + j * Cfg::NT, c_hi - 1);
+      gnc_gam[j] = p.gs_gamma[cc];
+      gnc_bet[j] = p.gs_beta[cc];
     }
   };
   auto gnc_finish = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < GNC_PT; ++j) {
-      const int qi = gnc_q0 + tid + j * Cfg::NT;
+      const int u = tid + j * Cfg::NT, qi = gnc_q0 + (u >> 1);
       long long a = 0, b = 0;
 #pragma unroll
-      for (int sdx = 0; sdx < GSUM_SHARDS; ++sdx) {
+      for (int sdx = 0; sdx < GSUM_SHARDS / 2; ++sdx) {
         a += (long long)(((unsigned long long)gnc_ld[j][sdx].y << 32) | gnc_ld[j][sdx].x);
         b += (long long)(((unsigned long long)gnc_ld[j][sdx].w << 32) | gnc_ld[j][sdx].z);
       }
-      if (qi < gnc_q1) {
-        gnc_pr[2 * (qi - gnc_q0)] = (double)a * (1.0 / (double)(1 << GSUM_BITS1));
-        gnc_pr[2 * (qi - gnc_q0) + 1] = (double)b * (1.0 / (double)(1 << GSUM_BITS2));
+      if (qi < gnc_q1) {   // (integer sums of four shards: exact; the two halves of a pair meet as doubles below)
+        gnc_pr[2 * u] = (double)a * (1.0 / (double)(1 << GSUM_BITS1));
+        gnc_pr[2 * u + 1] = (double)b * (1.0 / (double)(1 << GSUM_BITS2));
       }
     }
     __syncthreads();
     const double inv = 1.0 / ((double)gnc_cpg * (double)p.Hin * (double)p.Win);
-    for (int c = gnc_lo + tid; c < gnc_hi; c += Cfg::NT) {   // (as gn_finalize_kernel: fp64 statistics, fp32 scale / shift)
+#pragma unroll
+    for (int j = 0; j < GNC_CT; ++j) {   // (as gn_finalize_kernel: fp64 statistics, fp32 scale / shift)
+      const int c = gnc_lo + tid + j * Cfg::NT;
+      if (c >= gnc_hi) break;
       const int g = c / gnc_cpg, hp = gnc_cpg >> 1;
       double s1 = 0.0, s2 = 0.0;
-      for (int k = 0; k < hp; ++k) { s1 += gnc_pr[2 * (g * hp + k - gnc_q0)]; s2 += gnc_pr[2 * (g * hp + k - gnc_q0) + 1]; }
+      for (int k = 0; k < 2 * hp; ++k) { s1 += gnc_pr[2 * (2 * (g * hp - gnc_q0) + k)]; s2 += gnc_pr[2 * (2 * (g * hp - gnc_q0) + k) + 1]; }   // (pair, shard half) units
       const double mean = s1 * inv;
       double var = s2 * inv - mean * mean;
       var = var < 0.0 ? 0.0 : var;
       const double rstd = 1.0 / sqrt(var + (double)p.gs_eps);
-      const float scv = (float)rstd * p.gs_gamma[c];
+      const float scv = (float)rstd * gnc_gam[j];
       gnc_sc[c - gnc_lo] = scv;
-      gnc_sh[c - gnc_lo] = p.gs_beta[c] - (float)mean * scv;
+      gnc_sh[c - gnc_lo] = gnc_bet[j] - (float)mean * scv;
     }
     __syncthreads();
   };
@@ -832,7 +844,7 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_k32_kernel(const ConvParams p
     }
     if (p.gsum_out) {   // the consumer-side GroupNorm: even threads add their channel pair's sums (Cout is even: launcher)
       const float a2 = a_keep + __shfl_xor(a_keep, 1, 64), b2 = b_keep + __shfl_xor(b_keep, 1, 64);
-      if (tid < BN && !(tid & 1) && co0 + tid < p.Cout) gsum_add(p.gsum_out, n, p.Cout >> 1, (co0 + tid) >> 1, ty * tilesX + tx, a2, b2);
+      if (tid < BN && !(tid & 1) && co0 + tid < p.Cout) gsum_add(p.gsum_out, n, p.Cout >> 1, (co0 + tid) >> 1, xcc_id(), a2, b2);
     }
   }
 }
@@ -1128,7 +1140,7 @@ __global__ void __launch_bounds__(512, 2) conv_up2_k32_kernel(const ConvParams p
     }
     if (p.gsum_out) {   // the consumer-side GroupNorm (as conv_k32_kernel)
       const float a2 = a_keep + __shfl_xor(a_keep, 1, 64), b2 = b_keep + __shfl_xor(b_keep, 1, 64);
-      if (tid < BN && !(tid & 1) && co0 + tid < p.Cout) gsum_add(p.gsum_out, n, p.Cout >> 1, (co0 + tid) >> 1, (ty * tilesX + tx) * 2 + py, a2, b2);
+      if (tid < BN && !(tid & 1) && co0 + tid < p.Cout) gsum_add(p.gsum_out, n, p.Cout >> 1, (co0 + tid) >> 1, xcc_id(), a2, b2);
     }
   }
 }

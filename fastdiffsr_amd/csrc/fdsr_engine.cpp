@@ -771,6 +771,32 @@ int make_shape_plan(fdsr_handle h, int N, int H, int W, ShapePlan* sp) {
       off += align_up((size_t)N * (h->tensors[t].C / 2) * GSUM_SHARDS * 2 * sizeof(unsigned long long), 256);
     }
   sp->gsum_bytes = off - sp->off_gsum;
+  // which tensors are read by a GroupNorm'd conv that lands on a consumer-side kernel at this shape (a pure function of the shapes, as
+  // the split factor above): only their producers add pair sums (a large batch's producers would add them for nobody)
+  for (int prec = PREC_F16X3; prec <= PREC_BF16; ++prec) {
+    sp->gsum_wanted[prec].assign(h->tensors.size(), 0);
+    for (size_t i = 0; i < h->ops.size(); ++i) {
+      const Op& op = h->ops[i];
+      if (op.kind != Op::CONV || op.gn_slot < 0 || op.ck != CONV3_S1 || !h->weights[op.w].h_ok || op.gn_plain) continue;
+      const WeightEntry& w = h->weights[op.w];
+      ConvParams q{};
+      q.N = N; q.Hin = q.Hout = H >> op.lvl_out; q.Win = q.Wout = W >> op.lvl_out;
+      q.C0 = op.C0; q.C1 = op.C1; q.Cout = op.Cout; q.Cin_pad = w.h_cin_pad; q.Cout_pad = w.h_cout_pad;
+      q.ksplit = sp->op_ksplit[i];
+      q.gs_G = h->cfg.norm_groups;
+      q.gs_gamma = q.gs_beta = reinterpret_cast<const float*>(sp);      // (non-null stand-ins: only the shape fields are read)
+      q.gs0 = reinterpret_cast<const unsigned long long*>(sp);
+      q.res = op.res >= 0 ? reinterpret_cast<const float*>(sp) : nullptr;
+      if (op.rider >= 0) {                                               // (a rider changes which forms take the launch)
+        const Op& kr = h->ops[op.rider];
+        q.xr0 = reinterpret_cast<const float*>(sp); q.Cr0 = kr.C0; q.Cr1 = kr.C1; q.nkr = h->weights[kr.w].h_cin_pad / 16;
+        q.res = nullptr;
+      }
+      if (!conv_h_gnc_ok(op.ck, prec, q)) continue;
+      sp->gsum_wanted[prec][op.src0] = 1;
+      if (op.src1 >= 0) sp->gsum_wanted[prec][op.src1] = 1;
+    }
+  }
   const size_t arena0 = off;
   sp->tensor_off.assign(h->tensors.size(), 0);
   sp->part_off.assign(h->tensors.size(), 0);
@@ -875,10 +901,13 @@ int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, 
   }
   // consumer-side GroupNorm: sampling forwards of the 16-bit modes only (a training forward keeps the statistics for its backward, a debug
   // forward keeps every layer); the producers' tables start from zero
+  bool gsum_any = false;
+  if (h->prec != PREC_F32)
+    for (char c : sp.gsum_wanted[h->prec]) gsum_any |= c != 0;
   const bool gsum_on = g_tun.gn_consumer && h->prec != PREC_F32 && !h->training && !h->keep_stats && !h->debug && sp.gsum_bytes > 0 &&
-                       !(g_tun.knockout & 1);
+                       gsum_any && !(g_tun.knockout & 1);
   auto GSUM = [&](int t) -> unsigned long long* {
-    return (gsum_on && t >= 0 && sp.gsum_off[t]) ? reinterpret_cast<unsigned long long*>(ws + sp.gsum_off[t]) : nullptr;
+    return (gsum_on && t >= 0 && sp.gsum_off[t] && sp.gsum_wanted[h->prec][t]) ? reinterpret_cast<unsigned long long*>(ws + sp.gsum_off[t]) : nullptr;
   };
   std::fill(sp.tensor_gsum.begin(), sp.tensor_gsum.end(), 0);
   if (gsum_on) HIPCHK(h, hipMemsetAsync(ws + sp.off_gsum, 0, sp.gsum_bytes, st));

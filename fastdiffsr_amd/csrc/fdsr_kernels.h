@@ -74,10 +74,13 @@ struct ConvParams {
   float gb_drop;                     // 1/(1-p)
   // GroupNorm statistics WITHOUT a finalisation launch (small grids, where a dependent launch costs ~5 us whatever it does -- 45 of the 139
   // launches of a B = 1 step were gn_finalize): a producer adds the (sum, sum of squares) of every channel PAIR of its output tile, as
-  // fixed-point int64 (GSUM_BITS1 / GSUM_BITS2 fraction bits; integer adds commute, so a rerun is bitwise identical), to one of
-  // GSUM_SHARDS shards of the tensor's table gsum[n][pair][shard][2] with agent-scope atomics; the consumer (the MB = 2 instantiations of
-  // conv_k32_kernel, GNC) folds the pairs of the groups its K slice touches and forms scale / shift itself, in an LDS table, in its
-  // prologue.  Pair granularity: a skip tensor is normalised under two groupings (alone, and concatenated behind another tensor).
+  // fixed-point int64 (GSUM_BITS1 / GSUM_BITS2 fraction bits; integer adds commute, so a rerun is bitwise identical), to ITS XCD's
+  // shard of the tensor's table gsum[n][xcd][pair][2] -- an atomic that the XCD's own L2 executes (every adder of a shard runs on that
+  // XCD; the kernel boundary writes the lines back).  Agent-scope atomics, which execute at the memory side, serialised: 64 adders
+  // per word took splitk_reduce from 7.4 to 17.2 us per launch (profiles/r06_b1_gn_consumer_agent_atomics_per_kernel.txt).  The consumer
+  // (the MB = 2 instantiations of conv_k32_kernel, GNC) folds the shards and the pairs of the groups its K slice touches and forms
+  // scale / shift itself, in an LDS table, in its prologue.  Pair granularity: a skip tensor is normalised under two groupings (alone,
+  // and concatenated behind another tensor).
   unsigned long long* gsum_out;      // producer side: this launch's output tensor's table, or null
   const unsigned long long* gs0;     // consumer side: the tables of x0 / x1 (gs0 null: scale / shift come from gn_scale / gn_shift)
   const unsigned long long* gs1;
@@ -86,7 +89,7 @@ struct ConvParams {
   float gs_eps;
   int gs_G;                          // groups over the C0 + C1 concatenated channels
 };
-enum { GSUM_SHARDS = 4, GSUM_BITS1 = 16, GSUM_BITS2 = 12 };
+enum { GSUM_SHARDS = 8, GSUM_BITS1 = 16, GSUM_BITS2 = 12 };   // shards = XCDs
 // producer epilogues: v = (sum, sumsq) of one channel pair over this workgroup's pixels -> the table (fdsr_act_io.h: gsum_add)
 
 enum Precision { PREC_F32 = 0, PREC_F16X3 = 1, PREC_BF16 = 2 };

@@ -1,12 +1,12 @@
-# Round-5 evidence, collected on the GPU box into gpurun_out/r05 (copy what is to be judged into profiles/):
-#   gpurun --timeout 3000 -- 'bash tools/refresh_profiles_r05.sh'
+# Round-6 evidence, collected on the GPU box into gpurun_out/r06 (copy what is to be judged into profiles/):
+#   gpurun --timeout 3000 -- 'bash tools/refresh_profiles_r06.sh'
 # Every figure of the driver's bench line gets a rocprofv3 file made by the SAME bench.py command (program directly after `--`),
 # so each `frac` can be recomputed from profiles/: kernel stats for the headline (f16x3 B=16) and for every sub-record regime
 # (exact f32 B=16, bf16 B=64 + hipGraph, f16x3 B=1 + hipGraph, both training steps), PMC utilisation + a wave-cycle breakdown for
 # f16x3 B=16 and bf16 B=64, and the HBM traffic passes.  Counters are collected in runs of their own (no trace domains but
 # --kernel-trace).  Every step is bounded by `timeout` and reads nothing from stdin.
 set -x
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r05; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r06; mkdir -p $O
 cd $R
 python -c "import __graft_entry__ as g; g.build()" > $O/build.log 2>&1 < /dev/null
 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd.json 2> $O/bench_driver_cmd.err < /dev/null
