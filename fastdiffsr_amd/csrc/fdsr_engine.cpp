@@ -899,12 +899,13 @@ int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, 
     int rc = fill_temb(h, reinterpret_cast<float*>(ws + sp.off_temb), N, nl_dev, nl_scalar, st);
     if (rc) return rc;
   }
-  // consumer-side GroupNorm: sampling forwards of the 16-bit modes only (a training forward keeps the statistics for its backward, a debug
-  // forward keeps every layer); the producers' tables start from zero
+  // consumer-side GroupNorm: sampling forwards of the 16-bit modes only (a training forward keeps the statistics for its backward; a debug
+  // forward -- every layer in a buffer of its own -- takes the same kernels as a plain one, so the two stay bitwise equal); the
+  // producers' tables start from zero
   bool gsum_any = false;
   if (h->prec != PREC_F32)
     for (char c : sp.gsum_wanted[h->prec]) gsum_any |= c != 0;
-  const bool gsum_on = g_tun.gn_consumer && h->prec != PREC_F32 && !h->training && !h->keep_stats && !h->debug && sp.gsum_bytes > 0 &&
+  const bool gsum_on = g_tun.gn_consumer && h->prec != PREC_F32 && !h->training && !h->keep_stats && sp.gsum_bytes > 0 &&
                        gsum_any && !(g_tun.knockout & 1);
   auto GSUM = [&](int t) -> unsigned long long* {
     return (gsum_on && t >= 0 && sp.gsum_off[t] && sp.gsum_wanted[h->prec][t]) ? reinterpret_cast<unsigned long long*>(ws + sp.gsum_off[t]) : nullptr;
