@@ -21,6 +21,19 @@ eng = Engine(cfg); eng.load_state_dict(sd)
 bufs, sp = schedule_buffers(FASTDIFFSR_SCHEDULE_VAL); eng.set_schedule(sampling_scalars(bufs, sp))
 dt, _, _, _ = bench.run_config(eng, dev, 'f16x3', 1, 256, 40, 5, True, 'engine', want_profile=False)
 print('engine b1 graph: %.2f ms / image' % (1e3 * dt / 40))
+# the same replays with the GPU left idle for a few milliseconds in between, as a val loop leaves it (host post-processing of the image):
+# does the clock the chip holds depend on the gap?
+from fastdiffsr_amd.synth import synth_inputs
+cond, _ = synth_inputs(1, 256, 256, 1)
+cond = cond.to(dev); out = torch.empty(1, 3, 256, 256, device=dev)
+eng.set_precision('f16x3'); eng.set_seed(1)
+for gap in (0.0, 0.002, 0.005):
+    ts = []
+    for i in range(25):
+        torch.cuda.synchronize(); time.sleep(gap)
+        t0 = time.perf_counter(); eng.sample(cond, None, out=out, graph=True); torch.cuda.synchronize()
+        if i >= 5: ts.append(time.perf_counter() - t0)
+    print('engine b1 graph, %.0f ms idle before every replay: %.2f ms / image' % (1e3 * gap, 1e3 * sum(ts) / len(ts)))
 root = tempfile.mkdtemp(prefix='fdsr_b1_')
 try:
     bench.synth_folder(root, 48)
