@@ -131,3 +131,33 @@ def test_staging_ring_slots_are_owned_until_uploaded():
     assert not t.is_alive()
     assert (ops.to_device(got['late']).cpu().numpy() == 77).all()
     assert (ops.to_device(other).cpu().numpy() == 99).all()
+
+
+def test_landing_and_staging_rings_are_built_once_and_released():
+    """HipOps.land keeps ONE ring of three pinned buffers per (tag, shape, dtype) (round 6: `dict.setdefault` built -- and pinned -- a new
+    ring on every call: 4.8 ms of hipHostMalloc per B = 1 image); staging rings are named by a token that is never reused and go
+    away with release(owner); a loader that finds no free buffer raises instead of waiting for ever."""
+    import numpy as np
+    import torch
+    from fastdiffsr_amd import val
+    ops = val.HipOps('cuda')
+    t = torch.arange(2 * 4 * 4 * 3, dtype=torch.uint8, device='cuda').view(2, 4, 4, 3)
+    a = ops.land('sr', 1, t)
+    ring = ops._down[('sr', (2, 4, 4, 3), torch.uint8)]
+    b = ops.land('sr', 1, t + 1)
+    torch.cuda.synchronize()
+    assert a is b and ops._down[('sr', (2, 4, 4, 3), torch.uint8)] is ring and len(ring) == 3 and all(x.is_pinned() for x in ring)
+    assert (b.numpy().reshape(-1)[:5] == np.arange(1, 6)).all()
+    o1, o2 = ops.new_owner(), ops.new_owner()
+    assert o2 > o1
+    ops.to_device(ops.stage_host('HR', np.zeros((1, 4, 4, 3), np.uint8), owner=o1))
+    ops.to_device(ops.stage_host('HR', np.zeros((1, 4, 4, 3), np.uint8), owner=o2))
+    assert {k[0] for k in ops._up} == {o1, o2}
+    ops.release(o1)
+    assert {k[0] for k in ops._up} == {o2}
+    ops.STAGE_TIMEOUT = 0.2
+    held = [ops.stage_host('HR', np.zeros((1, 4, 4, 3), np.uint8), owner=o2) for _ in range(ops.RING)]
+    with pytest.raises(RuntimeError, match='never uploaded'):
+        ops.stage_host('HR', np.zeros((1, 4, 4, 3), np.uint8), owner=o2)
+    for h in held:
+        ops.to_device(h)
