@@ -118,3 +118,28 @@ def p_losses(sd, cfg, tab, hr: Tensor, sr: Tensor, t: Tensor, noise: Tensor) -> 
     x_t = a * hr + s * noise
     rec = unet_forward(sd, cfg, torch.cat([x_t, sr], dim=1), t)
     return F.mse_loss(rec, hr, reduction='sum')
+
+
+def train_step(sd, cfg: UNetConfig, tab, hr: Tensor, sr: Tensor, t: Tensor, noise: Tensor, lr: float, betas=(0.9, 0.999),
+               eps: float = 1e-8):
+    """DDPM.optimize_parameters (model/model.py:47-57) on the GDP sibling from fresh Adam state: l_pix = p_losses(...).sum() /
+    (b*c*h*w), backward by autograd over the restated forward, one Adam step.  Dropout off.  Returns (l_pix, grads {key: Tensor},
+    new_sd {key: Tensor}) as oracle.sr3_oracle.train_step."""
+    leaves = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()}
+    loss = p_losses(leaves, cfg, tab, hr, sr, t, noise)
+    b, c, h, w = hr.shape
+    l_pix = loss.sum() / int(b * c * h * w)
+    l_pix.backward()
+    grads = {k: v.grad for k, v in leaves.items() if v.grad is not None}
+    b1, b2 = betas
+    new_sd = {}
+    for k, w_ in sd.items():
+        g = grads.get(k)
+        if g is None:
+            new_sd[k] = w_.detach().clone()
+            continue
+        m = (1 - b1) * g
+        v = (1 - b2) * g * g
+        denom = (v.sqrt() / (1 - b2) ** 0.5) + eps
+        new_sd[k] = w_.detach() - (lr / (1 - b1)) * (m / denom)
+    return l_pix.detach(), grads, new_sd

@@ -483,6 +483,82 @@ def gdp_goldens():
     print('wrote gdp.npz: loss', loss.item(), 'frames', frames.shape)
 
 
+def gdp_train_goldens():
+    """(xiv) one optimisation step of the reference's GDP sibling (model/gdp_modules; DDPM.optimize_parameters, model.py:47-57 ->
+    gdp_modules/diffusion.py:277-299: the summed MSE between UNet(cat[q_sample(HR, t), SR], t) and HR) on the GDP test network of
+    gdp.npz (model_channels 64, mults 1-2-2, up/down ResBlocks, 2- and 2-head attention at 16 x 16 and 8 x 8), dropout off, fixed t
+    and noise: the loss, a (sum, sum of squares) pair for EVERY gradient, eleven named gradients in full (the input conv, a down ResBlock's conv,
+    an up ResBlock's norms / conv bias / scale-shift Linear bias, the attention's qkv / proj_out / norm, the time MLP) and those tensors after the
+    step.  Pins autograd over oracle/gdp_oracle.py, which the GPU tests then hold the engine's backward against."""
+    from unittest import mock
+    import_reference()
+    tvt, tvf = types.ModuleType('torchvision.transforms'), types.ModuleType('torchvision.transforms.functional')
+    tvt.functional = tvf
+    sys.modules.setdefault('torchvision.transforms', tvt)
+    sys.modules.setdefault('torchvision.transforms.functional', tvf)
+    sys.modules['torchvision'].transforms = sys.modules['torchvision.transforms']
+    from model.gdp_modules import diffusion as gdiff, unet as gunet
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    cfg = UNetConfig(in_channel=6, out_channel=3, inner_channel=64, norm_groups=32, channel_mults=(1, 2, 2), attn_res=(2, 4),
+                     res_blocks=1, dropout=0.1, image_size=32, variant='gdp')
+    net = gunet.UNet(image_size=32, in_channel=6, model_channels=64, out_channel=3, res_blocks=1, attention_resolutions=(2, 4),
+                     dropout=0.1, channel_mults=(1, 2, 2), inner_channel=64, norm_groups=32, attn_res=(16,))
+    sd = synth_state_dict(cfg, 13)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    sched = dict(schedule='linear', n_timestep=8, linear_start=1e-4, linear_end=2e-2)
+    G = gdiff.GaussianDiffusion(net, image_size=32, channels=3, loss_type='l1', conditional=True, schedule_opt=sched)
+    G.set_loss('cpu')
+    G.set_new_noise_schedule(sched, 'cpu')
+    G.eval()                                            # dropout off; everything else as in training
+    g = torch.Generator().manual_seed(84)
+    hr = torch.rand(2, 3, 32, 32, generator=g) * 2 - 1
+    sr = (hr + 0.2 * torch.randn(2, 3, 32, 32, generator=g)).clamp(-1, 1)
+    nz = torch.randn(2, 3, 32, 32, generator=g)
+    t = torch.tensor([6, 1], dtype=torch.long)
+    lr = 1e-4
+    opt = torch.optim.Adam(list(G.parameters()), lr=lr)
+    opt.zero_grad()
+    with mock.patch.object(torch, 'randint', lambda *a, **k: t):
+        l_pix = G({'HR': hr, 'SR': sr, 'LR': sr}, noise=nz)
+    b, c, h, w = hr.shape
+    l_pix = l_pix.sum() / int(b * c * h * w)
+    l_pix.backward()
+    named = dict(G.named_parameters())
+    layers = gdp_layers_of(cfg)
+    down = [L.name for L in layers if L.kind == 'res' and L.mode == 'down'][0]
+    up = [L.name for L in layers if L.kind == 'res' and L.mode == 'up'][0]
+    attn = [L.name for L in layers if L.kind == 'attn'][0]
+    full = ['input_blocks.0.0.weight', down + '.in_layers.2.weight', up + '.in_layers.0.weight', up + '.in_layers.2.bias',
+            up + '.emb_layers.1.bias', up + '.out_layers.0.weight', attn + '.qkv.weight', attn + '.proj_out.weight',
+            attn + '.norm.weight', 'time_embed.0.weight', 'time_embed.2.bias']
+    out = {'hr': hr.numpy(), 'sr': sr.numpy(), 'noise': nz.numpy(), 't': t.numpy(), 'lr': np.array(lr),
+           'l_pix': np.array(l_pix.item(), dtype=np.float64), 'weights_sha256': np.array(state_dict_sha256(sd)),
+           'full_keys': np.array(full)}
+    names, stats = [], []
+    for k, p_ in named.items():
+        if p_.grad is None:
+            continue
+        names.append(k[len('denoise_fn.'):])
+        g64 = p_.grad.double()
+        stats.append([g64.sum().item(), (g64 * g64).sum().item()])
+    out['grad_keys'] = np.array(names)
+    out['grad_stats'] = np.array(stats, dtype=np.float64)
+    for k in full:
+        out['grad/' + k] = named['denoise_fn.' + k].grad.numpy().copy()
+    opt.step()
+    for k in full:
+        out['after/' + k] = named['denoise_fn.' + k].detach().numpy().copy()
+    out['n_params_without_grad'] = np.array(sum(1 for p_ in named.values() if p_.grad is None))
+    np.savez_compressed(os.path.join(OUT, 'gdp_train_step.npz'), **out)
+    print('wrote gdp_train_step.npz: l_pix', l_pix.item(), 'tensors with grad', len(names), 'without', int(out['n_params_without_grad']))
+
+
+def gdp_layers_of(cfg):
+    from fastdiffsr_amd.gdp.arch import gdp_layers
+    return gdp_layers(cfg)
+
+
 def tesr_goldens():
     """(xi) TESR sibling (model/tesr_modules): UNet forwards incl. the SelfAttention levels, the sampler
     (continous=True frames and the final image) and the Charbonnier training-loss value, from the reference itself."""
@@ -703,6 +779,8 @@ if __name__ == '__main__':
         metric_goldens()          # only tests/golden/metrics_ssim.npz
     elif len(sys.argv) > 1 and sys.argv[1] == 'gdp':
         gdp_goldens()             # only tests/golden/gdp.npz
+    elif len(sys.argv) > 1 and sys.argv[1] == 'gdp_train':
+        gdp_train_goldens()       # only tests/golden/gdp_train_step.npz
     elif len(sys.argv) > 1 and sys.argv[1] == 'init':
         init_goldens()            # only tests/golden/init_weights.npz
     elif len(sys.argv) > 1 and sys.argv[1] == 'tesr_train':
@@ -720,4 +798,5 @@ if __name__ == '__main__':
         tesr_train_goldens()
         init_goldens()
         gdp_goldens()
+        gdp_train_goldens()
         metric_goldens()

@@ -347,6 +347,38 @@ def test_sr3_training_step_matches_reference(golden_dir):
         assert np.abs(aft - ref_aft).max() <= 2.1 * float(g['lr']), k
 
 
+def test_gdp_training_step_matches_reference(golden_dir):
+    """oracle.gdp_oracle.train_step vs one optimisation step of the reference's GDP sibling itself (gdp_modules p_losses :277-299: the
+    summed MSE against HR, then model.py:47-57; golden made by `oracle/make_goldens.py gdp_train`): loss, every gradient (sum / sum of
+    squares per tensor; eleven in full: up / down ResBlocks, the scale-shift Linear, multi-head attention, the time MLP), Adam."""
+    from oracle import gdp_oracle as GO
+    g = _load(golden_dir, 'gdp_train_step.npz')
+    cfg = UNetConfig(in_channel=6, out_channel=3, inner_channel=64, norm_groups=32, channel_mults=(1, 2, 2), attn_res=(2, 4),
+                     res_blocks=1, dropout=0.1, image_size=32, variant='gdp')
+    sd_np = synth_state_dict(cfg, 13)
+    assert state_dict_sha256(sd_np) == str(g['weights_sha256'])
+    sd = O.to_torch_sd(sd_np)
+    tab = O.schedule_tables(dict(schedule='linear', n_timestep=8, linear_start=1e-4, linear_end=2e-2))
+    hr, sr, nz = (torch.from_numpy(g[k]) for k in ('hr', 'sr', 'noise'))
+    t = torch.from_numpy(g['t']).long()
+    l_pix, grads, new_sd = GO.train_step(sd, cfg, tab, hr, sr, t, nz, lr=float(g['lr']))
+    assert abs(l_pix.item() - float(g['l_pix'])) <= 1e-6 * abs(float(g['l_pix']))
+    keys = [str(k) for k in g['grad_keys']]
+    assert sorted(keys) == sorted(grads.keys()) and int(g['n_params_without_grad']) == 0
+    for k, (s1, s2) in zip(keys, g['grad_stats']):
+        g64 = grads[k].double()
+        scale = max(np.sqrt(s2), 1e-12)
+        assert abs(g64.sum().item() - s1) <= 2e-4 * scale + 1e-9, k
+        assert abs((g64 * g64).sum().item() - s2) <= 2e-4 * s2 + 1e-18, k
+    for k in (str(x) for x in g['full_keys']):
+        ref = g['grad/' + k]
+        assert np.abs(grads[k].numpy() - ref).max() <= 2e-4 * np.abs(ref).max() + 1e-9, k
+        aft, ref_aft = new_sd[k].numpy(), g['after/' + k]
+        mask = np.abs(ref) > 1e-3 * np.abs(ref).max()
+        assert np.abs(aft - ref_aft)[mask].max() <= 2e-7, k
+        assert np.abs(aft - ref_aft).max() <= 2.1 * float(g['lr']), k
+
+
 def test_tesr_training_step_matches_reference(golden_dir):
     """oracle.tesr_oracle.train_step vs one optimisation step of the reference's TESR sibling itself (tesr_modules p_losses :224-250,
     Charbonnier mean, then model.py:47-57; golden made by `oracle/make_goldens.py tesr_train`)."""
