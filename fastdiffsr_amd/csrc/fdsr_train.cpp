@@ -54,7 +54,14 @@ int make_train_plan(fdsr_handle h, int N, int H, int W, TrainPlan* tp) {
   size_t tmpA = 256, tmpZ = 256, wg = 256, csb = 256, dbl = 256, attn = 256;
   int maxC = 8;
   for (const Op& op : h->ops) {
-    if (op.kind == Op::ATTN) attn = std::max(attn, attn_bwd_scratch_floats(N, (H >> op.lvl_in) * (W >> op.lvl_in)) * sizeof(float));
+    if (op.kind == Op::ATTN)
+      attn = std::max(attn, attn_bwd_scratch_floats(N, (H >> op.lvl_in) * (W >> op.lvl_in), op.heads) * sizeof(float));
+    if (op.kind == Op::POOL2 && op.gn_slot >= 0) {   // GDP down ResBlock: the pooled gradient spread back to the fine grid, then GroupNorm backward
+      const int Hi = H >> op.lvl_in, Wi = W >> op.lvl_in;
+      tmpA = std::max(tmpA, (size_t)N * Hi * Wi * op.C0 * sizeof(float));
+      dbl = std::max(dbl, gn_bwd_scratch_doubles(N, Hi, Wi, op.C0) * sizeof(double));
+      maxC = std::max(maxC, op.C0);
+    }
     if (op.kind == Op::SLAM) {
       const int hw = (H >> op.lvl_in) * (W >> op.lvl_in);
       csb = std::max(csb, clam_slam_bwd_scratch_floats(N, hw, op.C0, op.C0 / 16) * sizeof(float));
@@ -67,6 +74,7 @@ int make_train_plan(fdsr_handle h, int N, int H, int W, TrainPlan* tp) {
     const size_t fine = (size_t)(op.ck == CONV3_UP ? Ho * Wo : Hi * Wi);
     tmpA = std::max(tmpA, (size_t)N * fine * Cin * sizeof(float));
     if (op.ck == CONV3_S2) tmpZ = std::max(tmpZ, (size_t)N * Hi * Wi * op.Cout * sizeof(float));
+    if (op.ck == CONV3_UP && op.gn_slot >= 0) tmpZ = std::max(tmpZ, (size_t)N * Hi * Wi * Cin * sizeof(float));   // GDP up ResBlock
     wg = std::max(wg, wgrad_scratch_floats(op.ck, N, Ho, Wo, Cin, op.Cout) * sizeof(float));
     dbl = std::max(dbl, colsum_scratch_doubles(N, Ho * Wo, std::max(op.Cout, 8)) * sizeof(double));
     if (op.gn_slot >= 0) dbl = std::max(dbl, gn_bwd_scratch_doubles(N, Hi, Wi, Cin) * sizeof(double));
@@ -77,12 +85,13 @@ int make_train_plan(fdsr_handle h, int N, int H, int W, TrainPlan* tp) {
   tp->off_tmpZ = take(tmpZ);
   tp->off_S = take((size_t)N * maxC * sizeof(float));
   tp->off_dtemb = take((size_t)N * h->TE * sizeof(float));
-  tp->off_dwn = take((size_t)h->TE * h->cfg.inner_channel * sizeof(float));
+  const int ic = h->cfg.inner_channel, enc_dim = h->gdp ? ic : 0, hid_dim = h->gdp ? 4 * ic : 0, t_dim = h->gdp ? 4 * ic : 0;
+  tp->off_dwn = take((size_t)h->TE * (t_dim ? t_dim : ic) * sizeof(float));
   tp->off_dbn = take((size_t)h->TE * sizeof(float));
   tp->off_dbl = take(dbl);
   tp->off_wg = take(wg);
   tp->off_csb = take(csb);
-  tp->off_tb = take((size_t)N * 11 * h->cfg.inner_channel * sizeof(float));
+  tp->off_tb = take((size_t)N * temb_bwd_scratch_floats_per_image(ic, enc_dim, hid_dim, t_dim) * sizeof(float));
   tp->off_loss = take(256);
   tp->off_attn = take(attn);
   tp->off_noise = off;                  // the target noise of a step whose noise the engine draws itself (fdsr_train_grads_pairs)
@@ -104,10 +113,8 @@ int conv_K(fdsr_handle h, const Op& op) { return op.dst == h->t_eps ? 8 : op.Cou
 
 int train_prepare(fdsr_handle h) {
   if (h->train_ready) return FDSR_OK;
-  // FastDiffSR, and the two siblings built from the same blocks plus SelfAttention: SR3 (ddpm_modules: integer time, Swish in front of the
-  // per-block Linear) and TESR.  GDP (another UNet: FiLM GroupNorms, pooled up/down ResBlocks, multi-head attention) samples only.
-  if (h->cfg.variant == FDSR_VARIANT_GDP)
-    return fail(h, FDSR_E_INVALID, "the training step is implemented for the FastDiffSR, SR3 (ddpm) and TESR variants, not for GDP");
+  // FastDiffSR; the two siblings built from the same blocks plus SelfAttention: SR3 (ddpm_modules: integer time, Swish in front of the
+  // per-block Linear) and TESR; and GDP (gdp_modules: scale-shift GroupNorms, pooled / nearest-upsampled ResBlocks, heads of 64 channels).
   for (const Op& op : h->ops)
     if (op.kind == Op::CONV && op.src0 != h->t_in && (conv_K(h, op) % 8 || (op.C0 % 16) || (op.C1 % 16)))
       return fail(h, FDSR_E_INVALID, "training needs channel counts that are multiples of 16 (layer %s)", op.name.c_str());
@@ -435,18 +442,49 @@ int train_grads_impl(fdsr_handle h, const float* x_nchw, const float* hr_nchw, c
   touched[h->t_eps] = 1;
 
   // ---- backward over the plan ----
+  std::vector<const Op*> gn_of_slot((size_t)std::max(h->n_gn_slots, 1), nullptr);   // the finalisation op of a slot: its gamma / beta, its scale-shift columns
+  for (const Op& o : h->ops)
+    if (o.kind == Op::GN_FINALIZE && o.gn_slot >= 0) gn_of_slot[o.gn_slot] = &o;
+  float* temb_tab = reinterpret_cast<float*>(ws + sp.off_temb);   // [N][TE]: the step's per-block embedding rows (run_unet filled it)
   for (int oi = (int)h->ops.size() - 1; oi >= 0; --oi) {
     const Op& op = h->ops[oi];
     const int Hi = H >> op.lvl_in, Wi = W >> op.lvl_in;
-    if (op.kind == Op::ATTN) {   // SelfAttention core (SR3 / TESR, n_head = 1): d qkv from d O; the qkv tensor has no other reader
-      if (op.heads != 1) return fail(h, FDSR_E_INVALID, "the attention backward is implemented for one head");
+    if (op.kind == Op::ATTN) {   // attention core (SR3 / TESR: one head; GDP: heads of 64 channels): d qkv from d O; the qkv tensor has no other reader
       if (!touched[op.dst]) return fail(h, FDSR_E_STATE, "internal: gradient read before it was written");
       AttnBwdParams a{};
       a.qkv = TP(op.src0); a.dO = GT(op.dst); a.dqkv = GT(op.src0);
       a.scratch = reinterpret_cast<float*>(ws + tp.off_attn);
-      a.N = N; a.HW = Hi * Wi; a.C = op.C0;
+      a.N = N; a.HW = Hi * Wi; a.C = op.C0; a.heads = op.heads;
       if (!first(op.src0)) return fail(h, FDSR_E_STATE, "internal: the qkv tensor has a second reader");
       HIPCHK(h, launch_attn_bwd(a, st));
+      continue;
+    }
+    if (op.kind == Op::UP2X) {   // GDP up ResBlock, x' = nearest-x2(x): the 2x2 sums of d x'
+      if (!touched[op.dst]) return fail(h, FDSR_E_STATE, "internal: gradient read before it was written");
+      HIPCHK(h, launch_pool2_add(GT(op.dst), GT(op.src0), N, Hi, Wi, op.C0, first(op.src0), st));
+      continue;
+    }
+    if (op.kind == Op::POOL2) {  // GDP down ResBlock: avg_pool2(x) (the skip path) or avg_pool2(silu(norm(x))) (the main path)
+      if (!touched[op.dst]) return fail(h, FDSR_E_STATE, "internal: gradient read before it was written");
+      if (op.gn_slot < 0) {
+        HIPCHK(h, launch_unpool2_add(GT(op.dst), GT(op.src0), N, Hi >> 1, Wi >> 1, op.C0, 0.25f, first(op.src0), st));
+        continue;
+      }
+      const Op* gn = gn_of_slot[op.gn_slot];
+      if (!gn) return fail(h, FDSR_E_STATE, "internal: pooled GroupNorm without its finalisation op");
+      HIPCHK(h, launch_unpool2_add(GT(op.dst), tmpA, N, Hi >> 1, Wi >> 1, op.C0, 0.25f, true, st));
+      GnBwdParams g{};
+      g.dA = tmpA; g.x0 = TP(op.src0); g.C0 = op.C0;
+      g.scale = reinterpret_cast<const float*>(ws + sp.gn_off[op.gn_slot]);
+      g.shift = g.scale + (size_t)N * op.C0;
+      g.stats = reinterpret_cast<const float*>(ws + sp.gn_stats_off[op.gn_slot]);
+      g.gamma = P(gn->gamma);
+      g.dx0 = GT(op.src0);
+      g.assign0 = first(op.src0) ? 1 : 0;
+      g.dgamma = DG(gn->gamma); g.dbeta = DG(gn->beta);
+      g.scratch = dbl;
+      g.N = N; g.HW = Hi * Wi; g.H = Hi; g.G = G;
+      HIPCHK(h, launch_gn_bwd(g, st));
       continue;
     }
     if (op.kind == Op::SLAM) {
@@ -514,12 +552,14 @@ int train_grads_impl(fdsr_handle h, const float* x_nchw, const float* hr_nchw, c
     };
     if (op.gn_slot >= 0) {
       GnBwdParams g{};
+      const Op* gn = gn_of_slot[op.gn_slot];
+      const bool up = op.ck == CONV3_UP;     // GDP up ResBlock: conv over nearest-x2(silu(norm(x))): dA is the 2x2 sum of the fine-grid gradient
       // f16x3: the first half of the GroupNorm backward (g = dA * dropout * swish'(u) and its per-tile channel sums) runs in the epilogue
       // of the launch that produces dA, where that launch is a 16x16x32 kernel
       int gb_tiles = 0;
       {
         const size_t qo = h->wtq_off0[op.w];
-        if (h->prec == PREC_F16X3 && qo != SIZE_MAX) {
+        if (h->prec == PREC_F16X3 && qo != SIZE_MAX && !up) {
           ConvParams gb{};
           gb.gb_x0 = TP(op.src0); gb.gb_x1 = TP(op.src1); gb.gb_C0 = op.C0; gb.gb_G = G; gb.gb_plain = op.gn_plain ? 1 : 0;
           gb.gb_scale = reinterpret_cast<const float*>(ws + sp.gn_off[op.gn_slot]);
@@ -533,8 +573,9 @@ int train_grads_impl(fdsr_handle h, const float* x_nchw, const float* hr_nchw, c
           if ((rc = launch_dgrad_h(h, op, dy, K, Ho, Wo, qo, Cin, tmpA, false, N, st, &gb, &gb_tiles))) return rc;
         } else if ((rc = dgrad(dy, Ho, Wo, 0, Cin, tmpA, false))) return rc;
       }
+      if (up) HIPCHK(h, launch_pool2_add(tmpA, tmpZ, N, Hi, Wi, Cin, true, st));
       if (gb_tiles > 0) { g.g_part = gn_bwd_tile_part(dbl); g.g_nt = gb_tiles; }
-      g.dA = tmpA; g.x0 = TP(op.src0); g.x1 = TP(op.src1); g.C0 = op.C0; g.C1 = op.C1;
+      g.dA = up ? tmpZ : tmpA; g.x0 = TP(op.src0); g.x1 = TP(op.src1); g.C0 = op.C0; g.C1 = op.C1;
       g.scale = reinterpret_cast<const float*>(ws + sp.gn_off[op.gn_slot]);
       g.shift = g.scale + (size_t)N * Cin;
       g.stats = reinterpret_cast<const float*>(ws + sp.gn_stats_off[op.gn_slot]);
@@ -548,6 +589,11 @@ int train_grads_impl(fdsr_handle h, const float* x_nchw, const float* hr_nchw, c
       if (sp.training && op.drop_slot >= 0) {
         g.drop_mask = reinterpret_cast<const unsigned char*>(ws + sp.drop_off[op.drop_slot]);
         g.drop_scale = 1.0f / (1.0f - h->cfg.dropout);
+      }
+      if (gn && gn->film_off >= 0) {          // scale-shift norm: (s, t) are columns of the embedding table, their gradient goes to dtemb
+        g.film = temb_tab + gn->film_off; g.film_stride = h->TE;
+        g.beta = P(op.beta);
+        g.dfilm = dtemb + gn->film_off; g.dfilm_stride = h->TE;
       }
       HIPCHK(h, launch_gn_bwd(g, st));
     } else if (op.ck == CONV3_S2) {
@@ -572,13 +618,15 @@ int train_grads_impl(fdsr_handle h, const float* x_nchw, const float* hr_nchw, c
     t.dwn = reinterpret_cast<float*>(ws + tp.off_dwn); t.dbn = reinterpret_cast<float*>(ws + tp.off_dbn);
     t.scratch = reinterpret_cast<float*>(ws + tp.off_tb);
     t.inner = h->cfg.inner_channel; t.TE = h->TE; t.N = N;
-    t.swish_block = h->sr3 ? 1 : 0;
+    t.swish_block = (h->sr3 || h->gdp) ? 1 : 0;
+    if (h->gdp) { t.enc_dim = t.inner; t.hid_dim = t.t_dim = 4 * t.inner; t.cos_first = 1; }
+    const int t_dim = t.t_dim ? t.t_dim : t.inner;
     HIPCHK(h, launch_temb_bwd(t, st));
     for (int i = 0; i < h->n_schema; ++i) {               // scatter the concatenated tables back to the per-block tensors
       const WeightEntry& w = h->weights[i];
       if (!w.live) continue;
       if (w.sink == WeightEntry::NOISE_W)
-        HIPCHK(h, hipMemcpyAsync(DG(i), t.dwn + (size_t)w.row_off * t.inner, numel(w.shape) * sizeof(float), hipMemcpyDeviceToDevice, st));
+        HIPCHK(h, hipMemcpyAsync(DG(i), t.dwn + (size_t)w.row_off * t_dim, numel(w.shape) * sizeof(float), hipMemcpyDeviceToDevice, st));
       else if (w.sink == WeightEntry::NOISE_B)
         HIPCHK(h, hipMemcpyAsync(DG(i), t.dbn + w.row_off, numel(w.shape) * sizeof(float), hipMemcpyDeviceToDevice, st));
     }

@@ -38,6 +38,9 @@ hipError_t launch_sum_rows(const float* S, int N, int stride, int C, float* out,
 hipError_t launch_zero_insert(const float* dy, float* z, int N, int H, int W, int C, hipStream_t s);
 // dx [N,H,W,C] += (assign: =) sum of the 2x2 block of du [N,2H,2W,C]   (nearest x2 upsampling, transposed)
 hipError_t launch_pool2_add(const float* du, float* dx, int N, int H, int W, int C, bool assign, hipStream_t s);
+// dx [N,2H,2W,C] += (assign: =) scale * dy [N,H,W,C] at each of the four pixels of its 2x2 block   (2x2 average pooling, transposed:
+// scale = 0.25; the GDP sibling's down ResBlocks, gdp_modules/unet.py:369-375)
+hipError_t launch_unpool2_add(const float* dy, float* dx, int N, int H, int W, int C, float scale, bool assign, hipStream_t s);
 // dst[n][p][0..C) += (assign: =) src[n][p][off .. off+C) of a tensor with Cs channels (routes a concat half)
 hipError_t launch_add_slice(const float* src, float* dst, size_t npix, int Cs, int off, int C, bool assign, hipStream_t s);
 
@@ -65,6 +68,13 @@ struct GnBwdParams {
   // scale / shift.  g_part lives at the head of `scratch` (gn_bwd_tile_part()).
   const float* g_part;            // null: dA is the raw gradient w.r.t. the activated input
   int g_nt;
+  // scale-shift GroupNorm of the GDP sibling's ResBlocks (gdp_modules/unet.py:377-381): u = (xhat*gamma + beta) * (1 + s) + t with
+  // (s, t) = film[n*film_stride + c], film[n*film_stride + C + c] (two runs of C columns of the step's [N][TE] embedding table; scale
+  // and shift above already hold the folded form).  The effective gamma of image n is gamma*(1 + s); dgamma / dbeta sum (1 + s) times
+  // the per-image sums; dfilm (same layout, stride dfilm_stride) receives ds = gamma*sum(g*xhat) + beta*sum(g), dt = sum(g).
+  const float* film; int film_stride;
+  const float* beta;              // [C], read with film only
+  float* dfilm; int dfilm_stride;
 };
 size_t gn_bwd_scratch_doubles(int N, int H, int W, int C);
 inline float* gn_bwd_tile_part(double* scratch) { return reinterpret_cast<float*>(scratch); }   // room for ceil(W/32) * ceil(H/2) tiles per image
@@ -122,13 +132,21 @@ struct TembBwdParams {
   const float* nl;         // [N]
   const float* dtemb;      // [N][TE]
   float* dw1; float* db1; float* dw2; float* db2; float* dwn; float* dbn;   // written (=)
-  float* scratch;          // N * 11 * inner floats
+  float* scratch;          // N * temb_bwd_scratch_floats_per_image() floats
   int inner, TE, N;
   int swish_block;
+  // GDP sibling (gdp_modules/unet.py:120-138, :588-593, :336-342): timestep_embedding(enc_dim) = cat([cos, sin]) -> Linear(enc_dim, hid_dim)
+  // -> SiLU -> Linear(hid_dim, t_dim); every per-block Linear(t_dim, 2*Cout) sees SiLU(t).  Zero: the widths above (inner, 4 inner, inner).
+  int enc_dim, hid_dim, t_dim, cos_first;
 };
+inline size_t temb_bwd_scratch_floats_per_image(int inner, int enc_dim, int hid_dim, int t_dim) {
+  const size_t E = enc_dim ? enc_dim : inner, Hd = hid_dim ? hid_dim : 4 * inner, Td = t_dim ? t_dim : inner;
+  return E + 2 * Hd + 2 * Td;
+}
 hipError_t launch_temb_bwd(const TembBwdParams& p, hipStream_t s);
 
-// ---- SelfAttention backward (SR3 sibling: ddpm_modules/unet.py:99-127, n_head = 1) ---------------------------------
+// ---- SelfAttention backward (SR3 sibling: ddpm_modules/unet.py:99-127, n_head = 1; GDP sibling: QKVAttentionLegacy,
+// gdp_modules/unet.py:461-488, heads of C / heads channels laid out [head][q | k | v] along the channel axis) ----------------------
 // forward (fdsr_kernels.hip): S = Q K^T / sqrt(C), P = softmax_rows(S), O = P V on the NHWC qkv tensor [N][HW][q | k | v].
 // backward: P is recomputed by the forward's kernels; dP = dO V^T; dS = P (dP - rowsum(dP P)); dQ = dS K / sqrt(C);
 // dK = dS^T Q / sqrt(C); dV = P^T dO -- five fp32-MFMA products of a few MFLOP, every output element written by exactly one lane
@@ -139,8 +157,9 @@ struct AttnBwdParams {
   float* dqkv;             // [N][HW][3C], written (=)
   float* scratch;          // attn_bwd_scratch_floats(): P | dP -> dS
   int N, HW, C;
+  int heads;               // 0 or 1: one head over all C channels
 };
-size_t attn_bwd_scratch_floats(int N, int HW);
+size_t attn_bwd_scratch_floats(int N, int HW, int heads = 1);
 hipError_t launch_attn_bwd(const AttnBwdParams& p, hipStream_t s);
 
 // ---- optimiser -----------------------------------------------------------------------------------------------

@@ -263,6 +263,30 @@ hipError_t launch_pool2_add(const float* du, float* dx, int N, int H, int W, int
   return hipGetLastError();
 }
 
+// 2x2 average pooling, transposed: every fine pixel takes scale * dy of its block
+__global__ void __launch_bounds__(256) unpool2_add_kernel(const float* __restrict__ dy, float* __restrict__ dx, int H, int W, int cq,
+                                                          float scale, int assign, size_t total) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;   // over [N][2H][2W][cq]
+  if (i >= total) return;
+  const int c4 = (int)(i % cq);
+  size_t r = i / cq;
+  const int x = (int)(r % (2 * W));
+  r /= 2 * W;
+  const int y = (int)(r % (2 * H));
+  const size_t n = r / (2 * H);
+  const f32x4 v = *reinterpret_cast<const f32x4*>(dy + (((n * H + (y >> 1)) * W + (x >> 1)) * cq + c4) * 4);
+  f32x4 o = v * scale;
+  if (!assign) o += *reinterpret_cast<const f32x4*>(dx + i * 4);
+  *reinterpret_cast<f32x4*>(dx + i * 4) = o;
+}
+hipError_t launch_unpool2_add(const float* dy, float* dx, int N, int H, int W, int C, float scale, bool assign, hipStream_t s) {
+  if (C & 3) return hipErrorInvalidValue;
+  const size_t total = (size_t)N * 2 * H * 2 * W * (C >> 2);
+  hipLaunchKernelGGL(unpool2_add_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dy, dx, H, W, C >> 2, scale, assign ? 1 : 0,
+                     total);
+  return hipGetLastError();
+}
+
 __global__ void __launch_bounds__(256) add_slice_kernel(const float* __restrict__ src, float* __restrict__ dst, int Cs4, int off4,
                                                         int C4, size_t total, int assign) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;   // over [npix][C4]
@@ -303,6 +327,12 @@ __device__ __forceinline__ void gnb_elem(float x, float dA, float sc, float sh, 
   const float u = fmaf(x, sc, sh);
   const float sg = sigmoid_f(u);
   g = dA * (sg * (1.0f + u * (1.0f - sg)));     // d/du [u * sigmoid(u)]
+}
+
+// gamma as image n sees it: the scale-shift form (GnBwdParams::film) multiplies the affine output by (1 + s[n][c])
+__device__ __forceinline__ float gnb_gamma(const GnBwdParams& p, size_t n, int c) {
+  const float gam = p.gamma[c];
+  return p.film ? gam * (1.0f + p.film[n * p.film_stride + c]) : gam;
 }
 
 // grid (SLICES, N): per-(image, channel) partial sums of g and g*xhat over a pixel slice
@@ -379,7 +409,7 @@ __global__ void __launch_bounds__(256) gn_bwd_finalize_kernel(const GnBwdParams 
     double m1 = 0.0, m2 = 0.0;
     for (int k = 0; k < cpg; ++k) {
       const int c = g * cpg + k;
-      const double gam = (double)p.gamma[c];
+      const double gam = (double)gnb_gamma(p, n, c);
       m1 += gam * tot[((size_t)n * C + c) * 2];
       m2 += gam * tot[((size_t)n * C + c) * 2 + 1];
     }
@@ -421,7 +451,7 @@ __global__ void __launch_bounds__(256) gn_bwd_finalize_tiles_kernel(const GnBwdP
   if (tid == 0) {
     double m1 = 0.0, m2 = 0.0;
     for (int k = 0; k < cpg; ++k) {
-      const double gam = (double)p.gamma[g * cpg + k];
+      const double gam = (double)gnb_gamma(p, n, g * cpg + k);
       m1 += gam * sd[k][0];
       m2 += gam * sd[k][1];
     }
@@ -453,6 +483,23 @@ __global__ void __launch_bounds__(256) gn_bwd_affine_kernel(const double* __rest
   }
   dbeta[c] = (float)a;
   dgamma[c] = (float)b;
+}
+// the scale-shift form: the per-image sums weighted by (1 + s), and the gradient of (s, t) themselves
+__global__ void __launch_bounds__(256) gn_bwd_affine_film_kernel(const GnBwdParams p, const double* __restrict__ tot) {
+  const int C = p.C0 + p.C1, c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const double gam = (double)p.gamma[c], bet = (double)p.beta[c];
+  double a = 0.0, b = 0.0;
+  for (int n = 0; n < p.N; ++n) {
+    const double sa = tot[((size_t)n * C + c) * 2], sb = tot[((size_t)n * C + c) * 2 + 1];   // sum g, sum g*xhat
+    const double one_s = 1.0 + (double)p.film[(size_t)n * p.film_stride + c];
+    a += one_s * sa;
+    b += one_s * sb;
+    p.dfilm[(size_t)n * p.dfilm_stride + c] = (float)(gam * sb + bet * sa);
+    p.dfilm[(size_t)n * p.dfilm_stride + C + c] = (float)sa;
+  }
+  p.dbeta[c] = (float)a;
+  p.dgamma[c] = (float)b;
 }
 
 // elementwise: dx += rstd * (gamma*g - m1 - xhat*m2)      (GREADY: dA holds g already, see GnBwdParams::g_part)
@@ -487,7 +534,7 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const GnBwdParams p, 
     float gg, xh;
     gnb_elem(x[e], d[e], sc[e], sh[e], mean, rstd, GREADY ? 1 : p.plain, gg, xh);
     const float m1 = (float)gm[(n * p.G + g) * 2], m2 = (float)gm[(n * p.G + g) * 2 + 1];
-    o[e] += rstd * (p.gamma[c + e] * gg - m1 - xh * m2);
+    o[e] += rstd * (gnb_gamma(p, n, c + e) * gg - m1 - xh * m2);
   }
   *reinterpret_cast<f32x4*>(dxs + pix * Cs + cc) = o;
 }
@@ -499,16 +546,21 @@ hipError_t launch_gn_bwd(const GnBwdParams& p, hipStream_t s) {
   double* tot = part + gn_bwd_part_doubles(p.N, p.H, p.HW / p.H, C);
   double* gm = tot + (size_t)p.N * C * 2;
   const size_t total = (size_t)p.N * p.HW * (C >> 2);
+  if (p.film && (!p.beta || !p.dfilm || p.C1)) return hipErrorInvalidValue;
+  auto affine = [&]() {
+    if (p.film) hipLaunchKernelGGL(gn_bwd_affine_film_kernel, dim3((C + 255) / 256), dim3(256), 0, s, p, tot);
+    else hipLaunchKernelGGL(gn_bwd_affine_kernel, dim3((C + 255) / 256), dim3(256), 0, s, tot, p.N, C, p.dgamma, p.dbeta);
+  };
   if (p.g_part) {   // the input-gradient launch did the reduction (per-tile sums) and left g in dA
     if (C / p.G > 64 || p.g_nt <= 0 || (size_t)p.g_nt > gn_bwd_max_tiles(p.H, p.HW / p.H) || p.g_part != gn_bwd_tile_part(p.scratch)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(gn_bwd_finalize_tiles_kernel, dim3(p.N, p.G), dim3(256), 0, s, p, tot, gm);
-    hipLaunchKernelGGL(gn_bwd_affine_kernel, dim3((C + 255) / 256), dim3(256), 0, s, tot, p.N, C, p.dgamma, p.dbeta);
+    affine();
     hipLaunchKernelGGL(gn_bwd_apply_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, gm, total);
     return hipGetLastError();
   }
   hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(FDSR_GNB_SLICES, p.N), dim3(256), 0, s, p, part);
   hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(p.N), dim3(256), 0, s, p, part, tot, gm);
-  hipLaunchKernelGGL(gn_bwd_affine_kernel, dim3((C + 255) / 256), dim3(256), 0, s, tot, p.N, C, p.dgamma, p.dbeta);
+  affine();
   hipLaunchKernelGGL(gn_bwd_apply_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, gm, total);
   return hipGetLastError();
 }
@@ -1882,79 +1934,92 @@ hipError_t launch_clam_slam_bwd(const ClamSlamBwdParams& p, hipStream_t s) {
 // ---------------------------------------------------------------------------
 // noise-level embedding backward
 // ---------------------------------------------------------------------------
+// Widths: enc E, hidden Hd, t Td (FastDiffSR / SR3: inner, 4 inner, inner; GDP: mc, 4 mc, 4 mc -- TembBwdParams::enc_dim ...).
 // (1) per image: recompute enc / pre-activation / hid / t, then dt, dhid, dpre.  scratch per image:
-//     enc[inner] | hid[4 inner] | dt[inner] | dpre[4 inner] | t[inner]
+//     enc[E] | hid[Hd] | dt[Td] | dpre[Hd] | t[Td]
+struct TembDims { int E, Hd, Td; };
+__host__ __device__ __forceinline__ TembDims temb_dims(const TembBwdParams& p) {
+  return TembDims{p.enc_dim ? p.enc_dim : p.inner, p.hid_dim ? p.hid_dim : 4 * p.inner, p.t_dim ? p.t_dim : p.inner};
+}
 __global__ void __launch_bounds__(256) temb_bwd_image_kernel(const TembBwdParams p) {
-  extern __shared__ __attribute__((aligned(16))) float st[];   // enc[inner] | pre[hid] | hidv[hid] | dt[inner]
-  const int inner = p.inner, hid = 4 * inner, tid = threadIdx.x, n = blockIdx.x, half = inner / 2;
+  extern __shared__ __attribute__((aligned(16))) float st[];   // enc[E] | pre[Hd] | hidv[Hd] | dt[Td] | dt parts
+  const TembDims d = temb_dims(p);
+  const int E = d.E, hid = d.Hd, Td = d.Td, tid = threadIdx.x, n = blockIdx.x, half = E / 2;
   float* enc = st;
-  float* pre = enc + inner;
+  float* pre = enc + E;
   float* hv = pre + hid;
   float* dt = hv + hid;
   const float nl = p.nl[n];
   for (int k = tid; k < half; k += 256) {
     const float e = nl * p.freq[k];
-    enc[k] = sinf(e);
-    enc[half + k] = cosf(e);
+    enc[p.cos_first ? half + k : k] = sinf(e);
+    enc[p.cos_first ? k : half + k] = cosf(e);
   }
   __syncthreads();
   for (int j = tid; j < hid; j += 256) {
     float a = p.b1[j];
-    const float* w = p.w1 + (size_t)j * inner;
-    for (int k = 0; k < inner; ++k) a = fmaf(w[k], enc[k], a);
+    const float* w = p.w1 + (size_t)j * E;
+    for (int k = 0; k < E; ++k) a = fmaf(w[k], enc[k], a);
     pre[j] = a;
     hv[j] = a / (1.0f + expf(-a));
   }
-  {   // dt[k] = sum_o dtemb[n][o] * wn[o][k]: the o range in 256 / inner parts (one per thread group), parts added in order
-    float* dpart = dt + inner;                               // [parts][inner]
-    const int parts = 256 / inner > 0 ? 256 / inner : 1, part = tid / inner, k = tid % inner;
-    if (inner > 256) {                                       // wider than the workgroup: one part, threads stride over k
-      for (int kk = tid; kk < inner; kk += 256) {
-        float a = 0.f;
-        for (int o = 0; o < p.TE; ++o) a = fmaf(p.dtemb[(size_t)n * p.TE + o], p.wn[(size_t)o * inner + kk], a);
-        dpart[kk] = a;
+  {   // dt[k] = sum_o dtemb[n][o] * wn[o][k]: the o range in 256 / Td parts (one per thread group), parts added in order
+    float* dpart = dt + Td;                                  // [parts][Td]
+    const int parts = 256 / Td > 0 ? 256 / Td : 1, part = tid / Td, k = tid % Td;
+    if (Td > 256) {                                          // wider than the workgroup: one part, threads stride over k
+      for (int kk = tid; kk < Td; kk += 256) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int o = 0;
+        for (; o + 4 <= p.TE; o += 4) {
+          a0 = fmaf(p.dtemb[(size_t)n * p.TE + o], p.wn[(size_t)o * Td + kk], a0);
+          a1 = fmaf(p.dtemb[(size_t)n * p.TE + o + 1], p.wn[(size_t)(o + 1) * Td + kk], a1);
+          a2 = fmaf(p.dtemb[(size_t)n * p.TE + o + 2], p.wn[(size_t)(o + 2) * Td + kk], a2);
+          a3 = fmaf(p.dtemb[(size_t)n * p.TE + o + 3], p.wn[(size_t)(o + 3) * Td + kk], a3);
+        }
+        for (; o < p.TE; ++o) a0 = fmaf(p.dtemb[(size_t)n * p.TE + o], p.wn[(size_t)o * Td + kk], a0);
+        dpart[kk] = (a0 + a1) + (a2 + a3);
       }
     } else if (part < parts) {
       const int o0 = (int)((long)part * p.TE / parts), o1 = (int)((long)(part + 1) * p.TE / parts);
       float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
       int o = o0;
       for (; o + 4 <= o1; o += 4) {
-        a0 = fmaf(p.dtemb[(size_t)n * p.TE + o], p.wn[(size_t)o * inner + k], a0);
-        a1 = fmaf(p.dtemb[(size_t)n * p.TE + o + 1], p.wn[(size_t)(o + 1) * inner + k], a1);
-        a2 = fmaf(p.dtemb[(size_t)n * p.TE + o + 2], p.wn[(size_t)(o + 2) * inner + k], a2);
-        a3 = fmaf(p.dtemb[(size_t)n * p.TE + o + 3], p.wn[(size_t)(o + 3) * inner + k], a3);
+        a0 = fmaf(p.dtemb[(size_t)n * p.TE + o], p.wn[(size_t)o * Td + k], a0);
+        a1 = fmaf(p.dtemb[(size_t)n * p.TE + o + 1], p.wn[(size_t)(o + 1) * Td + k], a1);
+        a2 = fmaf(p.dtemb[(size_t)n * p.TE + o + 2], p.wn[(size_t)(o + 2) * Td + k], a2);
+        a3 = fmaf(p.dtemb[(size_t)n * p.TE + o + 3], p.wn[(size_t)(o + 3) * Td + k], a3);
       }
-      for (; o < o1; ++o) a0 = fmaf(p.dtemb[(size_t)n * p.TE + o], p.wn[(size_t)o * inner + k], a0);
-      dpart[part * inner + k] = (a0 + a1) + (a2 + a3);
+      for (; o < o1; ++o) a0 = fmaf(p.dtemb[(size_t)n * p.TE + o], p.wn[(size_t)o * Td + k], a0);
+      dpart[part * Td + k] = (a0 + a1) + (a2 + a3);
     }
     __syncthreads();
-    for (int kk = tid; kk < inner; kk += 256) {
+    for (int kk = tid; kk < Td; kk += 256) {
       float a = 0.f;
-      for (int q = 0; q < parts; ++q) a += dpart[q * inner + kk];
+      for (int q = 0; q < parts; ++q) a += dpart[q * Td + kk];
       dt[kk] = a;
     }
   }
   __syncthreads();
-  float* out = p.scratch + (size_t)n * 11 * inner;
-  for (int k = tid; k < inner; k += 256) {
-    out[k] = enc[k];
+  float* out = p.scratch + (size_t)n * (E + 2 * hid + 2 * Td);
+  for (int k = tid; k < E; k += 256) out[k] = enc[k];
+  for (int k = tid; k < Td; k += 256) {
     float t = p.b2[k];                                       // t[k] = b2[k] + sum_q w2[k][q] hid[q]: the input of the per-block Linear
     for (int q = 0; q < hid; ++q) t = fmaf(p.w2[(size_t)k * hid + q], hv[q], t);
-    if (p.swish_block) {                                     // SR3: the per-block Linear sees swish(t); what arrived in dt is d swish(t)
+    if (p.swish_block) {                                     // SR3 / GDP: the per-block Linear sees swish(t); what arrived in dt is d swish(t)
       const float sg = 1.0f / (1.0f + expf(-t));
       dt[k] *= sg * (1.0f + t * (1.0f - sg));
       t *= sg;
     }
-    out[5 * inner + k] = dt[k];
-    out[10 * inner + k] = t;
+    out[E + hid + k] = dt[k];
+    out[E + 2 * hid + Td + k] = t;
   }
   __syncthreads();
   for (int j = tid; j < hid; j += 256) {
     float a = 0.f;                                           // dhid[j] = sum_k dt[k] * w2[k][j]
-    for (int k = 0; k < inner; ++k) a = fmaf(dt[k], p.w2[(size_t)k * hid + j], a);
+    for (int k = 0; k < Td; ++k) a = fmaf(dt[k], p.w2[(size_t)k * hid + j], a);
     const float u = pre[j], sg = 1.0f / (1.0f + expf(-u));
-    out[inner + j] = hv[j];
-    out[6 * inner + j] = a * (sg * (1.0f + u * (1.0f - sg)));
+    out[E + j] = hv[j];
+    out[E + hid + Td + j] = a * (sg * (1.0f + u * (1.0f - sg)));
   }
 }
 
@@ -1962,14 +2027,16 @@ __global__ void __launch_bounds__(256) temb_bwd_image_kernel(const TembBwdParams
 __global__ void __launch_bounds__(256) temb_bwd_param_kernel(const TembBwdParams p, size_t total) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
-  const int inner = p.inner, hid = 4 * inner, TE = p.TE, N = p.N;
-  const size_t n_wn = (size_t)TE * inner, n_w2 = (size_t)inner * hid, n_w1 = (size_t)hid * inner;
+  const TembDims d = temb_dims(p);
+  const int E = d.E, hid = d.Hd, Td = d.Td, TE = p.TE, N = p.N;
+  const size_t n_wn = (size_t)TE * Td, n_w2 = (size_t)Td * hid, n_w1 = (size_t)hid * E, stride = (size_t)E + 2 * hid + 2 * Td;
+  const int o_hid = E, o_dt = E + hid, o_dpre = E + hid + Td, o_t = E + 2 * hid + Td;
   size_t j = i;
-  auto S = [&](int n, int off) { return p.scratch + (size_t)n * 11 * inner + off; };
+  auto S = [&](int n, int off) { return p.scratch + (size_t)n * stride + off; };
   if (j < n_wn) {                       // dwn[o][k] = sum_n dtemb[n][o] * t[n][k]
-    const int o = (int)(j / inner), k = (int)(j % inner);
+    const int o = (int)(j / Td), k = (int)(j % Td);
     float a = 0.f;
-    for (int n = 0; n < N; ++n) a += p.dtemb[(size_t)n * TE + o] * S(n, 10 * inner)[k];
+    for (int n = 0; n < N; ++n) a += p.dtemb[(size_t)n * TE + o] * S(n, o_t)[k];
     p.dwn[j] = a;
     return;
   }
@@ -1984,61 +2051,62 @@ __global__ void __launch_bounds__(256) temb_bwd_param_kernel(const TembBwdParams
   if (j < n_w2) {                       // dw2[k][q] = sum_n dt[n][k] * hid[n][q]
     const int k = (int)(j / hid), q = (int)(j % hid);
     float a = 0.f;
-    for (int n = 0; n < N; ++n) a += S(n, 5 * inner)[k] * S(n, inner)[q];
+    for (int n = 0; n < N; ++n) a += S(n, o_dt)[k] * S(n, o_hid)[q];
     p.dw2[j] = a;
     return;
   }
   j -= n_w2;
-  if (j < (size_t)inner) {              // db2[k]
+  if (j < (size_t)Td) {                 // db2[k]
     float a = 0.f;
-    for (int n = 0; n < N; ++n) a += S(n, 5 * inner)[j];
+    for (int n = 0; n < N; ++n) a += S(n, o_dt)[j];
     p.db2[j] = a;
     return;
   }
-  j -= inner;
+  j -= Td;
   if (j < n_w1) {                       // dw1[q][k] = sum_n dpre[n][q] * enc[n][k]
-    const int q = (int)(j / inner), k = (int)(j % inner);
+    const int q = (int)(j / E), k = (int)(j % E);
     float a = 0.f;
-    for (int n = 0; n < N; ++n) a += S(n, 6 * inner)[q] * S(n, 0)[k];
+    for (int n = 0; n < N; ++n) a += S(n, o_dpre)[q] * S(n, 0)[k];
     p.dw1[j] = a;
     return;
   }
   j -= n_w1;
   if (j < (size_t)hid) {                // db1[q]
     float a = 0.f;
-    for (int n = 0; n < N; ++n) a += S(n, 6 * inner)[j];
+    for (int n = 0; n < N; ++n) a += S(n, o_dpre)[j];
     p.db1[j] = a;
   }
 }
 
 hipError_t launch_temb_bwd(const TembBwdParams& p, hipStream_t s) {
-  const int inner = p.inner, hid = 4 * inner;
-  const int parts = 256 / inner > 0 ? 256 / inner : 1;   // dt partial sums live after dt in LDS
-  hipLaunchKernelGGL(temb_bwd_image_kernel, dim3(p.N), dim3(256), (size_t)(2 * inner + 2 * hid + parts * inner) * sizeof(float), s, p);
-  const size_t total = (size_t)p.TE * inner + p.TE + (size_t)inner * hid + inner + (size_t)hid * inner + hid;
+  const TembDims d = temb_dims(p);
+  const int parts = 256 / d.Td > 0 ? 256 / d.Td : 1;   // dt partial sums live after dt in LDS
+  hipLaunchKernelGGL(temb_bwd_image_kernel, dim3(p.N), dim3(256), (size_t)(d.E + 2 * d.Hd + d.Td + parts * d.Td) * sizeof(float), s, p);
+  const size_t total = (size_t)p.TE * d.Td + p.TE + (size_t)d.Td * d.Hd + d.Td + (size_t)d.Hd * d.E + d.Hd;
   hipLaunchKernelGGL(temb_bwd_param_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, total);
   return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------
-// SelfAttention backward (SR3 sibling)
+// SelfAttention backward (SR3 / TESR siblings: one head; GDP sibling: heads of C / heads channels)
 // ---------------------------------------------------------------------------
 // C[b][m][n] = alpha * sum_k A[b](m, k) B[b](k, n) with element strides on every operand, on v_mfma_f32_32x32x2_f32: one wave per
 // 32 x 32 tile of C (the forward's attn_scores_kernel with the strides made arguments).  The products of the attention backward are a
-// few MFLOP each; the strides let P^T, dS^T and the q / k / v channel slices of the NHWC qkv tensor be read in place.
+// few MFLOP each; the strides let P^T, dS^T and the q / k / v channel slices of the NHWC qkv tensor be read in place.  The batch index
+// is (image, head): operand X of batch b starts at (b / heads) * x_sb + (b % heads) * x_sh.
 struct SGemm {
-  const float* A; long a_sm, a_sk, a_sb;
-  const float* B; long b_sk, b_sn, b_sb;
-  float* C; long c_sm, c_sn, c_sb;
-  int M, Nn, K;
+  const float* A; long a_sm, a_sk, a_sb, a_sh;
+  const float* B; long b_sk, b_sn, b_sb, b_sh;
+  float* C; long c_sm, c_sn, c_sb, c_sh;
+  int M, Nn, K, heads;
   float alpha;
 };
 typedef float t_f32x16 __attribute__((ext_vector_type(16)));
 __global__ void __launch_bounds__(64) sgemm_strided_kernel(const SGemm g) {
   const int lane = threadIdx.x, r31 = lane & 31, h = lane >> 5;
-  const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32, b = blockIdx.z;
-  const float* A = g.A + (size_t)b * g.a_sb + (size_t)min(m0 + r31, g.M - 1) * g.a_sm;
-  const float* B = g.B + (size_t)b * g.b_sb + (size_t)min(n0 + r31, g.Nn - 1) * g.b_sn;
+  const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32, bi = blockIdx.z / g.heads, hd = blockIdx.z % g.heads;
+  const float* A = g.A + (size_t)bi * g.a_sb + (size_t)hd * g.a_sh + (size_t)min(m0 + r31, g.M - 1) * g.a_sm;
+  const float* B = g.B + (size_t)bi * g.b_sb + (size_t)hd * g.b_sh + (size_t)min(n0 + r31, g.Nn - 1) * g.b_sn;
   t_f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -2055,7 +2123,7 @@ __global__ void __launch_bounds__(64) sgemm_strided_kernel(const SGemm g) {
     for (int s2 = 0; s2 < 4; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s2], bv[s2], acc, 0, 0, 0);
   }
   const int col = n0 + r31;
-  float* C = g.C + (size_t)b * g.c_sb;
+  float* C = g.C + (size_t)bi * g.c_sb + (size_t)hd * g.c_sh;
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int row = m0 + (i & 3) + 8 * (i >> 2) + 4 * h;
@@ -2063,8 +2131,8 @@ __global__ void __launch_bounds__(64) sgemm_strided_kernel(const SGemm g) {
   }
 }
 
-static hipError_t launch_sgemm(const SGemm& g, int batch, hipStream_t s) {
-  hipLaunchKernelGGL(sgemm_strided_kernel, dim3((g.Nn + 31) / 32, (g.M + 31) / 32, batch), dim3(64), 0, s, g);
+static hipError_t launch_sgemm(const SGemm& g, int images, hipStream_t s) {
+  hipLaunchKernelGGL(sgemm_strided_kernel, dim3((g.Nn + 31) / 32, (g.M + 31) / 32, images * g.heads), dim3(64), 0, s, g);
   return hipGetLastError();
 }
 
@@ -2082,30 +2150,33 @@ __global__ void __launch_bounds__(256) attn_dsoftmax_rows_kernel(const float* __
   for (int i = lane; i < HW; i += 64) dr[i] = pr[i] * (dr[i] - a);
 }
 
-size_t attn_bwd_scratch_floats(int N, int HW) { return 2 * attn_scratch_floats(N, HW, 1); }
+size_t attn_bwd_scratch_floats(int N, int HW, int heads) { return 2 * attn_scratch_floats(N, HW, heads < 1 ? 1 : heads); }
 
 hipError_t launch_attn_bwd(const AttnBwdParams& p, hipStream_t s) {
-  const int N = p.N, HW = p.HW, C = p.C, HWp = (HW + 15) / 16 * 16;
-  if (C % 32) return hipErrorInvalidValue;
+  const int N = p.N, HW = p.HW, C = p.C, HWp = (HW + 15) / 16 * 16, heads = p.heads < 1 ? 1 : p.heads;
+  if (C % heads || (C / heads) % 32) return hipErrorInvalidValue;
+  const int ch = C / heads;
   float* P = p.scratch;
-  float* D = p.scratch + attn_scratch_floats(N, HW, 1);
-  hipError_t e = launch_attn_probs(p.qkv, P, N, HW, C, 1, s);
+  float* D = p.scratch + attn_scratch_floats(N, HW, heads);
+  hipError_t e = launch_attn_probs(p.qkv, P, N, HW, C, heads, s);
   if (e != hipSuccess) return e;
-  const float inv = 1.0f / sqrtf((float)C);
-  const long sq = (long)HW * 3 * C, so = (long)HW * C, sp = (long)HW * HWp;
+  const float inv = 1.0f / sqrtf((float)ch);
+  // channel offsets of q / k / v of head 0 and the step from head to head (fdsr_kernels.hip: attn_offsets)
+  const long ko = heads > 1 ? ch : C, vo = heads > 1 ? 2L * ch : 2L * C, hq = 3L * ch;
+  const long sq = (long)HW * 3 * C, so = (long)HW * C, sp = (long)HW * HWp, spn = sp * heads;
   // dP[i][j] = sum_c dO[i][c] V[j][c]
-  SGemm g{p.dO, C, 1, so, p.qkv + 2 * C, 1, 3L * C, sq, D, HWp, 1, sp, HW, HW, C, 1.0f};
+  SGemm g{p.dO, C, 1, so, ch, p.qkv + vo, 1, 3L * C, sq, hq, D, HWp, 1, spn, sp, HW, HW, ch, heads, 1.0f};
   if ((e = launch_sgemm(g, N, s)) != hipSuccess) return e;
-  const size_t rows = (size_t)N * HW;
+  const size_t rows = (size_t)N * heads * HW;
   hipLaunchKernelGGL(attn_dsoftmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, P, D, HW, HWp, rows);
   // dQ[i][c] = inv sum_j dS[i][j] K[j][c]
-  g = SGemm{D, HWp, 1, sp, p.qkv + C, 3L * C, 1, sq, p.dqkv, 3L * C, 1, sq, HW, C, HW, inv};
+  g = SGemm{D, HWp, 1, spn, sp, p.qkv + ko, 3L * C, 1, sq, hq, p.dqkv, 3L * C, 1, sq, hq, HW, ch, HW, heads, inv};
   if ((e = launch_sgemm(g, N, s)) != hipSuccess) return e;
   // dK[j][c] = inv sum_i dS[i][j] Q[i][c]
-  g = SGemm{D, 1, HWp, sp, p.qkv, 3L * C, 1, sq, p.dqkv + C, 3L * C, 1, sq, HW, C, HW, inv};
+  g = SGemm{D, 1, HWp, spn, sp, p.qkv, 3L * C, 1, sq, hq, p.dqkv + ko, 3L * C, 1, sq, hq, HW, ch, HW, heads, inv};
   if ((e = launch_sgemm(g, N, s)) != hipSuccess) return e;
   // dV[j][c] = sum_i P[i][j] dO[i][c]
-  g = SGemm{P, 1, HWp, sp, p.dO, C, 1, so, p.dqkv + 2 * C, 3L * C, 1, sq, HW, C, HW, 1.0f};
+  g = SGemm{P, 1, HWp, spn, sp, p.dO, C, 1, so, ch, p.dqkv + vo, 3L * C, 1, sq, hq, HW, ch, HW, heads, 1.0f};
   if ((e = launch_sgemm(g, N, s)) != hipSuccess) return e;
   return hipGetLastError();
 }

@@ -21,7 +21,7 @@ class _EngineLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, diffusion, x6, gamma, noise, *params):
         eng = diffusion._engine_for_training()
-        loss = eng.train_grads(x6, gamma, noise, diffusion.loss_type, 1.0)
+        loss = eng.train_grads(x6, gamma, noise, getattr(diffusion, 'engine_loss_type', diffusion.loss_type), 1.0)
         ctx.eng = eng
         ctx.keys = [k for k, p in diffusion.denoise_fn.named_parameters() if p.requires_grad]
         ctx.live = {k for k, _, live in eng.schema() if live}

@@ -49,12 +49,46 @@ class GaussianDiffusion(_d.GaussianDiffusion):
         s = self.sqrt_one_minus_alphas_cumprod[t].view(-1, 1, 1, 1)
         return a * x_start + s * noise
 
-    def p_losses(self, x_in, noise=None):                         # :266-285 (forward value; the training kernels serve FastDiffSR)
-        x_start = x_in['HR']
+    engine_loss_type = 'l2'                                      # :83-89: both loss types are the summed MSE
+
+    def _training_batch(self, x_in, noise=None):                  # :277-290, the part before the network
+        """The reference's draws: t = torch.randint(0, T, (b,)), then noise = randn_like(x_start), both from torch's generator of
+        x_start's device; the network sees cat([x_t, SR]) and its target is x_start = HR itself (it predicts x_0)."""
+        x_start = x_in['HR'].float()
         b = x_start.shape[0]
         t = torch.randint(0, self.num_timesteps, (b,), device=x_start.device).long()
         noise = torch.randn_like(x_start) if noise is None else noise
         x_t = self.q_sample(x_start, t, noise)
+        return torch.cat([x_t, x_in['SR'].float()], dim=1).contiguous(), t, x_start.contiguous()
+
+    def p_losses(self, x_in, noise=None):                         # :277-299
+        """The summed MSE between the network's x_0 and HR.  In train mode with autograd on the result carries a grad_fn whose backward
+        is the ENGINE's backward pass (scale-shift GroupNorms, pooled / upsampled ResBlocks, multi-head attention, the time MLP), so
+        the reference's `l_pix.sum() / n; backward(); optG.step()` (model.py:49-56) works unchanged on the module's Parameters."""
+        x6, t, target = self._training_batch(x_in, noise)
+        if self.denoise_fn.training and torch.is_grad_enabled():
+            params = [p for p in self.denoise_fn.parameters() if p.requires_grad]
+            return _d._EngineLoss.apply(self, x6, t.float(), target, *params)
         with torch.no_grad():
-            x_recon = self.denoise_fn(torch.cat([x_t, x_in['SR']], dim=1), t)
-        return self.loss_func(x_recon, x_start)
+            x_recon = self.denoise_fn(x6, t)
+        return self.loss_func(x_recon, target)
+
+    def optimize_step(self, x_in, lr, betas=(0.9, 0.999), eps=1e-8, noise=None, grad_hook=None, global_batch=None):
+        """DDPM.optimize_parameters entirely on the device (see fastdiffsr_amd.diffusion.GaussianDiffusion.optimize_step): forward,
+        loss / (b*c*h*w), backward, Adam on the engine's master copy; `grad_hook(engine)` runs between backward and the optimiser."""
+        b, c, h, w = x_in['HR'].shape
+        gb = int(global_batch) if global_batch is not None else int(b)
+        if gb < 1:
+            raise ValueError('optimize_step: the global batch is empty')
+        eng = self._engine_for_training()
+        if b > 0:
+            x6, t, target = self._training_batch(x_in, noise)
+            loss = eng.train_grads(x6, t.float(), target, 'l2', 1.0 / (gb * int(c * h * w)))
+        else:
+            eng.zero_grads(x_in['HR'].device)
+            loss = 0.0
+        if grad_hook is not None:
+            grad_hook(eng)
+        eng.adam_step(lr, betas, eps)
+        self.denoise_fn._engine_ahead = True
+        return loss / (gb * int(c * h * w))

@@ -282,7 +282,7 @@ int fdsr_set_dropout_seed(fdsr_handle h, uint64_t seed);
 int fdsr_debug_dropout_mask(fdsr_handle h, const char* block, const unsigned char** dev_off, int* n, int* hgt, int* wid,
                             int* ch, float* scale);
 
-/* ---- training step (FastDiffSR variant) -------------------------------------------------
+/* ---- training step (every variant) ------------------------------------------------
  * DDPM.optimize_parameters (model/model.py:47-57): zero_grad, l_pix = netG(data) = p_losses
  * (fastdiffsr_modules/diffusion.py:242-270), l_pix.sum() / (b*c*h*w), backward, Adam.step.  The engine keeps
  * an fp32 master copy of every executed checkpoint tensor, its gradient and the two Adam moments on the
@@ -303,7 +303,11 @@ int fdsr_train_workspace_bytes(fdsr_handle h, int batch, int height, int width, 
  *                terms sqrt(d^2 + 1e-6) (TESR's 'l1' is their mean, tesr_modules/unet.py:956-967: put the 1 / (b*c*h*w) of the mean into
  *                loss_scale beside the one of model.py:50-52)
  *   (SR3 / TESR variants: x_nchw = cat[SR, q_sample(HR, ...)] as their p_losses forms it, noise_level = the integer time t as a float
- *    (SR3, ddpm_modules/diffusion.py:279-291) or gamma (TESR); the backward then includes the SelfAttention blocks.)
+ *    (SR3, ddpm_modules/diffusion.py:279-291) or gamma (TESR); the backward then includes the SelfAttention blocks.
+ *    GDP variant, gdp_modules/diffusion.py:277-299: x_nchw = cat[q_sample(HR, t), SR], noise_level = t as a float, target_nchw = HR
+ *    itself -- the network predicts x_0 -- and loss_l2 = 1 for both of its loss types; the backward then runs through the scale-shift
+ *    GroupNorms (whose (scale, shift) gradient feeds each ResBlock's Linear and the time MLP), the average-pooled / nearest-upsampled
+ *    ResBlocks and the heads of QKVAttentionLegacy, gdp_modules/unet.py:276-439, :461-488.)
  *   loss_scale   the reference divides the summed loss by b*c*h*w before backward (model.py:50-52)
  *   loss_host    optional: receives the UNSCALED summed loss (what netG(data) returns); synchronises the stream
  * All pointers but loss_host are device pointers. */

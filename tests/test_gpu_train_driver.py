@@ -1,6 +1,7 @@
 """`python -m fastdiffsr_amd.train -c <config>` = the train phase of the reference's sr_mfe.py (:69-251): iterations with
 log lines, the validation pass every val_freq (val schedule, then back), checkpoints every save_checkpoint_freq, resume -- for
-which_model_G 'fastdiffsr' and for the SR3 sibling 'ddpm' (model/networks.py:82-119: the reference trains both through the same loop)."""
+which_model_G 'fastdiffsr' and for the siblings 'ddpm' (SR3) and 'gdp' (model/networks.py:82-119: the reference trains them all through the
+same loop; define_G builds the GDP UNet at its default width of 128 channels whatever `inner_channel` says)."""
 import json
 import os
 import sys
@@ -34,7 +35,7 @@ def _config(root, exp, which='fastdiffsr'):
         "wandb": {"project": "x"}}
 
 
-@pytest.mark.parametrize('which', ['fastdiffsr', 'ddpm'])
+@pytest.mark.parametrize('which', ['fastdiffsr', 'ddpm', 'gdp'])
 def test_train_driver_iterations_val_checkpoint_resume(tmp_path, which):
     from fastdiffsr_amd import train
     from fastdiffsr_amd.config import load_config
@@ -72,6 +73,7 @@ def test_train_driver_iterations_val_checkpoint_resume(tmp_path, which):
         d2, hist2 = train.run(opt2, log=lines2.append)
         assert any('Resuming training from epoch: 2, iter: 4.' in m for m in lines2)
         assert [s for s, v in hist2 if 'l_pix' in v] == [5, 6]
-        assert d2.netG.denoise_fn.engine.optimizer_state('downs.0.weight')[2] == 6          # Adam's step count carried over
+        first_conv = 'input_blocks.0.0.weight' if which == 'gdp' else 'downs.0.weight'
+        assert d2.netG.denoise_fn.engine.optimizer_state(first_conv)[2] == 6                # Adam's step count carried over
     finally:
         os.chdir(cwd)
