@@ -1348,7 +1348,12 @@ int sample_body(fdsr_handle h, const float* cond, const float* noise, float* out
     const int t = h->T - 1 - k;
     h->prof_step = (k % 4) == 0;
     // FastDiffSR: the network sees the noise level sqrt(alpha_bar) (:169-170); SR3: the integer time
+    // (probe "bf16_f16x3_steps": this step on the fp32-grade kernels; the plan, the workspace and both 16-bit weight forms serve either mode,
+    // x_t and the network output cross a step as fp32)
+    const int base_prec = h->prec, fs = g_tun.bf16_f16x3_steps;
+    if (base_prec == PREC_BF16 && ((fs > 0 && k < fs) || (fs < 0 && k >= h->T + fs))) h->prec = PREC_F16X3;
     int rc = run_unet(h, N, H, W, ws, nullptr, 0.f, st, h->d_temb_table + (size_t)t * h->TE);
+    h->prec = base_prec;
     if (rc) return rc;
     PosteriorParams pp{};
     pp.eps = eps;

@@ -118,6 +118,7 @@ struct Tunables {
   int knockout = 0;         // TIMING-ONLY probes, results are garbage: bit 1 leaves the gn_finalize launches out, bit 2 the splitk_reduce launches
                             // (the upper bound of what fusing them into their producers could save; EXPERIMENTS round 4)
   int gn_consumer = 1;      // small grids: GroupNorm scale / shift formed in the consumer conv's prologue from the producers' fixed-point group sums (no gn_finalize launch)
+  int bf16_f16x3_steps = 0; // PROBE (EXPERIMENTS R6): bf16 sampling runs the first n (n > 0) or the last -n (n < 0) reverse steps of the loop on the f16x3 kernels
   int sat_guard = 1;        // f16x3: sticky device flag when a RAW conv input exceeds the f16 range
   int drop_image_offset = 0;   // tests: the batch is images [offset, offset + N) of a larger one (its dropout masks follow)
   unsigned epoch = 0;

@@ -485,6 +485,7 @@ int set_tunable(const char* name, long long v) {
   else if (n == "strip") g_tun.strip = (int)v;
   else if (n == "strip_min_wgs") g_tun.strip_min_wgs = (long)v;
   else if (n == "gn_consumer") g_tun.gn_consumer = (int)v;
+  else if (n == "bf16_f16x3_steps") g_tun.bf16_f16x3_steps = (int)v;
   else if (n == "sat_guard") g_tun.sat_guard = (int)v;
   else if (n == "tail") g_tun.tail = (int)v;
   else if (n == "knockout") g_tun.knockout = (int)v;

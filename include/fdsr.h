@@ -248,7 +248,8 @@ enum fdsr_strip_bits {
  * launches of large grids on 4-wave workgroups, two per CU, 64 those with a rider too, 128 in bf16 too, 512 the bf16 launches with a rider, 1024 rider chunks first on the 8-wave rider kernels too (launches without a K split); default 1275 -- the 16x16x32-MFMA form of the
  * stride-1 3x3 launches), "k32_sb_min_wgs" (bit 32 from this many workgroups on; default 1024), "k32_stagger" (start delay of a CU's odd
  * workgroup slot in that form, 64-cycle units per K chunk; default 0), "gn_consumer" (0|1: small grids form GroupNorm scale / shift in the consumer conv's prologue from the producers' fixed-point
- * channel-pair sums instead of a gn_finalize launch; default 1), "sat_guard" (0|1), "tail" (0|1: the input / output convs of the 16-bit modes on their own bandwidth-shaped kernels),
+ * channel-pair sums instead of a gn_finalize launch; default 1), "sat_guard" (0|1), "bf16_f16x3_steps" (probe: bf16 sampling runs the first n, or for n < 0 the last -n, reverse steps on the f16x3 kernels; default 0),
+ * "tail" (0|1: the input / output convs of the 16-bit modes on their own bandwidth-shaped kernels),
  * "drop_image_offset" (the batch is images [k, k+N) of a larger one: its dropout masks are those images' masks).
  * Every setting computes the same function within the tested bounds; they exist so that tests can force each kernel
  * form and same-box A/B runs can price them.  Returns FDSR_E_INVALID for an unknown name.  Not for production use. */

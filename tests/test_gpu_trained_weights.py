@@ -42,8 +42,7 @@ def _pairs(n, size, seed):
     return hr, sr
 
 
-@pytest.fixture(scope='module')
-def trained():
+def make_trained():
     """(cfg, trained state dict as numpy, loss history): define_G's orthogonal init + STEPS optimisation steps on the engine."""
     from fastdiffsr_amd import networks
     from fastdiffsr_amd.config import dict_to_nonedict
@@ -77,6 +76,11 @@ def trained():
     del netG
     torch.cuda.empty_cache()
     return cfg, sd, losses
+
+
+@pytest.fixture(scope='module')
+def trained():
+    return make_trained()
 
 
 def test_training_moved_the_weights_and_the_loss(trained):
