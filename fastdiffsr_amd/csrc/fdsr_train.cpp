@@ -1,6 +1,8 @@
 // Training step of the FastDiffSR UNet on the device: forward in "keep" mode, loss, backward
 // pass, Adam, re-packing of the updated weights.  Reference: DDPM.optimize_parameters (model/model.py:47-57),
 // GaussianDiffusion.p_losses (model/fastdiffsr_modules/diffusion.py:242-270), UNet.forward (unet.py:299-323).
+// The siblings' plans (ddpm_modules, tesr_modules, gdp_modules) walk the same loop; their own ops -- the
+// attention core, GDP's pooled / upsampled ResBlocks and scale-shift GroupNorms -- are cases of it below.
 //
 // The backward walks the forward plan in reverse.  For a convolution op  y = conv(a) + b + shift (+ res),
 // a = swish(gn(x)) or a = x, x = cat(x0, x1):
@@ -10,7 +12,7 @@
 //   * dA      = conv(dy; W transposed, taps flipped) on the FORWARD kernel (stride 2: zero-inserted dy;
 //               upsample: 2x2 sum-pool afterwards)
 //   * dx0/dx1 += GroupNorm+Swish backward(dA)       or += dA where the conv reads its input raw
-// Gradient tensors are zeroed up front and every contribution is a += in stream order: deterministic.
+// The first contribution to a gradient tensor is a store, later ones accumulate, all in stream order: deterministic.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
