@@ -70,7 +70,8 @@ __device__ __forceinline__ float silu_k(float v) { return v * __builtin_amdgcn_r
 #endif
 #ifndef K32_DIAG        // timing-only probes of the staging (results are garbage; tools/pmc_variants.sh gives the clock beside the time -- a probe that
 #define K32_DIAG 0      // changes the operands changes the clock the chip holds): 1 no GroupNorm / Swish arithmetic, 2 nothing staged inside the K
-#endif                  // loop, 4 no statistics in the epilogue, 8 everything but the LDS store, 16 the staged values do not depend on the fetches
+#endif                  // loop, 4 no statistics in the epilogue, 8 everything but the LDS store, 16 the staged values do not depend on the fetches,
+                        // 32 every chunk reads chunk 0's weight fragments
 #ifndef K32_RFIRST   // small-workgroup rider kernels: rider chunks first
 #define K32_RFIRST 1
 #endif
@@ -367,6 +368,7 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_k32_kernel(const ConvParams p
   uint4 Wf[R][2][NP];
   const int wlane = 32 * (g & 1) + c15;          // + 16 ch: unit within the 32x32x16-order block
   auto load_w = [&](int kc, int tap, int slot) __attribute__((always_inline)) {
+    if (K32_DIAG & 32) kc = 0;   // (timing probe: every chunk multiplies chunk 0's fragments -- what a weight fetch that never misses would buy)
     const uint4* src = wq + ((((size_t)cot * nk16 + 2 * kc + (g >> 1)) * WN + wn) * 9 + tap) * (NP * 64) + wlane;
     if (RIDER && kc >= nk)   // the 1x1 conv's own fragments [cot][kc16][wn]
       src = reinterpret_cast<const uint4*>(p.wq_r) + (((size_t)cot * p.nkr + 2 * (kc - nk) + (g >> 1)) * WN + wn) * (NP * 64) + wlane;
