@@ -58,6 +58,9 @@ def _compare_all(eng, grads_ref, tag):
     print(f'gdp {tag}: {len(grads_ref)} gradients, worst {worst[1]} at {worst[0]:.3e} x max|g|')
 
 
+_ORACLE_STEP = {}
+
+
 @pytest.fixture(scope='module', params=['f32', 'f16x3'])
 def stepped(golden_dir, request):
     from fastdiffsr_amd.engine import Engine
@@ -73,7 +76,9 @@ def stepped(golden_dir, request):
     t = torch.from_numpy(g['t']).long()
     b, c, h, w = hr.shape
     loss = eng.train_grads(_x6(tab, hr, sr, t, nz).cuda(), t.float().cuda(), hr.cuda(), 'l2', 1.0 / (b * c * h * w))
-    l_ref, grads_ref, new_ref = GO.train_step(O.to_torch_sd(sd), cfg, tab, hr, sr, t, nz, lr=float(g['lr']))
+    if 'golden' not in _ORACLE_STEP:                            # one autograd step of the oracle serves both precisions
+        _ORACLE_STEP['golden'] = GO.train_step(O.to_torch_sd(sd), cfg, tab, hr, sr, t, nz, lr=float(g['lr']))
+    l_ref, grads_ref, new_ref = _ORACLE_STEP['golden']
     return cfg, sd, eng, loss, (b * c * h * w), l_ref, grads_ref, new_ref, g, request.param
 
 
@@ -128,10 +133,11 @@ def test_gdp_adam_update_and_rerun(stepped):
             assert np.abs(eng.get_weight(k) - ref.numpy())[mask].max() <= 3e-7, k
 
 
-@pytest.mark.parametrize('prec', ['f32', 'f16x3'])
+@pytest.mark.parametrize('prec', ['f16x3'])
 def test_gdp_gradients_off_the_tile_grid(prec):
     """48 x 32 input, three images, per-sample times incl. t = 0: the attention levels see 24 x 16 = 384 and 12 x 8 = 96 tokens, the
-    pooled / upsampled ResBlocks maps that are not square."""
+    pooled / upsampled ResBlocks maps that are not square.  (f16x3 only: the exact-fp32 convolution kernels see these shapes in
+    tests/test_gpu_train.py and in the two width tests below; the GDP-specific kernels are precision-independent.)"""
     from fastdiffsr_amd.engine import Engine
     from oracle import fdsr_oracle as O, gdp_oracle as GO
     cfg = UNetConfig(**CFG)
