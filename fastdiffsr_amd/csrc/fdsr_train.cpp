@@ -93,7 +93,7 @@ int make_train_plan(fdsr_handle h, int N, int H, int W, TrainPlan* tp) {
   tp->off_dbl = take(dbl);
   tp->off_wg = take(wg);
   tp->off_csb = take(csb);
-  tp->off_tb = take((size_t)N * temb_bwd_scratch_floats_per_image(ic, enc_dim, hid_dim, t_dim) * sizeof(float));
+  tp->off_tb = take((size_t)N * temb_bwd_scratch_floats_per_image(ic, enc_dim, hid_dim, t_dim, h->TE) * sizeof(float));
   tp->off_loss = take(256);
   tp->off_attn = take(attn);
   tp->off_noise = off;                  // the target noise of a step whose noise the engine draws itself (fdsr_train_grads_pairs)

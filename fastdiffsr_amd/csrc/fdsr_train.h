@@ -132,17 +132,14 @@ struct TembBwdParams {
   const float* nl;         // [N]
   const float* dtemb;      // [N][TE]
   float* dw1; float* db1; float* dw2; float* db2; float* dwn; float* dbn;   // written (=)
-  float* scratch;          // N * temb_bwd_scratch_floats_per_image() floats
+  float* scratch;          // N * temb_bwd_scratch_floats_per_image() floats: [N] records, then the row blocks' partial sums [N][blocks][t_dim]
   int inner, TE, N;
   int swish_block;
   // GDP sibling (gdp_modules/unet.py:120-138, :588-593, :336-342): timestep_embedding(enc_dim) = cat([cos, sin]) -> Linear(enc_dim, hid_dim)
   // -> SiLU -> Linear(hid_dim, t_dim); every per-block Linear(t_dim, 2*Cout) sees SiLU(t).  Zero: the widths above (inner, 4 inner, inner).
   int enc_dim, hid_dim, t_dim, cos_first;
 };
-inline size_t temb_bwd_scratch_floats_per_image(int inner, int enc_dim, int hid_dim, int t_dim) {
-  const size_t E = enc_dim ? enc_dim : inner, Hd = hid_dim ? hid_dim : 4 * inner, Td = t_dim ? t_dim : inner;
-  return E + 2 * Hd + 2 * Td;
-}
+size_t temb_bwd_scratch_floats_per_image(int inner, int enc_dim, int hid_dim, int t_dim, int TE);
 hipError_t launch_temb_bwd(const TembBwdParams& p, hipStream_t s);
 
 // ---- SelfAttention backward (SR3 sibling: ddpm_modules/unet.py:99-127, n_head = 1; GDP sibling: QKVAttentionLegacy,

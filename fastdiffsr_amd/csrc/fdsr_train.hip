@@ -1941,8 +1941,55 @@ struct TembDims { int E, Hd, Td; };
 __host__ __device__ __forceinline__ TembDims temb_dims(const TembBwdParams& p) {
   return TembDims{p.enc_dim ? p.enc_dim : p.inner, p.hid_dim ? p.hid_dim : 4 * p.inner, p.t_dim ? p.t_dim : p.inner};
 }
-__global__ void __launch_bounds__(256) temb_bwd_image_kernel(const TembBwdParams p) {
-  extern __shared__ __attribute__((aligned(16))) float st[];   // enc[E] | pre[Hd] | hidv[Hd] | dt[Td] | dt parts
+// (0) dt[k] = sum_o dtemb[n][o] * wn[o][k], the one large product of this backward (GDP at the reference's width: 30 000 x 512 per
+//     image): grid (N, blocks of FDSR_TEMB_BWD_ROWS rows o).  Within a block the rows split over 256 / Td thread groups; the groups'
+//     sums are added in order, and the image kernel adds the blocks in order: a fixed order whatever the grid.
+#define FDSR_TEMB_BWD_ROWS 512
+__host__ __device__ __forceinline__ int temb_bwd_blocks(int TE) { return (TE + FDSR_TEMB_BWD_ROWS - 1) / FDSR_TEMB_BWD_ROWS; }
+__global__ void __launch_bounds__(256) temb_bwd_dt_kernel(const TembBwdParams p, float* __restrict__ dt_blocks) {
+  extern __shared__ __attribute__((aligned(16))) float st[];   // [parts][Td]
+  const TembDims d = temb_dims(p);
+  const int Td = d.Td, tid = threadIdx.x, n = blockIdx.x, blk = blockIdx.y;
+  const int r0 = blk * FDSR_TEMB_BWD_ROWS, r1 = min(p.TE, r0 + FDSR_TEMB_BWD_ROWS);
+  const int parts = 256 / Td > 0 ? 256 / Td : 1, part = tid / Td, k = tid % Td;
+  const float* dte = p.dtemb + (size_t)n * p.TE;
+  if (Td > 256) {                                            // wider than the workgroup: one part, threads stride over k
+    for (int kk = tid; kk < Td; kk += 256) {
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      int o = r0;
+      for (; o + 4 <= r1; o += 4) {
+        a0 = fmaf(dte[o], p.wn[(size_t)o * Td + kk], a0);
+        a1 = fmaf(dte[o + 1], p.wn[(size_t)(o + 1) * Td + kk], a1);
+        a2 = fmaf(dte[o + 2], p.wn[(size_t)(o + 2) * Td + kk], a2);
+        a3 = fmaf(dte[o + 3], p.wn[(size_t)(o + 3) * Td + kk], a3);
+      }
+      for (; o < r1; ++o) a0 = fmaf(dte[o], p.wn[(size_t)o * Td + kk], a0);
+      st[kk] = (a0 + a1) + (a2 + a3);
+    }
+  } else if (part < parts) {
+    const int o0 = r0 + (int)((long)part * (r1 - r0) / parts), o1 = r0 + (int)((long)(part + 1) * (r1 - r0) / parts);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int o = o0;
+    for (; o + 4 <= o1; o += 4) {
+      a0 = fmaf(dte[o], p.wn[(size_t)o * Td + k], a0);
+      a1 = fmaf(dte[o + 1], p.wn[(size_t)(o + 1) * Td + k], a1);
+      a2 = fmaf(dte[o + 2], p.wn[(size_t)(o + 2) * Td + k], a2);
+      a3 = fmaf(dte[o + 3], p.wn[(size_t)(o + 3) * Td + k], a3);
+    }
+    for (; o < o1; ++o) a0 = fmaf(dte[o], p.wn[(size_t)o * Td + k], a0);
+    st[part * Td + k] = (a0 + a1) + (a2 + a3);
+  }
+  __syncthreads();
+  float* dst = dt_blocks + ((size_t)n * gridDim.y + blk) * Td;
+  for (int kk = tid; kk < Td; kk += 256) {
+    float a = 0.f;
+    for (int q = 0; q < parts; ++q) a += st[q * Td + kk];
+    dst[kk] = a;
+  }
+}
+
+__global__ void __launch_bounds__(256) temb_bwd_image_kernel(const TembBwdParams p, const float* __restrict__ dt_blocks, int nblk) {
+  extern __shared__ __attribute__((aligned(16))) float st[];   // enc[E] | pre[Hd] | hidv[Hd] | dt[Td]
   const TembDims d = temb_dims(p);
   const int E = d.E, hid = d.Hd, Td = d.Td, tid = threadIdx.x, n = blockIdx.x, half = E / 2;
   float* enc = st;
@@ -1963,41 +2010,10 @@ __global__ void __launch_bounds__(256) temb_bwd_image_kernel(const TembBwdParams
     pre[j] = a;
     hv[j] = a / (1.0f + expf(-a));
   }
-  {   // dt[k] = sum_o dtemb[n][o] * wn[o][k]: the o range in 256 / Td parts (one per thread group), parts added in order
-    float* dpart = dt + Td;                                  // [parts][Td]
-    const int parts = 256 / Td > 0 ? 256 / Td : 1, part = tid / Td, k = tid % Td;
-    if (Td > 256) {                                          // wider than the workgroup: one part, threads stride over k
-      for (int kk = tid; kk < Td; kk += 256) {
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        int o = 0;
-        for (; o + 4 <= p.TE; o += 4) {
-          a0 = fmaf(p.dtemb[(size_t)n * p.TE + o], p.wn[(size_t)o * Td + kk], a0);
-          a1 = fmaf(p.dtemb[(size_t)n * p.TE + o + 1], p.wn[(size_t)(o + 1) * Td + kk], a1);
-          a2 = fmaf(p.dtemb[(size_t)n * p.TE + o + 2], p.wn[(size_t)(o + 2) * Td + kk], a2);
-          a3 = fmaf(p.dtemb[(size_t)n * p.TE + o + 3], p.wn[(size_t)(o + 3) * Td + kk], a3);
-        }
-        for (; o < p.TE; ++o) a0 = fmaf(p.dtemb[(size_t)n * p.TE + o], p.wn[(size_t)o * Td + kk], a0);
-        dpart[kk] = (a0 + a1) + (a2 + a3);
-      }
-    } else if (part < parts) {
-      const int o0 = (int)((long)part * p.TE / parts), o1 = (int)((long)(part + 1) * p.TE / parts);
-      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-      int o = o0;
-      for (; o + 4 <= o1; o += 4) {
-        a0 = fmaf(p.dtemb[(size_t)n * p.TE + o], p.wn[(size_t)o * Td + k], a0);
-        a1 = fmaf(p.dtemb[(size_t)n * p.TE + o + 1], p.wn[(size_t)(o + 1) * Td + k], a1);
-        a2 = fmaf(p.dtemb[(size_t)n * p.TE + o + 2], p.wn[(size_t)(o + 2) * Td + k], a2);
-        a3 = fmaf(p.dtemb[(size_t)n * p.TE + o + 3], p.wn[(size_t)(o + 3) * Td + k], a3);
-      }
-      for (; o < o1; ++o) a0 = fmaf(p.dtemb[(size_t)n * p.TE + o], p.wn[(size_t)o * Td + k], a0);
-      dpart[part * Td + k] = (a0 + a1) + (a2 + a3);
-    }
-    __syncthreads();
-    for (int kk = tid; kk < Td; kk += 256) {
-      float a = 0.f;
-      for (int q = 0; q < parts; ++q) a += dpart[q * Td + kk];
-      dt[kk] = a;
-    }
+  for (int kk = tid; kk < Td; kk += 256) {                   // the row blocks of temb_bwd_dt_kernel, in order
+    float a = 0.f;
+    for (int b = 0; b < nblk; ++b) a += dt_blocks[((size_t)n * nblk + b) * Td + kk];
+    dt[kk] = a;
   }
   __syncthreads();
   float* out = p.scratch + (size_t)n * (E + 2 * hid + 2 * Td);
@@ -2078,10 +2094,17 @@ __global__ void __launch_bounds__(256) temb_bwd_param_kernel(const TembBwdParams
   }
 }
 
+size_t temb_bwd_scratch_floats_per_image(int inner, int enc_dim, int hid_dim, int t_dim, int TE) {
+  const size_t E = enc_dim ? enc_dim : inner, Hd = hid_dim ? hid_dim : 4 * inner, Td = t_dim ? t_dim : inner;
+  return E + 2 * Hd + 2 * Td + (size_t)temb_bwd_blocks(TE) * Td;   // the image kernel's record | the row blocks' partial dt
+}
+
 hipError_t launch_temb_bwd(const TembBwdParams& p, hipStream_t s) {
   const TembDims d = temb_dims(p);
-  const int parts = 256 / d.Td > 0 ? 256 / d.Td : 1;   // dt partial sums live after dt in LDS
-  hipLaunchKernelGGL(temb_bwd_image_kernel, dim3(p.N), dim3(256), (size_t)(d.E + 2 * d.Hd + d.Td + parts * d.Td) * sizeof(float), s, p);
+  const int parts = 256 / d.Td > 0 ? 256 / d.Td : 1, nblk = temb_bwd_blocks(p.TE);
+  float* dt_blocks = p.scratch + (size_t)p.N * (d.E + 2 * d.Hd + 2 * d.Td);   // [N][nblk][Td], behind the per-image records
+  hipLaunchKernelGGL(temb_bwd_dt_kernel, dim3(p.N, nblk), dim3(256), (size_t)parts * d.Td * sizeof(float), s, p, dt_blocks);
+  hipLaunchKernelGGL(temb_bwd_image_kernel, dim3(p.N), dim3(256), (size_t)(d.E + 2 * d.Hd + d.Td) * sizeof(float), s, p, dt_blocks, nblk);
   const size_t total = (size_t)p.TE * d.Td + p.TE + (size_t)d.Td * d.Hd + d.Td + (size_t)d.Hd * d.E + d.Hd;
   hipLaunchKernelGGL(temb_bwd_param_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, total);
   return hipGetLastError();
