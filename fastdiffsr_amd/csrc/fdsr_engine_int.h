@@ -181,6 +181,7 @@ struct fdsr_engine {
   bool f32_forms_stale = false;       // fp32 conv forms (d_params packs, d_wt) lag: f16x3 training steps refresh only what they read
   unsigned long long* d_copy_tab = nullptr;   // {src offset, dst offset, count} triples: master -> d_params for the non-conv tensors
   int n_copy_tab = 0;
+  size_t copy_tab_max = 0;                // elements of the largest entry of that table
 };
 
 namespace fdsr_int {

@@ -185,6 +185,7 @@ int train_prepare(fdsr_handle h) {
       tab.push_back(h->master_off[i]);
       tab.push_back(w.dev_off);
       tab.push_back(numel(w.shape));
+      h->copy_tab_max = std::max<size_t>(h->copy_tab_max, numel(w.shape));
     }
     h->n_copy_tab = (int)(tab.size() / 3);
     HIPCHK(h, hipMalloc((void**)&h->d_copy_tab, std::max<size_t>(tab.size(), 3) * sizeof(unsigned long long)));
@@ -209,7 +210,7 @@ int repack_from_master(fdsr_handle h, hipStream_t st, bool forward_forms, bool a
       HIPCHK(h, launch_pack_conv_f32(h->d_master + h->master_off[i], h->d_params + w.dev_off, (int)w.shape[0], (int)w.shape[1], w.ks,
                                      w.cout_pad, w.cin_pad, st));
     }
-    HIPCHK(h, launch_copy_table(h->d_master, h->d_params, h->d_copy_tab, h->n_copy_tab, st));
+    HIPCHK(h, launch_copy_table(h->d_master, h->d_params, h->d_copy_tab, h->n_copy_tab, st, h->copy_tab_max));
   }
   for (const Op& op : h->ops) {
     if (op.kind != Op::CONV || op.src0 == h->t_in) continue;

@@ -31,7 +31,7 @@ size_t colsum_scratch_doubles(int N, int HW, int C);
 // x[i] *= f
 hipError_t launch_scale_inplace(float* x, size_t n, float f, hipStream_t s);
 // dst[tab[3e+1] + i] = src[tab[3e] + i] for i < tab[3e+2], e < entries (many small tensors in one launch)
-hipError_t launch_copy_table(const float* src, float* dst, const unsigned long long* tab, int entries, hipStream_t s);
+hipError_t launch_copy_table(const float* src, float* dst, const unsigned long long* tab, int entries, hipStream_t s, size_t max_elems = 0);   // max_elems: the largest entry (sizes the grid)
 // out[c] = sum_n S[n*stride + c], c < C, in image order
 hipError_t launch_sum_rows(const float* S, int N, int stride, int C, float* out, hipStream_t s);
 // z [N,2H,2W,C] = dy [N,H,W,C] at the even positions, zero elsewhere (the stride-2 conv's transpose)

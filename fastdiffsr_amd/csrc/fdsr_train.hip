@@ -178,11 +178,14 @@ __global__ void __launch_bounds__(256) scale_inplace_kernel(float* __restrict__ 
 // dst[tab[3e+1] + i] = src[tab[3e] + i], i < tab[3e+2]: one workgroup per table entry (the small tensors of a model in one launch)
 __global__ void __launch_bounds__(256) copy_table_kernel(const float* __restrict__ src, float* __restrict__ dst,
                                                          const unsigned long long* __restrict__ tab) {
+  // grid (entries, split): a tensor's elements are dealt over the workgroups of its row (most entries are a few hundred
+  // floats; the GDP sibling's per-block Linears are 4 MB each -- one workgroup per tensor moved them at 76 GB/s)
   const unsigned long long so = tab[3 * blockIdx.x], dof = tab[3 * blockIdx.x + 1], n = tab[3 * blockIdx.x + 2];
-  for (unsigned long long i = threadIdx.x; i < n; i += 256) dst[dof + i] = src[so + i];
+  for (unsigned long long i = (unsigned long long)blockIdx.y * 256 + threadIdx.x; i < n; i += 256ull * gridDim.y) dst[dof + i] = src[so + i];
 }
-hipError_t launch_copy_table(const float* src, float* dst, const unsigned long long* tab, int entries, hipStream_t s) {
-  if (entries > 0) hipLaunchKernelGGL(copy_table_kernel, dim3(entries), dim3(256), 0, s, src, dst, tab);
+hipError_t launch_copy_table(const float* src, float* dst, const unsigned long long* tab, int entries, hipStream_t s, size_t max_elems) {
+  const unsigned split = (unsigned)std::min<size_t>(64, std::max<size_t>(1, (max_elems + 32767) / 32768));   // >= 32 K floats per workgroup of the largest entry
+  if (entries > 0) hipLaunchKernelGGL(copy_table_kernel, dim3(entries, split), dim3(256), 0, s, src, dst, tab);
   return hipGetLastError();
 }
 
