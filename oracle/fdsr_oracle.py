@@ -108,7 +108,7 @@ def swish(x: Tensor) -> Tensor:                              # unet.py:57-59
 
 def positional_encoding(noise_level: Tensor, dim: int) -> Tensor:   # unet.py:22-35
     count = dim // 2
-    step = torch.arange(count, dtype=noise_level.dtype) / count
+    step = torch.arange(count, dtype=noise_level.dtype, device=noise_level.device) / count
     enc = noise_level.unsqueeze(1) * torch.exp(-math.log(1e4) * step.unsqueeze(0))
     return torch.cat([torch.sin(enc), torch.cos(enc)], dim=-1)
 
@@ -206,7 +206,7 @@ def p_sample(sd, cfg: UNetConfig, tab: Dict[str, np.ndarray], x: Tensor, t: int,
 
     `noise` is the N(0,1) tensor the reference would draw with randn_like (ignored at t==0)."""
     B = x.shape[0]
-    nl = torch.FloatTensor([tab['sqrt_alphas_cumprod_prev_f64'][t + 1]]).repeat(B, 1)   # :169-170
+    nl = torch.FloatTensor([tab['sqrt_alphas_cumprod_prev_f64'][t + 1]]).repeat(B, 1).to(x.device)   # :169-170
     eps = unet_forward(sd, cfg, torch.cat([cond, x], dim=1), nl)                        # :173
     T = lambda k: torch.tensor(tab[k][t])                   # 0-dim fp32 tensor, as buffer[t]
     x0 = T('sqrt_recip_alphas_cumprod') * x - T('sqrt_recipm1_alphas_cumprod') * eps    # :157-159
