@@ -236,7 +236,7 @@ def family_label(precision):
     """Names of the kernels the 3x3 family's launches run on under the active options (what to sum in a rocprofv3 stats file)."""
     if precision == 'f32':
         return 'conv_mfma_f32_kernel'
-    bit = K32['F16X3'] if precision == 'f16x3' else K32['BF16']
+    bit = K32['F16X3'] if precision == 'f16x3' else K32['BF16']     # (the f16 mode takes the bf16 mode's kernel forms)
     names = []
     if STRIP_BITS & (STRIP['F16X3_64'] if precision == 'f16x3' else (STRIP['BF16_64'] | STRIP['BF16_CAT64'] | STRIP['BF16_RIDER'] | STRIP['BF16_CAT128'] | STRIP['BF16_COUT128'])):
         names.append('conv_strip_kernel')
@@ -299,7 +299,7 @@ def whole_path(ips_per_gpu, precision, S=256):
     """SURVEY 8d: the whole path against both roofs, per GPU (ideal-fused traffic 32.85 GB / image fp32, 16.4 bf16, at 256 x 256;
     FLOPs and bytes scale with the pixel count)."""
     px = (S / 256.0) ** 2
-    gb = (16.4 if precision == 'bf16' else 32.85) * px
+    gb = (16.4 if precision in ('bf16', 'f16') else 32.85) * px
     flops = FLOPS_PER_IMAGE * px
     return {'tflops': ips_per_gpu * flops / 1e12,
             'frac_mfma_peak': ips_per_gpu * flops / 1e12 / (PEAK_F32_MFMA if precision == 'f32' else PEAK_16BIT_MFMA),
@@ -366,7 +366,7 @@ def run_train(eng, dev, B, S, steps, warmup, rank=0, sync=None, allreduce=None, 
     g = torch.Generator().manual_seed(777 + rank)
     hr = (torch.rand(B, 3, S, S, generator=g) * 2 - 1).to(dev)
     sr = (hr + 0.1 * torch.randn(B, 3, S, S, generator=g).to(dev)).clamp(-1, 1)
-    eng.set_precision('f32' if precision == 'bf16' else precision)
+    eng.set_precision('f32' if precision in ('bf16', 'f16') else precision)
     eng.set_training(True)
     eng.set_seed(99 + rank)
     world = int(os.environ.get('WORLD_SIZE', 1))
@@ -787,7 +787,7 @@ def main():
                     help='skip the exact_f32 / bf16_b64_graph / b1_graph legs that ride in the same JSON line at N=1')
     ap.add_argument('--no-profile', action='store_true', help='skip the per-conv HIP-event timing')
     ap.add_argument('--no-facade', action='store_true', help='skip the file-based val_e2e / train_facade_b32 records (768 PNG writes + a 256-image val pass)')
-    ap.add_argument('--precision', default='f16x3', choices=['f32', 'f16x3', 'bf16'],
+    ap.add_argument('--precision', default='f16x3', choices=['f32', 'f16x3', 'bf16', 'f16'],
                     help='conv arithmetic: exact fp32 MFMA, fp32-grade split-f16 MFMA, or bf16')
     ap.add_argument('--graph', action='store_true', help='replay the 20-step loop as a hipGraph')
     ap.add_argument('--train', action='store_true',
@@ -938,6 +938,9 @@ def main():
                                         'configs[1] in exact fp32 MFMA arithmetic (v_mfma_f32_32x32x2_f32), B=16'),
                 'bf16_b64_graph': sub_record(eng, dev, 'bf16_b64_graph', 'bf16', 64, S, ks, kw, True,
                                              'configs[2]: B=64, bf16 activations + bf16 MFMA, 20-step loop replayed as a hipGraph'),
+                'f16_b64_graph': sub_record(eng, dev, 'f16_b64_graph', 'f16', 64, S, ks, kw, True,
+                                            'configs[2] workload in the f16 mode (round 6): one f16 MFMA per product + f16 activations -- the bf16 mode\'s '
+                                            'bytes and MFMA rate with 11 mantissa bits (PSNR against the oracle 74.6 dB where bf16 gives 57.6)'),
                 'b1_graph': sub_record(eng, dev, 'b1_graph', 'f16x3', 1, S, max(20, args.steps), max(5, args.warmup), True,
                                        'configs[0] regime (the reference val loop is B=1, sr_mfe.py:279-284): latency per image, hipGraph'),
             }

@@ -9,7 +9,7 @@ FDSR_MAX_MULTS = 8
 FDSR_SAMPLE_GRAPH = 1
 FDSR_METRIC_FIELDS = 8
 FDSR_SSIM_UNIFORM7, FDSR_SSIM_GAUSS11 = 1, 2
-PRECISIONS = {'f32': 0, 'f16x3': 1, 'bf16': 2}
+PRECISIONS = {'f32': 0, 'f16x3': 1, 'bf16': 2, 'f16': 3}
 
 
 class FdsrConfig(C.Structure):

@@ -44,6 +44,7 @@ struct ConvHCfg {
   static constexpr int TW = 32, NW = 8;
   static constexpr int KC = 16 * KSUB;        // input channels per staged chunk (KSUB > 1 only for 1x1)
   static constexpr int NP = PREC == PREC_F16X3 ? 2 : 1;
+  static constexpr int WNP = PREC == PREC_BF16 ? 1 : 2;   // planes per fragment of the weight arena the mode reads (PREC_F16: the f16x3 form, hi plane only)
   static constexpr int ROWB = NP * 32 * KSUB + 16;   // LDS bytes per halo pixel: KSUB x [16 hi | 16 lo] + pad (odd # of 16-B slots)
   static constexpr int PAD = KS / 2;
   static constexpr int HH = (TH - 1) * STRIDE + KS;
@@ -192,8 +193,7 @@ __global__ void __launch_bounds__(512, 2) conv_mfma_h_kernel(const ConvParams p)
         *reinterpret_cast<h4*>(dst + 32) = lo;
       } else {
         v = v * keep;
-        b4 hb = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
-        *reinterpret_cast<b4*>(dst) = hb;
+        *reinterpret_cast<uint2*>(dst) = stage4_16<PREC>(v);
       }
     }
   };
@@ -205,9 +205,9 @@ __global__ void __launch_bounds__(512, 2) conv_mfma_h_kernel(const ConvParams p)
   uint4 Bf[T][NP];
   auto load_b_tap = [&](int kc, int tap) {
     const int ts = tap / KSUB, sub = tap % KSUB;   // packed per 16-channel block: [cot][kc16][wn][spatial tap]
-    const uint4* src = wq + ((((size_t)cot * (nk * KSUB) + kc * KSUB + sub) * WN + wn) * (KS * KS) + ts) * (NP * 64) + lane;
+    const uint4* src = wq + ((((size_t)cot * (nk * KSUB) + kc * KSUB + sub) * WN + wn) * (KS * KS) + ts) * (Cfg::WNP * 64) + lane;
     if (RIDER && kc >= nk)   // the 1x1 conv's own fragments [cot][kc16][wn]: one tap, into slot 0
-      src = reinterpret_cast<const uint4*>(p.wq_r) + (((size_t)cot * p.nkr + (kc - nk)) * WN + wn) * (NP * 64) + lane;
+      src = reinterpret_cast<const uint4*>(p.wq_r) + (((size_t)cot * p.nkr + (kc - nk)) * WN + wn) * (Cfg::WNP * 64) + lane;
 #pragma unroll
     for (int pl = 0; pl < NP; ++pl) Bf[tap][pl] = src[pl * 64];
   };
@@ -276,7 +276,7 @@ __global__ void __launch_bounds__(512, 2) conv_mfma_h_kernel(const ConvParams p)
           acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, ahi), __builtin_bit_cast(h8, Bf[tap][NP - 1]), acc[mb], 0, 0, 0);
           acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, ahi), __builtin_bit_cast(h8, Bf[tap][0]), acc[mb], 0, 0, 0);
         } else {
-          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8, ahi), __builtin_bit_cast(b8, Bf[tap][0]), acc[mb], 0, 0, 0);
+          acc[mb] = mfma32_k16<PREC>(ahi, Bf[tap][0], acc[mb]);
         }
       }
       if (more && (tap == 0 || !next_rider)) load_b_tap(kc + 1, tap);   // same registers, next chunk
@@ -325,7 +325,7 @@ __global__ void __launch_bounds__(512, 2) conv_mfma_h_kernel(const ConvParams p)
           acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, ahi), __builtin_bit_cast(h8, Bf[0][NP - 1]), acc[mb], 0, 0, 0);
           acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, ahi), __builtin_bit_cast(h8, Bf[0][0]), acc[mb], 0, 0, 0);
         } else {
-          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8, ahi), __builtin_bit_cast(b8, Bf[0][0]), acc[mb], 0, 0, 0);
+          acc[mb] = mfma32_k16<PREC>(ahi, Bf[0][0], acc[mb]);
         }
       }
       if (kc + 1 < kc1) {
@@ -387,7 +387,7 @@ __global__ void __launch_bounds__(512, 2) conv_mfma_h_kernel(const ConvParams p)
   auto epilogue = [&](auto out16_tag) {
     constexpr bool OUT16 = decltype(out16_tag)::value;
     auto put = [&](size_t idx, float v) {
-      if (OUT16) reinterpret_cast<unsigned short*>(p.out)[idx] = f32_to_bf16_bits(v);
+      if (OUT16) reinterpret_cast<unsigned short*>(p.out)[idx] = PREC == PREC_F16 ? f32_to_f16_bits(v) : f32_to_bf16_bits(v);
       else p.out[idx] = v;
     };
     if (interior) {
@@ -442,7 +442,7 @@ __global__ void __launch_bounds__(512, 2) conv_mfma_h_kernel(const ConvParams p)
     }
   };
   H_STAMP();   // epilogue starts (accumulators final)
-  if (PREC == PREC_BF16 && !p.out_f32) epilogue(std::true_type{});
+  if (prec_is16(PREC) && !p.out_f32) epilogue(std::true_type{});
   else epilogue(std::false_type{});
   H_STAMP();   // stores issued
   if (p.part_out) {
@@ -518,7 +518,7 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const ConvParams p, 
       o[i] = ((size_t)(n * p.Hout + min(oy, p.Hout - 1)) * p.Wout + min(ox, p.Wout - 1)) * p.Cout + cch;
 #pragma unroll
       for (int s = 0; s < NS; ++s) sl[i][s] = *reinterpret_cast<const f32x4*>(p.kscratch + (size_t)min(s, last) * slice + o[i]);
-      if (OUT16) rv[i] = ActIO<PREC_BF16>::widen(ActIO<PREC_BF16>::load4(resp, o[i]));
+      if (OUT16) rv[i] = p.out_bf16 == 2 ? ActIO<PREC_F16>::widen(ActIO<PREC_F16>::load4(resp, o[i])) : ActIO<PREC_BF16>::widen(ActIO<PREC_BF16>::load4(resp, o[i]));
       else rv[i] = *reinterpret_cast<const f32x4*>(resp + o[i]);
     }
     __builtin_amdgcn_sched_barrier(0);   // every load above is issued before the first wait below (the scheduler otherwise waits for the constants first)
@@ -549,10 +549,7 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const ConvParams p, 
       }
       if (ok[i]) {
         if (OUT16) {
-          uint2 pk;
-          pk.x = (unsigned)f32_to_bf16_bits(a[0]) | ((unsigned)f32_to_bf16_bits(a[1]) << 16);
-          pk.y = (unsigned)f32_to_bf16_bits(a[2]) | ((unsigned)f32_to_bf16_bits(a[3]) << 16);
-          *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p.out) + o[i]) = pk;
+          *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p.out) + o[i]) = p.out_bf16 == 2 ? pack4_16<PREC_F16>(a) : pack4_16<PREC_BF16>(a);
         } else {
           *reinterpret_cast<f32x4*>(p.out + o[i]) = a;
         }
@@ -614,8 +611,8 @@ static hipError_t launch_h_t(const ConvParams& p, hipStream_t s, int* tiles) {
   const int sk = p.ksplit > 1 ? p.ksplit : 1;
   const int nwg = p.N * tilesX * tilesY * (p.Cout_pad / Cfg::BN) * sk;
   ConvParams q = p;
-  q.out_bf16 = (PREC == PREC_BF16 && !p.out_f32) ? 1 : 0;
-  if (KS == 3 && STRIDE == 1 && !UP && KSUB == 1 && (PREC == PREC_F16X3 || PREC == PREC_BF16) && conv_k32_ok(TH, WN, PREC, q)) {
+  q.out_bf16 = p.out_f32 ? 0 : prec_act16(PREC);
+  if (KS == 3 && STRIDE == 1 && !UP && KSUB == 1 && (PREC == PREC_F16X3 || prec_is16(PREC)) && conv_k32_ok(TH, WN, PREC, q)) {
     const hipError_t e = launch_conv_k32(TH, WN, PREC, q, nwg, s);   // the 16x16x32 form (fdsr_conv_k32.hip): same grid, same outputs
     if (e != hipSuccess) return e;
   } else {
@@ -765,7 +762,7 @@ hipError_t launch_conv_h(ConvKind kind, int prec, const ConvParams& p, hipStream
 #define XR(TH_, WN_)                                                                                     \
     if (TH == TH_ && WN == WN_)                                                                          \
       return prec == PREC_F16X3 ? launch_h_t<3, 1, false, TH_, WN_, PREC_F16X3, 1, true>(p, s, tiles)     \
-                                : launch_h_t<3, 1, false, TH_, WN_, PREC_BF16, 1, true>(p, s, tiles);
+                                : prec == PREC_F16 ? launch_h_t<3, 1, false, TH_, WN_, PREC_F16, 1, true>(p, s, tiles) : launch_h_t<3, 1, false, TH_, WN_, PREC_BF16, 1, true>(p, s, tiles);
     FDSR_CONVH_RIDER_SHAPES(XR)
 #undef XR
     return hipErrorInvalidValue;
@@ -773,7 +770,7 @@ hipError_t launch_conv_h(ConvKind kind, int prec, const ConvParams& p, hipStream
 #define X(KS_, ST_, UP_, TH_, WN_, KSUB_)                                                                \
   if (ks == KS_ && stride == ST_ && up == UP_ && TH == TH_ && WN == WN_ && ksub == KSUB_) {               \
     return prec == PREC_F16X3 ? launch_h_t<KS_, ST_, UP_, TH_, WN_, PREC_F16X3, KSUB_>(p, s, tiles)       \
-                              : launch_h_t<KS_, ST_, UP_, TH_, WN_, PREC_BF16, KSUB_>(p, s, tiles);       \
+                              : prec == PREC_F16 ? launch_h_t<KS_, ST_, UP_, TH_, WN_, PREC_F16, KSUB_>(p, s, tiles) : launch_h_t<KS_, ST_, UP_, TH_, WN_, PREC_BF16, KSUB_>(p, s, tiles);       \
   }
   FDSR_CONVH_SHAPES(X)
 #undef X
@@ -784,12 +781,14 @@ hipError_t kernels_h_init() {
   hipError_t e;
 #define X(KS_, ST_, UP_, TH_, WN_, KSUB_)                                                          \
   if ((e = init_h_t<KS_, ST_, UP_, TH_, WN_, PREC_F16X3, KSUB_>()) != hipSuccess) return e;         \
-  if ((e = init_h_t<KS_, ST_, UP_, TH_, WN_, PREC_BF16, KSUB_>()) != hipSuccess) return e;
+  if ((e = init_h_t<KS_, ST_, UP_, TH_, WN_, PREC_BF16, KSUB_>()) != hipSuccess) return e; \
+  if ((e = init_h_t<KS_, ST_, UP_, TH_, WN_, PREC_F16, KSUB_>()) != hipSuccess) return e;
   FDSR_CONVH_SHAPES(X)
 #undef X
 #define XR(TH_, WN_)                                                                                    \
   if ((e = init_h_t<3, 1, false, TH_, WN_, PREC_F16X3, 1, true>()) != hipSuccess) return e;              \
-  if ((e = init_h_t<3, 1, false, TH_, WN_, PREC_BF16, 1, true>()) != hipSuccess) return e;
+  if ((e = init_h_t<3, 1, false, TH_, WN_, PREC_BF16, 1, true>()) != hipSuccess) return e; \
+  if ((e = init_h_t<3, 1, false, TH_, WN_, PREC_F16, 1, true>()) != hipSuccess) return e;
   FDSR_CONVH_RIDER_SHAPES(XR)
 #undef XR
   if ((e = kernels_k32_init()) != hipSuccess) return e;

@@ -92,6 +92,7 @@ template <int TH, int WN, int PREC, int NW_ = 8>
 struct ConvK32Cfg {
   static constexpr int TW = 32, NW = NW_, KC = 32;
   static constexpr int NP = PREC == PREC_F16X3 ? 2 : 1;
+  static constexpr int WNP = PREC == PREC_BF16 ? 1 : 2;   // planes per fragment in the weight arena the mode reads (PREC_F16: the f16x3 form, hi plane only)
   static constexpr int ROWB = 64 * NP;           // LDS bytes per halo pixel (no pad: swizzled)
   static constexpr int HH = TH + 2, HWD = TW + 2, NPIX = HH * HWD;
   static constexpr int WM = NW / WN, BN = 32 * WN, MB = TH / WM;
@@ -354,9 +355,9 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_k32_kernel(const ConvParams p
       } else {
         const float keep = in_pix[i] >= 0 ? 1.f : 0.f;
         v = v * keep;
-        k_b4 hb = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
-        if (K32_DIAG & 8) { const uint2 u = __builtin_bit_cast(uint2, hb); asm volatile("" ::"v"(u.x), "v"(u.y)); }
-        else *reinterpret_cast<k_b4*>(dst) = hb;
+        const uint2 hb = stage4_16<PREC>(v);
+        if (K32_DIAG & 8) asm volatile("" ::"v"(hb.x), "v"(hb.y));
+        else *reinterpret_cast<uint2*>(dst) = hb;
       }
     }
   };
@@ -369,9 +370,9 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_k32_kernel(const ConvParams p
   const int wlane = 32 * (g & 1) + c15;          // + 16 ch: unit within the 32x32x16-order block
   auto load_w = [&](int kc, int tap, int slot) __attribute__((always_inline)) {
     if (K32_DIAG & 32) kc = 0;   // (timing probe: every chunk multiplies chunk 0's fragments -- what a weight fetch that never misses would buy)
-    const uint4* src = wq + ((((size_t)cot * nk16 + 2 * kc + (g >> 1)) * WN + wn) * 9 + tap) * (NP * 64) + wlane;
+    const uint4* src = wq + ((((size_t)cot * nk16 + 2 * kc + (g >> 1)) * WN + wn) * 9 + tap) * (Cfg::WNP * 64) + wlane;
     if (RIDER && kc >= nk)   // the 1x1 conv's own fragments [cot][kc16][wn]
-      src = reinterpret_cast<const uint4*>(p.wq_r) + (((size_t)cot * p.nkr + 2 * (kc - nk) + (g >> 1)) * WN + wn) * (NP * 64) + wlane;
+      src = reinterpret_cast<const uint4*>(p.wq_r) + (((size_t)cot * p.nkr + 2 * (kc - nk) + (g >> 1)) * WN + wn) * (Cfg::WNP * 64) + wlane;
 #pragma unroll
     for (int ch = 0; ch < 2; ++ch)
 #pragma unroll
@@ -457,8 +458,7 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_k32_kernel(const ConvParams p
       for (int ph = 0; ph < 2; ++ph)
 #pragma unroll
         for (int ch = 0; ch < 2; ++ch)
-          acc[mb][ph][ch] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(k_b8, Wf[ws][ch][0]),
-                                                                   __builtin_bit_cast(k_b8, Xf[xs][ph][0]), acc[mb][ph][ch], 0, 0, 0);
+          acc[mb][ph][ch] = mfma16_k32<PREC>(Wf[ws][ch][0], Xf[xs][ph][0], acc[mb][ph][ch]);
     }
   };
 
@@ -679,10 +679,7 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_k32_kernel(const ConvParams p
     constexpr bool OUT16 = decltype(out16_tag)::value;
     auto put4 = [&](size_t idx, k_f32x4 v) {
       if (OUT16) {
-        uint2 pk;
-        pk.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
-        pk.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
-        *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p.out) + idx) = pk;
+        *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p.out) + idx) = pack4_16<PREC>(v);
       } else {
         *reinterpret_cast<k_f32x4*>(p.out + idx) = v;
       }
@@ -806,7 +803,7 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_k32_kernel(const ConvParams p
     if (interior) epilogue_gnb(std::true_type{});
     else epilogue_gnb(std::false_type{});
   } else {
-    if (PREC == PREC_BF16 && !p.out_f32) epilogue(std::true_type{});
+    if (prec_is16(PREC) && !p.out_f32) epilogue(std::true_type{});
     else epilogue(std::false_type{});
   }
   if (p.part_out) {
@@ -863,6 +860,7 @@ template <int TH, int WN, int PREC>
 struct ConvUp2K32Cfg {
   static constexpr int TW = 32, KC = 32;
   static constexpr int NP = PREC == PREC_F16X3 ? 2 : 1;
+  static constexpr int WNP = PREC == PREC_BF16 ? 1 : 2;   // (as ConvK32Cfg)
   static constexpr int ROWB = 64 * NP;
   static constexpr int HH = TH + 1, HWD = TW + 2, NPIX = HH * HWD;
   static constexpr int WM = 8 / WN, BN = 32 * WN, MB = TH / WM;
@@ -958,8 +956,7 @@ __global__ void __launch_bounds__(512, 2) conv_up2_k32_kernel(const ConvParams p
       } else {
         const float keep = in_pix[i] >= 0 ? 1.f : 0.f;
         v = v * keep;
-        k_b4 hb = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
-        *reinterpret_cast<k_b4*>(buf + sd) = hb;
+        *reinterpret_cast<uint2*>(buf + sd) = stage4_16<PREC>(v);
       }
     }
   };
@@ -970,7 +967,7 @@ __global__ void __launch_bounds__(512, 2) conv_up2_k32_kernel(const ConvParams p
   uint4 Wf[R][2][NP];
   const int wlane = 32 * (g & 1) + c15;
   auto load_w = [&](int kc, int slot) {
-    const uint4* src = wq + ((((((size_t)cot * nk16 + 2 * kc + (g >> 1)) * WN + wn) * 2 + py) * 8 + slot) * (NP * 64)) + wlane;
+    const uint4* src = wq + ((((((size_t)cot * nk16 + 2 * kc + (g >> 1)) * WN + wn) * 2 + py) * 8 + slot) * (Cfg::WNP * 64)) + wlane;
 #pragma unroll
     for (int ch = 0; ch < 2; ++ch)
 #pragma unroll
@@ -1031,8 +1028,7 @@ __global__ void __launch_bounds__(512, 2) conv_up2_k32_kernel(const ConvParams p
       for (int ph = 0; ph < 2; ++ph)
 #pragma unroll
         for (int ch = 0; ch < 2; ++ch)
-          acc[mb][px][ph][ch] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(k_b8, Wf[ws][ch][0]),
-                                                                       __builtin_bit_cast(k_b8, Xf[xs][ph][0]), acc[mb][px][ph][ch], 0, 0, 0);
+          acc[mb][px][ph][ch] = mfma16_k32<PREC>(Wf[ws][ch][0], Xf[xs][ph][0], acc[mb][px][ph][ch]);
     }
   };
 
@@ -1083,7 +1079,7 @@ __global__ void __launch_bounds__(512, 2) conv_up2_k32_kernel(const ConvParams p
   k_f32x4 s1[2], s2[2];
 #pragma unroll
   for (int ch = 0; ch < 2; ++ch) s1[ch] = s2[ch] = k_f32x4{0.f, 0.f, 0.f, 0.f};
-  const bool out16 = PREC == PREC_BF16;   // bf16 mode: the upsample conv's output is a bf16 activation
+  const bool out16 = prec_is16(PREC);     // bf16 / f16 mode: the upsample conv's output is a 16-bit activation
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -1097,10 +1093,7 @@ __global__ void __launch_bounds__(512, 2) conv_up2_k32_kernel(const ConvParams p
             const size_t idx = ((size_t)(n * p.Hout + 2 * sy + py) * p.Wout + 2 * sx + px) * p.Cout + cob + 16 * ch;
             const k_f32x4 v = acc[mb][px][ph][ch] * winv + add[ch];
             if (out16) {
-              uint2 pk;
-              pk.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
-              pk.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
-              *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p.out) + idx) = pk;
+              *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p.out) + idx) = pack4_16<PREC>(v);
             } else {
               *reinterpret_cast<k_f32x4*>(p.out + idx) = v;
             }
@@ -1148,7 +1141,7 @@ __global__ void __launch_bounds__(512, 2) conv_up2_k32_kernel(const ConvParams p
 }
 
 bool conv_up2_k32_ok(int prec, const ConvParams& p) {
-  if (!(g_tun.k32 & FDSR_K32_UP2) || !(g_tun.k32 & (prec == PREC_BF16 ? FDSR_K32_BF16 : FDSR_K32_F16X3))) return false;
+  if (!(g_tun.k32 & FDSR_K32_UP2) || !(g_tun.k32 & (prec_is16(prec) ? FDSR_K32_BF16 : FDSR_K32_F16X3))) return false;
   return p.C1 == 0 && p.C0 % 32 == 0 && p.C0 == p.Cin_pad && p.Cout % 4 == 0 && !p.gn_scale && !p.res;
 }
 
@@ -1164,7 +1157,7 @@ static hipError_t launch_up2_k32_t(const ConvParams& q, int nwg, hipStream_t s) 
 hipError_t launch_conv_up2_k32(int TH, int WN, int prec, const ConvParams& q, int nwg, hipStream_t s) {
 #define X(TH_, WN_)                                                                                    \
   if (TH == TH_ && WN == WN_)                                                                          \
-    return prec == PREC_F16X3 ? launch_up2_k32_t<TH_, WN_, PREC_F16X3>(q, nwg, s) : launch_up2_k32_t<TH_, WN_, PREC_BF16>(q, nwg, s);
+    return prec == PREC_F16X3 ? launch_up2_k32_t<TH_, WN_, PREC_F16X3>(q, nwg, s) : prec == PREC_F16 ? launch_up2_k32_t<TH_, WN_, PREC_F16>(q, nwg, s) : launch_up2_k32_t<TH_, WN_, PREC_BF16>(q, nwg, s);
   FDSR_UP2_K32_SHAPES(X)
 #undef X
   return hipErrorInvalidValue;
@@ -1175,7 +1168,7 @@ hipError_t launch_conv_up2_k32(int TH, int WN, int prec, const ConvParams& q, in
 
 bool conv_k32_ok(int TH, int WN, int prec, const ConvParams& p) {
   // g_tun.k32 bits (default 27 = 1|2|8|16): 1 f16x3, 2 bf16 (+2.7 % at B=64 once the ring / pinning / peeled last chunk were in), 4 the 16-row tile with a rider (measured slower: off)
-  if (!(g_tun.k32 & (prec == PREC_BF16 ? FDSR_K32_BF16 : FDSR_K32_F16X3))) return false;
+  if (!(g_tun.k32 & (prec_is16(prec) ? FDSR_K32_BF16 : FDSR_K32_F16X3))) return false;
   if (TH == 16 && p.xr0 && !(g_tun.k32 & FDSR_K32_RIDER_16ROW)) return false;
   if (TH * WN != 32 && !(TH * WN == 16 && (g_tun.k32 & FDSR_K32_SMALL_GRID_2ROW))) return false;   // MB == 4 (bit 8: the 2-row tiles of small grids too)
   if (WN != 2 && WN != 4 && WN != 8) return false;
@@ -1212,14 +1205,14 @@ static bool k32_gnb_ok(int prec, const ConvParams& q) {
 // The small-workgroup form (NW = 4, two workgroups per CU) of the 64-cout launches: 6-row tiles (what two double-buffered f16x3 halo
 // images per CU leave room for).  Large grids only: a small grid wants all eight waves of a CU on its one
 // tile.  launch_conv_h asks before it picks a tile of its own; tiles / nwg are computed here.
-static int k32_small_rows(int prec, bool rider) { return prec == PREC_BF16 && !rider ? 8 : 6; }   // (the bf16 8-row tile with a rider spills 27 VGPRs)
+static int k32_small_rows(int prec, bool rider) { return prec_is16(prec) && !rider ? 8 : 6; }   // (the bf16 8-row tile with a rider spills 27 VGPRs)
 
 bool conv_k32_small_ok(ConvKind kind, int prec, const ConvParams& p) {
   if (!(g_tun.k32 & FDSR_K32_SMALL_WG_F16X3) || kind != CONV3_S1 || p.ksplit > 1 || p.Cout_pad != 64) return false;
-  if (prec == PREC_BF16 && !(g_tun.k32 & FDSR_K32_SMALL_WG_BF16)) return false;   // bf16: bit 128 (its 6-row tile measured -0.4 % end to end, its 8-row tile +1.0 %: on)
+  if (prec_is16(prec) && !(g_tun.k32 & FDSR_K32_SMALL_WG_BF16)) return false;   // bf16: bit 128 (its 6-row tile measured -0.4 % end to end, its 8-row tile +1.0 %: on)
   // launches with a rider: bit 64 in f16x3 (on since the rider chunks run FIRST on this form: +0.7 % end to end over the 32x32x16 rider
   // kernel; main chunks first it measured 4 - 7 % slower on those launches), bit 512 in bf16 (off: -0.4 %)
-  if (p.xr0 && !(g_tun.k32 & (prec == PREC_BF16 ? FDSR_K32_SMALL_WG_RIDER_BF16 : FDSR_K32_SMALL_WG_RIDER_F16X3))) return false;
+  if (p.xr0 && !(g_tun.k32 & (prec_is16(prec) ? FDSR_K32_SMALL_WG_RIDER_BF16 : FDSR_K32_SMALL_WG_RIDER_F16X3))) return false;
   if (!conv_k32_ok(8, 4, prec, p)) return false;          // the form's own conditions (an MB = 4 shape: no tile-size bits involved)
   const int th = k32_small_rows(prec, p.xr0 != nullptr);
   const long wgs = (long)p.N * ((p.Wout + 31) / 32) * ((p.Hout + th - 1) / th);
@@ -1232,7 +1225,7 @@ hipError_t launch_conv_k32_small(int prec, const ConvParams& p, hipStream_t s, i
   if (tiles) *tiles = tilesX * tilesY;
   const int nwg = p.N * tilesX * tilesY;
   ConvParams q = p;
-  q.out_bf16 = (prec == PREC_BF16 && !p.out_f32) ? 1 : 0;
+  q.out_bf16 = p.out_f32 ? 0 : prec_act16(prec);
   q.stagger = g_tun.k32_stagger;
   if (q.gb_x0) return k32_gnb_ok(prec, q) ? launch_k32_t<6, 2, PREC_F16X3, false, 4, true, true>(q, nwg, s) : hipErrorInvalidValue;
   if (q.drop_mask) {
@@ -1241,6 +1234,7 @@ hipError_t launch_conv_k32_small(int prec, const ConvParams& p, hipStream_t s, i
   }
   if (prec == PREC_F16X3)
     return q.xr0 ? launch_k32_t<6, 2, PREC_F16X3, true, 4>(q, nwg, s) : launch_k32_t<6, 2, PREC_F16X3, false, 4>(q, nwg, s);
+  if (prec == PREC_F16) return q.xr0 ? launch_k32_t<6, 2, PREC_F16, true, 4>(q, nwg, s) : launch_k32_t<8, 2, PREC_F16, false, 4>(q, nwg, s);
   return q.xr0 ? launch_k32_t<6, 2, PREC_BF16, true, 4>(q, nwg, s) : launch_k32_t<8, 2, PREC_BF16, false, 4>(q, nwg, s);
 }
 
@@ -1261,11 +1255,11 @@ hipError_t launch_conv_k32(int TH, int WN, int prec, const ConvParams& q, int nw
 #define X(TH_, WN_)                                                                                                      \
     if (TH == TH_ && WN == WN_) {                                                                                        \
       if (rf) return prec == PREC_F16X3 ? launch_k32_t<TH_, WN_, PREC_F16X3, true, 8, true, false, false, true>(q, nwg, s)   \
-                                        : launch_k32_t<TH_, WN_, PREC_BF16, true, 8, true, false, false, true>(q, nwg, s);    \
+                                        : prec == PREC_F16 ? launch_k32_t<TH_, WN_, PREC_F16, true, 8, true, false, false, true>(q, nwg, s) : launch_k32_t<TH_, WN_, PREC_BF16, true, 8, true, false, false, true>(q, nwg, s);    \
       if (q.xr0) return prec == PREC_F16X3 ? launch_k32_t<TH_, WN_, PREC_F16X3, true, 8, false, false, false, true>(q, nwg, s)  \
-                                           : launch_k32_t<TH_, WN_, PREC_BF16, true, 8, false, false, false, true>(q, nwg, s);   \
+                                           : prec == PREC_F16 ? launch_k32_t<TH_, WN_, PREC_F16, true, 8, false, false, false, true>(q, nwg, s) : launch_k32_t<TH_, WN_, PREC_BF16, true, 8, false, false, false, true>(q, nwg, s);   \
       return prec == PREC_F16X3 ? launch_k32_t<TH_, WN_, PREC_F16X3, false, 8, false, false, false, true>(q, nwg, s)      \
-                                : launch_k32_t<TH_, WN_, PREC_BF16, false, 8, false, false, false, true>(q, nwg, s);       \
+                                : prec == PREC_F16 ? launch_k32_t<TH_, WN_, PREC_F16, false, 8, false, false, false, true>(q, nwg, s) : launch_k32_t<TH_, WN_, PREC_BF16, false, 8, false, false, false, true>(q, nwg, s);       \
     }
     FDSR_K32_GNC_SHAPES(X)
 #undef X
@@ -1281,11 +1275,11 @@ hipError_t launch_conv_k32(int TH, int WN, int prec, const ConvParams& q, int nw
     }                                                                                                           \
     if (q.xr0 && q.ksplit <= 1 && (g_tun.k32 & FDSR_K32_RIDER_FIRST_8WAVE))                                                           \
       return prec == PREC_F16X3 ? launch_k32_t<TH_, WN_, PREC_F16X3, true, 8, true>(q, nwg, s)                  \
-                                : launch_k32_t<TH_, WN_, PREC_BF16, true, 8, true>(q, nwg, s);                  \
+                                : prec == PREC_F16 ? launch_k32_t<TH_, WN_, PREC_F16, true, 8, true>(q, nwg, s) : launch_k32_t<TH_, WN_, PREC_BF16, true, 8, true>(q, nwg, s);                  \
     if (q.xr0) return prec == PREC_F16X3 ? launch_k32_t<TH_, WN_, PREC_F16X3, true>(q, nwg, s)                  \
-                                         : launch_k32_t<TH_, WN_, PREC_BF16, true>(q, nwg, s);                  \
+                                         : prec == PREC_F16 ? launch_k32_t<TH_, WN_, PREC_F16, true>(q, nwg, s) : launch_k32_t<TH_, WN_, PREC_BF16, true>(q, nwg, s);                  \
     return prec == PREC_F16X3 ? launch_k32_t<TH_, WN_, PREC_F16X3, false>(q, nwg, s)                            \
-                              : launch_k32_t<TH_, WN_, PREC_BF16, false>(q, nwg, s);                            \
+                              : prec == PREC_F16 ? launch_k32_t<TH_, WN_, PREC_F16, false>(q, nwg, s) : launch_k32_t<TH_, WN_, PREC_BF16, false>(q, nwg, s);                            \
   }
   FDSR_K32_SHAPES(X)
 #undef X
@@ -1308,19 +1302,23 @@ hipError_t kernels_k32_init() {
   hipError_t e;
 #define X(TH_, WN_)                                                                 \
   if ((e = init_up2_k32_t<TH_, WN_, PREC_F16X3>()) != hipSuccess) return e;         \
-  if ((e = init_up2_k32_t<TH_, WN_, PREC_BF16>()) != hipSuccess) return e;
+  if ((e = init_up2_k32_t<TH_, WN_, PREC_BF16>()) != hipSuccess) return e; \
+  if ((e = init_up2_k32_t<TH_, WN_, PREC_F16>()) != hipSuccess) return e;
   FDSR_UP2_K32_SHAPES(X)
 #undef X
 #define X(TH_, WN_)                                                                        \
   if ((e = init_k32_t<TH_, WN_, PREC_F16X3, false>()) != hipSuccess) return e;             \
   if ((e = init_k32_t<TH_, WN_, PREC_F16X3, true>()) != hipSuccess) return e;              \
   if ((e = init_k32_t<TH_, WN_, PREC_BF16, false>()) != hipSuccess) return e;              \
+  if ((e = init_k32_t<TH_, WN_, PREC_F16, false>()) != hipSuccess) return e;              \
   if ((e = init_k32_t<TH_, WN_, PREC_BF16, true>()) != hipSuccess) return e;                \
+  if ((e = init_k32_t<TH_, WN_, PREC_F16, true>()) != hipSuccess) return e;                \
   if ((e = init_k32_t<TH_, WN_, PREC_F16X3, true, 8, true>()) != hipSuccess) return e;     \
   if ((e = init_k32_t<TH_, WN_, PREC_F16X3, false, 8, false, true>()) != hipSuccess) return e; \
   if ((e = init_k32_t<TH_, WN_, PREC_F16X3, false, 8, false, false, true>()) != hipSuccess) return e; \
   if ((e = init_k32_t<TH_, WN_, PREC_F16X3, true, 8, true, false, true>()) != hipSuccess) return e; \
-  if ((e = init_k32_t<TH_, WN_, PREC_BF16, true, 8, true>()) != hipSuccess) return e;
+  if ((e = init_k32_t<TH_, WN_, PREC_BF16, true, 8, true>()) != hipSuccess) return e; \
+  if ((e = init_k32_t<TH_, WN_, PREC_F16, true, 8, true>()) != hipSuccess) return e;
   FDSR_K32_SHAPES(X)
 #undef X
 #define X(TH_, WN_)                                                                                                     \
@@ -1328,8 +1326,11 @@ hipError_t kernels_k32_init() {
   if ((e = init_k32_t<TH_, WN_, PREC_F16X3, true, 8, false, false, false, true>()) != hipSuccess) return e;             \
   if ((e = init_k32_t<TH_, WN_, PREC_F16X3, true, 8, true, false, false, true>()) != hipSuccess) return e;              \
   if ((e = init_k32_t<TH_, WN_, PREC_BF16, false, 8, false, false, false, true>()) != hipSuccess) return e;             \
+  if ((e = init_k32_t<TH_, WN_, PREC_F16, false, 8, false, false, false, true>()) != hipSuccess) return e;             \
   if ((e = init_k32_t<TH_, WN_, PREC_BF16, true, 8, false, false, false, true>()) != hipSuccess) return e;              \
-  if ((e = init_k32_t<TH_, WN_, PREC_BF16, true, 8, true, false, false, true>()) != hipSuccess) return e;
+  if ((e = init_k32_t<TH_, WN_, PREC_F16, true, 8, false, false, false, true>()) != hipSuccess) return e;              \
+  if ((e = init_k32_t<TH_, WN_, PREC_BF16, true, 8, true, false, false, true>()) != hipSuccess) return e; \
+  if ((e = init_k32_t<TH_, WN_, PREC_F16, true, 8, true, false, false, true>()) != hipSuccess) return e;
   FDSR_K32_GNC_SHAPES(X)
 #undef X
   if ((e = init_k32_t<6, 2, PREC_F16X3, false, 4>()) != hipSuccess) return e;
@@ -1338,6 +1339,7 @@ hipError_t kernels_k32_init() {
   if ((e = init_k32_t<6, 2, PREC_F16X3, false, 4, true, false, true>()) != hipSuccess) return e;
   if ((e = init_k32_t<6, 2, PREC_F16X3, true, 4, true, false, true>()) != hipSuccess) return e;
   if ((e = init_k32_t<6, 2, PREC_BF16, true, 4>()) != hipSuccess) return e;
+  if ((e = init_k32_t<6, 2, PREC_F16, true, 4>()) != hipSuccess) return e;
   return hipSuccess;
 }
 

@@ -61,7 +61,8 @@ __device__ __forceinline__ float silu_s(float v) { return v * __builtin_amdgcn_r
 template <int PREC, int C0_, int C1_, int CR0_, int CR1_, int NPH>
 struct StripCfg {
   static constexpr int NP = PREC == PREC_F16X3 ? 2 : 1;
-  static constexpr int ESZ = PREC == PREC_BF16 ? 2 : 4;   // bytes per activation element in HBM
+  static constexpr int ESZ = prec_is16(PREC) ? 2 : 4;     // bytes per activation element in HBM
+  static constexpr int WNP = PREC == PREC_BF16 ? 1 : 2;   // planes per fragment of the weight arena the mode reads (PREC_F16: the f16x3 form, hi plane only)
   static constexpr int C0 = C0_, C1 = C1_, CIN = C0_ + C1_, KCH = CIN / 32, SW = 16 * NPH, HWD = SW + 2;
   static constexpr int OPP = CIN / 8;              // 8-channel units ("octs") per pixel and plane
   static constexpr int RB = 16 * OPP * NP;         // LDS bytes per staged pixel: [plane][oct] x 16 B, swizzled
@@ -78,7 +79,7 @@ struct StripCfg {
   // LDS: two activation row slots | two rider row slots | GroupNorm table | two output-row tiles | two residual-row tiles
   static constexpr int RSLOT_OFF = 2 * SLOT_BYTES;
   static constexpr int GTAB_OFF = RSLOT_OFF + 2 * RSLOT_BYTES;
-  static constexpr int OSZ = PREC == PREC_BF16 ? 2 : 4;   // bytes per output / residual element
+  static constexpr int OSZ = prec_is16(PREC) ? 2 : 4;     // bytes per output / residual element
   static constexpr int PB = 64 * OSZ;                  // bytes per pixel of a row tile
   static constexpr int UPP = PB / 16;                  // 16-byte units per pixel
   static constexpr int TILE_BYTES = SW * PB;           // one output (or residual) row of the strip, [pixel][64 couts], 16-byte units swizzled
@@ -123,6 +124,16 @@ template <> struct StripRaw<PREC_BF16> {
     b = __builtin_bit_cast(float, u & 0xffff0000u);
   }
 };
+template <> struct StripRaw<PREC_F16> {
+  uint4 v;
+  __device__ __forceinline__ void load(const unsigned char* ptr) { v = *reinterpret_cast<const uint4*>(ptr); }
+  __device__ __forceinline__ void pair(int k, float& a, float& b) const {
+    typedef _Float16 h2t __attribute__((ext_vector_type(2)));
+    const h2t h = __builtin_bit_cast(h2t, k == 0 ? v.x : (k == 1 ? v.y : (k == 2 ? v.z : v.w)));
+    a = (float)h[0];
+    b = (float)h[1];
+  }
+};
 template <> struct StripRaw<PREC_F16X3> {
   s_f32x4 a4, b4;
   __device__ __forceinline__ void load(const unsigned char* ptr) {
@@ -141,6 +152,16 @@ template <> struct StripRawPair<PREC_BF16> {
   __device__ __forceinline__ void pair(float& a, float& b) const {
     a = __builtin_bit_cast(float, v << 16);
     b = __builtin_bit_cast(float, v & 0xffff0000u);
+  }
+};
+template <> struct StripRawPair<PREC_F16> {
+  unsigned v;
+  __device__ __forceinline__ void load(const unsigned char* ptr) { v = *reinterpret_cast<const unsigned*>(ptr); }
+  __device__ __forceinline__ void pair(float& a, float& b) const {
+    typedef _Float16 h2t __attribute__((ext_vector_type(2)));
+    const h2t h = __builtin_bit_cast(h2t, v);
+    a = (float)h[0];
+    b = (float)h[1];
   }
 };
 template <> struct StripRawPair<PREC_F16X3> {
@@ -293,6 +314,10 @@ __global__ void __launch_bounds__(256, LB) conv_strip_kernel(const ConvParams p,
       // lo = f16(fma(hi, -1, v)), rounded once (as fdsr_conv_k32.hip)
       asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "v"(ca));
       asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "v"(cb));
+    } else if (PREC == PREC_F16) {
+      typedef _Float16 h2t __attribute__((ext_vector_type(2)));
+      const h2t h = {(_Float16)a, (_Float16)b};
+      hi = __builtin_bit_cast(unsigned, h);
     } else {
       typedef __bf16 b2t __attribute__((ext_vector_type(2)));
       const b2t h = {(__bf16)a, (__bf16)b};
@@ -349,14 +374,14 @@ __global__ void __launch_bounds__(256, LB) conv_strip_kernel(const ConvParams p,
     for (int kc = 0; kc < KCH; ++kc)
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
-        const uint4* src = wq + ((((size_t)cot * nk16 + 2 * kc + (g >> 1)) * wn_a + wna) * 9 + tap) * (NP * 64) + wlane;
+        const uint4* src = wq + ((((size_t)cot * nk16 + 2 * kc + (g >> 1)) * wn_a + wna) * 9 + tap) * (Cfg::WNP * 64) + wlane;
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl) Wf[tap / 3][tap % 3][kc][pl] = src[pl * 64];
       }
     if (RIDER) {   // the 1x1 conv's own fragments [cot][kc16][wn] (one tap)
       const uint4* wr = reinterpret_cast<const uint4*>(p.wq_r);
 #pragma unroll
-      for (int kc = 0; kc < KCR; ++kc) Wr[kc] = wr[(((size_t)cot * p.nkr + 2 * kc + (g >> 1)) * wn_a + wna) * (NP * 64) + wlane];
+      for (int kc = 0; kc < KCR; ++kc) Wr[kc] = wr[(((size_t)cot * p.nkr + 2 * kc + (g >> 1)) * wn_a + wna) * (Cfg::WNP * 64) + wlane];
     }
   }
 
@@ -452,9 +477,7 @@ __global__ void __launch_bounds__(256, LB) conv_strip_kernel(const ConvParams p,
     if (HAS_RES) v += IO::widen(*reinterpret_cast<const Quad*>(rtile + (oy & 1) * TILE + aq + 16 * PB * ph));
     unsigned char* dst = otile + (oy & 1) * TILE + aq + 16 * PB * ph;
     if (OSZ == 2) {
-      typedef __bf16 b2t __attribute__((ext_vector_type(2)));
-      const b2t lo = {(__bf16)v[0], (__bf16)v[1]}, hi = {(__bf16)v[2], (__bf16)v[3]};   // one v_cvt_pk_bf16_f32 each
-      *reinterpret_cast<uint2*>(dst) = uint2{__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
+      *reinterpret_cast<uint2*>(dst) = pack4_16<PREC>(v);   // (bf16: one v_cvt_pk_bf16_f32 per pair; f16: saturating)
     } else {
       *reinterpret_cast<s_f32x4*>(dst) = v;
     }
@@ -480,7 +503,7 @@ __global__ void __launch_bounds__(256, LB) conv_strip_kernel(const ConvParams p,
       c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(s_h8, wf[NP - 1]), __builtin_bit_cast(s_h8, xf[0]), c, 0, 0, 0);
       return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(s_h8, wf[0]), __builtin_bit_cast(s_h8, xf[0]), c, 0, 0, 0);
     }
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(s_b8, wf[0]), __builtin_bit_cast(s_b8, xf[0]), c, 0, 0, 0);
+    return mfma16_k32<PREC>(wf[0], xf[0], c);
   };
   auto step = [&](int iy, int it, auto rot_tag, auto epi_tag, auto flush_tag) __attribute__((always_inline)) {
     constexpr int ROT = decltype(rot_tag)::value;
@@ -561,8 +584,7 @@ __global__ void __launch_bounds__(256, LB) conv_strip_kernel(const ConvParams p,
         static_for<J0, J1e>([&](auto jc) __attribute__((always_inline)) { item(jc, S2{}); });
       } else {               // the rider's 1x1 product of input row iy belongs to output row iy
         constexpr int ph = (f - NF) % NPH, kc = (f - NF) / NPH;
-        acc[A1][ph] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(s_b8, Wr[kc]), __builtin_bit_cast(s_b8, Xf[f % XS][0]),
-                                                            acc[A1][ph], 0, 0, 0);
+        acc[A1][ph] = mfma16_k32<PREC>(Wr[kc], Xf[f % XS][0], acc[A1][ph]);
         static_for<J0, J1e>([&](auto jc) __attribute__((always_inline)) { item(jc, SA{}); });
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -656,7 +678,7 @@ __global__ void __launch_bounds__(256, LB) conv_strip_kernel(const ConvParams p,
 // registers), 4 (A/B) bf16 64 -> 64 on one workgroup per CU, 8 the bf16 launches with a concatenated input (64 + 64 -> 64,
 // 128 + 64 -> 64 under bit 32: 144 / 216 weight registers, one workgroup per CU), 16 the bf16 launches with a res_conv rider,
 // 64 the bf16 128-cout launches 128 -> 128 and 64 -> 128 (two workgroups of 64 couts per strip)
-static bool strip_wide(const ConvParams& p, int prec) { return prec != PREC_BF16 || (g_tun.strip & FDSR_STRIP_BF16_ONE_WG) || p.C1 || p.xr0 || p.C0 > 64; }
+static bool strip_wide(const ConvParams& p, int prec) { return !prec_is16(prec) || (g_tun.strip & FDSR_STRIP_BF16_ONE_WG) || p.C1 || p.xr0 || p.C0 > 64; }
 static long strip_min_wgs(const ConvParams& p, int prec) { return strip_wide(p, prec) ? g_tun.strip_min_wgs / 2 : g_tun.strip_min_wgs; }
 
 static int strip_seg_rows(const ConvParams& p, int SW, int prec) {
@@ -672,19 +694,19 @@ bool conv_strip_ok(ConvKind kind, int prec, const ConvParams& p) {
   if (kind != CONV3_S1 || p.ksplit > 1 || (p.Cout != 64 && p.Cout != 128) || p.Cout_pad != p.Cout) return false;
   if (!p.gn_scale || p.gn_plain || p.drop_mask) return false;
   if (p.Hin != p.Hout || p.Win != p.Wout || p.Wout % 64 || p.Hout < 3 || (size_t)p.Hout * p.Wout * 192 * 4 >= (1ull << 31)) return false;
-  if (prec == PREC_BF16 && p.out_f32) return false;
+  if (prec_is16(prec) && p.out_f32) return false;
   const int Cin = p.C0 + p.C1;
   if (Cin != p.Cin_pad) return false;
   bool shape;
   if (p.Cout == 128) {   // the 128-cout level: two workgroups of 64 couts read the same rows; 128 -> 128 (144 weight registers) and 64 -> 128, bf16
-    shape = prec == PREC_BF16 && (g_tun.strip & FDSR_STRIP_BF16_COUT128) && !p.xr0 && p.C1 == 0 && (p.C0 == 64 || p.C0 == 128);
+    shape = prec_is16(prec) && (g_tun.strip & FDSR_STRIP_BF16_COUT128) && !p.xr0 && p.C1 == 0 && (p.C0 == 64 || p.C0 == 128);
   } else if (p.xr0) {        // 64 -> 64 with a rider over (64 | 64) or (128 | 64) raw channels
     shape = prec == PREC_BF16 && (g_tun.strip & FDSR_STRIP_BF16_RIDER) && !p.res && p.C0 == 64 && p.C1 == 0 && p.Cr1 == 64 && (p.Cr0 == 64 || p.Cr0 == 128) &&
             p.nkr * 16 == p.Cr0 + p.Cr1;
   } else if (p.C1) {  // concatenated input (64 | 64) or (128 | 64), no residual (block1 of the up path)
-    shape = prec == PREC_BF16 && !p.res && p.C1 == 64 && ((p.C0 == 64 && (g_tun.strip & FDSR_STRIP_BF16_CAT64)) || (p.C0 == 128 && (g_tun.strip & FDSR_STRIP_BF16_CAT128)));   // (bit 32: 216 weight registers, spills)
+    shape = prec_is16(prec) && !p.res && p.C1 == 64 && ((p.C0 == 64 && (g_tun.strip & FDSR_STRIP_BF16_CAT64)) || (p.C0 == 128 && (g_tun.strip & FDSR_STRIP_BF16_CAT128)));   // (bit 32: 216 weight registers, spills)
   } else {
-    shape = p.C0 == 64 && (g_tun.strip & (prec == PREC_BF16 ? FDSR_STRIP_BF16_64 : FDSR_STRIP_F16X3_64));
+    shape = p.C0 == 64 && (g_tun.strip & (prec_is16(prec) ? FDSR_STRIP_BF16_64 : FDSR_STRIP_F16X3_64));
   }
   if (!shape) return false;
   const long wgs = (long)p.N * ((p.Wout + 63) / 64) * ((p.Hout + 15) / 16) * (p.Cout / 64);
@@ -705,6 +727,16 @@ static hipError_t launch_strip_t(const ConvParams& p, int wn_a, hipStream_t s, i
 hipError_t launch_conv_strip(int prec, const ConvParams& p, int wn_a, hipStream_t s, int* tiles) {
   if (prec == PREC_F16X3) {
     return p.res ? launch_strip_t<PREC_F16X3, 64, 0, 0, 0, true, 1>(p, wn_a, s, tiles) : launch_strip_t<PREC_F16X3, 64, 0, 0, 0, false, 1>(p, wn_a, s, tiles);
+  }
+  if (prec == PREC_F16) {   // the bf16 forms without a rider (a rider's weights carry a scale of their own in the f16 forms: those launches stay on the tile kernels)
+    if (p.xr0) return hipErrorInvalidValue;
+    if (p.C0 == 128 && !p.C1)
+      return p.res ? launch_strip_t<PREC_F16, 128, 0, 0, 0, true, 1>(p, wn_a, s, tiles) : launch_strip_t<PREC_F16, 128, 0, 0, 0, false, 1>(p, wn_a, s, tiles);
+    if (p.C1)
+      return p.C0 == 64 ? launch_strip_t<PREC_F16, 64, 64, 0, 0, false, 1>(p, wn_a, s, tiles) : launch_strip_t<PREC_F16, 128, 64, 0, 0, false, 1>(p, wn_a, s, tiles);
+    if (g_tun.strip & FDSR_STRIP_BF16_ONE_WG)
+      return p.res ? launch_strip_t<PREC_F16, 64, 0, 0, 0, true, 1>(p, wn_a, s, tiles) : launch_strip_t<PREC_F16, 64, 0, 0, 0, false, 1>(p, wn_a, s, tiles);
+    return p.res ? launch_strip_t<PREC_F16, 64, 0, 0, 0, true, 2>(p, wn_a, s, tiles) : launch_strip_t<PREC_F16, 64, 0, 0, 0, false, 2>(p, wn_a, s, tiles);
   }
   if (prec != PREC_BF16) return hipErrorInvalidValue;
   if (p.C0 == 128 && !p.C1)   // (Cout 128)
@@ -735,6 +767,10 @@ hipError_t kernels_strip_init() {
   X(PREC_BF16, 64, 64, 0, 0, false, 1) X(PREC_BF16, 128, 64, 0, 0, false, 1)
   X(PREC_BF16, 64, 0, 64, 64, false, 1) X(PREC_BF16, 64, 0, 128, 64, false, 1)
   X(PREC_BF16, 128, 0, 0, 0, false, 1) X(PREC_BF16, 128, 0, 0, 0, true, 1)
+  X(PREC_F16, 64, 0, 0, 0, false, 2) X(PREC_F16, 64, 0, 0, 0, true, 2)
+  X(PREC_F16, 64, 0, 0, 0, false, 1) X(PREC_F16, 64, 0, 0, 0, true, 1)
+  X(PREC_F16, 64, 64, 0, 0, false, 1) X(PREC_F16, 128, 64, 0, 0, false, 1)
+  X(PREC_F16, 128, 0, 0, 0, false, 1) X(PREC_F16, 128, 0, 0, 0, true, 1)
 #undef X
   return hipSuccess;
 }

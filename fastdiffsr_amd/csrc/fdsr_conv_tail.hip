@@ -32,7 +32,12 @@ __device__ __forceinline__ float silu_t(float v) { return v * __builtin_amdgcn_r
 // 8 fp32 -> the MFMA operand planes: f16x3: hi = f16(v), lo = f16(v - hi); bf16: one plane
 template <int PREC>
 __device__ __forceinline__ void to_planes(const float (&v)[8], uint4 (&pl)[PREC == PREC_F16X3 ? 2 : 1]) {
-  if (PREC == PREC_F16X3) {
+  if (PREC == PREC_F16) {          // one f16 plane (saturating)
+    t_h8 hi;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) hi[j] = (_Float16)__builtin_amdgcn_fmed3f(v[j], -65504.f, 65504.f);
+    pl[0] = __builtin_bit_cast(uint4, hi);
+  } else if (PREC == PREC_F16X3) {
     t_h8 hi, lo;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -168,7 +173,7 @@ __global__ void __launch_bounds__(256, 2) conv_in8_kernel(const ConvParams p, co
             acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(t_h8, w1), __builtin_bit_cast(t_h8, Xf[i][0]), acc[cb], 0, 0, 0);
             acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(t_h8, w0), __builtin_bit_cast(t_h8, Xf[i][0]), acc[cb], 0, 0, 0);
           } else {
-            acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(t_b8, w0), __builtin_bit_cast(t_b8, Xf[i][0]), acc[cb], 0, 0, 0);
+            acc[cb] = mfma16_k32<PREC>(w0, Xf[i][0], acc[cb]);
           }
         }
       // lane = pixel c15 of the group, output channels 16 cb + 4 g + 0..3
@@ -178,10 +183,7 @@ __global__ void __launch_bounds__(256, 2) conv_in8_kernel(const ConvParams p, co
         for (int cb = 0; cb < NCB; ++cb) {
           const t_f32x4 v = acc[cb] * winv + bias4[cb];
           if (p.out_bf16) {
-            uint2 pk;
-            pk.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
-            pk.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
-            *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p.out) + o + 16 * cb) = pk;
+            *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p.out) + o + 16 * cb) = PREC == PREC_F16 ? pack4_16<PREC_F16>(v) : pack4_16<PREC_BF16>(v);
           } else {
             *reinterpret_cast<t_f32x4*>(p.out + o + 16 * cb) = v;
           }
@@ -219,7 +221,7 @@ __global__ void __launch_bounds__(256, 2) conv_in8_kernel(const ConvParams p, co
 }
 
 bool conv_in8_ok(ConvKind kind, int prec, const ConvParams& p, int cin_real) {
-  if (!g_tun.tail || kind != CONV3_S1 || (prec != PREC_F16X3 && prec != PREC_BF16)) return false;
+  if (!g_tun.tail || kind != CONV3_S1 || (prec != PREC_F16X3 && !prec_is16(prec))) return false;
   if (p.C0 != 8 || p.C1 != 0 || cin_real > 8 || p.gn_scale || p.res || p.temb || p.xr0 || p.drop_mask || p.ksplit > 1) return false;
   return p.Cout == 16 || p.Cout == 32 || p.Cout == 48 || p.Cout == 64;
 }
@@ -241,10 +243,11 @@ hipError_t launch_conv_in8(int prec, const ConvParams& p, const float* wmaster, 
   const int resident = (slot >= 0 && slot < 8 && g_in8_resident[slot] > 0) ? g_in8_resident[slot] : 512;
   const int grid = ntiles < resident ? ntiles : resident;
   ConvParams q = p;
-  q.out_bf16 = (prec == PREC_BF16 && !p.out_f32) ? 1 : 0;
+  q.out_bf16 = p.out_f32 ? 0 : prec_act16(prec);
 #define IN8_CASE(NCB_)                                                                                                     \
   if (p.Cout == 16 * NCB_) {                                                                                               \
     if (prec == PREC_F16X3) hipLaunchKernelGGL((conv_in8_kernel<PREC_F16X3, NCB_>), dim3(grid), dim3(256), 0, s, q, wmaster, cin_real, ntiles); \
+    else if (prec == PREC_F16) hipLaunchKernelGGL((conv_in8_kernel<PREC_F16, NCB_>), dim3(grid), dim3(256), 0, s, q, wmaster, cin_real, ntiles);  \
     else hipLaunchKernelGGL((conv_in8_kernel<PREC_BF16, NCB_>), dim3(grid), dim3(256), 0, s, q, wmaster, cin_real, ntiles);  \
     return hipGetLastError();                                                                                              \
   }
@@ -374,7 +377,7 @@ __global__ void __launch_bounds__(256, NKS <= 2 ? 4 : 2) conv_out3_kernel(const 
           acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(t_h8, Wf[nb][i][NP - 1]), __builtin_bit_cast(t_h8, Xf[0]), acc[nb], 0, 0, 0);
           acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(t_h8, Wf[nb][i][0]), __builtin_bit_cast(t_h8, Xf[0]), acc[nb], 0, 0, 0);
         } else {
-          acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(t_b8, Wf[nb][i][0]), __builtin_bit_cast(t_b8, Xf[0]), acc[nb], 0, 0, 0);
+          acc[nb] = mfma16_k32<PREC>(Wf[nb][i][0], Xf[0], acc[nb]);
         }
       }
     }
@@ -407,7 +410,7 @@ __global__ void __launch_bounds__(256, NKS <= 2 ? 4 : 2) conv_out3_kernel(const 
 static size_t conv_out3_lds(int C) { return (size_t)(2 * C + 27 * OT_NPIX) * sizeof(float); }
 
 bool conv_out3_ok(ConvKind kind, int prec, const ConvParams& p) {
-  if (!g_tun.tail || kind != CONV3_S1 || (prec != PREC_F16X3 && prec != PREC_BF16)) return false;
+  if (!g_tun.tail || kind != CONV3_S1 || (prec != PREC_F16X3 && !prec_is16(prec))) return false;
   if (p.Cout < 1 || p.Cout > 3 || p.C1 != 0 || (p.C0 != 32 && p.C0 != 64 && p.C0 != 96 && p.C0 != 128)) return false;   // whole 32-channel k steps
   if (p.res || p.temb || p.xr0 || p.drop_mask || p.ksplit > 1 || p.part_out || !p.out_f32) return false;
   if (!p.gn_scale) return false;   // (a raw input would be clamped to the f16 range without the range flag: this kernel is the GroupNorm'd final conv's)
@@ -422,6 +425,7 @@ hipError_t launch_conv_out3(int prec, const ConvParams& p, const float* wmaster,
 #define OUT3_CASE(NKS_)                                                                                                                  \
   if (p.C0 == 32 * NKS_) {                                                                                                               \
     if (prec == PREC_F16X3) hipLaunchKernelGGL((conv_out3_kernel<PREC_F16X3, NKS_>), dim3(grid), dim3(256), lds, s, p, wmaster, cin_real, ntiles); \
+    else if (prec == PREC_F16) hipLaunchKernelGGL((conv_out3_kernel<PREC_F16, NKS_>), dim3(grid), dim3(256), lds, s, p, wmaster, cin_real, ntiles); \
     else hipLaunchKernelGGL((conv_out3_kernel<PREC_BF16, NKS_>), dim3(grid), dim3(256), lds, s, p, wmaster, cin_real, ntiles);           \
     return hipGetLastError();                                                                                                            \
   }
@@ -434,7 +438,8 @@ hipError_t kernels_tail_init() {
   hipError_t e;
 #define OUT3_INIT(NKS_)                                                                                                                                        \
   if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_out3_kernel<PREC_F16X3, NKS_>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)) != hipSuccess) return e; \
-  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_out3_kernel<PREC_BF16, NKS_>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)) != hipSuccess) return e;
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_out3_kernel<PREC_BF16, NKS_>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)) != hipSuccess) return e; \
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_out3_kernel<PREC_F16, NKS_>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)) != hipSuccess) return e;
   OUT3_INIT(1) OUT3_INIT(2) OUT3_INIT(3) OUT3_INIT(4)
 #undef OUT3_INIT
   int dev = 0, cus = 256;

@@ -30,6 +30,7 @@ template <int TH, int WN, int PREC>
 struct ConvUp2Cfg {
   static constexpr int TW = 32, KC = 16;
   static constexpr int NP = PREC == PREC_F16X3 ? 2 : 1;
+  static constexpr int WNP = PREC == PREC_BF16 ? 1 : 2;   // planes per fragment of the weight arena the mode reads (PREC_F16: the f16x3 form, hi plane only)
   static constexpr int ROWB = NP * 32 + 16;
   static constexpr int HH = TH + 1, HWD = TW + 2, NPIX = HH * HWD;
   static constexpr int WM = 8 / WN, BN = 32 * WN, MB = TH / WM;
@@ -109,8 +110,7 @@ __global__ void __launch_bounds__(512, 2) conv_up2_h_kernel(const ConvParams p) 
         *reinterpret_cast<h4*>(dst + 32) = lo;
       } else {
         v = v * keep;
-        b4 hb = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
-        *reinterpret_cast<b4*>(dst) = hb;
+        *reinterpret_cast<uint2*>(dst) = stage4_16<PREC>(v);
       }
     }
   };
@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(512, 2) conv_up2_h_kernel(const ConvParams p) 
   const int nk = p.Cin_pad / KC;
   uint4 Bf[8][NP];
   auto load_b_slot = [&](int kc, int slot) {
-    const uint4* src = wq + (((((size_t)cot * nk + kc) * WN + wn) * 2 + py) * 8 + slot) * (NP * 64) + lane;
+    const uint4* src = wq + (((((size_t)cot * nk + kc) * WN + wn) * 2 + py) * 8 + slot) * (Cfg::WNP * 64) + lane;
 #pragma unroll
     for (int pl = 0; pl < NP; ++pl) Bf[slot][pl] = src[pl * 64];
   };
@@ -150,7 +150,7 @@ __global__ void __launch_bounds__(512, 2) conv_up2_h_kernel(const ConvParams p) 
       c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, a[0]), __builtin_bit_cast(h8, b[NP - 1]), c, 0, 0, 0);
       c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, a[0]), __builtin_bit_cast(h8, b[0]), c, 0, 0, 0);
     } else {
-      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8, a[0]), __builtin_bit_cast(b8, b[0]), c, 0, 0, 0);
+      c = mfma32_k16<PREC>(a[0], b[0], c);
     }
   };
 
@@ -265,7 +265,7 @@ hipError_t launch_conv_up2_h(int prec, const ConvParams& p, hipStream_t s, int* 
   conv_h_config(CONV3_UP, p.Cout, &TH, &WN);
 #define X(TH_, WN_)                                                                           \
   if (WN == WN_) return prec == PREC_F16X3 ? launch_up2_t<TH_, WN_, PREC_F16X3>(p, s, tiles)  \
-                                           : launch_up2_t<TH_, WN_, PREC_BF16>(p, s, tiles);
+                                           : prec == PREC_F16 ? launch_up2_t<TH_, WN_, PREC_F16>(p, s, tiles) : launch_up2_t<TH_, WN_, PREC_BF16>(p, s, tiles);
   X(8, 2) X(4, 4) X(2, 8)
 #undef X
   return hipErrorInvalidValue;

@@ -773,7 +773,7 @@ int make_shape_plan(fdsr_handle h, int N, int H, int W, ShapePlan* sp) {
   sp->gsum_bytes = off - sp->off_gsum;
   // which tensors are read by a GroupNorm'd conv that lands on a consumer-side kernel at this shape (a pure function of the shapes, as
   // the split factor above): only their producers add pair sums (a large batch's producers would add them for nobody)
-  for (int prec = PREC_F16X3; prec <= PREC_BF16; ++prec) {
+  for (int prec = PREC_F16X3; prec <= PREC_F16; ++prec) {
     sp->gsum_wanted[prec].assign(h->tensors.size(), 0);
     for (size_t i = 0; i < h->ops.size(); ++i) {
       const Op& op = h->ops[i];
@@ -931,7 +931,7 @@ int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, 
   };
   const bool dropout_on = h->training && h->n_drop_slots > 0;
   if (dropout_on) {
-    if (h->prec == PREC_BF16)
+    if (prec_is16(h->prec))
       return fail(h, FDSR_E_INVALID, "train mode with dropout runs on the fp32-grade kernels: fdsr_set_precision(FDSR_PREC_F32 or _F16X3)");
     h->drop_step += 1;
   }
@@ -984,10 +984,10 @@ int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, 
           p.res = nullptr;
           p.xr0 = TP(kr.src0); p.xr1 = TP(kr.src1); p.Cr0 = kr.C0; p.Cr1 = kr.C1;
           p.nkr = wr.h_cin_pad / 16;
-          p.wq_r = h->d_wq + wr.hq_off[h->prec];
+          p.wq_r = h->d_wq + wr.hq_off[prec_wform(h->prec)];
           p.bias_r = P(kr.b);
-          p.w_inv_scale_r = wr.h_inv_scale[h->prec];
-          if (h->prec == PREC_F16X3) p.w_inv_scale_r_dev = h->d_hscale + 2 * (size_t)kr.w + 1;
+          p.w_inv_scale_r = wr.h_inv_scale[prec_wform(h->prec)];
+          if (prec_wform(h->prec) == PREC_F16X3) p.w_inv_scale_r_dev = h->d_hscale + 2 * (size_t)kr.w + 1;
         }
         if (op.gn_slot >= 0) {
           p.gn_scale = reinterpret_cast<const float*>(ws + sp.gn_off[op.gn_slot]);
@@ -1006,7 +1006,7 @@ int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, 
         }
         // bf16 mode keeps every activation but the packed input and eps as bf16 in HBM
         p.out_f32 = (op.dst == h->t_eps) ? 1 : 0;
-        p.out_bf16 = (h->prec == PREC_BF16 && op.dst != h->t_eps) ? 1 : 0;
+        p.out_bf16 = op.dst != h->t_eps ? prec_act16(h->prec) : 0;
         int nt = 0;
         p.N = N; p.Hin = Hi; p.Win = Wi;
         p.Hout = H >> op.lvl_out; p.Wout = W >> op.lvl_out;
@@ -1062,18 +1062,18 @@ int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, 
           HIPCHK(h, launch_conv_out3(h->prec, p, wmaster, (int)w.shape[1], st, &nt));
         } else if (h->prec != PREC_F32 && w.h_ok) {
           p.sat_flag = (h->prec == PREC_F16X3 && g_tun.sat_guard) ? h->d_sat : nullptr;
-          p.wq = h->d_wq + w.hq_off[h->prec];
-          p.w_inv_scale = w.h_inv_scale[h->prec];
+          p.wq = h->d_wq + w.hq_off[prec_wform(h->prec)];
+          p.w_inv_scale = w.h_inv_scale[prec_wform(h->prec)];
           p.Cin_pad = w.h_cin_pad;
           p.Cout_pad = w.h_cout_pad;
-          if (h->prec == PREC_F16X3) p.w_inv_scale_dev = h->d_hscale + 2 * (size_t)op.w + 1;
+          if (prec_wform(h->prec) == PREC_F16X3) p.w_inv_scale_dev = h->d_hscale + 2 * (size_t)op.w + 1;
           const bool no_up2 = !g_tun.up2;
           // (after optimiser steps the sub-pixel forms lag until fdsr_sync_weight_forms: training forwards use the generic kernel)
-          const bool up2_dev = h->prec == PREC_F16X3 && h->up2_dev_fresh;   // re-packed on the device by the last optimiser step
+          const bool up2_dev = prec_wform(h->prec) == PREC_F16X3 && h->up2_dev_fresh;   // re-packed on the device by the last optimiser step
           if (op.ck == CONV3_UP && !no_up2 && !op.force_generic && (!h->h_forms_stale || up2_dev)) {
             p.w_inv_scale_dev = up2_dev ? h->d_up2_inv + op.w : nullptr;
-            p.wq = h->d_wq + w.up2_off[h->prec];
-            p.w_inv_scale = w.up2_inv_scale[h->prec];
+            p.wq = h->d_wq + w.up2_off[prec_wform(h->prec)];
+            p.w_inv_scale = w.up2_inv_scale[prec_wform(h->prec)];
             if (gsum_on && p.part_out && GSUM(op.dst) && conv_h_gsum_ok(CONV3_UP, h->prec, p, true)) {
               p.gsum_out = GSUM(op.dst);
               sp.tensor_gsum[op.dst] = 1;
@@ -1106,7 +1106,7 @@ int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, 
           // once, in the element size the active mode keeps that tensor in (bf16 mode: 2 bytes for everything but the packed
           // network input and eps), plus the GroupNorm partial-sum appendix this launch writes (it stands where 8d has a second
           // read of each GroupNorm input: [N][tiles][Cout][2] fp32)
-          const double esz = h->prec == PREC_BF16 ? 2.0 : 4.0;
+          const double esz = prec_is16(h->prec) ? 2.0 : 4.0;
           const double esz_in = op.src0 == h->t_in ? 4.0 : esz, esz_out = p.out_f32 ? 4.0 : esz;
           const double out_elems = (double)N * p.Hout * p.Wout * op.Cout;
           h->prof_bytes += esz_in * N * (double)Hi * Wi * (op.src0 == h->t_in ? h->CP : op.C0 + op.C1) + esz_out * out_elems;
@@ -1117,25 +1117,25 @@ int run_unet(fdsr_handle h, int N, int H, int W, char* ws, const float* nl_dev, 
         break;
       }
       case Op::ATTN: {
-        HIPCHK(h, launch_self_attention(TP(op.src0), TP(op.aux), TP(op.dst), N, Hi * Wi, op.C0, op.heads, st, h->prec == PREC_BF16));
+        HIPCHK(h, launch_self_attention(TP(op.src0), TP(op.aux), TP(op.dst), N, Hi * Wi, op.C0, op.heads, st, prec_act16(h->prec)));
         break;
       }
       case Op::POOL2: {
         const float* sc = op.gn_slot >= 0 ? reinterpret_cast<const float*>(ws + sp.gn_off[op.gn_slot]) : nullptr;
-        HIPCHK(h, launch_pool2(TP(op.src0), sc, sc ? sc + (size_t)N * op.C0 : nullptr, TP(op.dst), N, Hi, Wi, op.C0, st, h->prec == PREC_BF16));
+        HIPCHK(h, launch_pool2(TP(op.src0), sc, sc ? sc + (size_t)N * op.C0 : nullptr, TP(op.dst), N, Hi, Wi, op.C0, st, prec_act16(h->prec)));
         break;
       }
       case Op::UP2X:
-        HIPCHK(h, launch_upsample2(TP(op.src0), TP(op.dst), N, Hi, Wi, op.C0, st, h->prec == PREC_BF16));
+        HIPCHK(h, launch_upsample2(TP(op.src0), TP(op.dst), N, Hi, Wi, op.C0, st, prec_act16(h->prec)));
         break;
       case Op::CLAM:
         HIPCHK(h, launch_clam_gate(TP(op.src0), N, Hi * Wi, op.C0, P(op.fc1), P(op.fc2), op.C0 / 16, gate, st,
-                                   h->prec == PREC_BF16));
+                                   prec_act16(h->prec)));
         break;
       case Op::SLAM: {
         int nt = 0;
         HIPCHK(h, launch_slam(TP(op.src0), gate, P(op.w), N, Hi, Wi, op.C0, TP(op.dst), PART(op.dst), st, &nt,
-                              h->prec == PREC_BF16));
+                              prec_act16(h->prec)));
         sp.tensor_nt[op.dst] = nt;
         break;
       }
@@ -1694,13 +1694,15 @@ int fdsr_resize_bicubic_u8(fdsr_handle h, const uint8_t* src_nhwc, int batch, in
 }
 
 int fdsr_set_precision(fdsr_handle h, int mode) {
-  if (!h || mode < 0 || mode > 2) return fail(h, FDSR_E_INVALID, "precision mode must be 0 (f32), 1 (f16x3) or 2 (bf16)");
-  if (mode == PREC_BF16) {
-    // bf16 mode stores activations as bf16: every conv but the packed-input one must run on the 16-bit
+  if (!h || mode < 0 || mode > PREC_F16) return fail(h, FDSR_E_INVALID, "precision mode must be 0 (f32), 1 (f16x3), 2 (bf16) or 3 (f16)");
+  if (prec_is16(mode)) {
+    // bf16 / f16 mode stores activations in 16 bits: every conv but the packed-input one must run on the 16-bit
     // kernels (attention and the GDP resampling kernels have bf16 forms of their own)
     for (const Op& op : h->ops) {
       if (op.kind == Op::CONV && !h->weights[op.w].h_ok && op.src0 != h->t_in)
-        return fail(h, FDSR_E_INVALID, "bf16 mode needs channel counts that are multiples of 16 (layer %s)", op.name.c_str());
+        return fail(h, FDSR_E_INVALID, "the 16-bit storage modes need channel counts that are multiples of 16 (layer %s)", op.name.c_str());
+      if (mode == PREC_F16 && op.kind == Op::ATTN)
+        return fail(h, FDSR_E_INVALID, "f16 mode: the attention kernels of the sibling denoisers read fp32 or bf16 activations (layer %s): use bf16 or f16x3", op.name.c_str());
     }
   }
   if (mode == PREC_F32 && h->f32_forms_stale) {   // f16x3 training steps refreshed only the fp32 forms they read
@@ -1800,7 +1802,7 @@ int fdsr_debug_tensor_elem_bytes(fdsr_handle h, const char* name, int* bytes) {
   if (!h || !name || !bytes) return fail(h, FDSR_E_INVALID, "null argument");
   for (size_t t = 0; t < h->tensors.size(); ++t)
     if (h->tensors[t].name == name) {
-      *bytes = (h->prec == PREC_BF16 && (int)t != h->t_in && (int)t != h->t_eps) ? 2 : 4;
+      *bytes = (prec_is16(h->prec) && (int)t != h->t_in && (int)t != h->t_eps) ? 2 : 4;
       return FDSR_OK;
     }
   return fail(h, FDSR_E_KEY, "no tensor named '%s'", name);

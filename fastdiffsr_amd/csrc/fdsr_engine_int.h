@@ -87,7 +87,7 @@ struct ShapePlan {
   std::vector<size_t> gsum_off;    // (0 = none)
   size_t off_gsum = 0, gsum_bytes = 0;
   std::vector<char> tensor_gsum;   // this forward's producer of the tensor filled its table (set at launch)
-  std::vector<char> gsum_wanted[3];   // per precision, per tensor: some GroupNorm'd conv that reads it would form its statistics itself at this shape
+  std::vector<char> gsum_wanted[4];   // per precision, per tensor: some GroupNorm'd conv that reads it would form its statistics itself at this shape
 };
 
 struct GraphEntry {

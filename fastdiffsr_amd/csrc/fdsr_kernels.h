@@ -92,7 +92,12 @@ struct ConvParams {
 enum { GSUM_SHARDS = 8, GSUM_BITS1 = 16, GSUM_BITS2 = 12 };   // shards = XCDs
 // producer epilogues: v = (sum, sumsq) of one channel pair over this workgroup's pixels -> the table (fdsr_act_io.h: gsum_add)
 
-enum Precision { PREC_F32 = 0, PREC_F16X3 = 1, PREC_BF16 = 2 };
+// PREC_F16 (round 6): ONE f16 product per multiply (the hi plane of the f16x3 weight forms, un-split activations) and f16
+// activations in HBM -- the bf16 mode's kernels, bytes and MFMA rate with 11 mantissa bits instead of 8.
+enum Precision { PREC_F32 = 0, PREC_F16X3 = 1, PREC_BF16 = 2, PREC_F16 = 3 };
+constexpr bool prec_is16(int prec) { return prec == PREC_BF16 || prec == PREC_F16; }       // 2-byte activations, one MFMA per product
+constexpr int prec_wform(int prec) { return prec == PREC_F16 ? PREC_F16X3 : prec; }         // the weight arena the mode reads (f16: the f16x3 form's hi plane)
+constexpr int prec_act16(int prec) { return prec == PREC_BF16 ? 1 : (prec == PREC_F16 ? 2 : 0); }   // ConvParams::out_bf16 / act_bf16 codes: 0 fp32, 1 bf16, 2 f16
 
 // Debug / A-B options of the launchers (fdsr_debug_option in include/fdsr.h).  Process-wide, never read from the
 // environment: a library behind a C ABI must not change numerics paths because of a stray variable.  `epoch` moves with

@@ -292,7 +292,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_f32_kernel(const ConvParams 
             const size_t off = ((size_t)(n * p.Hout + oy) * p.Wout + ox) * p.Cout + co;
             float v = acc[mb][nb][i] + add;
             if (p.res) v += rv[mb][i];
-            if (p.out_bf16) reinterpret_cast<unsigned short*>(p.out)[off] = __builtin_bit_cast(unsigned short, (__bf16)v);
+            if (p.out_bf16) reinterpret_cast<unsigned short*>(p.out)[off] = f32_to_16_bits(v, p.out_bf16);   // 1 bf16, 2 f16
             else p.out[off] = v;
             s1[nb] += v;
             s2[nb] += v * v;
@@ -566,9 +566,10 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-// four consecutive channels of an activation tensor kept as fp32 (BF = false) or bf16 (BF = true, bf16 mode)
-template <bool BF>
+// four consecutive channels of an activation tensor kept as fp32 (BF = 0), bf16 (BF = 1, bf16 mode) or f16 (BF = 2, f16 mode)
+template <int BF>
 __device__ __forceinline__ f32x4 ldq(const float* base, size_t idx) {
+  if (BF == 2) return ActIO<PREC_F16>::widen(ActIO<PREC_F16>::load4(base, idx));
   if (BF) {
     const uint2 q = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + idx);
     f32x4 r = {__builtin_bit_cast(float, q.x << 16), __builtin_bit_cast(float, q.x & 0xffff0000u),
@@ -577,9 +578,11 @@ __device__ __forceinline__ f32x4 ldq(const float* base, size_t idx) {
   }
   return *reinterpret_cast<const f32x4*>(base + idx);
 }
-template <bool BF>
+template <int BF>
 __device__ __forceinline__ void stq(float* base, size_t idx, f32x4 v) {
-  if (BF) {
+  if (BF == 2) {
+    *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(base) + idx) = pack4_16<PREC_F16>(v);
+  } else if (BF) {
     uint2 pk;
     pk.x = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)v[0]) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)v[1]) << 16);
     pk.y = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)v[2]) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)v[3]) << 16);
@@ -590,7 +593,7 @@ __device__ __forceinline__ void stq(float* base, size_t idx, f32x4 v) {
 }
 
 // Phase 1, grid (FDSR_CLAM_SLICES, N): per-channel sum and maximum of one pixel slice.
-template <bool BF>
+template <int BF>
 __global__ void __launch_bounds__(256) clam_pool_kernel(const float* __restrict__ x, int HW, int C, float* __restrict__ pool) {
   __shared__ __attribute__((aligned(16))) float ps[256 * 8];
   const int tid = threadIdx.x, sl = blockIdx.x, n = blockIdx.y;
@@ -672,8 +675,9 @@ hipError_t launch_clam_gate(const float* x, int N, int HW, int C, const float* f
   if (C > 1024 || (C & 3)) return hipErrorInvalidValue;
   float* gate = scratch;
   float* pool = scratch + (size_t)N * C;
-  if (act_bf16) hipLaunchKernelGGL(clam_pool_kernel<true>, dim3(FDSR_CLAM_SLICES, N), dim3(256), 0, s, x, HW, C, pool);
-  else hipLaunchKernelGGL(clam_pool_kernel<false>, dim3(FDSR_CLAM_SLICES, N), dim3(256), 0, s, x, HW, C, pool);
+  if (act_bf16 == 2) hipLaunchKernelGGL(clam_pool_kernel<2>, dim3(FDSR_CLAM_SLICES, N), dim3(256), 0, s, x, HW, C, pool);
+  else if (act_bf16) hipLaunchKernelGGL(clam_pool_kernel<1>, dim3(FDSR_CLAM_SLICES, N), dim3(256), 0, s, x, HW, C, pool);
+  else hipLaunchKernelGGL(clam_pool_kernel<0>, dim3(FDSR_CLAM_SLICES, N), dim3(256), 0, s, x, HW, C, pool);
   const size_t lds = (size_t)(2 * C + 2 * Cr) * sizeof(float);
   hipLaunchKernelGGL(clam_gate_kernel, dim3(N), dim3(256), lds, s, pool, HW, C, fc1, fc2, Cr, gate);
   return hipGetLastError();
@@ -683,7 +687,7 @@ hipError_t launch_clam_gate(const float* x, int N, int HW, int C, const float* f
 // SLAM on y = x*gate: channel mean/max -> 7x7 conv -> sigmoid -> scale   (unet.py:151-173)
 // ---------------------------------------------------------------------------
 // Phase 1, grid (ceil(HW/16), N): one wave per pixel, map[n][0] = mean_c y, map[n][1] = max_c y.
-template <bool BF>
+template <int BF>
 __global__ void __launch_bounds__(256) slam_map_kernel(const float* __restrict__ x, const float* __restrict__ gate, int HW, int C,
                                                        float* __restrict__ map) {
   const int tid = threadIdx.x, n = blockIdx.y, wave = tid >> 6, lane = tid & 63;
@@ -709,7 +713,7 @@ __global__ void __launch_bounds__(256) slam_map_kernel(const float* __restrict__
 
 // Phase 2, grid (tiles of 2 x 32 pixels, N): 7x7 conv + sigmoid on the map, out = sig * (gate * x), and the
 // per-tile channel statistics of out (GroupNorm input of the next block, mid.1.block1).
-template <bool BF>
+template <int BF>
 __global__ void __launch_bounds__(256) slam_apply_kernel(const float* __restrict__ x, const float* __restrict__ gate,
                                                          const float* __restrict__ map, const float* __restrict__ w7, int H, int W,
                                                          int C, float* out, float* part_out) {
@@ -810,12 +814,14 @@ hipError_t launch_slam(const float* x, float* scratch, const float* w7, int N, i
   const int HW = H * W;
   const float* gate = scratch;
   float* map = scratch + (size_t)N * C + (size_t)N * FDSR_CLAM_SLICES * C * 2;
-  if (act_bf16) hipLaunchKernelGGL(slam_map_kernel<true>, dim3((HW + 15) / 16, N), dim3(256), 0, s, x, gate, HW, C, map);
-  else hipLaunchKernelGGL(slam_map_kernel<false>, dim3((HW + 15) / 16, N), dim3(256), 0, s, x, gate, HW, C, map);
+  if (act_bf16 == 2) hipLaunchKernelGGL(slam_map_kernel<2>, dim3((HW + 15) / 16, N), dim3(256), 0, s, x, gate, HW, C, map);
+  else if (act_bf16) hipLaunchKernelGGL(slam_map_kernel<1>, dim3((HW + 15) / 16, N), dim3(256), 0, s, x, gate, HW, C, map);
+  else hipLaunchKernelGGL(slam_map_kernel<0>, dim3((HW + 15) / 16, N), dim3(256), 0, s, x, gate, HW, C, map);
   const int nt = ((W + 31) / 32) * ((H + 1) / 2);
   if (tiles) *tiles = nt;
-  if (act_bf16) hipLaunchKernelGGL(slam_apply_kernel<true>, dim3(nt, N), dim3(256), 0, s, x, gate, map, w7, H, W, C, out, part_out);
-  else hipLaunchKernelGGL(slam_apply_kernel<false>, dim3(nt, N), dim3(256), 0, s, x, gate, map, w7, H, W, C, out, part_out);
+  if (act_bf16 == 2) hipLaunchKernelGGL(slam_apply_kernel<2>, dim3(nt, N), dim3(256), 0, s, x, gate, map, w7, H, W, C, out, part_out);
+  else if (act_bf16) hipLaunchKernelGGL(slam_apply_kernel<1>, dim3(nt, N), dim3(256), 0, s, x, gate, map, w7, H, W, C, out, part_out);
+  else hipLaunchKernelGGL(slam_apply_kernel<0>, dim3(nt, N), dim3(256), 0, s, x, gate, map, w7, H, W, C, out, part_out);
   return hipGetLastError();
 }
 
@@ -1242,6 +1248,7 @@ hipError_t launch_attn_probs(const float* qkv, float* S, int N, int HW, int C, i
 }
 
 hipError_t launch_self_attention(const float* qkv, float* S, float* O, int N, int HW, int C, int heads, hipStream_t s, int act_bf16) {
+  if (act_bf16 == 2) return hipErrorInvalidValue;   // (no f16-storage form of the attention kernels: fdsr_set_precision refuses the mode for the variants that attend)
   if (heads < 1 || C % heads || (C / heads) % 32) return hipErrorInvalidValue;
   const int HWp = (HW + 15) / 16 * 16, ch = C / heads;
   // QKVAttentionLegacy scales q and k by ch^-1/4 each (gdp_modules/unet.py:480-483); SelfAttention divides by sqrt(C)
@@ -1297,11 +1304,8 @@ __global__ void __launch_bounds__(256) pool2_kernel(const float* __restrict__ x,
       acc += v;
     }
   acc = acc * 0.25f;
-  if (PREC == PREC_BF16) {
-    uint2 pk;
-    pk.x = (unsigned)f32_to_bf16_bits(acc[0]) | ((unsigned)f32_to_bf16_bits(acc[1]) << 16);
-    pk.y = (unsigned)f32_to_bf16_bits(acc[2]) | ((unsigned)f32_to_bf16_bits(acc[3]) << 16);
-    *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(out) + i * 4) = pk;
+  if (prec_is16(PREC)) {
+    *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(out) + i * 4) = pack4_16<PREC>(acc);
   } else {
     *reinterpret_cast<f32x4*>(out + i * 4) = acc;
   }
@@ -1312,7 +1316,8 @@ hipError_t launch_pool2(const float* x, const float* gn_scale, const float* gn_s
   if ((C & 3) || (H & 1) || (W & 1)) return hipErrorInvalidValue;
   const size_t total = (size_t)N * (H >> 1) * (W >> 1) * (C >> 2);
   const dim3 grid((unsigned)((total + 255) / 256));
-  if (act_bf16) hipLaunchKernelGGL(pool2_kernel<PREC_BF16>, grid, dim3(256), 0, s, x, gn_scale, gn_shift, out, H, W, C >> 2, total);
+  if (act_bf16 == 2) hipLaunchKernelGGL(pool2_kernel<PREC_F16>, grid, dim3(256), 0, s, x, gn_scale, gn_shift, out, H, W, C >> 2, total);
+  else if (act_bf16) hipLaunchKernelGGL(pool2_kernel<PREC_BF16>, grid, dim3(256), 0, s, x, gn_scale, gn_shift, out, H, W, C >> 2, total);
   else hipLaunchKernelGGL(pool2_kernel<PREC_F16X3>, grid, dim3(256), 0, s, x, gn_scale, gn_shift, out, H, W, C >> 2, total);
   return hipGetLastError();
 }

@@ -360,7 +360,7 @@ namespace {
 int train_grads_impl(fdsr_handle h, const float* x_nchw, const float* hr_nchw, const float* sr_nchw, const float* noise_level,
                      const float* target_nchw, int loss_l2, float loss_scale, float* loss_host, int batch, int height, int width,
                      void* workspace, size_t workspace_bytes, void* hip_stream) {
-  if (h->prec == PREC_BF16)
+  if (prec_is16(h->prec))
     return fail(h, FDSR_E_INVALID, "the training step runs the fp32-grade kernels: fdsr_set_precision(FDSR_PREC_F32 or FDSR_PREC_F16X3) first");
   if (h->cfg.in_channel != 6 || h->cfg.out_channel != 3) return fail(h, FDSR_E_INVALID, "training needs in_channel=6, out_channel=3");
   int rc = check_ready(h, false);

@@ -381,8 +381,8 @@ class Engine:
         cnt = n.value * hh.value * ww.value * ch.value
         eb = C.c_int()
         _lib.check(self.h, self.lib.fdsr_debug_tensor_elem_bytes(self.h, name.encode(), C.byref(eb)))
-        if eb.value == 2:       # bf16 mode keeps activations as bf16
-            flat = self._ws[o:o + 2 * cnt].view(torch.bfloat16).float()
+        if eb.value == 2:       # bf16 / f16 mode keeps activations in 16 bits
+            flat = self._ws[o:o + 2 * cnt].view(torch.float16 if self.precision == 'f16' else torch.bfloat16).float()
         else:
             flat = self._ws[o:o + 4 * cnt].view(torch.float32)
         return flat.view(n.value, hh.value, ww.value, ch.value).permute(0, 3, 1, 2).contiguous()

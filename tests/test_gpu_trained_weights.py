@@ -130,6 +130,14 @@ def test_trained_weights_f16x3_raise_and_bf16_vs_oracle(trained):
     print(f'trained-like weights: exact f32 max|d| = {d32:.3e}; bf16 PSNR(out, oracle out) = {psnr_vs_oracle:.2f} dB (rmse {rmse:.3e}, '
           f'max|d| {(ob - ref).abs().max().item():.3e}), PSNR(out, HR) - PSNR(oracle, HR) = {dps:+.5f} dB at {O.psnr_u8(u8(ref), u8(hr)):.2f} dB')
     assert d32 <= 1e-3
+    # f16 storage + one f16 MFMA per product (FDSR_PREC_F16): the bf16 mode's speed with 11 mantissa bits
+    eng.set_precision('f16')
+    oh = eng.sample(sr.cuda(), noise.cuda()).cpu()
+    rm_h = (oh - ref).pow(2).mean().sqrt().item()
+    dps_h = O.psnr_u8(u8(oh), u8(hr)) - O.psnr_u8(u8(ref), u8(hr))
+    print(f'trained-like weights: f16 PSNR(out, oracle out) = {20 * math.log10(2.0 / max(rm_h, 1e-12)):.2f} dB (rmse {rm_h:.3e}, max|d| '
+          f'{(oh - ref).abs().max().item():.3e}), PSNR(out, HR) - PSNR(oracle, HR) = {dps_h:+.5f} dB')
+    assert 20 * math.log10(2.0 / max(rm_h, 1e-12)) >= 60.0 and abs(dps_h) <= 0.02
     # the same loop on the CPU with PyTorch's bf16 autocast (convolutions and linears in bf16, everything else fp32): how far does
     # the number format alone move the image?
     with torch.autocast('cpu', dtype=torch.bfloat16):
