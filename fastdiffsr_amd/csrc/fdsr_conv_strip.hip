@@ -91,7 +91,7 @@ struct StripCfg {
   static_assert(256 % (C0_ / 8) == 0 && (C1_ == 0 || 256 % (C1_ / 8) == 0) && (CR0_ == 0 || 256 % (CR0_ / 8) == 0) &&
                 (CR1_ == 0 || 256 % (CR1_ / 8) == 0), "a thread keeps one oct index per tensor");
   static_assert(RB == 128 || RB == 256 || RB == 384 || RB == 512, "swizzles below are verified for these pixel strides");
-  static_assert(CR == 0 || (PREC == PREC_BF16 && (RRB == 256 || RRB == 384)), "riders: bf16 only (one weight scale)");
+  static_assert(CR == 0 || (prec_is16(PREC) && (RRB == 256 || RRB == 384)), "riders: the 2-byte modes (f16: launched only while the rider and the main conv share one weight scale, conv_strip_ok)");
   static_assert(NIT >= 1 && NIT <= 4 && 256 % UPP == 0, "row-tile map");
   static_assert(SLOT_BYTES + 16 * (NPH - 1) * RB < 65536 && RSLOT_BYTES < 65536, "fragment offsets must fit the ds_read immediate");
   // ---- the step's schedule: which item of vector work sits behind which slot's MFMAs ----
@@ -701,7 +701,10 @@ bool conv_strip_ok(ConvKind kind, int prec, const ConvParams& p) {
   if (p.Cout == 128) {   // the 128-cout level: two workgroups of 64 couts read the same rows; 128 -> 128 (144 weight registers) and 64 -> 128, bf16
     shape = prec_is16(prec) && (g_tun.strip & FDSR_STRIP_BF16_COUT128) && !p.xr0 && p.C1 == 0 && (p.C0 == 64 || p.C0 == 128);
   } else if (p.xr0) {        // 64 -> 64 with a rider over (64 | 64) or (128 | 64) raw channels
-    shape = prec == PREC_BF16 && (g_tun.strip & FDSR_STRIP_BF16_RIDER) && !p.res && p.C0 == 64 && p.C1 == 0 && p.Cr1 == 64 && (p.Cr0 == 64 || p.Cr0 == 128) &&
+    // (f16: the two products share the accumulators, so the rider's power-of-two weight scale must be the main conv's -- both are 2^12 unless a
+    // tensor holds weights beyond 8; otherwise the launch stays on the tile kernels, which re-scale between the two phases)
+    if (prec == PREC_F16 && p.w_inv_scale > 0.f && p.w_inv_scale_r > 0.f && p.w_inv_scale_r != p.w_inv_scale) return false;   // (a shape query without scales: assume the form)
+    shape = prec_is16(prec) && (g_tun.strip & FDSR_STRIP_BF16_RIDER) && !p.res && p.C0 == 64 && p.C1 == 0 && p.Cr1 == 64 && (p.Cr0 == 64 || p.Cr0 == 128) &&
             p.nkr * 16 == p.Cr0 + p.Cr1;
   } else if (p.C1) {  // concatenated input (64 | 64) or (128 | 64), no residual (block1 of the up path)
     shape = prec_is16(prec) && !p.res && p.C1 == 64 && ((p.C0 == 64 && (g_tun.strip & FDSR_STRIP_BF16_CAT64)) || (p.C0 == 128 && (g_tun.strip & FDSR_STRIP_BF16_CAT128)));   // (bit 32: 216 weight registers, spills)
@@ -728,8 +731,9 @@ hipError_t launch_conv_strip(int prec, const ConvParams& p, int wn_a, hipStream_
   if (prec == PREC_F16X3) {
     return p.res ? launch_strip_t<PREC_F16X3, 64, 0, 0, 0, true, 1>(p, wn_a, s, tiles) : launch_strip_t<PREC_F16X3, 64, 0, 0, 0, false, 1>(p, wn_a, s, tiles);
   }
-  if (prec == PREC_F16) {   // the bf16 forms without a rider (a rider's weights carry a scale of their own in the f16 forms: those launches stay on the tile kernels)
-    if (p.xr0) return hipErrorInvalidValue;
+  if (prec == PREC_F16) {   // the bf16 mode's forms
+    if (p.xr0)
+      return p.Cr0 == 64 ? launch_strip_t<PREC_F16, 64, 0, 64, 64, false, 1>(p, wn_a, s, tiles) : launch_strip_t<PREC_F16, 64, 0, 128, 64, false, 1>(p, wn_a, s, tiles);
     if (p.C0 == 128 && !p.C1)
       return p.res ? launch_strip_t<PREC_F16, 128, 0, 0, 0, true, 1>(p, wn_a, s, tiles) : launch_strip_t<PREC_F16, 128, 0, 0, 0, false, 1>(p, wn_a, s, tiles);
     if (p.C1)
@@ -770,6 +774,7 @@ hipError_t kernels_strip_init() {
   X(PREC_F16, 64, 0, 0, 0, false, 2) X(PREC_F16, 64, 0, 0, 0, true, 2)
   X(PREC_F16, 64, 0, 0, 0, false, 1) X(PREC_F16, 64, 0, 0, 0, true, 1)
   X(PREC_F16, 64, 64, 0, 0, false, 1) X(PREC_F16, 128, 64, 0, 0, false, 1)
+  X(PREC_F16, 64, 0, 64, 64, false, 1) X(PREC_F16, 64, 0, 128, 64, false, 1)
   X(PREC_F16, 128, 0, 0, 0, false, 1) X(PREC_F16, 128, 0, 0, 0, true, 1)
 #undef X
   return hipSuccess;

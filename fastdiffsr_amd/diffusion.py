@@ -186,7 +186,7 @@ class GaussianDiffusion(nn.Module):
         eng = unet.engine
         # 'f32' (everything exact fp32) or 'f16x3' (every convolution -- forward, input and weight gradients -- fp32-grade on
         # split-f16 MFMAs)
-        eng.set_precision('f32' if self.precision == 'bf16' else self.precision)
+        eng.set_precision('f32' if self.precision in ('bf16', 'f16') else self.precision)
         eng.set_training(unet.training and unet.cfg.dropout > 0, seed_from_torch=True)   # Dropout(p) of block2 is live in .train() mode
         return eng
 

@@ -81,7 +81,7 @@ class GaussianDiffusion(nn.Module):
         unet = self.denoise_fn
         unet.sync_weights(for_training=True)
         eng = unet.engine
-        eng.set_precision('f32' if self.precision == 'bf16' else self.precision)
+        eng.set_precision('f32' if self.precision in ('bf16', 'f16') else self.precision)
         eng.set_training(unet.training and unet.cfg.dropout > 0, seed_from_torch=True)
         return eng
 

@@ -146,6 +146,6 @@ class UNet(nn.Module):
         # (Philox) and runs the exact-fp32 kernels for such a forward
         live_dropout = self.training and self.cfg.dropout > 0
         self.engine.set_training(live_dropout, seed_from_torch=True)
-        if live_dropout and getattr(self.engine, 'precision', 'f32') == 'bf16':
+        if live_dropout and getattr(self.engine, 'precision', 'f32') in ('bf16', 'f16'):
             self.engine.set_precision('f16x3')       # live dropout needs one of the fp32-grade modes
         return self.engine.unet_forward(x, time)    # the f16x3 range guard and its f32 re-run live in Engine (on_saturation)

@@ -401,7 +401,7 @@ def main(argv=None, diffusion=None, ops=None):
     ap.add_argument('-debug', '-d', action='store_true')
     ap.add_argument('--batch', type=int, default=1)
     ap.add_argument('--cond-from-lr', action='store_true')
-    ap.add_argument('--precision', default='f16x3', choices=['f32', 'f16x3', 'bf16'])
+    ap.add_argument('--precision', default='f16x3', choices=['f32', 'f16x3', 'bf16', 'f16'])
     ap.add_argument('--results', default=None)
     ap.add_argument('--max-images', type=int, default=None)
     ap.add_argument('--no-save', action='store_true')
