@@ -1701,8 +1701,6 @@ int fdsr_set_precision(fdsr_handle h, int mode) {
     for (const Op& op : h->ops) {
       if (op.kind == Op::CONV && !h->weights[op.w].h_ok && op.src0 != h->t_in)
         return fail(h, FDSR_E_INVALID, "the 16-bit storage modes need channel counts that are multiples of 16 (layer %s)", op.name.c_str());
-      if (mode == PREC_F16 && op.kind == Op::ATTN)
-        return fail(h, FDSR_E_INVALID, "f16 mode: the attention kernels of the sibling denoisers read fp32 or bf16 activations (layer %s): use bf16 or f16x3", op.name.c_str());
     }
   }
   if (mode == PREC_F32 && h->f32_forms_stale) {   // f16x3 training steps refreshed only the fp32 forms they read

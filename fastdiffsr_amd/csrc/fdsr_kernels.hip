@@ -1180,7 +1180,9 @@ size_t attn_scratch_floats(int N, int HW, int heads) { return (size_t)N * heads 
 // ---- bf16 mode (activations stored as bf16): Q K^T and P V on v_mfma_f32_32x32x16_bf16 -- the "MFMA bf16 QK^T.V contraction" of
 // BASELINE.json's north_star, for the siblings that do attend (ddpm_modules/unet.py:99, tesr_modules).  Scores and the softmax stay
 // fp32; P is rounded to bf16 as it enters the second product; O is stored as bf16.
+// PREC: PREC_BF16 or PREC_F16 (the f16 mode's twin: the same kernels on v_mfma_f32_32x32x16_f16, O stored as f16)
 typedef __bf16 bfrag8 __attribute__((ext_vector_type(8)));
+template <int PREC>
 __global__ void __launch_bounds__(64) attn_scores_bf16_kernel(const unsigned short* __restrict__ qkv, float* __restrict__ S, int HW, int HWp,
                                                               int C, int heads, float inv_div) {
   const int lane = threadIdx.x, r31 = lane & 31, h = lane >> 5;
@@ -1197,7 +1199,7 @@ __global__ void __launch_bounds__(64) attn_scores_bf16_kernel(const unsigned sho
   for (int k = 0; k < ch; k += 16) {
     const uint4 a = *reinterpret_cast<const uint4*>(qrow + k);
     const uint4 bb = *reinterpret_cast<const uint4*>(krow + k);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bfrag8, a), __builtin_bit_cast(bfrag8, bb), acc, 0, 0, 0);
+    acc = mfma32_k16<PREC>(a, bb, acc);
   }
   const int col = n0 + r31;
 #pragma unroll
@@ -1207,6 +1209,7 @@ __global__ void __launch_bounds__(64) attn_scores_bf16_kernel(const unsigned sho
   }
 }
 
+template <int PREC>
 __global__ void __launch_bounds__(64) attn_pv_bf16_kernel(const float* __restrict__ P, const unsigned short* __restrict__ qkv,
                                                           unsigned short* __restrict__ O, int HW, int HWp, int C, int heads) {
   const int lane = threadIdx.x, r31 = lane & 31, h = lane >> 5;
@@ -1221,18 +1224,22 @@ __global__ void __launch_bounds__(64) attn_pv_bf16_kernel(const float* __restric
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
   for (int k = 0; k < HWp; k += 16) {                       // HWp is a multiple of 16; pad keys carry P == 0
     const f32x4 p0 = *reinterpret_cast<const f32x4*>(prow + k), p1 = *reinterpret_cast<const f32x4*>(prow + k + 4);
-    bfrag8 a, bv;
+    uint4 a, bv;                                            // probabilities (in [0, 1]) rounded to the mode's format; V as stored
+    {
+      const uint2 lo = stage4_16<PREC>(p0), hi = stage4_16<PREC>(p1);
+      a = uint4{lo.x, lo.y, hi.x, hi.y};
+    }
+    unsigned short vv[8];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { a[j] = (__bf16)p0[j]; a[4 + j] = (__bf16)p1[j]; }
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-      bv[j] = __builtin_bit_cast(__bf16, vcol[(size_t)min(k + 8 * h + j, HW - 1) * 3 * C]);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bv, acc, 0, 0, 0);
+    for (int j = 0; j < 8; ++j) vv[j] = vcol[(size_t)min(k + 8 * h + j, HW - 1) * 3 * C];
+    bv = uint4{(unsigned)vv[0] | ((unsigned)vv[1] << 16), (unsigned)vv[2] | ((unsigned)vv[3] << 16), (unsigned)vv[4] | ((unsigned)vv[5] << 16),
+               (unsigned)vv[6] | ((unsigned)vv[7] << 16)};
+    acc = mfma32_k16<PREC>(a, bv, acc);
   }
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int row = m0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-    if (row < HW) O[((size_t)b * HW + row) * C + hd * ch + n0 + r31] = __builtin_bit_cast(unsigned short, (__bf16)acc[i]);
+    if (row < HW) O[((size_t)b * HW + row) * C + hd * ch + n0 + r31] = PREC == PREC_F16 ? f32_to_f16_bits(acc[i]) : f32_to_bf16_bits(acc[i]);
   }
 }
 
@@ -1248,18 +1255,19 @@ hipError_t launch_attn_probs(const float* qkv, float* S, int N, int HW, int C, i
 }
 
 hipError_t launch_self_attention(const float* qkv, float* S, float* O, int N, int HW, int C, int heads, hipStream_t s, int act_bf16) {
-  if (act_bf16 == 2) return hipErrorInvalidValue;   // (no f16-storage form of the attention kernels: fdsr_set_precision refuses the mode for the variants that attend)
   if (heads < 1 || C % heads || (C / heads) % 32) return hipErrorInvalidValue;
   const int HWp = (HW + 15) / 16 * 16, ch = C / heads;
   // QKVAttentionLegacy scales q and k by ch^-1/4 each (gdp_modules/unet.py:480-483); SelfAttention divides by sqrt(C)
   const float inv_div = 1.0f / sqrtf((float)ch);
   const size_t rows = (size_t)N * heads * HW;
   const dim3 gs((HW + 31) / 32, (HW + 31) / 32, N * heads), gp(C / 32, (HW + 31) / 32, N);
-  if (act_bf16) {
+  if (act_bf16) {   // 1 bf16, 2 f16
     const unsigned short* q16 = reinterpret_cast<const unsigned short*>(qkv);
-    hipLaunchKernelGGL(attn_scores_bf16_kernel, gs, dim3(64), 0, s, q16, S, HW, HWp, C, heads, inv_div);
+    if (act_bf16 == 2) hipLaunchKernelGGL(attn_scores_bf16_kernel<PREC_F16>, gs, dim3(64), 0, s, q16, S, HW, HWp, C, heads, inv_div);
+    else hipLaunchKernelGGL(attn_scores_bf16_kernel<PREC_BF16>, gs, dim3(64), 0, s, q16, S, HW, HWp, C, heads, inv_div);
     hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, S, HW, HWp, rows);
-    hipLaunchKernelGGL(attn_pv_bf16_kernel, gp, dim3(64), 0, s, S, q16, reinterpret_cast<unsigned short*>(O), HW, HWp, C, heads);
+    if (act_bf16 == 2) hipLaunchKernelGGL(attn_pv_bf16_kernel<PREC_F16>, gp, dim3(64), 0, s, S, q16, reinterpret_cast<unsigned short*>(O), HW, HWp, C, heads);
+    else hipLaunchKernelGGL(attn_pv_bf16_kernel<PREC_BF16>, gp, dim3(64), 0, s, S, q16, reinterpret_cast<unsigned short*>(O), HW, HWp, C, heads);
     return hipGetLastError();
   }
   hipLaunchKernelGGL(attn_scores_kernel, gs, dim3(64), 0, s, qkv, S, HW, HWp, C, heads, inv_div);

@@ -161,8 +161,8 @@ int fdsr_randn(fdsr_handle h, float* dst_nchw, int batch, int height, int width,
 #define FDSR_PREC_BF16 2
 /*   FDSR_PREC_F16    (round 6) one f16 MFMA per product -- the hi plane of the f16x3 weight forms against un-split f16 activations --
  *                    and f16 activations in HBM: the bf16 mode's bytes and MFMA rate with 11 mantissa bits instead of 8.  Stores
- *                    saturate at +-65504.  Judged on PSNR like bf16 (|delta| stays above 1e-3); FastDiffSR variant and the siblings
- *                    without attention (FDSR_E_INVALID otherwise); sampling only. */
+ *                    saturate at +-65504.  Judged on PSNR like bf16 (|delta| stays above 1e-3); every variant (the siblings' attention
+ *                    kernels have f16 twins of their bf16 forms); sampling only. */
 #define FDSR_PREC_F16 3
 int fdsr_set_precision(fdsr_handle h, int mode);
 

@@ -8,7 +8,7 @@ f16 activations in HBM: the bf16 mode's kernels, bytes and MFMA rate with 11 man
     strip kernels, the tail kernels, split K) at least 70 dB from the f16x3 result; hipGraph replay and a rerun bitwise; batch
     permutation bitwise;
   * values beyond the f16 range saturate instead of turning into inf;
-  * the variants that attend are refused with a message (their attention kernels read fp32 or bf16 activations).
+  * the siblings (SR3, TESR, GDP): their attention kernels' f16 twins, a loop against f16x3 beside bf16.
 The trained-like-weights figure (0.19 dB for bf16) is in tests/test_gpu_trained_weights.py."""
 import math
 
@@ -133,11 +133,30 @@ def test_f16_stores_saturate(full):
     assert torch.isfinite(out).all()
 
 
-def test_f16_refused_where_attention_reads_other_formats():
-    from fastdiffsr_amd import _lib
+@pytest.mark.parametrize('variant', ['ddpm', 'tesr', 'gdp'])
+def test_f16_siblings_attention(variant):
+    """The siblings attend (ddpm_modules/unet.py:99, tesr_modules, gdp_modules/unet.py:392-488): their bf16 attention kernels have an f16
+    twin (v_mfma_f32_32x32x16_f16, probabilities rounded to f16, O stored as f16).  A sampling loop in f16 against f16x3, beside bf16."""
     from fastdiffsr_amd.engine import Engine
-    e = Engine(UNetConfig(in_channel=6, out_channel=3, inner_channel=32, channel_mults=(1, 2), attn_res=(16,), res_blocks=1, image_size=32,
-                          variant='ddpm'))
-    with pytest.raises(_lib.FdsrError, match='attention'):
-        e.set_precision('f16')
-    e.set_precision('bf16')
+    if variant == 'gdp':
+        cfg = UNetConfig(in_channel=6, out_channel=3, inner_channel=64, norm_groups=32, channel_mults=(1, 2, 2), attn_res=(2, 4), res_blocks=1,
+                         dropout=0.0, image_size=32, variant='gdp')
+    else:
+        cfg = UNetConfig(in_channel=6, out_channel=3, inner_channel=32, norm_groups=32, channel_mults=(1, 2, 2, 4), attn_res=(8,), res_blocks=1,
+                         dropout=0.0, image_size=32, variant=variant)
+    eng = Engine(cfg)
+    eng.load_state_dict(synth_state_dict(cfg, 5))
+    bufs, sp = schedule_buffers(dict(schedule='linear', n_timestep=8, linear_start=1e-4, linear_end=2e-2))
+    eng.set_schedule(sampling_scalars(bufs, sp))
+    cond, noise = synth_inputs(2, 32, 32, 9 if variant in ('ddpm', 'gdp') else 8)
+    c, n = cond.cuda(), noise.cuda()
+    eng.set_precision('f16x3')
+    ref = eng.sample(c, n).clone()
+    eng.set_precision('bf16')
+    pb = _psnr(eng.sample(c, n), ref)
+    eng.set_precision('f16')
+    out = eng.sample(c, n).clone()
+    p = _psnr(out, ref)
+    print(f'{variant}: f16 {p:.2f} dB from the f16x3 result (bf16: {pb:.2f})')
+    assert torch.isfinite(out).all() and torch.equal(out, eng.sample(c, n, graph=True))
+    assert p >= pb + 8.0 and p >= 55.0
