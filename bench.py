@@ -538,6 +538,22 @@ def facade_records(cfg, sd, dev, S, engine_ips, n_images=256, batch=16):
                             'H2D as uint8, 20-step loop (torch-drawn noise, hipGraph replay from the 2nd batch), device tensor2img + MSE/PSNR/SSIM/ERGAS, '
                             'D2H as uint8, one .tif per image -- wall clock of the whole call',
                 'dataset_build_seconds': t_make, 'host_cores': host_cores()}
+            # the same call in the f16 mode (round 6) at B = 64, engine-drawn noise: does the harness around the loop keep up with 2.2 x the rate?
+            try:
+                V.run(opt, batch=64, precision='f16', rng='engine', results=os.path.join(root, 'warm16'), max_images=128, log=log.append, diffusion=model)
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                r16 = V.run(opt, batch=64, precision='f16', rng='engine', results=os.path.join(root, 'out16'), log=log.append, diffusion=model)
+                torch.cuda.synchronize(dev)
+                dt16 = time.perf_counter() - t0
+                recs['val_e2e_f16'] = {
+                    'value': r16['images'] / dt16, 'unit': 'images/s', 'images': r16['images'], 'batch': 64, 'dtype': 'f16', 'seconds': dt16,
+                    'files_written': len(os.listdir(os.path.join(root, 'out16'))),
+                    'sampling_seconds': r16['sample_seconds_this_rank'], 'sampling_share': r16['sample_seconds_this_rank'] / dt16,
+                    'sr_psnr': r16['sr_psnr'], 'sr_psnr_f16x3': r['sr_psnr'], 'sr_ssim': r16['sr_ssim'],
+                    'workload': 'fastdiffsr_amd.val.run(precision="f16", batch=64, rng="engine") over the same folder: wall clock of the whole call'}
+            except Exception as e:
+                recs['val_e2e_f16'] = {'error': f'{type(e).__name__}: {e}'}
             del model
             torch.cuda.empty_cache()
         except Exception as e:
@@ -955,7 +971,7 @@ def main():
                     res['sub_records'].update(facade_records(cfg, sd, dev, S, ips))
                 except Exception as e:
                     err = {'error': f'{type(e).__name__}: {e}'}
-                    res['sub_records'].update({'val_e2e': err, 'train_facade_b32': err})
+                    res['sub_records'].update({'val_e2e': err, 'val_e2e_f16': err, 'train_facade_b32': err})
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'], ref = cpu_baseline(cfg, sd)
             eng.set_precision(args.precision)
