@@ -960,6 +960,8 @@ def main():
                 'b1_graph': sub_record(eng, dev, 'b1_graph', 'f16x3', 1, S, max(20, args.steps), max(5, args.warmup), True,
                                        'configs[0] regime (the reference val loop is B=1, sr_mfe.py:279-284): latency per image, hipGraph'),
             }
+            res['sub_records']['b1_graph_f16'] = sub_record(eng, dev, 'b1_graph_f16', 'f16', 1, S, max(20, args.steps), max(5, args.warmup), True,
+                                                            'the B=1 val regime in the f16 mode (PSNR-grade: 74.6 dB from the oracle image): latency per image, hipGraph')
             # the reference's second driver: infer.py runs B=1 at 512 x 512 (infer.py:59-79, :112-113; config/sr_fastdiffsr_infer_x4.json)
             res['sub_records']['infer_512_b1'] = sub_record(eng, dev, 'infer_512_b1', 'f16x3', 1, 512, max(10, args.steps // 2), max(3, args.warmup // 2), True,
                                                             "infer.py's regime: B=1 at 512 x 512 (128 -> 512), f16x3, hipGraph; ms_per_step = latency per image")
