@@ -97,3 +97,13 @@ def test_kernel_form_bits_match_the_header():
         expr = re.search(prefix + r'DEFAULT = ([0-9| ]+)', txt).group(1)
         assert eval(expr) == default
     assert _lib.bit_names(_lib.STRIP, 91) == 'BF16_64|F16X3_64|BF16_CAT64|BF16_RIDER|BF16_COUT128'
+
+
+def test_precision_codes_mirror_the_header():
+    """`_lib.PRECISIONS` (what Engine.set_precision passes) against the FDSR_PREC_* defines of include/fdsr.h, the f16 mode included."""
+    import re
+    from fastdiffsr_amd import _lib
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include', 'fdsr.h')).read()
+    defs = {m.group(1).lower(): int(m.group(2)) for m in re.finditer(r'#define\s+FDSR_PREC_(\w+)\s+(\d+)', text)}
+    assert defs == _lib.PRECISIONS, (defs, _lib.PRECISIONS)
+    assert defs['f16'] == 3
