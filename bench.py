@@ -650,6 +650,13 @@ def dist_sub_records(cfg, sd, eng, dev, rank, world, S):
                                   'workload': 'configs[3]: bf16, batch 64 per GPU sharded over the ranks, 20-step loop as a hipGraph, weights broadcast once'}
     else:
         recs['bf16_b64_graph'] = {'error': err or 'failed on another rank'}
+    dt, err = measure(lambda: run_config(eng, dev, 'f16', 64, S, steps, warmup, True, 'engine', rank=rank, want_profile=False)[0])
+    if dt != float('inf'):
+        recs['f16_b64_graph'] = {'value': world * 64 * steps / dt, 'unit': 'images/s', 'n_gpus': world, 'ms_per_step': 1e3 * dt / steps, 'steps': steps,
+                                 'warmup': warmup, 'dtype': 'f16', 'batch_per_gpu': 64, 'global_batch': 64 * world, 'hipgraph': True,
+                                 'workload': 'the configs[3] workload in the f16 mode (one f16 MFMA per product, f16 activations): batch 64 per GPU'}
+    else:
+        recs['f16_b64_graph'] = {'error': err or 'failed on another rank'}
 
     def train():
         e2 = Engine(cfg)

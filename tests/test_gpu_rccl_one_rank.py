@@ -45,7 +45,7 @@ def test_bench_rccl_path_with_one_rank():
     # under torch.distributed every rank also measures configs[3] (bf16 B=64/GPU, hipGraph) and configs[4] (data-parallel training
     # step, B=32/GPU, gradient all-reduce through RCCL): the multi-GPU lines of the driver's scaling run carry them
     sub = res['sub_records']
-    assert set(sub) == {'bf16_b64_graph', 'train_step_b32'}
+    assert set(sub) == {'bf16_b64_graph', 'f16_b64_graph', 'train_step_b32'}
     for k, v in sub.items():
         assert 'error' not in v, (k, v)
         assert v['value'] > 0 and v['n_gpus'] == 1
