@@ -12,6 +12,8 @@ HR / bicubic-SR pairs, Dropout(0.2) live.  On those weights:
       HR at 25.4 dB -- on trained-like weights the bf16 mode is NOT within north_star's 0.01 dB, which the random-init checks
       (13 dB against any HR) could not show; the fp32-grade f16x3 mode is (|delta| 6e-7).  PyTorch-CPU under bf16 autocast -- the
       oracle's own arithmetic with bf16 convolutions -- is run beside it to tell the storage format from the implementation.
+  (c) the same in the f16 mode (FDSR_PREC_F16, built in round 6 because of (b)): PSNR(f16 image, oracle image) >= 70 dB and the PSNR
+      difference against HR within north_star's 0.01 dB.  MEASURED: 82.0 dB (rmse 1.6e-4, max|d| 5.3e-4) and +0.0009 dB.
 """
 import math
 
@@ -137,7 +139,7 @@ def test_trained_weights_f16x3_raise_and_bf16_vs_oracle(trained):
     dps_h = O.psnr_u8(u8(oh), u8(hr)) - O.psnr_u8(u8(ref), u8(hr))
     print(f'trained-like weights: f16 PSNR(out, oracle out) = {20 * math.log10(2.0 / max(rm_h, 1e-12)):.2f} dB (rmse {rm_h:.3e}, max|d| '
           f'{(oh - ref).abs().max().item():.3e}), PSNR(out, HR) - PSNR(oracle, HR) = {dps_h:+.5f} dB')
-    assert 20 * math.log10(2.0 / max(rm_h, 1e-12)) >= 60.0 and abs(dps_h) <= 0.02
+    assert 20 * math.log10(2.0 / max(rm_h, 1e-12)) >= 70.0 and abs(dps_h) <= 0.01      # north_star's bound, on trained-like weights (measured 82.0 dB, +0.0009 dB)
     # the same loop on the CPU with PyTorch's bf16 autocast (convolutions and linears in bf16, everything else fp32): how far does
     # the number format alone move the image?
     with torch.autocast('cpu', dtype=torch.bfloat16):
