@@ -24,9 +24,15 @@ CFG = dict(in_channel=6, out_channel=3, inner_channel=64, norm_groups=32, channe
 SCHED = dict(schedule='linear', n_timestep=8, linear_start=1e-4, linear_end=2e-2)
 
 
+_TYPICAL = {}
+
+
 def _typical(grads_ref):
-    """The median over the step's tensors of max |g|: the scale a real gradient of this step has."""
-    return float(np.median([float(v.abs().max()) for v in grads_ref.values()]))
+    """The median over the step's tensors of max |g|: the scale a real gradient of this step has (computed once per set of gradients)."""
+    key = id(grads_ref)
+    if key not in _TYPICAL:
+        _TYPICAL[key] = (grads_ref, float(np.median([float(v.abs().max()) for v in grads_ref.values()])))   # (the dict is kept alive with its value)
+    return _TYPICAL[key][1]
 
 
 def _noise(grads_ref):

@@ -17,9 +17,15 @@ pytestmark = pytest.mark.gpu
 # elsewhere) on both sides -- an absolute floor beside the relative bound
 
 
+_TYPICAL = {}
+
+
 def _typical(grads_ref):
-    """The median over the step's tensors of max |g|: the scale a real gradient of this step has."""
-    return float(np.median([float(v.abs().max()) for v in grads_ref.values()]))
+    """The median over the step's tensors of max |g|: the scale a real gradient of this step has (computed once per set of gradients)."""
+    key = id(grads_ref)
+    if key not in _TYPICAL:
+        _TYPICAL[key] = (grads_ref, float(np.median([float(v.abs().max()) for v in grads_ref.values()])))   # (the dict is kept alive with its value)
+    return _TYPICAL[key][1]
 
 
 def _noise(grads_ref):
