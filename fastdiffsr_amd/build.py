@@ -8,9 +8,11 @@ CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 LIB = os.path.join(CSRC, 'libfdsr_hip.so')
 # -fno-slp-vectorize: packed f32 VALU (v_pk_fma_f32 ...) next to MFMAs is slower than the scalar forms on
 # gfx950 (MI355X_MICROARCH.md, cycle constants); +0.8 % end to end in a same-box A/B
+# fdsr_conv_strip.hip compiles three times (-DSTRIP_PART: the host side + f16x3 kernels, the bf16 kernels, the f16 kernels): objects of their own, in parallel
 SOURCES = [('fdsr_kernels.hip', ['-O3']), ('fdsr_conv_h.hip', ['-O3', '-fno-slp-vectorize']),
            ('fdsr_conv_up2.hip', ['-O3', '-fno-slp-vectorize']),
-           ('fdsr_conv_k32.hip', ['-O3', '-fno-slp-vectorize']), ('fdsr_conv_strip.hip', ['-O3', '-fno-slp-vectorize']), ('fdsr_conv_tail.hip', ['-O3', '-fno-slp-vectorize']),
+           ('fdsr_conv_k32.hip', ['-O3', '-fno-slp-vectorize']), ('fdsr_conv_strip.hip', ['-O3', '-fno-slp-vectorize']),
+           ('fdsr_conv_strip.hip', ['-O3', '-fno-slp-vectorize', '-DSTRIP_PART=2']), ('fdsr_conv_strip.hip', ['-O3', '-fno-slp-vectorize', '-DSTRIP_PART=3']), ('fdsr_conv_tail.hip', ['-O3', '-fno-slp-vectorize']),
            ('fdsr_val.hip', ['-O3']), ('fdsr_train.hip', ['-O3']), ('fdsr_engine.cpp', ['-O2']), ('fdsr_train.cpp', ['-O2'])]
 COMMON = ['--offload-arch=gfx950', '-std=c++17', '-fPIC', '-Wno-unused-result']
 
@@ -82,7 +84,8 @@ def build(force=False, verbose=True):
 
     def compile_one(item):
         src, flags = item
-        obj = os.path.join(CSRC, src.replace('.', '_') + '.o')   # fdsr_train.hip and fdsr_train.cpp both exist
+        part = ''.join('_part' + f.split('=')[1] for f in flags if f.startswith('-DSTRIP_PART='))
+        obj = os.path.join(CSRC, src.replace('.', '_') + part + '.o')   # fdsr_train.hip and fdsr_train.cpp both exist; fdsr_conv_strip.hip compiles in three parts
         extra = ['-DFDSR_SRC_SHA256="%s"' % stamp] if src == 'fdsr_engine.cpp' else []
         key = _object_key(src, flags + extra)
         keyfile = obj + '.key'       # objects whose inputs did not change are reused (kernel files take ~30 s each)
@@ -95,7 +98,7 @@ def build(force=False, verbose=True):
         open(keyfile, 'w').write(key)
         return obj
 
-    with ThreadPoolExecutor(max_workers=min(7, len(SOURCES))) as ex:
+    with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
         objs = list(ex.map(compile_one, SOURCES))
     cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-Wl,-z,defs'] + objs + ['-o', LIB]   # a missing object fails HERE, not at dlopen
     if verbose:

@@ -674,6 +674,30 @@ __global__ void __launch_bounds__(256, LB) conv_strip_kernel(const ConvParams p,
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// The instantiations, and where they are compiled: each takes 15 - 30 s of hipcc, so the file is compiled THREE times in parallel
+// (fastdiffsr_amd/build.py): -DSTRIP_PART=0 (default) the host side and the f16x3 kernels, =2 the bf16 kernels, =3 the f16 kernels;
+// part 0 only declares the others (extern template: their host stubs and device code live in the other two objects).
+#ifndef STRIP_PART
+#define STRIP_PART 0
+#endif
+#define STRIP_INSTANCES_F16X3(X) X(PREC_F16X3, 64, 0, 0, 0, false, 1) X(PREC_F16X3, 64, 0, 0, 0, true, 1)
+#define STRIP_INSTANCES_16(X, P)                                                                                  \
+  X(P, 64, 0, 0, 0, false, 2) X(P, 64, 0, 0, 0, true, 2) X(P, 64, 0, 0, 0, false, 1) X(P, 64, 0, 0, 0, true, 1)      \
+  X(P, 64, 64, 0, 0, false, 1) X(P, 128, 64, 0, 0, false, 1) X(P, 64, 0, 64, 64, false, 1) X(P, 64, 0, 128, 64, false, 1) \
+  X(P, 128, 0, 0, 0, false, 1) X(P, 128, 0, 0, 0, true, 1)
+#define STRIP_DEFINE(P, A, B, C, D, R, L) template __global__ void conv_strip_kernel<P, A, B, C, D, 4, R, L>(const ConvParams, const int, const int);
+#define STRIP_DECLARE(P, A, B, C, D, R, L) extern template __global__ void conv_strip_kernel<P, A, B, C, D, 4, R, L>(const ConvParams, const int, const int);
+#if STRIP_PART == 2
+STRIP_INSTANCES_16(STRIP_DEFINE, PREC_BF16)
+#elif STRIP_PART == 3
+STRIP_INSTANCES_16(STRIP_DEFINE, PREC_F16)
+#else
+STRIP_INSTANCES_16(STRIP_DECLARE, PREC_BF16)
+STRIP_INSTANCES_16(STRIP_DECLARE, PREC_F16)
+#endif
+
+#if STRIP_PART == 0
+// ---------------------------------------------------------------------------------------------------------------------------
 // g_tun.strip bits: 1 bf16 64 -> 64 launches (two workgroups per CU), 2 the f16x3 ones (one per CU: hi / lo weight planes = 144
 // registers), 4 (A/B) bf16 64 -> 64 on one workgroup per CU, 8 the bf16 launches with a concatenated input (64 + 64 -> 64,
 // 128 + 64 -> 64 under bit 32: 144 / 216 weight registers, one workgroup per CU), 16 the bf16 launches with a res_conv rider,
@@ -764,20 +788,13 @@ static hipError_t init_strip_t() {
 
 hipError_t kernels_strip_init() {
   hipError_t e;
-#define X(...) if ((e = init_strip_t<__VA_ARGS__>()) != hipSuccess) return e;
-  X(PREC_BF16, 64, 0, 0, 0, false, 2) X(PREC_BF16, 64, 0, 0, 0, true, 2)
-  X(PREC_BF16, 64, 0, 0, 0, false, 1) X(PREC_BF16, 64, 0, 0, 0, true, 1)
-  X(PREC_F16X3, 64, 0, 0, 0, false, 1) X(PREC_F16X3, 64, 0, 0, 0, true, 1)
-  X(PREC_BF16, 64, 64, 0, 0, false, 1) X(PREC_BF16, 128, 64, 0, 0, false, 1)
-  X(PREC_BF16, 64, 0, 64, 64, false, 1) X(PREC_BF16, 64, 0, 128, 64, false, 1)
-  X(PREC_BF16, 128, 0, 0, 0, false, 1) X(PREC_BF16, 128, 0, 0, 0, true, 1)
-  X(PREC_F16, 64, 0, 0, 0, false, 2) X(PREC_F16, 64, 0, 0, 0, true, 2)
-  X(PREC_F16, 64, 0, 0, 0, false, 1) X(PREC_F16, 64, 0, 0, 0, true, 1)
-  X(PREC_F16, 64, 64, 0, 0, false, 1) X(PREC_F16, 128, 64, 0, 0, false, 1)
-  X(PREC_F16, 64, 0, 64, 64, false, 1) X(PREC_F16, 64, 0, 128, 64, false, 1)
-  X(PREC_F16, 128, 0, 0, 0, false, 1) X(PREC_F16, 128, 0, 0, 0, true, 1)
+#define X(P, A, B, C, D, R, L) if ((e = init_strip_t<P, A, B, C, D, R, L>()) != hipSuccess) return e;
+  STRIP_INSTANCES_F16X3(X)
+  STRIP_INSTANCES_16(X, PREC_BF16)
+  STRIP_INSTANCES_16(X, PREC_F16)
 #undef X
   return hipSuccess;
 }
+#endif   // STRIP_PART == 0
 
 }  // namespace fdsr
